@@ -1,0 +1,1062 @@
+/*
+ * ORACLE -- test infrastructure only.  Never linked, imported or executed by the product
+ * path (boundmpc_amd/); only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may use it, and there only as the checker / CPU baseline.
+ *
+ * Plain-C (scalar, fp64) restatement of the BoundMPC per-step optimal-control problem and
+ * of a CPU solver for it.  The problem definition follows the reference line by line
+ * (paths relative to /root/reference/bound_mpc/bound_mpc):
+ *   BoundMPC/casadi_ocp_formulation.py:9-391   variables, bounds, 43 constraints/stage, objective, p layout
+ *   BoundMPC/bound_mpc_functions.py:13-310     segment select, reference, errors, objective, integrator
+ *   BoundMPC/mpc_utils_casadi.py:6-165         rotation-error linearisation, projections, quartic tubes
+ *   BoundMPC/jerk_trajectory_casadi.py:78-175  hat-function jerk integrator (closed form)
+ *   RobotModel/RobotModel.py:7-100,1055-1107,1270-1303  iiwa14 fk_pos/velocity_ee/omega_ee (geometric chain)
+ *   BoundMPC/BoundMPC.py:120-148,445-465       tolerance / success semantics
+ *
+ * The reference hands this NLP to CasADi -> Ipopt -> MUMPS (third-party, pip `casadi`,
+ * unpinned, absent from the image).  Ipopt cannot be run here and the
+ * reference holds no solution vectors, so the SOLUTION is "parity unpinned" against Ipopt;
+ * what is pinned: f and g against oracle/nlp.py (itself pinned on golden vectors from the
+ * reference's numeric leaves), KKT residuals of every solution (computed here and
+ * independently by complex-step in tests), and an independent scipy solve
+ * (oracle/solve_scipy.py).
+ *
+ * Solver: primal-dual interior point on the reference's multiple-shooting variables
+ * (same cold start), exact Lagrangian Hessian, Newton system solved stage by stage with a
+ * Riccati recursion on a 35-dimensional reduced node state (lifted variables pos/v and
+ * the trapezoidal omega term eliminated node-locally), l1-merit backtracking line search.
+ * The quadratic tube constraints  l^2 - w^2 <= 0  of the reference are handled in the
+ * equivalent two-sided form  -w <= l <= w  (same feasible set, same minimisers); g and
+ * lam_g are reported in the reference's squared form.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NZ 44
+#define NG 43
+#define NE 36 /* equalities per stage */
+#define NS 35 /* reduced node state: q dq ddq j (28) | phi dphi ddphi jphi | iota(3) */
+#define NU 8
+#define NW 43 /* NS + NU */
+#define NI 57 /* internal inequality rows per node */
+
+enum { ZJ = 0, ZJPHI = 7, ZQ = 8, ZDQ = 15, ZDDQ = 22, ZPOS = 29, ZIW = 32, ZV = 35, ZW = 38, ZPHI = 41, ZDPHI = 42, ZDDPHI = 43 };
+enum { GQ = 0, GDQ = 7, GDDQ = 14, GPOS = 21, GIW = 24, GV = 27, GW = 30, GPHI = 33, GDPHI = 34, GDDPHI = 35 };
+enum { SQ = 0, SDQ = 7, SDDQ = 14, SJ = 21, SPHI = 28, SDPHI = 29, SDDPHI = 30, SJPHI = 31, SIOTA = 32 };
+/* inequality rows */
+enum { IJU = 0, IJL = 8, IQU = 16, IQL = 23, IDQU = 30, IDQL = 37, IPHI0 = 44, IPHIMAX = 45, IDPHIMAX = 46, ITUBE = 47 };
+
+static const double Q_LIM_DEG[7] = {165, 115, 165, 115, 165, 115, 170};
+static const double DQ_LIM_DEG[7] = {85, 85, 100, 75, 130, 135, 135};
+#define U_LIM 35.0
+#define PI 3.14159265358979323846
+
+typedef struct {
+    double tol;          /* KKT tolerance (default 1e-6; reference Ipopt tol 1e-5, BoundMPC.py:121) */
+    int max_iter;        /* BoundMPC.py:122 -> 500 */
+    double mu_init;      /* 0.1 */
+    double mu_min_fac;   /* mu_min = tol * mu_min_fac (0.1) */
+    double slack_push;   /* 1e-2 */
+    int exact_hessian;   /* 1 */
+    int verbose;
+} bmpc_oracle_opts;
+
+typedef struct {
+    int N, S, np;
+    double h;
+    bmpc_oracle_opts o;
+} Cfg;
+
+/* ------------------------------------------------------------------------------------------
+ * parameter vector view (casadi_ocp_formulation.py:361-376; CasADi column-major blocks)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const double *q0, *dq0, *ddq0, *p0, *v0, *iw_ref0, *dtau_init, *init_par, *init_o1, *init_o2, *x_phi_d, *jerk_cur;
+    double phi0, dphi0, ddphi0, jerk_phi, phi_max, dphi_max;
+    const double *phi_switch, *jacr, *jacl, *p_ref, *dp_ref, *dp_normed, *bp1, *bp2, *br1, *br2, *a[5], *w, *v1, *v2, *v3, *qd;
+} Par;
+
+static void par_view(const double *p, int S, Par *P) {
+    int o = 0;
+    P->q0 = p + o; o += 7; P->dq0 = p + o; o += 7; P->ddq0 = p + o; o += 7;
+    P->phi0 = p[o++]; P->dphi0 = p[o++]; P->ddphi0 = p[o++];
+    P->p0 = p + o; o += 6; P->v0 = p + o; o += 6; P->iw_ref0 = p + o; o += 3; P->dtau_init = p + o; o += 3;
+    P->init_par = p + o; o += 3 * S; P->init_o1 = p + o; o += 3 * S; P->init_o2 = p + o; o += 3 * S; /* [seg][xyz] */
+    P->x_phi_d = p + o; o += 3; P->jerk_cur = p + o; o += 7; P->jerk_phi = p[o++];
+    P->phi_switch = p + o; o += S + 1;
+    P->jacr = p + o; o += 9; P->jacl = p + o; o += 9;                        /* [col][row] */
+    P->p_ref = p + o; o += 6 * S; P->dp_ref = p + o; o += 6 * S; P->dp_normed = p + o; o += 3 * S; /* [coord][seg] */
+    P->bp1 = p + o; o += 3 * S; P->bp2 = p + o; o += 3 * S; P->br1 = p + o; o += 3 * S; P->br2 = p + o; o += 3 * S;
+    for (int i = 0; i < 5; i++) { P->a[i] = p + o; o += 9 * (S + 1); }       /* a4,a3,a2,a1,a0 : [chan][seg] */
+    P->w = p + o; o += 15; P->phi_max = p[o++]; P->dphi_max = p[o++];
+    P->v1 = p + o; o += 3 * S; P->v2 = p + o; o += 3 * S; P->v3 = p + o; o += 3 * S; P->qd = p + o; o += 7;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * small vector helpers
+ * ---------------------------------------------------------------------------------------- */
+static inline void cross(const double *a, const double *b, double *c) {
+    double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    c[0] = x; c[1] = y; c[2] = z;
+}
+static inline double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+/* ------------------------------------------------------------------------------------------
+ * iiwa14 kinematics as a geometric chain: joint axes (z,y,z,-y,z,y,z), translations along the
+ * local z axis 0.36 before joint 2, 0.42 before joint 4, 0.40 before joint 6, tool 0.297
+ * (RobotModel.py:9-16; equality with fk_pos/jacobian_fk/velocity_ee/omega_ee pinned by G1)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    double a[7][3];   /* joint axes in base frame */
+    double r[7][3];   /* tool point minus a point on axis j */
+    double w[7][3];   /* a_j x r_j  (= J_v column) */
+    double pos[3];
+    double v[6];      /* [J_v dq ; J_w dq] */
+    double D[6][7];   /* d(J dq)/dq_i */
+    double dq[7];
+} Kin;
+
+static void kin_eval(const double *q, const double *dq, Kin *K) {
+    static const double preZ[7] = {0.0, 0.1575 + 0.2025, 0.0, 0.2375 + 0.1825, 0.0, 0.2175 + 0.1825, 0.0};
+    static const double toolZ = 0.081 + (0.071 + 0.145);
+    static const int axis[7] = {2, 1, 2, -1, 2, 1, 2}; /* 2 = +z, 1 = +y, -1 = -y */
+    double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, o[3] = {0, 0, 0}, O[7][3];
+    for (int j = 0; j < 7; j++) {
+        for (int i = 0; i < 3; i++) o[i] += R[i][2] * preZ[j];
+        double c = cos(q[j]), s = sin(q[j]);
+        if (axis[j] == 2) {
+            for (int i = 0; i < 3; i++) { K->a[j][i] = R[i][2]; O[j][i] = o[i]; }
+            for (int i = 0; i < 3; i++) { double c0 = R[i][0], c1 = R[i][1]; R[i][0] = c * c0 + s * c1; R[i][1] = -s * c0 + c * c1; }
+        } else {
+            double sg = (axis[j] == 1) ? 1.0 : -1.0;
+            for (int i = 0; i < 3; i++) { K->a[j][i] = sg * R[i][1]; O[j][i] = o[i]; }
+            s *= sg; /* rotation about -y by q == rotation about +y by -q */
+            for (int i = 0; i < 3; i++) { double c0 = R[i][0], c2 = R[i][2]; R[i][0] = c * c0 - s * c2; R[i][2] = s * c0 + c * c2; }
+        }
+    }
+    for (int i = 0; i < 3; i++) K->pos[i] = o[i] + R[i][2] * toolZ;
+    for (int j = 0; j < 7; j++) {
+        for (int i = 0; i < 3; i++) K->r[j][i] = K->pos[i] - O[j][i];
+        cross(K->a[j], K->r[j], K->w[j]);
+        K->dq[j] = dq[j];
+    }
+    for (int i = 0; i < 6; i++) K->v[i] = 0;
+    for (int j = 0; j < 7; j++) for (int i = 0; i < 3; i++) { K->v[i] += dq[j] * K->w[j][i]; K->v[3 + i] += dq[j] * K->a[j][i]; }
+    /* D_v[:,i] = a_i x V>=_i + W<_i x w_i ;  D_w[:,i] = a_i x W>_i */
+    double Wlt[3] = {0, 0, 0};
+    for (int i = 0; i < 7; i++) {
+        double Vge[3] = {0, 0, 0}, Wgt[3] = {0, 0, 0}, t1[3], t2[3];
+        for (int j = i; j < 7; j++) for (int c2 = 0; c2 < 3; c2++) Vge[c2] += dq[j] * K->w[j][c2];
+        for (int j = i + 1; j < 7; j++) for (int c2 = 0; c2 < 3; c2++) Wgt[c2] += dq[j] * K->a[j][c2];
+        cross(K->a[i], Vge, t1); cross(Wlt, K->w[i], t2);
+        for (int c2 = 0; c2 < 3; c2++) K->D[c2][i] = t1[c2] + t2[c2];
+        cross(K->a[i], Wgt, t1);
+        for (int c2 = 0; c2 < 3; c2++) K->D[3 + c2][i] = t1[c2];
+        for (int c2 = 0; c2 < 3; c2++) Wlt[c2] += dq[i] * K->a[i][c2];
+    }
+}
+
+/* Hessian of  mu_p.pos(q) + mu_v.(J_v dq) + mu_w.(J_w dq)  w.r.t. y = (q, dq): W[14][14] */
+static void kin_hess(const Kin *K, const double *mu_p, const double *mu_v, const double *mu_w, double W[14][14]) {
+    memset(W, 0, sizeof(double) * 14 * 14);
+    double Wlt[8][3]; /* sum_{j<i} dq_j a_j */
+    for (int c = 0; c < 3; c++) Wlt[0][c] = 0;
+    for (int i = 0; i < 7; i++) for (int c = 0; c < 3; c++) Wlt[i + 1][c] = Wlt[i][c] + K->dq[i] * K->a[i][c];
+    for (int l = 0; l < 7; l++) {
+        double Vge[3] = {0, 0, 0}, Wgt[3] = {0, 0, 0};
+        for (int j = l; j < 7; j++) for (int c = 0; c < 3; c++) Vge[c] += K->dq[j] * K->w[j][c];
+        for (int j = l + 1; j < 7; j++) for (int c = 0; c < 3; c++) Wgt[c] += K->dq[j] * K->a[j][c];
+        double alV[3], alW[3];
+        cross(K->a[l], Vge, alV); cross(K->a[l], Wgt, alW);
+        for (int i = 0; i <= l; i++) {
+            double t[3], u[3], Wil[3], val;
+            cross(K->a[i], K->w[l], t);            /* a_i x (a_l x r_l) */
+            val = dot3(mu_p, t);
+            cross(Wlt[i], t, u); val += dot3(mu_v, u); /* W<_i x (a_i x (a_l x r_l)) */
+            cross(K->a[i], alV, u); val += dot3(mu_v, u);
+            for (int c = 0; c < 3; c++) Wil[c] = Wlt[l][c] - Wlt[i][c];
+            cross(Wil, K->w[l], t); cross(K->a[i], t, u); val += dot3(mu_v, u);
+            cross(K->a[i], alW, u); val += dot3(mu_w, u);
+            W[i][l] = val; W[l][i] = val;
+        }
+    }
+    for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) {
+        double t[3], val;
+        if (i <= j) cross(K->a[i], K->w[j], t); else cross(K->a[j], K->w[i], t);
+        val = dot3(mu_v, t);
+        if (i < j) { cross(K->a[i], K->a[j], t); val += dot3(mu_w, t); }
+        W[i][7 + j] = val; W[7 + j][i] = val;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * node quantities depending on (pos, iw, phi): reference, tubes, errors
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int seg, segb;                 /* active segment; index used for bp1/bp2 (reference quirk) */
+    double x;                      /* phi - phi_start */
+    double d[3], rho[3], dp[6];    /* dp_ref[:3], dp_ref[3:], all six */
+    double dh[3], bp1[3], bp2[3], br1[3], br2[3];
+    double ep[3], er[3], erpar[3]; /* e_p, e_r, e_r_par */
+    double l1[3], l2[3], l3[3];    /* J_l^T v1, v2, v3 */
+    double rr[3];                  /* J_r rho */
+    double Jl[3][3];
+    double sig, sig1, sig2;
+    double c[5], w[5];             /* tube rows: c_m (incl. -offset), half width |w_m| */
+    double gc[5][7];               /* d c_m / d(pos, iw, phi) */
+    double c2[5];                  /* d2 c_m / dphi2 */
+    double w1[5], w2[5];           /* d|w_m|/dphi, d2|w_m|/dphi2 */
+} NodeRef;
+
+static void node_ref(const Cfg *C, const Par *P, const double *pos, const double *iw, double phi, NodeRef *R) {
+    const int S = C->S;
+    const double *sw = P->phi_switch;
+    int seg = S - 1;
+    for (int i = S - 2; i >= 0; i--) if (phi < sw[i + 1]) seg = i;  /* bound_mpc_functions.py:13-20 */
+    R->seg = seg;
+    R->segb = (seg < S - 2) ? seg : (S - 2 >= 0 ? S - 2 : 0);       /* :34-40 on an S-row array */
+    if (R->segb < 0) R->segb = 0;
+    /* a-arrays have S+1 rows; row S (only when phi >= sw[S]) is undefined in the reference -> row S-1 */
+    int sega = seg;
+    double x = phi - sw[seg];
+    R->x = x;
+    for (int c = 0; c < 6; c++) R->dp[c] = P->dp_ref[c * S + seg];
+    for (int c = 0; c < 3; c++) {
+        R->d[c] = R->dp[c]; R->rho[c] = R->dp[3 + c];
+        R->dh[c] = P->dp_normed[c * S + seg];
+        R->bp1[c] = P->bp1[c * S + R->segb]; R->bp2[c] = P->bp2[c * S + R->segb];
+        R->br1[c] = P->br1[c * S + seg]; R->br2[c] = P->br2[c * S + seg];
+    }
+    double b[9], b1[9], b2[9];
+    for (int ch = 0; ch < 9; ch++) {
+        double a4 = P->a[0][ch * (S + 1) + sega], a3 = P->a[1][ch * (S + 1) + sega], a2 = P->a[2][ch * (S + 1) + sega],
+               a1 = P->a[3][ch * (S + 1) + sega], a0 = P->a[4][ch * (S + 1) + sega];
+        b[ch] = (((a4 * x + a3) * x + a2) * x + a1) * x + a0;
+        b1[ch] = ((4 * a4 * x + 3 * a3) * x + 2 * a2) * x + a1;
+        b2[ch] = (12 * a4 * x + 6 * a3) * x + 2 * a2;
+    }
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) R->Jl[r][c] = P->jacl[c * 3 + r];
+    double v1[3], v2[3], v3[3];
+    for (int c = 0; c < 3; c++) { v1[c] = P->v1[c * S + seg]; v2[c] = P->v2[c * S + seg]; v3[c] = P->v3[c * S + seg]; }
+    for (int c = 0; c < 3; c++) {
+        R->rr[c] = 0;
+        for (int k = 0; k < 3; k++) R->rr[c] += P->jacr[k * 3 + c] * R->rho[k];
+        R->l1[c] = R->l2[c] = R->l3[c] = 0;
+        for (int r = 0; r < 3; r++) { R->l1[c] += R->Jl[r][c] * v1[r]; R->l2[c] += R->Jl[r][c] * v2[r]; R->l3[c] += R->Jl[r][c] * v3[r]; }
+    }
+    /* errors (mpc_utils_casadi.py:6-10,52; bound_mpc_functions.py:166-189) */
+    double dlt[3];
+    for (int c = 0; c < 3; c++) R->ep[c] = pos[c] - (P->p_ref[c * S + seg] + R->d[c] * x);
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int c = 0; c < 3; c++) s += R->Jl[r][c] * (iw[c] - P->p0[3 + c]) - P->jacr[c * 3 + r] * (P->p_ref[(3 + c) * S + seg] + R->rho[c] * x - P->iw_ref0[c]);
+        dlt[r] = s; R->er[r] = P->dtau_init[r] + s;
+    }
+    double s1 = dot3(dlt, v1), s2 = dot3(dlt, v2), s3 = dot3(dlt, v3);
+    const double *ipar = P->init_par + 3 * seg, *io1 = P->init_o1 + 3 * seg, *io2 = P->init_o2 + 3 * seg;
+    for (int c = 0; c < 3; c++) R->erpar[c] = ipar[c] + s2 * R->dh[c];
+    double a = 100.0 * (phi - (P->phi_max - 0.02));
+    R->sig = 1.0 / (1.0 + exp(-a));
+    R->sig1 = 100.0 * R->sig * (1.0 - R->sig);
+    R->sig2 = 100.0 * R->sig1 * (1.0 - 2.0 * R->sig);
+    /* tube rows */
+    double dhdh = dot3(R->dh, R->dh), b1b1 = dot3(R->br1, R->br1), b2b2 = dot3(R->br2, R->br2);
+    double v1rr = dot3(v1, R->rr), v2rr = dot3(v2, R->rr), v3rr = dot3(v3, R->rr);
+    memset(R->gc, 0, sizeof(R->gc));
+    /* m=0 tangential orientation (casadi_ocp_formulation.py:317-319) */
+    R->c[0] = dot3(R->dh, ipar) + s2 * dhdh;
+    for (int c = 0; c < 3; c++) R->gc[0][3 + c] = dhdh * R->l2[c];
+    R->gc[0][6] = -dhdh * v2rr; R->c2[0] = 0;
+    { double wv = b[8], sg = wv >= 0 ? 1.0 : -1.0; R->w[0] = sg * wv; R->w1[0] = sg * b1[8]; R->w2[0] = sg * b2[8]; }
+    /* m=1,2 orthogonal position (:325-331, bound_mpc_functions.py:298-310) */
+    for (int m = 0; m < 2; m++) {
+        const double *bp = m ? R->bp2 : R->bp1;
+        double off = 0.5 * (b[m] + b[2 + m]), off1 = 0.5 * (b1[m] + b1[2 + m]), off2 = 0.5 * (b2[m] + b2[2 + m]);
+        double hw = 0.5 * (b[m] - b[2 + m]), sg = hw >= 0 ? 1.0 : -1.0;
+        R->c[1 + m] = dot3(R->ep, bp) - off;
+        for (int c = 0; c < 3; c++) R->gc[1 + m][c] = bp[c];
+        R->gc[1 + m][6] = -dot3(R->d, bp) - off1; R->c2[1 + m] = -off2;
+        R->w[1 + m] = sg * hw; R->w1[1 + m] = sg * 0.5 * (b1[m] - b1[2 + m]); R->w2[1 + m] = sg * 0.5 * (b2[m] - b2[2 + m]);
+    }
+    /* m=3,4 orthogonal orientation (:339-346) */
+    for (int m = 0; m < 2; m++) {
+        const double *br = m ? R->br2 : R->br1, *io = m ? io2 : io1, *l = m ? R->l3 : R->l1;
+        double bb = m ? b2b2 : b1b1, sc = m ? s3 : s1, vrr = m ? v3rr : v1rr;
+        double off = 0.5 * (b[4 + m] + b[6 + m]), off1 = 0.5 * (b1[4 + m] + b1[6 + m]), off2 = 0.5 * (b2[4 + m] + b2[6 + m]);
+        double hw = 0.5 * (b[4 + m] - b[6 + m]), sg = hw >= 0 ? 1.0 : -1.0;
+        R->c[3 + m] = dot3(br, io) + sc * bb - off;
+        for (int c = 0; c < 3; c++) R->gc[3 + m][3 + c] = bb * l[c];
+        R->gc[3 + m][6] = -bb * vrr - off1; R->c2[3 + m] = -off2;
+        R->w[3 + m] = sg * hw; R->w1[3 + m] = sg * 0.5 * (b1[4 + m] - b1[6 + m]); R->w2[3 + m] = sg * 0.5 * (b2[4 + m] - b2[6 + m]);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * workspace for one problem
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int N;
+    double *Z;        /* [N][44]   node k+1 variables = reference stage k */
+    double *t, *nu;   /* [N][57] slacks / multipliers of internal inequality rows */
+    double *lam;      /* [N][36] equality multipliers (adjoint) */
+    double *g;        /* [N][36] equality residuals */
+    double *hin;      /* [N][57] inequality values */
+    double *gradZ;    /* [N][44] d(f + nu.h)/dZ (uses nu) */
+    double *Rj;       /* [N][8] stationarity residual w.r.t. the jerks */
+    Kin *Kp;          /* [N] kinematics at the predicted (q^,dq^) of node k+1 */
+    Kin *Kv;          /* [N] kinematics at the node variables (q,dq) of node k (k=0: parameters) */
+    NodeRef *R;       /* [N] */
+    double f;
+    /* Newton step */
+    double *dZ, *dt, *dnu;
+    /* Riccati storage */
+    double *Kg;       /* [N][8][35] feedback */
+    double *kff;      /* [N][8] */
+    double *Qt, *qt;  /* [N][35][35], [N][35] reduced node Hessian / gradient */
+    double *Xt;       /* [N][35][35] cross term node k+1 (rows) x node k (cols) */
+    double *T;        /* [N][44][35] */
+    double *rloc;     /* [N][44] */
+    double *A;        /* [N][35][43] */
+    double *rdyn;     /* [N][35] */
+    double *Zt, *tt;  /* trial point */
+} Work;
+
+static Work *work_alloc(int N) {
+    Work *W = (Work *)calloc(1, sizeof(Work));
+    W->N = N;
+#define AL(n) (double *)calloc((size_t)(n), sizeof(double))
+    W->Z = AL(N * NZ); W->t = AL(N * NI); W->nu = AL(N * NI); W->lam = AL(N * NE); W->g = AL(N * NE); W->hin = AL(N * NI);
+    W->gradZ = AL(N * NZ); W->Rj = AL(N * NU); W->dZ = AL(N * NZ); W->dt = AL(N * NI); W->dnu = AL(N * NI);
+    W->Kg = AL(N * NU * NS); W->kff = AL(N * NU); W->Qt = AL(N * NS * NS); W->qt = AL(N * NS); W->Xt = AL(N * NS * NS);
+    W->T = AL(N * NZ * NS); W->rloc = AL(N * NZ); W->A = AL(N * NS * NW); W->rdyn = AL(N * NS); W->Zt = AL(N * NZ); W->tt = AL(N * NI);
+    W->Kp = (Kin *)calloc(N, sizeof(Kin)); W->Kv = (Kin *)calloc(N, sizeof(Kin)); W->R = (NodeRef *)calloc(N, sizeof(NodeRef));
+    return W;
+}
+static void work_free(Work *W) {
+    free(W->Z); free(W->t); free(W->nu); free(W->lam); free(W->g); free(W->hin); free(W->gradZ); free(W->Rj); free(W->dZ); free(W->dt);
+    free(W->dnu); free(W->Kg); free(W->kff); free(W->Qt); free(W->qt); free(W->Xt); free(W->T); free(W->rloc); free(W->A); free(W->rdyn);
+    free(W->Zt); free(W->tt); free(W->Kp); free(W->Kv); free(W->R); free(W);
+}
+
+/* node k (0..N) accessors: node 0 from parameters, node k>=1 = Z[k-1] */
+static inline const double *nd_q(const Par *P, const double *Z, int k) { return k ? Z + (k - 1) * NZ + ZQ : P->q0; }
+static inline const double *nd_dq(const Par *P, const double *Z, int k) { return k ? Z + (k - 1) * NZ + ZDQ : P->dq0; }
+static inline const double *nd_ddq(const Par *P, const double *Z, int k) { return k ? Z + (k - 1) * NZ + ZDDQ : P->ddq0; }
+static inline const double *nd_j(const Par *P, const double *Z, int k) { return k ? Z + (k - 1) * NZ + ZJ : P->jerk_cur; }
+static inline double nd_jphi(const Par *P, const double *Z, int k) { return k ? Z[(k - 1) * NZ + ZJPHI] : P->jerk_phi; }
+static inline const double *nd_p(const Par *P, const double *Z, int k) { return k ? Z + (k - 1) * NZ + ZPOS : P->p0; }
+static inline const double *nd_v(const Par *P, const double *Z, int k) { return k ? Z + (k - 1) * NZ + ZV : P->v0; }
+static inline double nd_phi(const Par *P, const double *Z, int k, int d) {
+    if (k) return Z[(k - 1) * NZ + ZPHI + d];
+    return d == 0 ? P->phi0 : (d == 1 ? P->dphi0 : P->ddphi0);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * function evaluation: f, equality residuals g[N][36], inequality values h[N][57]
+ * (casadi_ocp_formulation.py:88-349)
+ * ---------------------------------------------------------------------------------------- */
+static double eval_values(const Cfg *C, const Par *P, const double *Z, Kin *Kp, Kin *Kv, NodeRef *Rf, double *g, double *hin) {
+    const int N = C->N;
+    const double h = C->h, h2 = h * h, h3 = h2 * h;
+    const double *w = P->w;
+    double f = 0;
+    for (int k = 0; k < N; k++) {
+        const double *q = nd_q(P, Z, k), *dq = nd_dq(P, Z, k), *ddq = nd_ddq(P, Z, k), *j0 = nd_j(P, Z, k);
+        const double *Zn = Z + k * NZ;
+        double qn[7], dqn[7], ddqn[7];
+        for (int i = 0; i < 7; i++) {   /* jerk_trajectory_casadi.py:78-175 closed form */
+            qn[i] = q[i] + h * dq[i] + h2 / 2 * ddq[i] + h3 / 8 * j0[i] + h3 / 24 * Zn[ZJ + i];
+            dqn[i] = dq[i] + h * ddq[i] + h2 / 3 * j0[i] + h2 / 6 * Zn[ZJ + i];
+            ddqn[i] = ddq[i] + h / 2 * (j0[i] + Zn[ZJ + i]);
+        }
+        double ph = nd_phi(P, Z, k, 0), dph = nd_phi(P, Z, k, 1), ddph = nd_phi(P, Z, k, 2), jp0 = nd_jphi(P, Z, k), jp1 = Zn[ZJPHI];
+        double phn = ph + h * dph + h2 / 2 * ddph + h3 / 8 * jp0 + h3 / 24 * jp1;
+        double dphn = dph + h * ddph + h2 / 3 * jp0 + h2 / 6 * jp1;
+        double ddphn = ddph + h / 2 * (jp0 + jp1);
+        kin_eval(qn, dqn, &Kp[k]);
+        kin_eval(q, dq, &Kv[k]);
+        double *gk = g + k * NE;
+        const double *pk = nd_p(P, Z, k);
+        for (int i = 0; i < 7; i++) { gk[GQ + i] = qn[i] - Zn[ZQ + i]; gk[GDQ + i] = dqn[i] - Zn[ZDQ + i]; gk[GDDQ + i] = ddqn[i] - Zn[ZDDQ + i]; }
+        for (int i = 0; i < 3; i++) {
+            gk[GPOS + i] = Kp[k].pos[i] - Zn[ZPOS + i];
+            gk[GIW + i] = pk[3 + i] + 0.5 * h * (Kv[k].v[3 + i] + Kp[k].v[3 + i]) - Zn[ZIW + i];   /* bound_mpc_functions.py:278-280 */
+        }
+        for (int i = 0; i < 6; i++) gk[GV + i] = Kp[k].v[i] - Zn[ZV + i];
+        gk[GPHI] = phn - Zn[ZPHI]; gk[GDPHI] = dphn - Zn[ZDPHI]; gk[GDDPHI] = ddphn - Zn[ZDDPHI];
+        /* node k+1 cost and inequalities */
+        NodeRef *R = &Rf[k];
+        node_ref(C, P, Zn + ZPOS, Zn + ZIW, Zn[ZPHI], R);
+        const double *vprev = nd_v(P, Z, k);
+        double epo[3], ero[3], dde = dot3(R->d, R->ep);
+        for (int c = 0; c < 3; c++) {
+            epo[c] = R->sig * R->ep[c] + (1 - R->sig) * dde * R->d[c];
+            ero[c] = R->sig * R->er[c] + (1 - R->sig) * R->erpar[c];
+        }
+        double fk = w[1] * dot3(ero, ero) + w[0] * dot3(epo, epo);
+        for (int c = 0; c < 6; c++) {
+            double rv = Zn[ZV + c] - Zn[ZDPHI] * R->dp[c];
+            double ra = (Zn[ZV + c] - vprev[c]) / h - Zn[ZDDPHI] * R->dp[c];
+            fk += w[2] * rv * rv + w[5] * ra * ra;
+        }
+        for (int i = 0; i < 7; i++) {
+            double dqd = Zn[ZQ + i] - P->qd[i];
+            fk += w[10] * dqd * dqd + w[11] * Zn[ZDQ + i] * Zn[ZDQ + i] + w[12] * Zn[ZDDQ + i] * Zn[ZDDQ + i] + w[13] * Zn[ZJ + i] * Zn[ZJ + i];
+        }
+        double e0 = P->x_phi_d[0] - Zn[ZPHI], e1 = P->x_phi_d[1] - Zn[ZDPHI], e2 = P->x_phi_d[2] - Zn[ZDDPHI];
+        fk += w[6] * e0 * e0 + w[7] * e1 * e1 + w[8] * e2 * e2 + w[9] * Zn[ZJPHI] * Zn[ZJPHI];
+        f += fk;
+        double *hk = hin + k * NI;
+        for (int i = 0; i < 8; i++) { hk[IJU + i] = Zn[ZJ + i] - U_LIM; hk[IJL + i] = -Zn[ZJ + i] - U_LIM; }
+        for (int i = 0; i < 7; i++) {
+            double ql = Q_LIM_DEG[i] * PI / 180, dl = DQ_LIM_DEG[i] * PI / 180;
+            hk[IQU + i] = Zn[ZQ + i] - ql; hk[IQL + i] = -Zn[ZQ + i] - ql;
+            hk[IDQU + i] = Zn[ZDQ + i] - dl; hk[IDQL + i] = -Zn[ZDQ + i] - dl;
+        }
+        hk[IPHI0] = -Zn[ZPHI]; hk[IPHIMAX] = Zn[ZPHI] - P->phi_max; hk[IDPHIMAX] = Zn[ZDPHI] - P->dphi_max;
+        for (int m = 0; m < 5; m++) { hk[ITUBE + 2 * m] = R->c[m] - R->w[m]; hk[ITUBE + 2 * m + 1] = -R->c[m] - R->w[m]; }
+    }
+    return f;
+}
+
+/* reference-form constraint vector g[43N] from the internal quantities */
+static void fill_g_ref(const Cfg *C, const Par *P, const double *Z, const double *g, const NodeRef *Rf, double *gout) {
+    for (int k = 0; k < C->N; k++) {
+        double *o = gout + k * NG;
+        const double *Zn = Z + k * NZ;
+        memcpy(o, g + k * NE, NE * sizeof(double));
+        o[36] = Zn[ZPHI] - P->phi_max; o[37] = Zn[ZDPHI] - P->dphi_max;
+        for (int m = 0; m < 5; m++) o[38 + m] = Rf[k].c[m] * Rf[k].c[m] - Rf[k].w[m] * Rf[k].w[m];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * gradient of the node-local cost + inequality terms w.r.t. Z_k (44) and v_prev (6).
+ * nuv: multipliers used on the inequality rows (nu for the KKT residual, nu_hat for the QP)
+ * ---------------------------------------------------------------------------------------- */
+static void node_grad(const Cfg *C, const Par *P, const double *Zn, const double *vprev, const NodeRef *R, const double *nuv,
+                      double *gz, double *gvprev) {
+    const double *w = P->w; const double h = C->h;
+    memset(gz, 0, NZ * sizeof(double));
+    double dde = dot3(R->d, R->ep), dd = dot3(R->d, R->d), epo[3], ero[3], eperp[3], erd[3];
+    for (int c = 0; c < 3; c++) {
+        eperp[c] = R->ep[c] - dde * R->d[c];
+        epo[c] = R->sig * R->ep[c] + (1 - R->sig) * dde * R->d[c];
+        erd[c] = R->er[c] - R->erpar[c];
+        ero[c] = R->sig * R->er[c] + (1 - R->sig) * R->erpar[c];
+    }
+    /* e_p_obj: d/dpos = sig I + (1-sig) d d^T ; d/dphi = -Pi d + sig' e_perp */
+    double depo = dot3(R->d, epo);
+    double gphi = 0;
+    for (int c = 0; c < 3; c++) gz[ZPOS + c] += 2 * w[0] * (R->sig * epo[c] + (1 - R->sig) * depo * R->d[c]);
+    gphi += 2 * w[0] * (-(R->sig * depo + (1 - R->sig) * depo * dd) + R->sig1 * dot3(eperp, epo));
+    /* e_r_obj */
+    double dhero = dot3(R->dh, ero);
+    for (int c = 0; c < 3; c++) {
+        double s = 0;
+        for (int r = 0; r < 3; r++) s += R->sig * R->Jl[r][c] * ero[r];
+        gz[ZIW + c] += 2 * w[1] * (s + (1 - R->sig) * dhero * R->l2[c]);
+    }
+    {   /* d e_r_obj / dphi = -sig rr - (1-sig) dh (v2.rr) + sig' (e_r - e_r_par);  v2.rr = -gc[0][6]/dhdh */
+        double dhdh = dot3(R->dh, R->dh), v2rr = dhdh != 0 ? -R->gc[0][6] / dhdh : 0.0;
+        gphi += 2 * w[1] * (-R->sig * dot3(R->rr, ero) - (1 - R->sig) * v2rr * dhero + R->sig1 * dot3(erd, ero));
+    }
+    double gdphi = 0, gddphi = 0;
+    for (int c = 0; c < 6; c++) {
+        double rv = Zn[ZV + c] - Zn[ZDPHI] * R->dp[c];
+        double ra = (Zn[ZV + c] - vprev[c]) / h - Zn[ZDDPHI] * R->dp[c];
+        gz[ZV + c] += 2 * w[2] * rv + 2 * w[5] * ra / h;
+        gdphi += -2 * w[2] * rv * R->dp[c];
+        gddphi += -2 * w[5] * ra * R->dp[c];
+        gvprev[c] = -2 * w[5] * ra / h;
+    }
+    for (int i = 0; i < 7; i++) {
+        gz[ZQ + i] += 2 * w[10] * (Zn[ZQ + i] - P->qd[i]); gz[ZDQ + i] += 2 * w[11] * Zn[ZDQ + i];
+        gz[ZDDQ + i] += 2 * w[12] * Zn[ZDDQ + i]; gz[ZJ + i] += 2 * w[13] * Zn[ZJ + i];
+    }
+    gphi += -2 * w[6] * (P->x_phi_d[0] - Zn[ZPHI]);
+    gdphi += -2 * w[7] * (P->x_phi_d[1] - Zn[ZDPHI]);
+    gddphi += -2 * w[8] * (P->x_phi_d[2] - Zn[ZDDPHI]);
+    gz[ZJPHI] += 2 * w[9] * Zn[ZJPHI];
+    /* inequality rows */
+    for (int i = 0; i < 8; i++) gz[ZJ + i] += nuv[IJU + i] - nuv[IJL + i];
+    for (int i = 0; i < 7; i++) { gz[ZQ + i] += nuv[IQU + i] - nuv[IQL + i]; gz[ZDQ + i] += nuv[IDQU + i] - nuv[IDQL + i]; }
+    gphi += -nuv[IPHI0] + nuv[IPHIMAX]; gdphi += nuv[IDPHIMAX];
+    for (int m = 0; m < 5; m++) {
+        double nu_u = nuv[ITUBE + 2 * m], nu_l = nuv[ITUBE + 2 * m + 1];
+        for (int c = 0; c < 3; c++) { gz[ZPOS + c] += (nu_u - nu_l) * R->gc[m][c]; gz[ZIW + c] += (nu_u - nu_l) * R->gc[m][3 + c]; }
+        gphi += (nu_u - nu_l) * R->gc[m][6] - (nu_u + nu_l) * R->w1[m];
+    }
+    gz[ZPHI] += gphi; gz[ZDPHI] += gdphi; gz[ZDDPHI] += gddphi;
+}
+
+/* transpose-Jacobian product of stage k (node k -> k+1) dynamics: given lam (36), accumulate into
+ * gx (node k's 44 variables; may be NULL for k = 0) and gj1 (8, jerks of node k+1) */
+static void stage_adjoint(const Cfg *C, const Kin *Kp, const Kin *Kv, const double *lam, double *gx, double *gj1) {
+    const double h = C->h, h2 = h * h, h3 = h2 * h;
+    double muq[7], mudq[7], mw[3], mv[3];
+    for (int c = 0; c < 3; c++) { mv[c] = lam[GV + c]; mw[c] = lam[GW + c] + 0.5 * h * lam[GIW + c]; }
+    for (int i = 0; i < 7; i++) {
+        double s = lam[GQ + i], s2 = lam[GDQ + i];
+        for (int c = 0; c < 3; c++) {
+            s += Kp->w[i][c] * lam[GPOS + c] + Kp->D[c][i] * mv[c] + Kp->D[3 + c][i] * mw[c];
+            s2 += Kp->w[i][c] * mv[c] + Kp->a[i][c] * mw[c];
+        }
+        muq[i] = s; mudq[i] = s2;
+    }
+    for (int i = 0; i < 7; i++) {
+        double mdd = lam[GDDQ + i];
+        gj1[i] += h3 / 24 * muq[i] + h2 / 6 * mudq[i] + h / 2 * mdd;
+        if (gx) {
+            double eq = 0, edq = 0;
+            for (int c = 0; c < 3; c++) { eq += Kv->D[3 + c][i] * lam[GIW + c]; edq += Kv->a[i][c] * lam[GIW + c]; }
+            gx[ZQ + i] += muq[i] + 0.5 * h * eq;
+            gx[ZDQ + i] += h * muq[i] + mudq[i] + 0.5 * h * edq;
+            gx[ZDDQ + i] += h2 / 2 * muq[i] + h * mudq[i] + mdd;
+            gx[ZJ + i] += h3 / 8 * muq[i] + h2 / 3 * mudq[i] + h / 2 * mdd;
+        }
+    }
+    gj1[7] += h3 / 24 * lam[GPHI] + h2 / 6 * lam[GDPHI] + h / 2 * lam[GDDPHI];
+    if (gx) {
+        gx[ZPHI] += lam[GPHI]; gx[ZDPHI] += h * lam[GPHI] + lam[GDPHI]; gx[ZDDPHI] += h2 / 2 * lam[GPHI] + h * lam[GDPHI] + lam[GDDPHI];
+        gx[ZJPHI] += h3 / 8 * lam[GPHI] + h2 / 3 * lam[GDPHI] + h / 2 * lam[GDDPHI];
+        for (int c = 0; c < 3; c++) gx[ZIW + c] += lam[GIW + c];
+    }
+}
+
+/* Adjoint sweep: multipliers lam[N][36] that zero the stationarity residual of every state variable,
+ * and the remaining residual Rj[N][8] w.r.t. the jerks.  gradZ receives d(f + nuv.h)/dZ. */
+static void adjoint(const Cfg *C, const Par *P, Work *W, const double *Z, const double *nuv, double *lam, double *Rj, double *gradZ) {
+    const int N = C->N;
+    double gprev[6];
+    for (int k = N - 1; k >= 0; k--) { /* node k+1 */
+        double gv_next[6] = {0, 0, 0, 0, 0, 0};
+        if (k < N - 1) memcpy(gv_next, gprev, sizeof(gprev)); /* d f_{k+2} / d v_{k+1} */
+        double *gz = gradZ + k * NZ;
+        node_grad(C, P, Z + k * NZ, nd_v(P, Z, k), &W->R[k], nuv + k * NI, gz, gprev);
+        for (int c = 0; c < 6; c++) gz[ZV + c] += gv_next[c];
+    }
+    /* tot = gradZ[k] + (dF_{k+1}/d node_{k+1})^T lam_{k+1} ; lam_k = tot[x-part] */
+    double tot[NZ];
+    for (int k = N - 1; k >= 0; k--) {
+        memcpy(tot, gradZ + k * NZ, sizeof(tot));
+        if (k < N - 1) {
+            double dummy[NU] = {0};
+            stage_adjoint(C, &W->Kp[k + 1], &W->Kv[k + 1], lam + (k + 1) * NE, tot, dummy);
+        }
+        double *lk = lam + k * NE;
+        for (int i = 0; i < 7; i++) { lk[GQ + i] = tot[ZQ + i]; lk[GDQ + i] = tot[ZDQ + i]; lk[GDDQ + i] = tot[ZDDQ + i]; }
+        for (int i = 0; i < 3; i++) { lk[GPOS + i] = tot[ZPOS + i]; lk[GIW + i] = tot[ZIW + i]; }
+        for (int i = 0; i < 6; i++) lk[GV + i] = tot[ZV + i];
+        lk[GPHI] = tot[ZPHI]; lk[GDPHI] = tot[ZDPHI]; lk[GDDPHI] = tot[ZDDPHI];
+        for (int c = 0; c < 7; c++) Rj[k * NU + c] = tot[ZJ + c];
+        Rj[k * NU + 7] = tot[ZJPHI];
+    }
+    /* jerk of node k+1 also enters stage k itself */
+    for (int k = 0; k < N; k++) {
+        double gj1[NU] = {0};
+        stage_adjoint(C, &W->Kp[k], &W->Kv[k], lam + k * NE, NULL, gj1);
+        for (int c = 0; c < NU; c++) Rj[k * NU + c] += gj1[c];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Newton system assembly
+ * ---------------------------------------------------------------------------------------- */
+/* node-local Hessian (44x44) of  f + barrier terms  at node k+1; sg = nu/t, nu = multipliers */
+static void node_hess(const Cfg *C, const Par *P, const double *Zn, const NodeRef *R, const double *sg, const double *nu,
+                      int has_next, double *H /* [44][44] */) {
+    const double *w = P->w; const double h = C->h; const int ex = C->o.exact_hessian;
+    memset(H, 0, NZ * NZ * sizeof(double));
+#define HH(a, b) H[(a) * NZ + (b)]
+    double dde = dot3(R->d, R->ep), dd = dot3(R->d, R->d), epo[3], ero[3], eperp[3], erd[3];
+    for (int c = 0; c < 3; c++) {
+        eperp[c] = R->ep[c] - dde * R->d[c];
+        epo[c] = R->sig * R->ep[c] + (1 - R->sig) * dde * R->d[c];
+        erd[c] = R->er[c] - R->erpar[c];
+        ero[c] = R->sig * R->er[c] + (1 - R->sig) * R->erpar[c];
+    }
+    double dhdh = dot3(R->dh, R->dh), v2rr = dhdh != 0 ? -R->gc[0][6] / dhdh : 0.0;
+    /* Jacobians of e_p_obj w.r.t. (pos, phi) and e_r_obj w.r.t. (iw, phi): 3 x 4 each */
+    double Jp[3][4], Jr[3][4];
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) {
+            Jp[r][c] = (r == c ? R->sig : 0.0) + (1 - R->sig) * R->d[r] * R->d[c];
+            Jr[r][c] = R->sig * R->Jl[r][c] + (1 - R->sig) * R->dh[r] * R->l2[c];
+        }
+        Jp[r][3] = -(R->sig * R->d[r] + (1 - R->sig) * dd * R->d[r]) + R->sig1 * eperp[r];
+        Jr[r][3] = -R->sig * R->rr[r] - (1 - R->sig) * R->dh[r] * v2rr + R->sig1 * erd[r];
+    }
+    const int ip[4] = {ZPOS, ZPOS + 1, ZPOS + 2, ZPHI}, ir[4] = {ZIW, ZIW + 1, ZIW + 2, ZPHI};
+    for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) {
+        double sp = 0, sr = 0;
+        for (int r = 0; r < 3; r++) { sp += Jp[r][a] * Jp[r][b]; sr += Jr[r][a] * Jr[r][b]; }
+        HH(ip[a], ip[b]) += 2 * w[0] * sp; HH(ir[a], ir[b]) += 2 * w[1] * sr;
+    }
+    if (ex) {
+        double depo = dot3(R->d, epo), dhero = dot3(R->dh, ero);
+        for (int c = 0; c < 3; c++) {
+            double sp = R->sig1 * (epo[c] - depo * R->d[c]);
+            double jl = 0; for (int r = 0; r < 3; r++) jl += ero[r] * R->Jl[r][c];
+            double sr = R->sig1 * (jl - dhero * R->l2[c]);
+            HH(ZPOS + c, ZPHI) += 2 * w[0] * sp; HH(ZPHI, ZPOS + c) += 2 * w[0] * sp;
+            HH(ZIW + c, ZPHI) += 2 * w[1] * sr; HH(ZPHI, ZIW + c) += 2 * w[1] * sr;
+        }
+        double spp = 0, srr = 0;
+        for (int c = 0; c < 3; c++) {
+            spp += epo[c] * (R->sig2 * eperp[c] - 2 * R->sig1 * (R->d[c] - dd * R->d[c]));
+            srr += ero[c] * (R->sig2 * erd[c] + 2 * R->sig1 * (-R->rr[c] + R->dh[c] * v2rr));
+        }
+        HH(ZPHI, ZPHI) += 2 * w[0] * spp + 2 * w[1] * srr;
+    }
+    /* velocity and acceleration tracking */
+    double dpdp = 0; for (int c = 0; c < 6; c++) dpdp += R->dp[c] * R->dp[c];
+    for (int c = 0; c < 6; c++) {
+        HH(ZV + c, ZV + c) += 2 * w[2] + 2 * w[5] / (h * h) + (has_next ? 2 * w[5] / (h * h) : 0.0);
+        HH(ZV + c, ZDPHI) += -2 * w[2] * R->dp[c]; HH(ZDPHI, ZV + c) += -2 * w[2] * R->dp[c];
+        HH(ZV + c, ZDDPHI) += -2 * w[5] / h * R->dp[c]; HH(ZDDPHI, ZV + c) += -2 * w[5] / h * R->dp[c];
+    }
+    HH(ZDPHI, ZDPHI) += 2 * w[2] * dpdp + 2 * w[7];
+    HH(ZDDPHI, ZDDPHI) += 2 * w[5] * dpdp + 2 * w[8];
+    HH(ZPHI, ZPHI) += 2 * w[6];
+    HH(ZJPHI, ZJPHI) += 2 * w[9];
+    for (int i = 0; i < 7; i++) {
+        HH(ZQ + i, ZQ + i) += 2 * w[10] + sg[IQU + i] + sg[IQL + i];
+        HH(ZDQ + i, ZDQ + i) += 2 * w[11] + sg[IDQU + i] + sg[IDQL + i];
+        HH(ZDDQ + i, ZDDQ + i) += 2 * w[12];
+        HH(ZJ + i, ZJ + i) += 2 * w[13];
+    }
+    for (int i = 0; i < 8; i++) HH(ZJ + i, ZJ + i) += sg[IJU + i] + sg[IJL + i];
+    HH(ZPHI, ZPHI) += sg[IPHI0] + sg[IPHIMAX];
+    HH(ZDPHI, ZDPHI) += sg[IDPHIMAX];
+    const int it[7] = {ZPOS, ZPOS + 1, ZPOS + 2, ZIW, ZIW + 1, ZIW + 2, ZPHI};
+    for (int m = 0; m < 5; m++) {
+        double gu[7], gl[7];
+        for (int a = 0; a < 7; a++) { gu[a] = R->gc[m][a]; gl[a] = -R->gc[m][a]; }
+        gu[6] -= R->w1[m]; gl[6] -= R->w1[m];
+        double su = sg[ITUBE + 2 * m], sl = sg[ITUBE + 2 * m + 1];
+        for (int a = 0; a < 7; a++) for (int b = 0; b < 7; b++) HH(it[a], it[b]) += su * gu[a] * gu[b] + sl * gl[a] * gl[b];
+        if (ex) HH(ZPHI, ZPHI) += nu[ITUBE + 2 * m] * (R->c2[m] - R->w2[m]) + nu[ITUBE + 2 * m + 1] * (-R->c2[m] - R->w2[m]);
+    }
+#undef HH
+}
+
+/* T (44x35) and rloc (44) of node k+1 (index k); A (35x43) and rdyn (35) of stage k */
+static void build_maps(const Cfg *C, Work *W, int k) {
+    const double h = C->h, h2 = h * h, h3 = h2 * h;
+    double *T = W->T + (size_t)k * NZ * NS, *rl = W->rloc + k * NZ, *A = W->A + (size_t)k * NS * NW, *rd = W->rdyn + k * NS;
+    const Kin *Kp = &W->Kp[k];
+    const double *g = W->g + k * NE;
+    memset(T, 0, NZ * NS * sizeof(double)); memset(rl, 0, NZ * sizeof(double));
+    memset(A, 0, NS * NW * sizeof(double)); memset(rd, 0, NS * sizeof(double));
+#define TT(a, b) T[(a) * NS + (b)]
+#define AA(a, b) A[(a) * NW + (b)]
+    for (int i = 0; i < 7; i++) { TT(ZJ + i, SJ + i) = 1; TT(ZQ + i, SQ + i) = 1; TT(ZDQ + i, SDQ + i) = 1; TT(ZDDQ + i, SDDQ + i) = 1; }
+    TT(ZJPHI, SJPHI) = 1; TT(ZPHI, SPHI) = 1; TT(ZDPHI, SDPHI) = 1; TT(ZDDPHI, SDDPHI) = 1;
+    for (int c = 0; c < 3; c++) {
+        double rp = g[GPOS + c], rv = g[GV + c], rw = g[GW + c];
+        TT(ZIW + c, SIOTA + c) = 1;
+        for (int i = 0; i < 7; i++) {
+            TT(ZPOS + c, SQ + i) = Kp->w[i][c];
+            TT(ZIW + c, SQ + i) = 0.5 * h * Kp->D[3 + c][i]; TT(ZIW + c, SDQ + i) = 0.5 * h * Kp->a[i][c];
+            TT(ZV + c, SQ + i) = Kp->D[c][i]; TT(ZV + c, SDQ + i) = Kp->w[i][c];
+            TT(ZW + c, SQ + i) = Kp->D[3 + c][i]; TT(ZW + c, SDQ + i) = Kp->a[i][c];
+            rp -= Kp->w[i][c] * g[GQ + i];
+            rv -= Kp->D[c][i] * g[GQ + i] + Kp->w[i][c] * g[GDQ + i];
+            rw -= Kp->D[3 + c][i] * g[GQ + i] + Kp->a[i][c] * g[GDQ + i];
+        }
+        rl[ZPOS + c] = rp; rl[ZV + c] = rv; rl[ZW + c] = rw;
+    }
+    for (int i = 0; i <= 7; i++) { /* i == 7: path chain */
+        int sq = i < 7 ? SQ + i : SPHI, sdq = i < 7 ? SDQ + i : SDPHI, sddq = i < 7 ? SDDQ + i : SDDPHI, sj = i < 7 ? SJ + i : SJPHI, su = NS + i;
+        AA(sq, sq) = 1; AA(sq, sdq) = h; AA(sq, sddq) = h2 / 2; AA(sq, sj) = h3 / 8; AA(sq, su) = h3 / 24;
+        AA(sdq, sdq) = 1; AA(sdq, sddq) = h; AA(sdq, sj) = h2 / 3; AA(sdq, su) = h2 / 6;
+        AA(sddq, sddq) = 1; AA(sddq, sj) = h / 2; AA(sddq, su) = h / 2;
+        AA(sj, su) = 1;
+        int gq = i < 7 ? GQ + i : GPHI, gdq = i < 7 ? GDQ + i : GDPHI, gddq = i < 7 ? GDDQ + i : GDDPHI;
+        rd[sq] = g[gq]; rd[sdq] = g[gdq]; rd[sddq] = g[gddq];
+    }
+    for (int c = 0; c < 3; c++) {
+        AA(SIOTA + c, SIOTA + c) = 1;
+        double r = g[GIW + c];
+        for (int i = 0; i < 7; i++) {
+            r -= 0.5 * h * (Kp->D[3 + c][i] * g[GQ + i] + Kp->a[i][c] * g[GDQ + i]);
+            if (k >= 1) {
+                const Kin *Kpp = &W->Kp[k - 1], *Kv = &W->Kv[k];
+                AA(SIOTA + c, SQ + i) = 0.5 * h * (Kpp->D[3 + c][i] + Kv->D[3 + c][i]);
+                AA(SIOTA + c, SDQ + i) = 0.5 * h * (Kpp->a[i][c] + Kv->a[i][c]);
+            }
+        }
+        rd[SIOTA + c] = r;
+    }
+#undef TT
+#undef AA
+}
+
+static int chol8(double *R8, double *L) { /* R8 [8][8] sym -> L lower */
+    for (int i = 0; i < NU; i++) for (int j = 0; j <= i; j++) {
+        double s = R8[i * NU + j];
+        for (int k = 0; k < j; k++) s -= L[i * NU + k] * L[j * NU + k];
+        if (i == j) { if (!(s > 1e-13)) return 0; L[i * NU + i] = sqrt(s); }
+        else L[i * NU + j] = s / L[j * NU + j];
+    }
+    return 1;
+}
+static void chol8_solve(const double *L, double *b) {
+    for (int i = 0; i < NU; i++) { double s = b[i]; for (int k = 0; k < i; k++) s -= L[i * NU + k] * b[k]; b[i] = s / L[i * NU + i]; }
+    for (int i = NU - 1; i >= 0; i--) { double s = b[i]; for (int k = i + 1; k < NU; k++) s -= L[k * NU + i] * b[k]; b[i] = s / L[i * NU + i]; }
+}
+
+/* Build the reduced QP (Qt, qt, Xt) for the current iterate; nuh = barrier-modified multipliers */
+static void build_qp(const Cfg *C, const Par *P, Work *W, const double *sg, const double *nuh) {
+    const int N = C->N; const double h = C->h; const double *w = P->w;
+    double *H = (double *)malloc(NZ * NZ * sizeof(double)), *HT = (double *)malloc(NZ * NS * sizeof(double));
+    double *gh = (double *)calloc(N * NZ, sizeof(double));
+    /* QP gradient in Z space: d(f + nuh.h)/dZ */
+    double gprev[6];
+    for (int k = N - 1; k >= 0; k--) {
+        double gv_next[6] = {0, 0, 0, 0, 0, 0};
+        if (k < N - 1) memcpy(gv_next, gprev, sizeof(gprev));
+        node_grad(C, P, W->Z + k * NZ, nd_v(P, W->Z, k), &W->R[k], nuh + k * NI, gh + k * NZ, gprev);
+        for (int c = 0; c < 6; c++) gh[k * NZ + ZV + c] += gv_next[c];
+    }
+    for (int k = 0; k < N; k++) build_maps(C, W, k);
+    for (int k = 0; k < N; k++) {
+        const double *T = W->T + (size_t)k * NZ * NS, *rl = W->rloc + k * NZ;
+        double *Q = W->Qt + (size_t)k * NS * NS, *q = W->qt + k * NS;
+        node_hess(C, P, W->Z + k * NZ, &W->R[k], sg + k * NI, W->nu + k * NI, k < N - 1, H);
+        for (int a = 0; a < NZ; a++) for (int b = 0; b < NS; b++) { double s = 0; for (int c = 0; c < NZ; c++) s += H[a * NZ + c] * T[c * NS + b]; HT[a * NS + b] = s; }
+        for (int a = 0; a < NS; a++) for (int b = 0; b < NS; b++) { double s = 0; for (int c = 0; c < NZ; c++) s += T[c * NS + a] * HT[c * NS + b]; Q[a * NS + b] = s; }
+        double tmp[NZ];
+        for (int a = 0; a < NZ; a++) { double s = gh[k * NZ + a]; for (int c = 0; c < NZ; c++) s += H[a * NZ + c] * rl[c]; tmp[a] = s; }
+        for (int a = 0; a < NS; a++) { double s = 0; for (int c = 0; c < NZ; c++) s += T[c * NS + a] * tmp[c]; q[a] = s; }
+        if (C->o.exact_hessian) {
+            double Wy[14][14], mw[3];
+            const double *lam = W->lam + k * NE, *g = W->g + k * NE;
+            for (int c = 0; c < 3; c++) mw[c] = lam[GW + c] + 0.5 * h * lam[GIW + c];
+            kin_hess(&W->Kp[k], lam + GPOS, lam + GV, mw, Wy);
+            for (int a = 0; a < 14; a++) {
+                double s = 0;
+                for (int b = 0; b < 14; b++) { Q[(a < 7 ? SQ + a : SDQ + a - 7) * NS + (b < 7 ? SQ + b : SDQ + b - 7)] += Wy[a][b]; s += Wy[a][b] * (b < 7 ? g[GQ + b] : g[GDQ + b - 7]); }
+                q[a < 7 ? SQ + a : SDQ + a - 7] -= s;
+            }
+            if (k < N - 1) {
+                const double *l1 = W->lam + (k + 1) * NE; double z3[3] = {0, 0, 0};
+                for (int c = 0; c < 3; c++) mw[c] = 0.5 * h * l1[GIW + c];
+                kin_hess(&W->Kv[k + 1], z3, z3, mw, Wy);
+                for (int a = 0; a < 14; a++) for (int b = 0; b < 14; b++) Q[(a < 7 ? SQ + a : SDQ + a - 7) * NS + (b < 7 ? SQ + b : SDQ + b - 7)] += Wy[a][b];
+            }
+        }
+    }
+    /* acceleration cross terms between node k+1 (rows) and node k (cols), k >= 1 */
+    for (int k = 1; k < N; k++) {
+        const double *Tn = W->T + (size_t)k * NZ * NS, *Tp = W->T + (size_t)(k - 1) * NZ * NS;
+        const double *rn = W->rloc + k * NZ, *rp = W->rloc + (k - 1) * NZ;
+        double *X = W->Xt + (size_t)k * NS * NS;
+        const double *dp = W->R[k].dp;
+        /* X^Z[ZV+c][ZV+c] = -2 w_a/h^2 ; X^Z[ZDDPHI][ZV+c] = 2 w_a/h dp[c] */
+        for (int a = 0; a < NS; a++) for (int b = 0; b < NS; b++) {
+            double s = 0;
+            for (int c = 0; c < 6; c++) s += (-2 * w[5] / (h * h) * Tn[(ZV + c) * NS + a] + 2 * w[5] / h * dp[c] * Tn[ZDDPHI * NS + a]) * Tp[(ZV + c) * NS + b];
+            X[a * NS + b] = s;
+        }
+        for (int a = 0; a < NS; a++) {
+            double s = 0, s2 = 0;
+            for (int c = 0; c < 6; c++) {
+                s += (-2 * w[5] / (h * h) * Tn[(ZV + c) * NS + a] + 2 * w[5] / h * dp[c] * Tn[ZDDPHI * NS + a]) * rp[ZV + c];
+                s2 += Tp[(ZV + c) * NS + a] * (-2 * w[5] / (h * h) * rn[ZV + c] + 2 * w[5] / h * dp[c] * rn[ZDDPHI]);
+            }
+            W->qt[k * NS + a] += s; W->qt[(k - 1) * NS + a] += s2;
+        }
+    }
+    free(H); free(HT); free(gh);
+}
+
+/* Riccati backward + forward; returns 0 if a stage's M_jj is not positive definite */
+static int riccati(const Cfg *C, Work *W, double delta) {
+    const int N = C->N;
+    double P[NS * NS], pv[NS], M[NW * NW], m[NW], PF[NS * NW], Pr[NS], L[NU * NU], R8[NU * NU];
+    memcpy(P, W->Qt + (size_t)(N - 1) * NS * NS, sizeof(P)); memcpy(pv, W->qt + (N - 1) * NS, sizeof(pv));
+    for (int a = 0; a < NS; a++) P[a * NS + a] += delta;
+    for (int k = N - 1; k >= 0; k--) {
+        const double *F = W->A + (size_t)k * NS * NW, *r = W->rdyn + k * NS;
+        for (int a = 0; a < NS; a++) {
+            for (int b = 0; b < NW; b++) { double s = 0; for (int c = 0; c < NS; c++) s += P[a * NS + c] * F[c * NW + b]; PF[a * NW + b] = s; }
+            double s = pv[a]; for (int c = 0; c < NS; c++) s += P[a * NS + c] * r[c]; Pr[a] = s;
+        }
+        for (int a = 0; a < NW; a++) {
+            for (int b = 0; b < NW; b++) { double s = 0; for (int c = 0; c < NS; c++) s += F[c * NW + a] * PF[c * NW + b]; M[a * NW + b] = s; }
+            double s = 0; for (int c = 0; c < NS; c++) s += F[c * NW + a] * Pr[c]; m[a] = s;
+        }
+        if (k >= 1) {
+            const double *X = W->Xt + (size_t)k * NS * NS;
+            for (int a = 0; a < NW; a++) for (int b = 0; b < NS; b++) {
+                double s = 0; for (int c = 0; c < NS; c++) s += F[c * NW + a] * X[c * NS + b];
+                M[a * NW + b] += s; M[b * NW + a] += s;
+            }
+            for (int b = 0; b < NS; b++) { double s = 0; for (int c = 0; c < NS; c++) s += X[c * NS + b] * r[c]; m[b] += s; }
+        }
+        for (int a = 0; a < NU; a++) for (int b = 0; b < NU; b++) R8[a * NU + b] = M[(NS + a) * NW + NS + b];
+        if (!chol8(R8, L)) return 0;
+        double *Kg = W->Kg + (size_t)k * NU * NS, *kf = W->kff + k * NU;
+        for (int b = 0; b < NS; b++) {
+            double col[NU]; for (int a = 0; a < NU; a++) col[a] = -M[(NS + a) * NW + b];
+            chol8_solve(L, col);
+            for (int a = 0; a < NU; a++) Kg[a * NS + b] = col[a];
+        }
+        for (int a = 0; a < NU; a++) kf[a] = -m[NS + a];
+        chol8_solve(L, kf);
+        if (k >= 1) {
+            const double *Q = W->Qt + (size_t)(k - 1) * NS * NS, *q = W->qt + (k - 1) * NS;
+            for (int a = 0; a < NS; a++) {
+                for (int b = 0; b < NS; b++) { double s = Q[a * NS + b] + M[a * NW + b]; for (int c = 0; c < NU; c++) s += M[a * NW + NS + c] * Kg[c * NS + b]; P[a * NS + b] = s; }
+                double s = q[a] + m[a]; for (int c = 0; c < NU; c++) s += M[a * NW + NS + c] * kf[c]; pv[a] = s;
+                P[a * NS + a] += delta;
+            }
+            /* keep P symmetric against round-off */
+            for (int a = 0; a < NS; a++) for (int b = 0; b < a; b++) { double s = 0.5 * (P[a * NS + b] + P[b * NS + a]); P[a * NS + b] = s; P[b * NS + a] = s; }
+        }
+    }
+    double ds[NS], wv[NW], dsn[NS];
+    memset(ds, 0, sizeof(ds));
+    for (int k = 0; k < N; k++) {
+        const double *F = W->A + (size_t)k * NS * NW, *r = W->rdyn + k * NS, *Kg = W->Kg + (size_t)k * NU * NS, *kf = W->kff + k * NU;
+        const double *T = W->T + (size_t)k * NZ * NS, *rl = W->rloc + k * NZ;
+        for (int a = 0; a < NS; a++) wv[a] = ds[a];
+        for (int a = 0; a < NU; a++) { double s = kf[a]; for (int b = 0; b < NS; b++) s += Kg[a * NS + b] * ds[b]; wv[NS + a] = s; }
+        for (int a = 0; a < NS; a++) { double s = r[a]; for (int b = 0; b < NW; b++) s += F[a * NW + b] * wv[b]; dsn[a] = s; }
+        for (int a = 0; a < NZ; a++) { double s = rl[a]; for (int b = 0; b < NS; b++) s += T[a * NS + b] * dsn[b]; W->dZ[k * NZ + a] = s; }
+        memcpy(ds, dsn, sizeof(ds));
+    }
+    return 1;
+}
+
+/* grad h_i . dZ for the 57 rows of one node */
+static void ineq_dir(const NodeRef *R, const double *dZ, double *out) {
+    for (int i = 0; i < 8; i++) { out[IJU + i] = dZ[ZJ + i]; out[IJL + i] = -dZ[ZJ + i]; }
+    for (int i = 0; i < 7; i++) { out[IQU + i] = dZ[ZQ + i]; out[IQL + i] = -dZ[ZQ + i]; out[IDQU + i] = dZ[ZDQ + i]; out[IDQL + i] = -dZ[ZDQ + i]; }
+    out[IPHI0] = -dZ[ZPHI]; out[IPHIMAX] = dZ[ZPHI]; out[IDPHIMAX] = dZ[ZDPHI];
+    for (int m = 0; m < 5; m++) {
+        double s = R->gc[m][6] * dZ[ZPHI];
+        for (int c = 0; c < 3; c++) s += R->gc[m][c] * dZ[ZPOS + c] + R->gc[m][3 + c] * dZ[ZIW + c];
+        out[ITUBE + 2 * m] = s - R->w1[m] * dZ[ZPHI]; out[ITUBE + 2 * m + 1] = -s - R->w1[m] * dZ[ZPHI];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * interior-point driver for one problem
+ * ---------------------------------------------------------------------------------------- */
+typedef struct { int iters, status; double f, kkt, mu; } SolveInfo;
+
+static void kkt_errors(const Cfg *C, const Work *W, double mu, double *ed, double *ep, double *ec, double *sd, double *sc) {
+    const int N = C->N;
+    double d = 0, p = 0, c = 0, sl = 0, sn = 0;
+    for (int i = 0; i < N * NU; i++) d = fmax(d, fabs(W->Rj[i]));
+    for (int i = 0; i < N * NE; i++) { p = fmax(p, fabs(W->g[i])); sl += fabs(W->lam[i]); }
+    for (int i = 0; i < N * NI; i++) { p = fmax(p, fabs(W->hin[i] + W->t[i])); c = fmax(c, fabs(W->nu[i] * W->t[i] - mu)); sn += W->nu[i]; }
+    *ed = d; *ep = p; *ec = c;
+    *sd = fmax(100.0, (sl + sn) / (N * (NE + NI))) / 100.0;
+    *sc = fmax(100.0, sn / (N * NI)) / 100.0;
+}
+
+static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, SolveInfo *info) {
+    const int N = C->N;
+    Par Pp; par_view(p, C->S, &Pp); const Par *P = &Pp;
+    const bmpc_oracle_opts *o = &C->o;
+    memcpy(W->Z, x0, sizeof(double) * N * NZ);
+    double mu = o->mu_init, mu_min = o->tol * o->mu_min_fac, rho = 1.0, delta_last = 0.0;
+    W->f = eval_values(C, P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
+    for (int i = 0; i < N * NI; i++) { W->t[i] = fmax(-W->hin[i], o->slack_push); W->nu[i] = mu / W->t[i]; }
+    double *sg = (double *)malloc(N * NI * sizeof(double)), *nuh = (double *)malloc(N * NI * sizeof(double));
+    double *gf = (double *)malloc(N * NZ * sizeof(double)), *zero_nu = (double *)calloc(N * NI, sizeof(double));
+    double *hdir = (double *)malloc(NI * sizeof(double)), *gt = (double *)malloc(N * NE * sizeof(double)), *ht = (double *)malloc(N * NI * sizeof(double));
+    int it = 0, status = 1;
+    double E0 = 0;
+    for (it = 0; it <= o->max_iter; it++) {
+        adjoint(C, P, W, W->Z, W->nu, W->lam, W->Rj, W->gradZ);
+        double ed, ep, ec0, ecm, sd, sc;
+        kkt_errors(C, W, 0.0, &ed, &ep, &ec0, &sd, &sc);
+        E0 = fmax(fmax(ed / sd, ep), ec0 / sc);
+        if (o->verbose) fprintf(stderr, "it %3d f %.8e dual %.2e prim %.2e compl %.2e mu %.1e rho %.1e\n", it, W->f, ed, ep, ec0, mu, rho);
+        if (E0 <= o->tol) { status = 0; break; }
+        if (it == o->max_iter) break;
+        for (;;) {
+            kkt_errors(C, W, mu, &ed, &ep, &ecm, &sd, &sc);
+            double Emu = fmax(fmax(ed / sd, ep), ecm / sc);
+            if (Emu <= 10.0 * mu && mu > mu_min) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5))); else break;
+        }
+        for (int i = 0; i < N * NI; i++) {
+            sg[i] = W->nu[i] / W->t[i];
+            nuh[i] = (mu + W->nu[i] * (W->hin[i] + W->t[i])) / W->t[i];
+        }
+        build_qp(C, P, W, sg, nuh);
+        double delta = 0.0; int ok = 0;
+        for (int tries = 0; tries < 40; tries++) {
+            if (riccati(C, W, delta)) { ok = 1; break; }
+            if (delta == 0.0) delta = delta_last > 0 ? fmax(1e-20, delta_last / 3.0) : 1e-4;
+            else delta *= (delta_last > 0 ? 8.0 : 100.0);
+            if (delta > 1e20) break;
+        }
+        if (!ok) { status = 3; break; }
+        if (delta > 0) delta_last = delta;
+        /* slack and multiplier directions, fraction to the boundary */
+        double tau = fmax(0.99, 1.0 - mu), ap = 1.0, ad = 1.0, dbar = 0;
+        for (int k = 0; k < N; k++) {
+            ineq_dir(&W->R[k], W->dZ + k * NZ, hdir);
+            for (int i = 0; i < NI; i++) {
+                int id = k * NI + i;
+                double r = W->hin[id] + W->t[id];
+                W->dt[id] = -r - hdir[i];
+                W->dnu[id] = mu / W->t[id] - W->nu[id] - sg[id] * W->dt[id];
+                if (W->dt[id] < 0) ap = fmin(ap, -tau * W->t[id] / W->dt[id]);
+                if (W->dnu[id] < 0) ad = fmin(ad, -tau * W->nu[id] / W->dnu[id]);
+                dbar += -mu * W->dt[id] / W->t[id];
+            }
+        }
+        /* l1 merit function */
+        adjoint(C, P, W, W->Z, zero_nu, gt, ht, gf); /* gf = grad f ; gt/ht scratch (lam, Rj overwritten below again) */
+        double gfd = 0; for (int i = 0; i < N * NZ; i++) gfd += gf[i] * W->dZ[i];
+        double theta = 0, bar = 0;
+        for (int i = 0; i < N * NE; i++) theta += fabs(W->g[i]);
+        for (int i = 0; i < N * NI; i++) { theta += fabs(W->hin[i] + W->t[i]); bar -= mu * log(W->t[i]); }
+        double dphi = gfd + dbar;
+        if (theta > 1e-14) { double rt = dphi / (0.9 * theta); if (rho < rt) rho = rt + 1.0; }
+        double D = dphi - rho * theta, phi0 = W->f + bar + rho * theta;
+        double alpha = ap; int accepted = 0; double ft = 0;
+        for (int ls = 0; ls < 30; ls++) {
+            for (int i = 0; i < N * NZ; i++) W->Zt[i] = W->Z[i] + alpha * W->dZ[i];
+            for (int i = 0; i < N * NI; i++) W->tt[i] = W->t[i] + alpha * W->dt[i];
+            ft = eval_values(C, P, W->Zt, W->Kp, W->Kv, W->R, gt, ht);
+            double th = 0, br = 0;
+            for (int i = 0; i < N * NE; i++) th += fabs(gt[i]);
+            for (int i = 0; i < N * NI; i++) { th += fabs(ht[i] + W->tt[i]); br -= mu * log(W->tt[i]); }
+            double phi = ft + br + rho * th;
+            if (phi <= phi0 + 1e-4 * alpha * D + 1e-13 * fabs(phi0)) { accepted = 1; break; }
+            alpha *= 0.5;
+        }
+        if (!accepted) { /* take the smallest step anyway; status reports it if convergence fails */
+            if (o->verbose) fprintf(stderr, "   line search failed (D=%.3e)\n", D);
+        }
+        memcpy(W->Z, W->Zt, sizeof(double) * N * NZ); memcpy(W->t, W->tt, sizeof(double) * N * NI);
+        memcpy(W->g, gt, sizeof(double) * N * NE); memcpy(W->hin, ht, sizeof(double) * N * NI);
+        W->f = ft;
+        for (int i = 0; i < N * NI; i++) {
+            double v = W->nu[i] + ad * W->dnu[i];
+            double lo = mu / (1e10 * W->t[i]), hi = 1e10 * mu / W->t[i];
+            W->nu[i] = fmin(fmax(v, lo), hi);
+        }
+        if (o->verbose) fprintf(stderr, "   alpha_p %.3e (max %.3e) alpha_d %.3e delta %.1e\n", alpha, ap, ad, delta);
+    }
+    info->iters = it; info->status = status; info->f = W->f; info->kkt = E0; info->mu = mu;
+    free(sg); free(nuh); free(gf); free(zero_nu); free(hdir); free(gt); free(ht);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * exported API (ctypes)
+ * ---------------------------------------------------------------------------------------- */
+void bmpc_oracle_default_opts(bmpc_oracle_opts *o) {
+    o->tol = 1e-6; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0;
+}
+
+static void write_outputs(const Cfg *C, const Par *P, Work *W, double *x, double *g, double *lam_g, double *lam_x) {
+    const int N = C->N;
+    if (x) memcpy(x, W->Z, sizeof(double) * N * NZ);
+    if (g) fill_g_ref(C, P, W->Z, W->g, W->R, g);
+    if (lam_g) for (int k = 0; k < N; k++) {
+        memcpy(lam_g + k * NG, W->lam + k * NE, NE * sizeof(double));
+        lam_g[k * NG + 36] = W->nu[k * NI + IPHIMAX]; lam_g[k * NG + 37] = W->nu[k * NI + IDPHIMAX];
+        for (int m = 0; m < 5; m++) {
+            double wm = W->R[k].w[m];
+            lam_g[k * NG + 38 + m] = wm > 0 ? (W->nu[k * NI + ITUBE + 2 * m] + W->nu[k * NI + ITUBE + 2 * m + 1]) / (2 * wm) : 0.0;
+        }
+    }
+    if (lam_x) for (int k = 0; k < N; k++) {
+        double *l = lam_x + k * NZ; const double *nu = W->nu + k * NI;
+        memset(l, 0, NZ * sizeof(double));
+        for (int i = 0; i < 8; i++) l[ZJ + i] = nu[IJU + i] - nu[IJL + i];
+        for (int i = 0; i < 7; i++) { l[ZQ + i] = nu[IQU + i] - nu[IQL + i]; l[ZDQ + i] = nu[IDQU + i] - nu[IDQL + i]; }
+        l[ZPHI] = -nu[IPHI0];
+    }
+}
+
+/* f and g (reference form, 43 per stage) at x */
+int bmpc_oracle_eval(int N, int S, double h, const double *p, const double *x, double *f, double *g) {
+    Cfg C; C.N = N; C.S = S; C.h = h; C.np = 141 + 91 * S; bmpc_oracle_default_opts(&C.o);
+    Par P; par_view(p, S, &P);
+    Work *W = work_alloc(N);
+    memcpy(W->Z, x, sizeof(double) * N * NZ);
+    *f = eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
+    fill_g_ref(&C, &P, W->Z, W->g, W->R, g);
+    work_free(W);
+    return 0;
+}
+
+/* Lagrangian gradient pieces at (x, nu_internal[N][57]): adjoint multipliers lam[N][36], Rj[N][8] */
+int bmpc_oracle_adjoint(int N, int S, double h, const double *p, const double *x, const double *nu, double *lam, double *Rj, double *gradZ) {
+    Cfg C; C.N = N; C.S = S; C.h = h; C.np = 141 + 91 * S; bmpc_oracle_default_opts(&C.o);
+    Par P; par_view(p, S, &P);
+    Work *W = work_alloc(N);
+    memcpy(W->Z, x, sizeof(double) * N * NZ);
+    eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
+    adjoint(&C, &P, W, W->Z, nu, lam, Rj, gradZ);
+    work_free(W);
+    return 0;
+}
+
+void bmpc_oracle_kin(const double *q, const double *dq, const double *mu_p, const double *mu_v, const double *mu_w,
+                     double *pos, double *v, double *J /*[6][7]*/, double *D /*[6][7]*/, double *Wout /*[14][14]*/) {
+    Kin K; kin_eval(q, dq, &K);
+    memcpy(pos, K.pos, 3 * sizeof(double)); memcpy(v, K.v, 6 * sizeof(double));
+    for (int c = 0; c < 3; c++) for (int j = 0; j < 7; j++) { J[c * 7 + j] = K.w[j][c]; J[(3 + c) * 7 + j] = K.a[j][c]; }
+    memcpy(D, K.D, 42 * sizeof(double));
+    double W[14][14]; kin_hess(&K, mu_p, mu_v, mu_w, W); memcpy(Wout, W, sizeof(W));
+}
+
+/* One Newton direction at (x, t, nu, mu) -- exposed so tests can compare it with a dense KKT solve */
+int bmpc_oracle_newton_dir(int N, int S, double h, const double *p, const double *x, const double *t, const double *nu, double mu,
+                           int exact, double delta, double *dZ) {
+    Cfg C; C.N = N; C.S = S; C.h = h; C.np = 141 + 91 * S; bmpc_oracle_default_opts(&C.o); C.o.exact_hessian = exact;
+    Par P; par_view(p, S, &P);
+    Work *W = work_alloc(N);
+    memcpy(W->Z, x, sizeof(double) * N * NZ); memcpy(W->t, t, sizeof(double) * N * NI); memcpy(W->nu, nu, sizeof(double) * N * NI);
+    eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
+    adjoint(&C, &P, W, W->Z, W->nu, W->lam, W->Rj, W->gradZ);
+    double *sg = (double *)malloc(N * NI * sizeof(double)), *nuh = (double *)malloc(N * NI * sizeof(double));
+    for (int i = 0; i < N * NI; i++) { sg[i] = nu[i] / t[i]; nuh[i] = (mu + nu[i] * (W->hin[i] + t[i])) / t[i]; }
+    build_qp(&C, &P, W, sg, nuh);
+    int ok = riccati(&C, W, delta);
+    memcpy(dZ, W->dZ, sizeof(double) * N * NZ);
+    free(sg); free(nuh); work_free(W);
+    return ok ? 0 : 3;
+}
+
+int bmpc_oracle_solve(int N, int S, double h, const bmpc_oracle_opts *opts, int B, const double *p, const double *x0,
+                      double *x, double *g, double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, int nthreads) {
+    Cfg C; C.N = N; C.S = S; C.h = h; C.np = 141 + 91 * S;
+    if (opts) C.o = *opts; else bmpc_oracle_default_opts(&C.o);
+    const int nw = N * NZ, ng = N * NG;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+    {
+        Work *W = work_alloc(N);
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < B; b++) {
+            SolveInfo info; Par P; par_view(p + (size_t)b * C.np, S, &P);
+            solve_one(&C, p + (size_t)b * C.np, x0 + (size_t)b * nw, W, &info);
+            /* refresh node data at the final point for the outputs */
+            W->f = eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
+            write_outputs(&C, &P, W, x ? x + (size_t)b * nw : NULL, g ? g + (size_t)b * ng : NULL,
+                          lam_g ? lam_g + (size_t)b * ng : NULL, lam_x ? lam_x + (size_t)b * nw : NULL);
+            if (f) f[b] = info.f; if (iters) iters[b] = info.iters; if (status) status[b] = info.status; if (kkt) kkt[b] = info.kkt;
+        }
+        work_free(W);
+    }
+    return 0;
+}

@@ -190,6 +190,10 @@ def reference_function(phi, P):
     sw = P["phi_switch"]
     S = len(sw) - 1
     iS, iS1, ist = seg_index(phi, sw)
+    # Row S of a4..a0 is np.empty garbage in the reference (BoundMPC.py:235-240) and is only
+    # selected once phi >= phi_switch[S]; it is defined here (and in the build) as a copy of
+    # row S-1 -- a deliberate, documented deviation.
+    iS1 = min(iS1, S - 1)
     dp_d = P["dp_ref"][:, iS]
     phi_start = sw[ist]
     p_d = dp_d * (phi - phi_start) + P["p_ref"][:, iS]
@@ -301,6 +305,39 @@ def nlp_eval(x, p, N, S, h):
         pk = pk_new
         phik, dphik, ddphik = phik_n, dphik_n, ddphik_n
     return f, g.reshape(-1)
+
+
+def internal_ineq(x, p, N, S):
+    """The build's internal inequality rows h[N][57] <= 0 (two-sided form of the reference's
+    squared tube constraints plus the simple bounds), in the row order of oracle/bmpc_oracle.c.
+    Equivalent feasible set: l^2 - w^2 <= 0  <=>  -|w| <= l <= |w|."""
+    P = unpack_p(p, S)
+    z = x.reshape(N, NZ)
+    dt = np.result_type(x.dtype, p.dtype)
+    H = np.zeros((N, 57), dtype=dt)
+    for k in range(N):
+        zk = z[k]
+        ref = reference_function(zk[IPHI], P)
+        err = error_function(zk[IP:IP + 6], ref, P)
+        H[k, 0:8] = zk[0:8] - U_LIM
+        H[k, 8:16] = -zk[0:8] - U_LIM
+        H[k, 16:23] = zk[IQ:IQ + 7] - Q_LIM
+        H[k, 23:30] = -zk[IQ:IQ + 7] - Q_LIM
+        H[k, 30:37] = zk[IDQ:IDQ + 7] - DQ_LIM
+        H[k, 37:44] = -zk[IDQ:IDQ + 7] - DQ_LIM
+        H[k, 44] = -zk[IPHI]
+        H[k, 45] = zk[IPHI] - P["phi_max"][0]
+        H[k, 46] = zk[IDPHI] - P["dphi_max"][0]
+        bp = (ref["bound_upper"] - ref["bound_lower"]) / 2
+        c = [ref["dp_normed_d"] @ err["e_r_par"],
+             err["e_p"] @ ref["bp1"] - ref["e_p_off"][0], err["e_p"] @ ref["bp2"] - ref["e_p_off"][1],
+             ref["br1"] @ err["e_r_orth1"] - ref["e_r_off"][0], ref["br2"] @ err["e_r_orth2"] - ref["e_r_off"][1]]
+        w = [ref["r_par_bound"], bp[0], bp[1], bp[2], bp[3]]
+        for m in range(5):
+            wm = w[m] if np.real(w[m]) >= 0 else -w[m]
+            H[k, 47 + 2 * m] = c[m] - wm
+            H[k, 48 + 2 * m] = -c[m] - wm
+    return H.reshape(-1)
 
 
 def bounds(N):

@@ -108,13 +108,20 @@ class _StubSolver:
         self.calls.append((x0.copy(), p.copy()))
         if self.answer is None:
             raise _Captured()
-        x = np.asarray(self.answer(x0, p), dtype=float).ravel()
+        ans = self.answer(x0, p)
         ng = len(lbg)
-        return {"x": x.reshape(-1, 1), "g": np.zeros((ng, 1)), "f": 0.0,
+        g = np.zeros((ng, 1))
+        self._ok, self._it = True, 0
+        if isinstance(ans, tuple):
+            ans, g, self._ok, self._it = ans
+            g = np.asarray(g, dtype=float).reshape(-1, 1)
+        x = np.asarray(ans, dtype=float).ravel()
+        return {"x": x.reshape(-1, 1), "g": g, "f": 0.0,
                 "lam_x": np.zeros_like(x), "lam_g": np.zeros(ng)}
 
     def stats(self):
-        return {"iter_count": 0, "success": True, "return_status": "stub"}
+        return {"iter_count": getattr(self, "_it", 0), "success": getattr(self, "_ok", True),
+                "return_status": "stub"}
 
 
 def experiment_setup(which, RobotModel, get_default_path, R):
@@ -188,7 +195,8 @@ def make_mpc(BoundMPCmod, setup, weights, n=10, dt=0.1, nr_segs=4):
     stub = _StubSolver()
 
     def fake_setup(N, nr_joints, nr_segs_, dt_, *a, **k):
-        return stub, [0.0] * (44 * N), [0.0] * (44 * N), [0.0] * (43 * N), [0.0] * (43 * N), []
+        lbg = ([0.0] * 36 + [-np.inf] * 7) * N      # casadi_ocp_formulation.py:272-349 (restated)
+        return stub, [0.0] * (44 * N), [0.0] * (44 * N), lbg, [0.0] * (43 * N), []
     BoundMPCmod.setup_optimization_problem = fake_setup
     params = _Params(n=n, dt=dt, weights=list(weights), nr_segs=nr_segs)
     s = setup
@@ -203,9 +211,10 @@ def make_mpc(BoundMPCmod, setup, weights, n=10, dt=0.1, nr_segs=4):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--g7-from", default=None,
-                    help="npz with arrays x_exp1[ticks][440] (solutions of the build's solver) to "
-                         "drive the reference closed loop and record G6(ticks)/G7")
+    ap.add_argument("--closed-loop", type=int, default=0, metavar="TICKS",
+                    help="drive the reference's own host code (step(), compute_return_data, integrate_joint) "
+                         "for TICKS ticks with the CPU oracle solver (oracle/bmpc_oracle.c) standing where "
+                         "Ipopt would be, and record G6(ticks)/G7")
     args = ap.parse_args()
     _install_standins()
     from scipy.spatial.transform import Rotation as R
@@ -370,17 +379,21 @@ def main():
         np.savez_compressed(os.path.join(OUT, f"g6_pack_exp{which}_tick0.npz"), **out)
 
     # ---- G6 (ticks) / G7: drive the reference's host code with the build's solutions ---------------
-    if args.g7_from:
-        data = np.load(args.g7_from)
+    if args.closed_loop:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(OUT)))
+        from oracle import c_oracle
+        opts = c_oracle.default_opts()
         for which in (1, 2):
-            key = f"x_exp{which}"
-            if key not in data:
-                continue
-            xs = data[key]
             setup = experiment_setup(which, RobotModel, get_default_path, R)
             mpc, stub = make_mpc(B, setup, w64, dt=0.1)
-            it = {"i": 0}
-            stub.answer = lambda x0, p: xs[it["i"]]
+            stats = []
+
+            def answer(x0, p):
+                p = p.copy(); p[~UNDEF_MASK()] = 0.0
+                out = c_oracle.solve(p, x0, 10, 4, 0.1, opts, 1)
+                stats.append((int(out["iters"][0]), int(out["status"][0]), float(out["kkt"][0])))
+                return out["x"][0], out["g"][0], int(out["status"][0]) == 0, int(out["iters"][0])
+            stub.answer = answer
             q = setup["q0"].copy(); dq_ = np.zeros(7); ddq_ = np.zeros(7); jerk = np.zeros(7)
             v = np.zeros(6); p_lie = setup["p0fk"].copy()
             x_phi_d = np.array([mpc.phi_max[0], 0, 0])
@@ -388,9 +401,10 @@ def main():
                                    "traj_p", "traj_v", "traj_a", "traj_q", "traj_dq", "traj_ddq", "traj_dddq",
                                    "traj_phi", "traj_dphi", "traj_ddphi", "traj_dddphi",
                                    "phi_current", "dphi_current", "ddphi_current", "dddphi_current",
-                                   "pr_ref", "iw_ref", "sector")}
-            for i in range(xs.shape[0]):
-                it["i"] = i
+                                   "pr_ref", "iw_ref", "sector", "iters", "status", "kkt", "error_count")}
+            for i in range(args.closed_loop):
+                if mpc.phi_max[0] - mpc.phi_current[0] <= 0.01:   # experiment1_runner.py:109
+                    break
                 p_lie, jac, _ = rm.forward_kinematics(q, dq_)
                 st = dict(q=q.copy(), dq=dq_.copy(), ddq=ddq_.copy(), jerk=jerk.copy(), p_lie=p_lie.copy(), v=v.copy())
                 traj, _, _, _, _ = mpc.step(q, dq_, ddq_, p_lie, v, x_phi_d, jerk)
@@ -398,7 +412,9 @@ def main():
                 for k_, v_ in st.items():
                     rec[k_].append(v_)
                 p = p.copy(); p[~UNDEF_MASK()] = 0.0
-                rec["x0"].append(x0); rec["p"].append(p); rec["x"].append(xs[i])
+                rec["x0"].append(x0); rec["p"].append(p); rec["x"].append(np.array(mpc.prev_solution, dtype=float).copy())
+                rec["iters"].append(stats[-1][0]); rec["status"].append(stats[-1][1]); rec["kkt"].append(stats[-1][2])
+                rec["error_count"].append(mpc.error_count)
                 for k_ in ("p", "v", "a", "q", "dq", "ddq", "dddq", "phi", "dphi", "ddphi", "dddphi"):
                     rec["traj_" + k_].append(np.array(traj[k_], dtype=float).copy())
                 rec["phi_current"].append(mpc.phi_current[0]); rec["dphi_current"].append(mpc.dphi_current[0])
