@@ -1,0 +1,1161 @@
+// bmpc_wave.inl -- the BoundMPC OCP solver as a "wave program": ONE problem per 64-lane
+// wavefront (CDNA4 wave64), lanes cooperating through LDS, N-scaling arrays in a per-wave
+// global scratch slab (L2 / Infinity-Cache resident).
+//
+// The same text is compiled
+//   * by hipcc for gfx950 inside bmpc_hip.hip (the product), where a "phase"
+//     (LANES_BEGIN ... LANES_END) is the body executed by the 64 lanes followed by a
+//     workgroup barrier (the workgroup IS one wave), and
+//   * by g++ inside tests/emu/bmpc_emu.cpp (TEST-ONLY lane emulator, never shipped or loaded
+//     by the product), where a phase is a loop over the 64 lanes in a configurable order --
+//     running forward and reverse lane orders exposes any intra-phase cross-lane dependence.
+//
+// What is solved (reference: /root/reference/bound_mpc/bound_mpc/BoundMPC/
+// casadi_ocp_formulation.py:9-391 with bound_mpc_functions.py:13-310, mpc_utils_casadi.py:6-165,
+// jerk_trajectory_casadi.py:78-175, RobotModel/RobotModel.py:62-100,1055-1107,1270-1303):
+// the N-stage, 44-variable/43-constraint-per-stage NLP the reference hands to
+// CasADi->Ipopt->MUMPS at BoundMPC.py:446-453.  Algorithm: primal-dual interior point with
+// the exact Lagrangian Hessian; the block-tridiagonal Newton system is factorised stage by
+// stage (Riccati recursion on a 35-dim reduced node state, lifted pos/v variables and the
+// trapezoidal omega coupling eliminated node-locally), l1-merit backtracking line search.
+//
+// Lane maps: evaluation = one lane per kinematic evaluation point (2N points); adjoint /
+// forward sweeps = one lane per state component; Riccati = one lane per COLUMN of the
+// 43x43 stage matrix, column held in registers (two in-register passes of F^T P F exploit the
+// integrator-chain sparsity of F); inequality rows = one lane per row (57 per node).
+#pragma once
+
+namespace bmpc {
+
+// ----------------------------------------------------------------------------------------
+// dimensions and index maps
+// ----------------------------------------------------------------------------------------
+constexpr int NZ = 44, NG = 43, NE = 36, NS = 35, NU = 8, NW = 43, NI = 57, SMAX = 4, NPMAX = 141 + 91 * SMAX;
+enum { ZJ = 0, ZJPHI = 7, ZQ = 8, ZDQ = 15, ZDDQ = 22, ZPOS = 29, ZIW = 32, ZV = 35, ZW = 38, ZPHI = 41, ZDPHI = 42, ZDDPHI = 43 };
+enum { GQ = 0, GDQ = 7, GDDQ = 14, GPOS = 21, GIW = 24, GV = 27, GW = 30, GPHI = 33, GDPHI = 34, GDDPHI = 35 };
+enum { SQ = 0, SDQ = 7, SDDQ = 14, SJ = 21, SPHI = 28, SDPHI = 29, SDDPHI = 30, SJPHI = 31, SIOTA = 32 };
+enum { IJU = 0, IJL = 8, IQU = 16, IQL = 23, IDQU = 30, IDQL = 37, IPHI0 = 44, IPHIMAX = 45, IDPHIMAX = 46, ITUBE = 47 };
+// kinematics record (stride KREC): aT[3][7], wT[3][7], D[6][7], pos[3], v[6], dq[7]
+enum { KA = 0, KW = 21, KD = 42, KPOS = 84, KV = 87, KDQ = 93, KREC = 104 };
+// node-reference record (stride RREC)
+enum { RSEG = 0, RX = 1, RDP = 2, RDH = 8, REP = 11, RER = 14, RERPAR = 17, RL2 = 20, RRR = 23, RV2RR = 26, RSIG = 27, RSIG1 = 28,
+       RSIG2 = 29, RC = 30, RWD = 35, RW1 = 40, RW2 = 45, RC2 = 50, RGC = 55 /* [5][4]: 3 vector comps + phi */, RREC = 80 };
+// parameter offsets (casadi_ocp_formulation.py:361-376) as functions of S
+struct POff {
+    int q0, dq0, ddq0, phi0, p0, v0, iwref0, dtau, ipar, io1, io2, xphid, jerk, jerkphi, sw, jacr, jacl, pref, dpref, dpn, bp1, bp2,
+        br1, br2, a[5], w, phimax, dphimax, v1, v2, v3, qd, size;
+};
+BMPC_HD inline POff make_poff(int S) {
+    POff o; int c = 0;
+    o.q0 = c; c += 7; o.dq0 = c; c += 7; o.ddq0 = c; c += 7; o.phi0 = c; c += 3; o.p0 = c; c += 6; o.v0 = c; c += 6;
+    o.iwref0 = c; c += 3; o.dtau = c; c += 3; o.ipar = c; c += 3 * S; o.io1 = c; c += 3 * S; o.io2 = c; c += 3 * S;
+    o.xphid = c; c += 3; o.jerk = c; c += 7; o.jerkphi = c; c += 1; o.sw = c; c += S + 1; o.jacr = c; c += 9; o.jacl = c; c += 9;
+    o.pref = c; c += 6 * S; o.dpref = c; c += 6 * S; o.dpn = c; c += 3 * S; o.bp1 = c; c += 3 * S; o.bp2 = c; c += 3 * S;
+    o.br1 = c; c += 3 * S; o.br2 = c; c += 3 * S;
+    for (int i = 0; i < 5; i++) { o.a[i] = c; c += 9 * (S + 1); }
+    o.w = c; c += 15; o.phimax = c; c += 1; o.dphimax = c; c += 1; o.v1 = c; c += 3 * S; o.v2 = c; c += 3 * S; o.v3 = c; c += 3 * S;
+    o.qd = c; c += 7; o.size = c;
+    return o;
+}
+
+// LDS layout (doubles)
+enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV = L_RED + 6 * 64, L_PR = L_PV + 36, L_QT = L_PR + 36,
+       L_RD = L_QT + 36, L_DS = L_RD + 36, L_DSN = L_DS + 36, L_DU = L_DSN + 36, L_MV = L_DU + 8, L_AE = L_MV + 44, L_K0 = L_AE + 42,
+       L_K1 = L_K0 + KREC, L_KV = L_K1 + KREC, L_XT = L_KV + KREC, L_NC = L_XT + 15 * 14, L_WY = L_NC + 160, L_WV = L_WY + 196, L_TOT = L_WV + 196,
+       L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_SIZE = L_FLAG + 8 };
+// node-cost work area inside L_NC
+enum { NC_HPP = 0, NC_HRR = 9, NC_HPF = 18, NC_HRF = 21, NC_SC = 24 /* hff,hdd,hddd,cv */, NC_A1 = 28 /* Hpp*Jp 3x7 */, NC_A2 = 49 /* Hrr*Ehat 3x14 */,
+       NC_GL = 91 /* 44 */, NC_RL = 135 /* 9 */, NC_GY = 144 /* 14 */ };
+
+struct Opts {
+    double tol; int max_iter; double mu_init; double mu_min_fac; double slack_push; int exact_hessian; int verbose;
+};
+
+// global scratch layout (doubles) for horizon N
+struct Scr {
+    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, size;
+};
+BMPC_HD inline Scr make_scr(int N) {
+    Scr s; int c = 0;
+    s.Z = c; c += N * NZ; s.ZT = c; c += N * NZ; s.T = c; c += N * NI; s.TT = c; c += N * NI; s.NUm = c; c += N * NI;
+    s.LAM = c; c += N * NE; s.G = c; c += N * NE; s.GT = c; c += N * NE; s.HIN = c; c += N * NI; s.HT = c; c += N * NI;
+    s.DZ = c; c += N * NZ; s.DT = c; c += N * NI; s.DNU = c; c += N * NI; s.GH = c; c += N * NZ; s.GVP = c; c += N * 8;
+    s.RJ = c; c += N * NU; s.KIN = c; c += 2 * N * KREC; s.REF = c; c += N * RREC; s.KT = c; c += N * NS * NU; s.KF = c; c += N * NU;
+    s.RDY = c; c += N * 36; s.AES = c; c += N * 42; s.RLV = c; c += N * 12;
+    s.size = (c + 15) & ~15;
+    return s;
+}
+
+struct Problem {           // per-problem global pointers
+    const double *p, *x0;
+    double *x, *g, *lam_g, *lam_x, *f, *kkt;
+    int *iters, *status;
+};
+
+struct Wave {
+    int N, S; double h; Opts o;
+    double *L;             // LDS base (L_SIZE doubles)
+    double *G;             // scratch base
+#ifdef BMPC_EMU
+    int order[64];
+#endif
+};
+
+// ----------------------------------------------------------------------------------------
+// small helpers
+// ----------------------------------------------------------------------------------------
+BMPC_D inline void cross3(const double *a, const double *b, double *c) {
+    double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    c[0] = x; c[1] = y; c[2] = z;
+}
+BMPC_D inline double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+BMPC_D inline double qlim(int i) { const double d[7] = {165, 115, 165, 115, 165, 115, 170}; return d[i] * 3.14159265358979323846 / 180.0; }
+BMPC_D inline double dqlim(int i) { const double d[7] = {85, 85, 100, 75, 130, 135, 135}; return d[i] * 3.14159265358979323846 / 180.0; }
+constexpr double ULIM = 35.0;
+
+// node k (0..N) variable access: node 0 from the parameter vector, node k>=1 = Z[k-1]
+BMPC_D inline double ndv(const double *PAR, const POff &po, const double *Z, int k, int zoff, int poff) {
+    return k ? Z[(k - 1) * NZ + zoff] : PAR[poff];
+}
+
+// ----------------------------------------------------------------------------------------
+// kinematics of one evaluation point (sequential, one lane): iiwa14 as a geometric chain,
+// joint axes (z,y,z,-y,z,y,z), link offsets along local z (RobotModel.py:9-16).
+// Writes the record rec[KREC]: axes, J_v columns, D = d(J dq)/dq, pos, v = J dq, dq.
+// ----------------------------------------------------------------------------------------
+BMPC_D inline void kin_point(const double *q, const double *dq, double *rec) {
+    const double preZ[7] = {0.0, 0.1575 + 0.2025, 0.0, 0.2375 + 0.1825, 0.0, 0.2175 + 0.1825, 0.0};
+    const double toolZ = 0.081 + (0.071 + 0.145);
+    double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, o[3] = {0, 0, 0}, O[7][3], a[7][3], w[7][3];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        for (int i = 0; i < 3; i++) o[i] += R[i][2] * preZ[j];
+        double s, c;
+        BMPC_SINCOS(q[j], &s, &c);
+        if ((j & 1) == 0) {   // +z joints 0,2,4,6
+            for (int i = 0; i < 3; i++) { a[j][i] = R[i][2]; O[j][i] = o[i]; }
+            for (int i = 0; i < 3; i++) { double c0 = R[i][0], c1 = R[i][1]; R[i][0] = c * c0 + s * c1; R[i][1] = -s * c0 + c * c1; }
+        } else {              // +y joints 1,5 ; -y joint 3
+            const double sg = (j == 3) ? -1.0 : 1.0;
+            for (int i = 0; i < 3; i++) { a[j][i] = sg * R[i][1]; O[j][i] = o[i]; }
+            s *= sg;
+            for (int i = 0; i < 3; i++) { double c0 = R[i][0], c2 = R[i][2]; R[i][0] = c * c0 - s * c2; R[i][2] = s * c0 + c * c2; }
+        }
+    }
+    double pos[3], v[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 3; i++) pos[i] = o[i] + R[i][2] * toolZ;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        double r[3];
+        for (int i = 0; i < 3; i++) r[i] = pos[i] - O[j][i];
+        cross3(a[j], r, w[j]);
+        for (int i = 0; i < 3; i++) { v[i] += dq[j] * w[j][i]; v[3 + i] += dq[j] * a[j][i]; }
+    }
+    // D_v[:,i] = a_i x V>=_i + W<_i x w_i ;  D_w[:,i] = a_i x W>_i   (suffix sums built backwards)
+    double Vge[3] = {0, 0, 0}, Wgt[3] = {0, 0, 0}, Wlt[3];
+    for (int c = 0; c < 3; c++) Wlt[c] = v[3 + c];   // total angular velocity, peeled from the top
+#pragma unroll
+    for (int i = 6; i >= 0; i--) {
+        double t1[3], t2[3];
+        for (int c = 0; c < 3; c++) { Vge[c] += dq[i] * w[i][c]; Wlt[c] -= dq[i] * a[i][c]; }
+        if (i == 0) for (int c = 0; c < 3; c++) Wlt[c] = 0.0;   // exact zero (matches the forward prefix sum)
+        cross3(a[i], Vge, t1); cross3(Wlt, w[i], t2);
+        for (int c = 0; c < 3; c++) rec[KD + c * 7 + i] = t1[c] + t2[c];
+        cross3(a[i], Wgt, t1);
+        for (int c = 0; c < 3; c++) rec[KD + (3 + c) * 7 + i] = t1[c];
+        for (int c = 0; c < 3; c++) Wgt[c] += dq[i] * a[i][c];
+    }
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        for (int c = 0; c < 3; c++) { rec[KA + c * 7 + j] = a[j][c]; rec[KW + c * 7 + j] = w[j][c]; }
+        rec[KDQ + j] = dq[j];
+    }
+    for (int c = 0; c < 3; c++) rec[KPOS + c] = pos[c];
+    for (int c = 0; c < 6; c++) rec[KV + c] = v[c];
+}
+
+// one entry (ya,yb), ya<=yb, of the Hessian of  mu_p.pos + mu_v.(J_v dq) + mu_w.(J_w dq)  w.r.t. y=(q,dq);
+// rec is a kinematics record (read with computed addresses: keep it in LDS)
+BMPC_D inline void ldA(const double *rec, int j, double *o) { o[0] = rec[KA + j]; o[1] = rec[KA + 7 + j]; o[2] = rec[KA + 14 + j]; }
+BMPC_D inline void ldW(const double *rec, int j, double *o) { o[0] = rec[KW + j]; o[1] = rec[KW + 7 + j]; o[2] = rec[KW + 14 + j]; }
+BMPC_D inline double kin_hess_entry(const double *rec, const double *mu_p, const double *mu_v, const double *mu_w, int ya, int yb) {
+    const double *dq = rec + KDQ;
+    if (yb < 7) {                       // q_i q_l, i <= l
+        const int i = ya, l = yb;
+        double Wlt_i[3] = {0, 0, 0}, Wil[3] = {0, 0, 0}, Vge[3] = {0, 0, 0}, Wgt[3] = {0, 0, 0};
+        for (int j = 0; j < 7; j++) {
+            const double d = dq[j];
+            double aj[3], wj[3]; ldA(rec, j, aj); ldW(rec, j, wj);
+            const double m0 = j < i ? d : 0.0, m1 = (j >= i && j < l) ? d : 0.0, m2 = j >= l ? d : 0.0, m3 = j > l ? d : 0.0;
+            for (int c = 0; c < 3; c++) { Wlt_i[c] += m0 * aj[c]; Wil[c] += m1 * aj[c]; Vge[c] += m2 * wj[c]; Wgt[c] += m3 * aj[c]; }
+        }
+        double ai[3], al[3], wl[3]; ldA(rec, i, ai); ldA(rec, l, al); ldW(rec, l, wl);
+        double t[3], u[3], val;
+        cross3(ai, wl, t); val = dot3(mu_p, t);
+        cross3(Wlt_i, t, u); val += dot3(mu_v, u);
+        cross3(al, Vge, t); cross3(ai, t, u); val += dot3(mu_v, u);
+        cross3(Wil, wl, t); cross3(ai, t, u); val += dot3(mu_v, u);
+        cross3(al, Wgt, t); cross3(ai, t, u); val += dot3(mu_w, u);
+        return val;
+    } else if (ya < 7) {                // q_i dq_j
+        const int i = ya, j = yb - 7;
+        const int lo = i <= j ? i : j, hi = i <= j ? j : i;
+        double alo[3], whi[3], t[3], val;
+        ldA(rec, lo, alo); ldW(rec, hi, whi);
+        cross3(alo, whi, t); val = dot3(mu_v, t);
+        if (i < j) { double aj[3]; ldA(rec, j, aj); cross3(alo, aj, t); val += dot3(mu_w, t); }
+        return val;
+    }
+    return 0.0;                         // dq dq
+}
+
+// ----------------------------------------------------------------------------------------
+// node quantities depending on (pos, iw, phi): segment, tubes, errors -> record rr[RREC]
+// (bound_mpc_functions.py:13-20,34-40,43-149,152-202; mpc_utils_casadi.py:6-10,52,163)
+// ----------------------------------------------------------------------------------------
+BMPC_D inline void node_ref(const double *PAR, const POff &po, int S, const double *pos, const double *iw, double phi, double *rr) {
+    const double *sw = PAR + po.sw;
+    int seg = S - 1;
+    for (int i = S - 2; i >= 0; i--) if (phi < sw[i + 1]) seg = i;
+    int segb = (seg < S - 2) ? seg : (S - 2);
+    if (segb < 0) segb = 0;
+    const double x = phi - sw[seg];
+    rr[RSEG] = (double)seg; rr[RX] = x;
+    double dp[6], d[3], rho[3], dh[3], bp1[3], bp2[3], br1[3], br2[3], v1[3], v2[3], v3[3];
+    for (int c = 0; c < 6; c++) { dp[c] = PAR[po.dpref + c * S + seg]; rr[RDP + c] = dp[c]; }
+    for (int c = 0; c < 3; c++) {
+        d[c] = dp[c]; rho[c] = dp[3 + c];
+        dh[c] = PAR[po.dpn + c * S + seg]; rr[RDH + c] = dh[c];
+        bp1[c] = PAR[po.bp1 + c * S + segb]; bp2[c] = PAR[po.bp2 + c * S + segb];
+        br1[c] = PAR[po.br1 + c * S + seg]; br2[c] = PAR[po.br2 + c * S + seg];
+        v1[c] = PAR[po.v1 + c * S + seg]; v2[c] = PAR[po.v2 + c * S + seg]; v3[c] = PAR[po.v3 + c * S + seg];
+    }
+    double b[9], b1[9], b2[9];
+    for (int ch = 0; ch < 9; ch++) {   // row S of the a-arrays is undefined in the reference (BoundMPC.py:235-240): row seg <= S-1 is used
+        const double a4 = PAR[po.a[0] + ch * (S + 1) + seg], a3 = PAR[po.a[1] + ch * (S + 1) + seg], a2 = PAR[po.a[2] + ch * (S + 1) + seg],
+                     a1 = PAR[po.a[3] + ch * (S + 1) + seg], a0 = PAR[po.a[4] + ch * (S + 1) + seg];
+        b[ch] = (((a4 * x + a3) * x + a2) * x + a1) * x + a0;
+        b1[ch] = ((4 * a4 * x + 3 * a3) * x + 2 * a2) * x + a1;
+        b2[ch] = (12 * a4 * x + 6 * a3) * x + 2 * a2;
+    }
+    const double *jacl = PAR + po.jacl, *jacr = PAR + po.jacr;   // [col][row]
+    double rrv[3], l1[3], l2[3], l3[3];
+    for (int c = 0; c < 3; c++) {
+        rrv[c] = jacr[0 * 3 + c] * rho[0] + jacr[1 * 3 + c] * rho[1] + jacr[2 * 3 + c] * rho[2];
+        l1[c] = l2[c] = l3[c] = 0;
+        for (int r = 0; r < 3; r++) { const double jl = jacl[c * 3 + r]; l1[c] += jl * v1[r]; l2[c] += jl * v2[r]; l3[c] += jl * v3[r]; }
+        rr[RRR + c] = rrv[c]; rr[RL2 + c] = l2[c];
+    }
+    double ep[3], dlt[3];
+    for (int c = 0; c < 3; c++) { ep[c] = pos[c] - (PAR[po.pref + c * S + seg] + d[c] * x); rr[REP + c] = ep[c]; }
+    for (int r = 0; r < 3; r++) {
+        double s = 0;
+        for (int c = 0; c < 3; c++)
+            s += jacl[c * 3 + r] * (iw[c] - PAR[po.p0 + 3 + c]) - jacr[c * 3 + r] * (PAR[po.pref + (3 + c) * S + seg] + rho[c] * x - PAR[po.iwref0 + c]);
+        dlt[r] = s; rr[RER + r] = PAR[po.dtau + r] + s;
+    }
+    const double s1 = dot3(dlt, v1), s2 = dot3(dlt, v2), s3 = dot3(dlt, v3);
+    const double *ipar = PAR + po.ipar + 3 * seg, *io1 = PAR + po.io1 + 3 * seg, *io2 = PAR + po.io2 + 3 * seg;
+    for (int c = 0; c < 3; c++) rr[RERPAR + c] = ipar[c] + s2 * dh[c];
+    const double aa = 100.0 * (phi - (PAR[po.phimax] - 0.02));
+    const double sig = 1.0 / (1.0 + BMPC_EXP(-aa));
+    rr[RSIG] = sig; rr[RSIG1] = 100.0 * sig * (1.0 - sig); rr[RSIG2] = 100.0 * (100.0 * sig * (1.0 - sig)) * (1.0 - 2.0 * sig);
+    const double dhdh = dot3(dh, dh), b1b1 = dot3(br1, br1), b2b2 = dot3(br2, br2);
+    const double v1rr = dot3(v1, rrv), v2rr = dot3(v2, rrv), v3rr = dot3(v3, rrv);
+    rr[RV2RR] = v2rr;
+    // m = 0 tangential orientation
+    rr[RC + 0] = dot3(dh, ipar) + s2 * dhdh;
+    for (int c = 0; c < 3; c++) rr[RGC + 0 * 4 + c] = dhdh * l2[c];
+    rr[RGC + 0 * 4 + 3] = -dhdh * v2rr; rr[RC2 + 0] = 0;
+    { const double wv = b[8], sg = wv >= 0 ? 1.0 : -1.0; rr[RWD + 0] = sg * wv; rr[RW1 + 0] = sg * b1[8]; rr[RW2 + 0] = sg * b2[8]; }
+    for (int m = 0; m < 2; m++) {   // orthogonal position
+        const double *bp = m ? bp2 : bp1;
+        const double off = 0.5 * (b[m] + b[2 + m]), off1 = 0.5 * (b1[m] + b1[2 + m]), off2 = 0.5 * (b2[m] + b2[2 + m]);
+        const double hw = 0.5 * (b[m] - b[2 + m]), sg = hw >= 0 ? 1.0 : -1.0;
+        rr[RC + 1 + m] = dot3(ep, bp) - off;
+        for (int c = 0; c < 3; c++) rr[RGC + (1 + m) * 4 + c] = bp[c];
+        rr[RGC + (1 + m) * 4 + 3] = -dot3(d, bp) - off1; rr[RC2 + 1 + m] = -off2;
+        rr[RWD + 1 + m] = sg * hw; rr[RW1 + 1 + m] = sg * 0.5 * (b1[m] - b1[2 + m]); rr[RW2 + 1 + m] = sg * 0.5 * (b2[m] - b2[2 + m]);
+    }
+    for (int m = 0; m < 2; m++) {   // orthogonal orientation
+        const double *br = m ? br2 : br1, *io = m ? io2 : io1, *l = m ? l3 : l1;
+        const double bb = m ? b2b2 : b1b1, sc = m ? s3 : s1, vrr = m ? v3rr : v1rr;
+        const double off = 0.5 * (b[4 + m] + b[6 + m]), off1 = 0.5 * (b1[4 + m] + b1[6 + m]), off2 = 0.5 * (b2[4 + m] + b2[6 + m]);
+        const double hw = 0.5 * (b[4 + m] - b[6 + m]), sg = hw >= 0 ? 1.0 : -1.0;
+        rr[RC + 3 + m] = dot3(br, io) + sc * bb - off;
+        for (int c = 0; c < 3; c++) rr[RGC + (3 + m) * 4 + c] = bb * l[c];
+        rr[RGC + (3 + m) * 4 + 3] = -bb * vrr - off1; rr[RC2 + 3 + m] = -off2;
+        rr[RWD + 3 + m] = sg * hw; rr[RW1 + 3 + m] = sg * 0.5 * (b1[4 + m] - b1[6 + m]); rr[RW2 + 3 + m] = sg * 0.5 * (b2[4 + m] - b2[6 + m]);
+    }
+}
+// tube row m uses pos (m = 1,2) or iw (m = 0,3,4) as its 3-vector variable
+BMPC_D inline int tube_voff(int m) { return (m == 1 || m == 2) ? ZPOS : ZIW; }
+
+// gradient of the node-local cost + sum_i nuv_i h_i w.r.t. Z_k (gz[44]) and v_prev (gvp[6])
+BMPC_D inline void node_grad(const double *PAR, const POff &po, double h, const double *Zn, const double *vprev, const double *rr,
+                             const double *nuv, double *gz, double *gvp) {
+    const double *w = PAR + po.w;
+    for (int i = 0; i < NZ; i++) gz[i] = 0;
+    const double *d = rr + RDP, *dh = rr + RDH, *ep = rr + REP, *er = rr + RER, *erpar = rr + RERPAR, *l2 = rr + RL2, *rrv = rr + RRR;
+    const double sig = rr[RSIG], sig1 = rr[RSIG1];
+    const double dde = dot3(d, ep), dd = dot3(d, d);
+    double epo[3], ero[3], eperp[3], erd[3];
+    for (int c = 0; c < 3; c++) {
+        eperp[c] = ep[c] - dde * d[c]; epo[c] = sig * ep[c] + (1 - sig) * dde * d[c];
+        erd[c] = er[c] - erpar[c]; ero[c] = sig * er[c] + (1 - sig) * erpar[c];
+    }
+    const double depo = dot3(d, epo), dhero = dot3(dh, ero);
+    double gphi = 0, gdphi = 0, gddphi = 0;
+    for (int c = 0; c < 3; c++) gz[ZPOS + c] += 2 * w[0] * (sig * epo[c] + (1 - sig) * depo * d[c]);
+    gphi += 2 * w[0] * (-(sig * depo + (1 - sig) * depo * dd) + sig1 * dot3(eperp, epo));
+    const double *jacl = PAR + po.jacl;
+    for (int c = 0; c < 3; c++) {
+        double s = 0;
+        for (int r = 0; r < 3; r++) s += sig * jacl[c * 3 + r] * ero[r];
+        gz[ZIW + c] += 2 * w[1] * (s + (1 - sig) * dhero * l2[c]);
+    }
+    gphi += 2 * w[1] * (-sig * dot3(rrv, ero) - (1 - sig) * rr[RV2RR] * dhero + sig1 * dot3(erd, ero));
+    for (int c = 0; c < 6; c++) {
+        const double rv = Zn[ZV + c] - Zn[ZDPHI] * d[c];
+        const double ra = (Zn[ZV + c] - vprev[c]) / h - Zn[ZDDPHI] * d[c];
+        gz[ZV + c] += 2 * w[2] * rv + 2 * w[5] * ra / h;
+        gdphi += -2 * w[2] * rv * d[c]; gddphi += -2 * w[5] * ra * d[c];
+        gvp[c] = -2 * w[5] * ra / h;
+    }
+    for (int i = 0; i < 7; i++) {
+        gz[ZQ + i] += 2 * w[10] * (Zn[ZQ + i] - PAR[po.qd + i]); gz[ZDQ + i] += 2 * w[11] * Zn[ZDQ + i];
+        gz[ZDDQ + i] += 2 * w[12] * Zn[ZDDQ + i]; gz[ZJ + i] += 2 * w[13] * Zn[ZJ + i];
+    }
+    gphi += -2 * w[6] * (PAR[po.xphid + 0] - Zn[ZPHI]);
+    gdphi += -2 * w[7] * (PAR[po.xphid + 1] - Zn[ZDPHI]);
+    gddphi += -2 * w[8] * (PAR[po.xphid + 2] - Zn[ZDDPHI]);
+    gz[ZJPHI] += 2 * w[9] * Zn[ZJPHI];
+    for (int i = 0; i < 8; i++) gz[ZJ + i] += nuv[IJU + i] - nuv[IJL + i];
+    for (int i = 0; i < 7; i++) { gz[ZQ + i] += nuv[IQU + i] - nuv[IQL + i]; gz[ZDQ + i] += nuv[IDQU + i] - nuv[IDQL + i]; }
+    gphi += -nuv[IPHI0] + nuv[IPHIMAX]; gdphi += nuv[IDPHIMAX];
+    for (int m = 0; m < 5; m++) {
+        const double nu_u = nuv[ITUBE + 2 * m], nu_l = nuv[ITUBE + 2 * m + 1];
+        const int vo = tube_voff(m);
+        for (int c = 0; c < 3; c++) gz[vo + c] += (nu_u - nu_l) * rr[RGC + m * 4 + c];
+        gphi += (nu_u - nu_l) * rr[RGC + m * 4 + 3] - (nu_u + nu_l) * rr[RW1 + m];
+    }
+    gz[ZPHI] += gphi; gz[ZDPHI] += gdphi; gz[ZDDPHI] += gddphi;
+}
+
+// value of internal inequality row i (0..56) at node variables Zn with reference record rr
+BMPC_D inline double ineq_val(const double *PAR, const POff &po, const double *Zn, const double *rr, int i) {
+    if (i < IJL) return Zn[ZJ + i] - ULIM;
+    if (i < IQU) return -Zn[ZJ + i - IJL] - ULIM;
+    if (i < IQL) return Zn[ZQ + i - IQU] - qlim(i - IQU);
+    if (i < IDQU) return -Zn[ZQ + i - IQL] - qlim(i - IQL);
+    if (i < IDQL) return Zn[ZDQ + i - IDQU] - dqlim(i - IDQU);
+    if (i < IPHI0) return -Zn[ZDQ + i - IDQL] - dqlim(i - IDQL);
+    if (i == IPHI0) return -Zn[ZPHI];
+    if (i == IPHIMAX) return Zn[ZPHI] - PAR[po.phimax];
+    if (i == IDPHIMAX) return Zn[ZDPHI] - PAR[po.dphimax];
+    const int m = (i - ITUBE) >> 1;
+    return ((i - ITUBE) & 1) ? (-rr[RC + m] - rr[RWD + m]) : (rr[RC + m] - rr[RWD + m]);
+}
+// grad h_i . dZ
+BMPC_D inline double ineq_dir(const double *dZ, const double *rr, int i) {
+    if (i < IJL) return dZ[ZJ + i];
+    if (i < IQU) return -dZ[ZJ + i - IJL];
+    if (i < IQL) return dZ[ZQ + i - IQU];
+    if (i < IDQU) return -dZ[ZQ + i - IQL];
+    if (i < IDQL) return dZ[ZDQ + i - IDQU];
+    if (i < IPHI0) return -dZ[ZDQ + i - IDQL];
+    if (i == IPHI0) return -dZ[ZPHI];
+    if (i == IPHIMAX) return dZ[ZPHI];
+    if (i == IDPHIMAX) return dZ[ZDPHI];
+    const int m = (i - ITUBE) >> 1, vo = tube_voff(m);
+    const double s = rr[RGC + m * 4 + 0] * dZ[vo] + rr[RGC + m * 4 + 1] * dZ[vo + 1] + rr[RGC + m * 4 + 2] * dZ[vo + 2] + rr[RGC + m * 4 + 3] * dZ[ZPHI];
+    return (((i - ITUBE) & 1) ? -s : s) - rr[RW1 + m] * dZ[ZPHI];
+}
+
+// integrator-chain coefficients CF[f'][f]: row field f' (q,dq,ddq,j of the next node) vs column field f (q,dq,ddq,j,u)
+BMPC_D inline double chain_cf(double h, int fr, int fc) {
+    const double h2 = h * h, h3 = h2 * h;
+    if (fr == 0) return fc == 0 ? 1.0 : fc == 1 ? h : fc == 2 ? h2 / 2 : fc == 3 ? h3 / 8 : h3 / 24;
+    if (fr == 1) return fc == 0 ? 0.0 : fc == 1 ? 1.0 : fc == 2 ? h : fc == 3 ? h2 / 3 : h2 / 6;
+    if (fr == 2) return fc <= 1 ? 0.0 : fc == 2 ? 1.0 : h / 2;
+    return fc == 4 ? 1.0 : 0.0;
+}
+BMPC_D inline int srow(int f, int i) { return i < 7 ? f * 7 + i : 28 + f; }   // reduced-state index of (field, chain)
+
+struct LaneRegs { double mc[44]; double kc[8]; };
+
+// ----------------------------------------------------------------------------------------
+// wave-uniform deterministic reductions through LDS (RED has 6 x 64 slots)
+// ----------------------------------------------------------------------------------------
+BMPC_D inline double red_sum(const double *r) { double s = 0; for (int i = 0; i < 64; i++) s += r[i]; return s; }
+BMPC_D inline double red_max(const double *r) { double s = r[0]; for (int i = 1; i < 64; i++) s = r[i] > s ? r[i] : s; return s; }
+BMPC_D inline double red_min(const double *r) { double s = r[0]; for (int i = 1; i < 64; i++) s = r[i] < s ? r[i] : s; return s; }
+
+// ========================================================================================
+//                                   the wave program
+// ========================================================================================
+
+// Evaluate at Zs: kinematic records, node references, equality residuals Gd[N][36], inequality
+// values Hd[N][57]; returns the objective (wave-uniform).
+BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, int oZ, int oG, int oH) {
+    const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
+    double *L = W.L, *G = W.G;
+    const double *PAR = L + L_PAR, *Zs = G + oZ;
+    LANES_BEGIN
+        if (lane < 2 * N) {
+            const int k = lane < N ? lane : lane - N;
+            double q[7], dq[7];
+            if (lane < N) {   // predicted point of node k+1 (jerk_trajectory_casadi.py closed form; bound_mpc_functions.py:254-260)
+                double *gk = G + oG + k * NE;
+                const double *Zn = Zs + k * NZ;
+                for (int i = 0; i < 7; i++) {
+                    const double q0 = ndv(PAR, po, Zs, k, ZQ + i, po.q0 + i), d0 = ndv(PAR, po, Zs, k, ZDQ + i, po.dq0 + i),
+                                 dd0 = ndv(PAR, po, Zs, k, ZDDQ + i, po.ddq0 + i), j0 = ndv(PAR, po, Zs, k, ZJ + i, po.jerk + i), j1 = Zn[ZJ + i];
+                    q[i] = q0 + h * d0 + h2 / 2 * dd0 + h3 / 8 * j0 + h3 / 24 * j1;
+                    dq[i] = d0 + h * dd0 + h2 / 3 * j0 + h2 / 6 * j1;
+                    const double ddqn = dd0 + h / 2 * (j0 + j1);
+                    gk[GQ + i] = q[i] - Zn[ZQ + i]; gk[GDQ + i] = dq[i] - Zn[ZDQ + i]; gk[GDDQ + i] = ddqn - Zn[ZDDQ + i];
+                }
+            } else {
+                for (int i = 0; i < 7; i++) { q[i] = ndv(PAR, po, Zs, k, ZQ + i, po.q0 + i); dq[i] = ndv(PAR, po, Zs, k, ZDQ + i, po.dq0 + i); }
+            }
+            kin_point(q, dq, G + sc.KIN + lane * KREC);
+        }
+    LANES_END
+    LANES_BEGIN
+        double fk = 0;
+        if (lane < N) {
+            const int k = lane;
+            const double *Zn = Zs + k * NZ, *kp = G + sc.KIN + k * KREC, *kv = G + sc.KIN + (N + k) * KREC;
+            double *gk = G + oG + k * NE, *rr = G + sc.REF + k * RREC;
+            for (int i = 0; i < 3; i++) {
+                gk[GPOS + i] = kp[KPOS + i] - Zn[ZPOS + i];
+                gk[GIW + i] = ndv(PAR, po, Zs, k, ZIW + i, po.p0 + 3 + i) + 0.5 * h * (kv[KV + 3 + i] + kp[KV + 3 + i]) - Zn[ZIW + i];
+            }
+            for (int i = 0; i < 6; i++) gk[GV + i] = kp[KV + i] - Zn[ZV + i];
+            const double ph = ndv(PAR, po, Zs, k, ZPHI, po.phi0), dph = ndv(PAR, po, Zs, k, ZDPHI, po.phi0 + 1),
+                         ddph = ndv(PAR, po, Zs, k, ZDDPHI, po.phi0 + 2), jp0 = ndv(PAR, po, Zs, k, ZJPHI, po.jerkphi), jp1 = Zn[ZJPHI];
+            gk[GPHI] = ph + h * dph + h2 / 2 * ddph + h3 / 8 * jp0 + h3 / 24 * jp1 - Zn[ZPHI];
+            gk[GDPHI] = dph + h * ddph + h2 / 3 * jp0 + h2 / 6 * jp1 - Zn[ZDPHI];
+            gk[GDDPHI] = ddph + h / 2 * (jp0 + jp1) - Zn[ZDDPHI];
+            node_ref(PAR, po, W.S, Zn + ZPOS, Zn + ZIW, Zn[ZPHI], rr);
+            // objective of node k+1 (bound_mpc_functions.py:205-246; casadi_ocp_formulation.py:227-265)
+            const double *w = PAR + po.w, *d = rr + RDP;
+            const double sig = rr[RSIG], dde = dot3(d, rr + REP);
+            double epo[3], ero[3];
+            for (int c = 0; c < 3; c++) { epo[c] = sig * rr[REP + c] + (1 - sig) * dde * d[c]; ero[c] = sig * rr[RER + c] + (1 - sig) * rr[RERPAR + c]; }
+            fk = w[1] * dot3(ero, ero) + w[0] * dot3(epo, epo);
+            for (int c = 0; c < 6; c++) {
+                const double vp = ndv(PAR, po, Zs, k, ZV + c, po.v0 + c);
+                const double rv = Zn[ZV + c] - Zn[ZDPHI] * d[c], ra = (Zn[ZV + c] - vp) / h - Zn[ZDDPHI] * d[c];
+                fk += w[2] * rv * rv + w[5] * ra * ra;
+            }
+            for (int i = 0; i < 7; i++) {
+                const double dqd = Zn[ZQ + i] - PAR[po.qd + i];
+                fk += w[10] * dqd * dqd + w[11] * Zn[ZDQ + i] * Zn[ZDQ + i] + w[12] * Zn[ZDDQ + i] * Zn[ZDDQ + i] + w[13] * Zn[ZJ + i] * Zn[ZJ + i];
+            }
+            const double e0 = PAR[po.xphid] - Zn[ZPHI], e1 = PAR[po.xphid + 1] - Zn[ZDPHI], e2 = PAR[po.xphid + 2] - Zn[ZDDPHI];
+            fk += w[6] * e0 * e0 + w[7] * e1 * e1 + w[8] * e2 * e2 + w[9] * Zn[ZJPHI] * Zn[ZJPHI];
+        }
+        L[L_RED + lane] = fk;
+    LANES_END
+    const double f = red_sum(L + L_RED);
+    LANES_BEGIN   // inequality values, one lane per row
+        for (int id = lane; id < N * NI; id += 64) {
+            const int k = id / NI, i = id - k * NI;
+            G[oH + id] = ineq_val(PAR, po, Zs + k * NZ, G + sc.REF + k * RREC, i);
+        }
+    LANES_END
+    return f;
+}
+
+// mu_q, mu_dq of stage kk (node kk -> kk+1) from lam_kk and the predicted-point record, into L_MU[0..15]
+// (lanes 0..7; chain 7 = path parameter)
+BMPC_D inline void stage_mu(Wave &W, const Scr &sc, int kk, int lane) {
+    double *L = W.L, *G = W.G; const double h = W.h;
+    if (lane < 8) {
+        const double *lam = G + sc.LAM + kk * NE;
+        if (lane < 7) {
+            const int i = lane; const double *kp = G + sc.KIN + kk * KREC;
+            double s = lam[GQ + i], s2 = lam[GDQ + i];
+            for (int c = 0; c < 3; c++) {
+                const double mv = lam[GV + c], mw = lam[GW + c] + 0.5 * h * lam[GIW + c];
+                s += kp[KW + c * 7 + i] * lam[GPOS + c] + kp[KD + c * 7 + i] * mv + kp[KD + (3 + c) * 7 + i] * mw;
+                s2 += kp[KW + c * 7 + i] * mv + kp[KA + c * 7 + i] * mw;
+            }
+            L[L_MU + i] = s; L[L_MU + 8 + i] = s2;
+        } else { L[L_MU + 7] = lam[GPHI]; L[L_MU + 15] = lam[GDPHI]; }
+    }
+}
+
+// Adjoint sweep with multipliers nu (scratch offset oNU; scale = 0 -> objective only is NOT supported here):
+// LAM[N][36], RJ[N][8]; GH receives d(f + nu.h)/dZ.
+BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU, bool use_hat, double mu) {
+    const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
+    double *L = W.L, *G = W.G;
+    const double *PAR = L + L_PAR, *Zs = G + sc.Z;
+    LANES_BEGIN
+        if (lane < N) {
+            const int k = lane;
+            double nuv[NI], vprev[6];
+            for (int i = 0; i < NI; i++) {
+                const double nu = G[oNU + k * NI + i];
+                if (use_hat) { const double t = G[sc.T + k * NI + i]; nuv[i] = (mu + nu * (G[sc.HIN + k * NI + i] + t)) / t; }
+                else nuv[i] = nu;
+            }
+            for (int c = 0; c < 6; c++) vprev[c] = ndv(PAR, po, Zs, k, ZV + c, po.v0 + c);
+            double gz[NZ], gvp[6];
+            node_grad(PAR, po, h, Zs + k * NZ, vprev, G + sc.REF + k * RREC, nuv, gz, gvp);
+            for (int i = 0; i < NZ; i++) G[sc.GH + k * NZ + i] = gz[i];
+            for (int c = 0; c < 6; c++) G[sc.GVP + k * 8 + c] = gvp[c];
+        }
+    LANES_END
+    LANES_BEGIN
+        for (int id = lane; id < (N - 1) * 6; id += 64) { const int k = id / 6, c = id - k * 6; G[sc.GH + k * NZ + ZV + c] += G[sc.GVP + (k + 1) * 8 + c]; }
+    LANES_END
+    if (use_hat) return;   // QP gradient only
+    for (int k = N - 1; k >= 0; k--) {
+        if (k < N - 1) {
+            LANES_BEGIN
+                stage_mu(W, sc, k + 1, lane);
+            LANES_END
+        }
+        LANES_BEGIN
+            if (lane < NZ) {
+                const int z = lane;
+                double tot = G[sc.GH + k * NZ + z];
+                if (k < N - 1) {
+                    const double *lam1 = G + sc.LAM + (k + 1) * NE, *kv = G + sc.KIN + (N + k + 1) * KREC;
+                    // field / chain of this component
+                    int f = -1, i = 0;
+                    if (z < 7) { f = 3; i = z; } else if (z == ZJPHI) { f = 3; i = 7; }
+                    else if (z < ZDQ) { f = 0; i = z - ZQ; } else if (z < ZDDQ) { f = 1; i = z - ZDQ; } else if (z < ZPOS) { f = 2; i = z - ZDDQ; }
+                    else if (z >= ZPHI) { f = z - ZPHI; i = 7; }
+                    if (f >= 0) {
+                        const double mdd = i < 7 ? lam1[GDDQ + i] : lam1[GDDPHI];
+                        tot += chain_cf(h, 0, f) * L[L_MU + i] + chain_cf(h, 1, f) * L[L_MU + 8 + i] + chain_cf(h, 2, f) * mdd;
+                        if (i < 7 && f <= 1) {
+                            double e = 0;
+                            for (int c = 0; c < 3; c++) e += (f == 0 ? kv[KD + (3 + c) * 7 + i] : kv[KA + c * 7 + i]) * lam1[GIW + c];
+                            tot += 0.5 * h * e;
+                        }
+                    } else if (z >= ZIW && z < ZIW + 3) tot += lam1[GIW + z - ZIW];
+                }
+                if (z < 7) G[sc.RJ + k * NU + z] = tot;
+                else if (z == ZJPHI) G[sc.RJ + k * NU + 7] = tot;
+                else {
+                    const int e = z < ZPOS ? z - ZQ : (z < ZPHI ? GPOS + (z - ZPOS) : GPHI + (z - ZPHI));
+                    G[sc.LAM + k * NE + e] = tot;
+                }
+            } else if (lane < NZ + 8 && k < N - 1) {   // jerk of node k+2 enters stage k+1
+                const int i = lane - NZ; const double *lam1 = G + sc.LAM + (k + 1) * NE;
+                const double mdd = i < 7 ? lam1[GDDQ + i] : lam1[GDDPHI];
+                G[sc.RJ + (k + 1) * NU + i] += h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd;
+            }
+        LANES_END
+    }
+    LANES_BEGIN
+        stage_mu(W, sc, 0, lane);
+    LANES_END
+    LANES_BEGIN
+        if (lane < 8) {
+            const int i = lane; const double *lam0 = G + sc.LAM;
+            const double mdd = i < 7 ? lam0[GDDQ + i] : lam0[GDDPHI];
+            G[sc.RJ + i] += h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd;
+        }
+    LANES_END
+}
+
+// ----------------------------------------------------------------------------------------
+// Node cost: reduced Hessian/gradient of node k+1 (index k) ADDED into PM / PV.
+// Q~ = T^T H T + W  (T eliminates the lifted pos / v variables and the omega part of iw),
+// q~ = T^T (g^ + H r) - W g_y + acceleration cross gradients.  delta = Hessian regularisation.
+// ----------------------------------------------------------------------------------------
+BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k, double mu, double delta) {
+    const int N = W.N; const double h = W.h; const int ex = W.o.exact_hessian;
+    double *L = W.L, *G = W.G;
+    const double *PAR = L + L_PAR, *w = PAR + po.w;
+    const double *Zn = G + sc.Z + k * NZ, *rr = G + sc.REF + k * RREC, *gk = G + sc.G + k * NE;
+    const double *tk = G + sc.T + k * NI, *nuk = G + sc.NUm + k * NI;
+    double *NC = L + L_NC, *K0 = L + L_K0, *KV1 = L + L_KV, *WY = L + L_WY, *WV = L + L_WV;
+    const bool has_next = k < N - 1;
+    // phase 1: stage records, small Hessian blocks, lifted residuals
+    LANES_BEGIN
+        for (int id = lane; id < KREC; id += 64) {
+            K0[id] = G[sc.KIN + k * KREC + id];
+            KV1[id] = has_next ? G[sc.KIN + (N + k + 1) * KREC + id] : 0.0;
+        }
+        if (lane < 14) NC[NC_GY + lane] = lane < 7 ? gk[GQ + lane] : gk[GDQ + lane - 7];
+        if (lane >= 16 && lane < 16 + 9) {   // H_pp (a,b) and H_rr (a,b)
+            const int a = (lane - 16) / 3, b = (lane - 16) % 3;
+            const double sig = rr[RSIG], *d = rr + RDP, *dh = rr + RDH, *l2 = rr + RL2, *jacl = PAR + po.jacl;
+            double sp = 0, sr = 0;
+            for (int r = 0; r < 3; r++) {
+                const double jpa = (r == a ? sig : 0.0) + (1 - sig) * d[r] * d[a], jpb = (r == b ? sig : 0.0) + (1 - sig) * d[r] * d[b];
+                const double jra = sig * jacl[a * 3 + r] + (1 - sig) * dh[r] * l2[a], jrb = sig * jacl[b * 3 + r] + (1 - sig) * dh[r] * l2[b];
+                sp += jpa * jpb; sr += jra * jrb;
+            }
+            double hp = 2 * w[0] * sp, hr = 2 * w[1] * sr;
+            for (int m = 0; m < 5; m++) {
+                const double su = nuk[ITUBE + 2 * m] / tk[ITUBE + 2 * m], sl = nuk[ITUBE + 2 * m + 1] / tk[ITUBE + 2 * m + 1];
+                const double gg = (su + sl) * rr[RGC + m * 4 + a] * rr[RGC + m * 4 + b];
+                if (m == 1 || m == 2) hp += gg; else hr += gg;
+            }
+            NC[NC_HPP + a * 3 + b] = hp; NC[NC_HRR + a * 3 + b] = hr;
+        }
+        if (lane >= 32 && lane < 35) {       // H_{pos,phi}, H_{iw,phi}
+            const int a = lane - 32;
+            const double sig = rr[RSIG], sig1 = rr[RSIG1], *d = rr + RDP, *dh = rr + RDH, *l2 = rr + RL2, *jacl = PAR + po.jacl;
+            const double dde = dot3(d, rr + REP), dd = dot3(d, d);
+            double sp = 0, sr = 0, epo[3], ero[3];
+            for (int r = 0; r < 3; r++) {
+                const double eperp = rr[REP + r] - dde * d[r], erd = rr[RER + r] - rr[RERPAR + r];
+                epo[r] = sig * rr[REP + r] + (1 - sig) * dde * d[r]; ero[r] = sig * rr[RER + r] + (1 - sig) * rr[RERPAR + r];
+                const double jpa = (r == a ? sig : 0.0) + (1 - sig) * d[r] * d[a], jpf = -(sig * d[r] + (1 - sig) * dd * d[r]) + sig1 * eperp;
+                const double jra = sig * jacl[a * 3 + r] + (1 - sig) * dh[r] * l2[a], jrf = -sig * rr[RRR + r] - (1 - sig) * dh[r] * rr[RV2RR] + sig1 * erd;
+                sp += jpa * jpf; sr += jra * jrf;
+            }
+            double hp = 2 * w[0] * sp, hr = 2 * w[1] * sr;
+            if (ex) {
+                const double depo = dot3(d, epo), dhero = dot3(dh, ero);
+                double jl = 0; for (int r = 0; r < 3; r++) jl += ero[r] * jacl[a * 3 + r];
+                hp += 2 * w[0] * sig1 * (epo[a] - depo * d[a]); hr += 2 * w[1] * sig1 * (jl - dhero * l2[a]);
+            }
+            for (int m = 0; m < 5; m++) {
+                const double su = nuk[ITUBE + 2 * m] / tk[ITUBE + 2 * m], sl = nuk[ITUBE + 2 * m + 1] / tk[ITUBE + 2 * m + 1];
+                const double gpu_ = rr[RGC + m * 4 + 3] - rr[RW1 + m], gpl_ = -rr[RGC + m * 4 + 3] - rr[RW1 + m];
+                const double gg = su * rr[RGC + m * 4 + a] * gpu_ - sl * rr[RGC + m * 4 + a] * gpl_;
+                if (m == 1 || m == 2) hp += gg; else hr += gg;
+            }
+            NC[NC_HPF + a] = hp; NC[NC_HRF + a] = hr;
+        }
+        if (lane == 40) {                     // scalar blocks: H_phiphi, H_dphidphi, H_ddphiddphi, c_v
+            const double sig = rr[RSIG], sig1 = rr[RSIG1], sig2 = rr[RSIG2], *d = rr + RDP, *dh = rr + RDH;
+            const double dde = dot3(d, rr + REP), dd = dot3(d, d);
+            double sp = 0, sr = 0, spp = 0, srr = 0, dpdp = 0;
+            for (int r = 0; r < 3; r++) {
+                const double eperp = rr[REP + r] - dde * d[r], erd = rr[RER + r] - rr[RERPAR + r];
+                const double epo = sig * rr[REP + r] + (1 - sig) * dde * d[r], ero = sig * rr[RER + r] + (1 - sig) * rr[RERPAR + r];
+                const double jpf = -(sig * d[r] + (1 - sig) * dd * d[r]) + sig1 * eperp, jrf = -sig * rr[RRR + r] - (1 - sig) * dh[r] * rr[RV2RR] + sig1 * erd;
+                sp += jpf * jpf; sr += jrf * jrf;
+                spp += epo * (sig2 * eperp - 2 * sig1 * (d[r] - dd * d[r]));
+                srr += ero * (sig2 * erd + 2 * sig1 * (-rr[RRR + r] + dh[r] * rr[RV2RR]));
+            }
+            for (int c = 0; c < 6; c++) dpdp += d[c] * d[c];
+            double hff = 2 * w[0] * sp + 2 * w[1] * sr + 2 * w[6] + nuk[IPHI0] / tk[IPHI0] + nuk[IPHIMAX] / tk[IPHIMAX];
+            if (ex) hff += 2 * w[0] * spp + 2 * w[1] * srr;
+            for (int m = 0; m < 5; m++) {
+                const double su = nuk[ITUBE + 2 * m] / tk[ITUBE + 2 * m], sl = nuk[ITUBE + 2 * m + 1] / tk[ITUBE + 2 * m + 1];
+                const double gpu_ = rr[RGC + m * 4 + 3] - rr[RW1 + m], gpl_ = -rr[RGC + m * 4 + 3] - rr[RW1 + m];
+                hff += su * gpu_ * gpu_ + sl * gpl_ * gpl_;
+                if (ex) hff += nuk[ITUBE + 2 * m] * (rr[RC2 + m] - rr[RW2 + m]) + nuk[ITUBE + 2 * m + 1] * (-rr[RC2 + m] - rr[RW2 + m]);
+            }
+            NC[NC_SC + 0] = hff;
+            NC[NC_SC + 1] = 2 * w[2] * dpdp + 2 * w[7] + nuk[IDPHIMAX] / tk[IDPHIMAX];
+            NC[NC_SC + 2] = 2 * w[5] * dpdp + 2 * w[8];
+            NC[NC_SC + 3] = 2 * w[2] + 2 * w[5] / (h * h) * (has_next ? 2.0 : 1.0);
+        }
+    LANES_END
+    // phase 2: lifted residuals r (pos 3, v 6), A1 = Hpp Jp, A2 = Hrr Ehat, multipliers for the kinematic curvature
+    LANES_BEGIN
+        if (lane < 9) {
+            NC[NC_RL + lane] = G[sc.RLV + k * 12 + lane];
+        } else if (lane >= 16 && lane < 16 + 21) {
+            const int c = (lane - 16) / 7, i = (lane - 16) % 7; double s = 0;
+            for (int b = 0; b < 3; b++) s += NC[NC_HPP + c * 3 + b] * K0[KW + b * 7 + i];
+            NC[NC_A1 + c * 7 + i] = s;
+        }
+        if (lane < 42) {                       // uses a second slot of lanes 0..41 for A2 (distinct outputs from the branch above)
+            const int c = lane / 14, y = lane % 14; double s = 0;
+            for (int b = 0; b < 3; b++) s += NC[NC_HRR + c * 3 + b] * (y < 7 ? K0[KD + (3 + b) * 7 + y] : K0[KA + b * 7 + y - 7]);
+            NC[NC_A2 + c * 14 + y] = 0.5 * h * s;
+        }
+        if (lane >= 48 && lane < 60) {         // curvature multipliers: [0..2] mu_p, [3..5] mu_v, [6..8] mu_w (predicted point), [9..11] mu_w (node variables)
+            const int c = (lane - 48) % 3, g = (lane - 48) / 3; const double *lam = G + sc.LAM + k * NE;
+            double v = 0;
+            if (g == 0) v = lam[GPOS + c]; else if (g == 1) v = lam[GV + c]; else if (g == 2) v = lam[GW + c] + 0.5 * h * lam[GIW + c];
+            else v = has_next ? 0.5 * h * G[sc.LAM + (k + 1) * NE + GIW + c] : 0.0;
+            L[L_MU + 4 + 0 + (lane - 48)] = v;   // L_MU[4..15]
+        }
+    LANES_END
+    // phase 3: Z-space gradient gl = g^ + H r + cross terms (44), kinematic curvature W (14x14)
+    LANES_BEGIN
+        if (lane < NZ) {
+            const int z = lane; double g = G[sc.GH + k * NZ + z];
+            const double *rl = NC + NC_RL, cv = NC[NC_SC + 3], *d = rr + RDP;
+            if (z >= ZPOS && z < ZPOS + 3) { for (int b = 0; b < 3; b++) g += NC[NC_HPP + (z - ZPOS) * 3 + b] * rl[b]; }
+            else if (z == ZPHI) { for (int b = 0; b < 3; b++) g += NC[NC_HPF + b] * rl[b]; }
+            else if (z >= ZV && z < ZV + 6) {
+                const int c = z - ZV; g += cv * rl[3 + c];
+                if (k >= 1) g += -2 * w[5] / (h * h) * G[sc.RLV + (k - 1) * 12 + 3 + c];
+                if (has_next) g += -2 * w[5] / (h * h) * G[sc.RLV + (k + 1) * 12 + 3 + c];
+            } else if (z == ZDPHI) { for (int c = 0; c < 6; c++) g += -2 * w[2] * d[c] * rl[3 + c]; }
+            else if (z == ZDDPHI) {
+                for (int c = 0; c < 6; c++) g += -2 * w[5] / h * d[c] * rl[3 + c];
+                if (k >= 1) for (int c = 0; c < 6; c++) g += 2 * w[5] / h * d[c] * G[sc.RLV + (k - 1) * 12 + 3 + c];
+            }
+            NC[NC_GL + z] = g;
+        }
+        for (int id = lane; id < 105; id += 64) {   // upper triangle of the 14x14 curvature block
+            int a = 0, rem = id; while (rem >= 14 - a) { rem -= 14 - a; a++; }
+            const int b = a + rem;
+            double v = 0, v2 = 0;
+            if (ex) {
+                v = kin_hess_entry(K0, L + L_MU + 4, L + L_MU + 7, L + L_MU + 10, a, b);
+                if (has_next) { const double z3[3] = {0, 0, 0}; v2 = kin_hess_entry(KV1, z3, z3, L + L_MU + 13, a, b); }
+            }
+            WY[a * 14 + b] = v; WY[b * 14 + a] = v; WV[a * 14 + b] = v2; WV[b * 14 + a] = v2;
+        }
+    LANES_END
+    // (RLV of all nodes is produced by wave_prepare_rlv() before the backward sweep.)
+    // phase 4: add Q~ into PM and q~ into PV
+    LANES_BEGIN
+        const double *A1 = NC + NC_A1, *A2 = NC + NC_A2, cv = NC[NC_SC + 3], *d = rr + RDP, *gl = NC + NC_GL;
+        // (a) 17 x 17 block over (q, dq, iota): entries id = a*17+b, a<=b handled once and mirrored
+        for (int id = lane; id < 17 * 17; id += 64) {
+            const int a = id / 17, b = id - a * 17;
+            if (a > b) continue;
+            double v = 0;
+            if (b < 14) {
+                if (b < 7) for (int c = 0; c < 3; c++) v += K0[KW + c * 7 + a] * A1[c * 7 + b];                       // Jp^T Hpp Jp (q-q)
+                for (int c = 0; c < 3; c++) v += 0.5 * h * (a < 7 ? K0[KD + (3 + c) * 7 + a] : K0[KA + c * 7 + a - 7]) * A2[c * 14 + b];   // Ehat^T Hrr Ehat
+                double gv = 0;
+                for (int c6 = 0; c6 < 6; c6++) {
+                    const double ga = a < 7 ? K0[KD + c6 * 7 + a] : (c6 < 3 ? K0[KW + c6 * 7 + a - 7] : K0[KA + (c6 - 3) * 7 + a - 7]);
+                    const double gb = b < 7 ? K0[KD + c6 * 7 + b] : (c6 < 3 ? K0[KW + c6 * 7 + b - 7] : K0[KA + (c6 - 3) * 7 + b - 7]);
+                    gv += ga * gb;
+                }
+                v += cv * gv + WY[a * 14 + b] + WV[a * 14 + b];
+            } else if (a < 14) { v = A2[(b - 14) * 14 + a]; }                                                       // (y, iota)
+            else { v = NC[NC_HRR + (a - 14) * 3 + (b - 14)]; }                                                        // (iota, iota)
+            const int ra = a < 14 ? a : SIOTA + a - 14, rb = b < 14 ? b : SIOTA + b - 14;
+            if (a == b) {
+                double dg = delta;
+                if (a < 7) dg += 2 * w[10] + nuk[IQU + a] / tk[IQU + a] + nuk[IQL + a] / tk[IQL + a];
+                else if (a < 14) dg += 2 * w[11] + nuk[IDQU + a - 7] / tk[IDQU + a - 7] + nuk[IDQL + a - 7] / tk[IDQL + a - 7];
+                L[L_PM + ra * 36 + ra] += v + dg;
+            } else { L[L_PM + ra * 36 + rb] += v; L[L_PM + rb * 36 + ra] += v; }
+        }
+        if (lane < NS) {   // gradient q~
+            const int r = lane; double v;
+            if (r < 14) {
+                const int a = r; v = gl[a < 7 ? ZQ + a : ZDQ + a - 7];
+                if (a < 7) for (int c = 0; c < 3; c++) v += K0[KW + c * 7 + a] * gl[ZPOS + c];
+                for (int c = 0; c < 3; c++) v += 0.5 * h * (a < 7 ? K0[KD + (3 + c) * 7 + a] : K0[KA + c * 7 + a - 7]) * gl[ZIW + c];
+                for (int c6 = 0; c6 < 6; c6++) v += (a < 7 ? K0[KD + c6 * 7 + a] : (c6 < 3 ? K0[KW + c6 * 7 + a - 7] : K0[KA + (c6 - 3) * 7 + a - 7])) * gl[ZV + c6];
+                double s = 0; for (int b = 0; b < 14; b++) s += WY[a * 14 + b] * NC[NC_GY + b];
+                v -= s;
+            } else if (r < SJ) v = gl[ZDDQ + r - SDDQ];
+            else if (r < SPHI) v = gl[ZJ + r - SJ];
+            else if (r == SPHI) v = gl[ZPHI]; else if (r == SDPHI) v = gl[ZDPHI]; else if (r == SDDPHI) v = gl[ZDDPHI];
+            else if (r == SJPHI) v = gl[ZJPHI];
+            else v = gl[ZIW + r - SIOTA];
+            L[L_PV + r] += v;
+        }
+    LANES_END
+    LANES_BEGIN
+        const double *A2 = NC + NC_A2, *d = rr + RDP, *gl = NC + NC_GL;
+        // (b) couplings with phi, dphi, ddphi and the remaining diagonal
+        if (lane < 17) {
+            const int a = lane, ra = a < 14 ? a : SIOTA + a - 14;
+            double vf = 0, vd = 0, vdd = 0;
+            if (a < 14) {
+                if (a < 7) for (int c = 0; c < 3; c++) vf += K0[KW + c * 7 + a] * NC[NC_HPF + c];
+                for (int c = 0; c < 3; c++) vf += 0.5 * h * (a < 7 ? K0[KD + (3 + c) * 7 + a] : K0[KA + c * 7 + a - 7]) * NC[NC_HRF + c];
+                for (int c6 = 0; c6 < 6; c6++) {
+                    const double ga = a < 7 ? K0[KD + c6 * 7 + a] : (c6 < 3 ? K0[KW + c6 * 7 + a - 7] : K0[KA + (c6 - 3) * 7 + a - 7]);
+                    vd += -2 * w[2] * d[c6] * ga; vdd += -2 * w[5] / h * d[c6] * ga;
+                }
+            } else vf = NC[NC_HRF + a - 14];
+            L[L_PM + ra * 36 + SPHI] += vf; L[L_PM + SPHI * 36 + ra] += vf;
+            L[L_PM + ra * 36 + SDPHI] += vd; L[L_PM + SDPHI * 36 + ra] += vd;
+            L[L_PM + ra * 36 + SDDPHI] += vdd; L[L_PM + SDDPHI * 36 + ra] += vdd;
+        } else if (lane >= 20 && lane < 20 + 18) {
+            const int r = lane - 20;   // diagonal of ddq (7), j (7), phi, dphi, ddphi, jphi
+            int idx; double v;
+            if (r < 7) { idx = SDDQ + r; v = 2 * w[12]; }
+            else if (r < 14) { const int i = r - 7; idx = SJ + i; v = 2 * w[13] + nuk[IJU + i] / tk[IJU + i] + nuk[IJL + i] / tk[IJL + i]; }
+            else if (r == 14) { idx = SPHI; v = NC[NC_SC + 0]; }
+            else if (r == 15) { idx = SDPHI; v = NC[NC_SC + 1]; }
+            else if (r == 16) { idx = SDDPHI; v = NC[NC_SC + 2]; }
+            else { idx = SJPHI; v = 2 * w[9] + nuk[IJU + 7] / tk[IJU + 7] + nuk[IJL + 7] / tk[IJL + 7]; }
+            L[L_PM + idx * 36 + idx] += v + delta;
+        }
+    LANES_END
+}
+
+// lifted residuals r_pos (3), r_v (6) of every node: r = g_lifted - G g_y   (needed across neighbouring nodes)
+BMPC_D inline void wave_prepare_rlv(Wave &W, const Scr &sc) {
+    const int N = W.N; double *G = W.G;
+    LANES_BEGIN
+        for (int id = lane; id < N * 9; id += 64) {
+            const int k = id / 9, c9 = id - k * 9;
+            const double *gk = G + sc.G + k * NE, *kp = G + sc.KIN + k * KREC;
+            double r;
+            if (c9 < 3) { r = gk[GPOS + c9]; for (int i = 0; i < 7; i++) r -= kp[KW + c9 * 7 + i] * gk[GQ + i]; }
+            else {
+                const int c6 = c9 - 3; r = gk[GV + c6];
+                for (int i = 0; i < 7; i++) r -= kp[KD + c6 * 7 + i] * gk[GQ + i] + (c6 < 3 ? kp[KW + c6 * 7 + i] : kp[KA + (c6 - 3) * 7 + i]) * gk[GDQ + i];
+            }
+            G[sc.RLV + k * 12 + c9] = r;
+        }
+    LANES_END
+}
+
+// Gv[c6][y] of a kinematics record: d(v)/d(q,dq) = [D | J]
+BMPC_D inline double gv_at(const double *rec, int c6, int y) {
+    return y < 7 ? rec[KD + c6 * 7 + y] : (c6 < 3 ? rec[KW + c6 * 7 + y - 7] : rec[KA + (c6 - 3) * 7 + y - 7]);
+}
+
+// ----------------------------------------------------------------------------------------
+// Riccati backward sweep.  Returns false (wave-uniform) if some stage's M_jj is not positive definite.
+// ----------------------------------------------------------------------------------------
+BMPC_D inline bool wave_backward(Wave &W, const POff &po, const Scr &sc, double mu, double delta, LaneRegs *LR) {
+    const int N = W.N; const double h = W.h;
+    double *L = W.L, *G = W.G;
+    const double *PAR = L + L_PAR, *w = PAR + po.w;
+    LANES_BEGIN
+        for (int id = lane; id < 35 * 36; id += 64) L[L_PM + id] = 0.0;
+        if (lane < 36) L[L_PV + lane] = 0.0;
+    LANES_END
+    for (int k = N - 1; k >= 0; k--) {
+        wave_node_cost(W, po, sc, k, mu, delta);          // PM/PV now hold the value function of node k+1
+        // ---- stage data: rdyn, iota coupling AE (3x14), acceleration cross block XT (15x14) ----
+        LANES_BEGIN   // L_K0 holds Kp[k] (loaded by wave_node_cost); load Kp[k-1] and Kv[k]
+            if (k >= 1) for (int id = lane; id < KREC; id += 64) { L[L_K1 + id] = G[sc.KIN + (k - 1) * KREC + id]; L[L_KV + id] = G[sc.KIN + (N + k) * KREC + id]; }
+        LANES_END
+        LANES_BEGIN
+            const double *K0 = L + L_K0, *K1 = L + L_K1, *KVk = L + L_KV, *gk = G + sc.G + k * NE;
+            if (lane < NS) {
+                const int r = lane; double v = 0;
+                if (r < SJ) v = gk[r];                       // q, dq, ddq defects share the ordering
+                else if (r >= SPHI && r <= SDDPHI) v = gk[GPHI + r - SPHI];
+                else if (r >= SIOTA) {
+                    const int c = r - SIOTA; v = gk[GIW + c];
+                    for (int i = 0; i < 7; i++) v -= 0.5 * h * (K0[KD + (3 + c) * 7 + i] * gk[GQ + i] + K0[KA + c * 7 + i] * gk[GDQ + i]);
+                }
+                L[L_RD + r] = v; G[sc.RDY + k * 36 + r] = v;
+            }
+            if (lane < 42) {
+                const int a = lane / 14, y = lane % 14; double v = 0;
+                if (k >= 1) v = 0.5 * h * (y < 7 ? K1[KD + (3 + a) * 7 + y] + KVk[KD + (3 + a) * 7 + y] : K1[KA + a * 7 + y - 7] + KVk[KA + a * 7 + y - 7]);
+                L[L_AE + lane] = v; G[sc.AES + k * 42 + lane] = v;
+            }
+            if (k >= 1) {
+                const double *dpn = G + sc.REF + k * RREC + RDP;
+                for (int id = lane; id < 15 * 14; id += 64) {
+                    const int r = id / 14, c = id - r * 14; double v = 0;
+                    for (int c6 = 0; c6 < 6; c6++) {
+                        const double cr = r < 14 ? -2 * w[5] / (h * h) * gv_at(K0, c6, r) : 2 * w[5] / h * dpn[c6];
+                        v += cr * gv_at(K1, c6, c);
+                    }
+                    L[L_XT + id] = v;
+                }
+            }
+        LANES_END
+        LANES_BEGIN   // PR = PV + P' rdyn   (symmetric P': read columns)
+            if (lane < NS) { double s = L[L_PV + lane]; for (int c = 0; c < NS; c++) s += L[L_PM + c * 36 + lane] * L[L_RD + c]; L[L_PR + lane] = s; }
+        LANES_END
+        // ---- M = F^T P' F (+ cross terms), one COLUMN per lane, held in registers ----
+        LANES_BEGIN
+            double *mc = LR[LIDX].mc;
+            if (lane <= NW) {
+                const int c = lane;
+                double t1[NS];
+                // column structure of F
+                int f = -1, ci = 0, io = -1;
+                if (c < 28) { f = c / 7; ci = c % 7; } else if (c < 32) { f = c - 28; ci = 7; } else if (c < 35) { io = c - 32; } else if (c < NW) { f = 4; ci = c - 35; }
+                if (c < NW) {
+                    double cf0 = 0, cf1 = 0, cf2 = 0, cf3 = 0, ae0 = 0, ae1 = 0, ae2 = 0; int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+                    if (f >= 0) {
+                        cf0 = chain_cf(h, 0, f); cf1 = chain_cf(h, 1, f); cf2 = chain_cf(h, 2, f); cf3 = chain_cf(h, 3, f);
+                        i0 = srow(0, ci); i1 = srow(1, ci); i2 = srow(2, ci); i3 = srow(3, ci);
+                        if (ci < 7 && f <= 1) { ae0 = L[L_AE + 0 * 14 + f * 7 + ci]; ae1 = L[L_AE + 1 * 14 + f * 7 + ci]; ae2 = L[L_AE + 2 * 14 + f * 7 + ci]; }
+                    } else { cf0 = 1.0; i0 = SIOTA + io; }
+#pragma unroll
+                    for (int r = 0; r < NS; r++) {
+                        const double *row = L + L_PM + r * 36;
+                        t1[r] = cf0 * row[i0] + cf1 * row[i1] + cf2 * row[i2] + cf3 * row[i3] + ae0 * row[SIOTA] + ae1 * row[SIOTA + 1] + ae2 * row[SIOTA + 2];
+                    }
+                    if (k >= 1 && c < 14) {   // + X S : rows y+ (14) and ddphi+
+#pragma unroll
+                        for (int r = 0; r < 14; r++) t1[r] += L[L_XT + r * 14 + c];
+                        t1[SDDPHI] += L[L_XT + 14 * 14 + c];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < NS; r++) t1[r] = L[L_PR + r];
+                }
+                // second pass: mc = F^T t1
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int rq = srow(0, i), rdq = srow(1, i), rddq = srow(2, i), rj = srow(3, i);
+                    double a_q = t1[rq], a_dq = h * t1[rq] + t1[rdq];
+                    if (i < 7) {
+                        a_q += L[L_AE + i] * t1[SIOTA] + L[L_AE + 14 + i] * t1[SIOTA + 1] + L[L_AE + 28 + i] * t1[SIOTA + 2];
+                        a_dq += L[L_AE + 7 + i] * t1[SIOTA] + L[L_AE + 21 + i] * t1[SIOTA + 1] + L[L_AE + 35 + i] * t1[SIOTA + 2];
+                    }
+                    mc[rq] = a_q; mc[rdq] = a_dq;
+                    mc[rddq] = h * h / 2 * t1[rq] + h * t1[rdq] + t1[rddq];
+                    mc[rj] = h * h * h / 8 * t1[rq] + h * h / 3 * t1[rdq] + h / 2 * t1[rddq];
+                    mc[NS + i] = h * h * h / 24 * t1[rq] + h * h / 6 * t1[rdq] + h / 2 * t1[rddq] + t1[rj];
+                }
+                mc[SIOTA] = t1[SIOTA]; mc[SIOTA + 1] = t1[SIOTA + 1]; mc[SIOTA + 2] = t1[SIOTA + 2];
+                if (k >= 1) {   // + S^T X^T F  (rows y_k)
+                    if (c < NW) {
+                        if (f >= 0 && ci < 7) {
+                            const double c0 = chain_cf(h, 0, f), c1 = chain_cf(h, 1, f);
+#pragma unroll
+                            for (int y = 0; y < 14; y++) mc[y] += c0 * L[L_XT + ci * 14 + y] + c1 * L[L_XT + (7 + ci) * 14 + y];
+                        } else if (f >= 0) {
+                            const double c2 = chain_cf(h, 2, f);
+#pragma unroll
+                            for (int y = 0; y < 14; y++) mc[y] += c2 * L[L_XT + 14 * 14 + y];
+                        }
+                    } else {    // gradient column: X^T rdyn
+#pragma unroll
+                        for (int y = 0; y < 14; y++) {
+                            double s = L[L_XT + 14 * 14 + y] * L[L_RD + SDDPHI];
+                            for (int r = 0; r < 14; r++) s += L[L_XT + r * 14 + y] * L[L_RD + r];
+                            mc[y] += s;
+                        }
+                    }
+                }
+                // publish the jerk rows (M_js | M_jj | m_j)
+#pragma unroll
+                for (int a = 0; a < NU; a++) L[L_SR + a * 44 + c] = mc[NS + a];
+            }
+        LANES_END
+        // ---- 8x8 Cholesky (every lane, identical data), gains, Schur complement ----
+        LANES_BEGIN
+            double *mc = LR[LIDX].mc, *kc = LR[LIDX].kc;
+            double Lc[NU][NU]; bool pd = true;
+#pragma unroll
+            for (int i = 0; i < NU; i++) {
+#pragma unroll
+                for (int j = 0; j <= i; j++) {
+                    double s = L[L_SR + i * 44 + NS + j];
+                    for (int q = 0; q < j; q++) s -= Lc[i][q] * Lc[j][q];
+                    if (i == j) { if (!(s > 1e-13)) { pd = false; s = 1.0; } Lc[i][i] = BMPC_SQRT(s); }
+                    else Lc[i][j] = s / Lc[j][j];
+                }
+            }
+            if (lane == 0) L[L_FLAG] = pd ? 1.0 : 0.0;
+            if (pd && lane <= NW && lane != NS + 0 && !(lane > NS && lane < NW)) {
+                // lanes 0..34 (state columns) and lane 43 (gradient column): solve R k = -M_j,col
+                const int c = lane;
+#pragma unroll
+                for (int a = 0; a < NU; a++) kc[a] = -mc[NS + a];
+#pragma unroll
+                for (int i = 0; i < NU; i++) { double s = kc[i]; for (int q = 0; q < i; q++) s -= Lc[i][q] * kc[q]; kc[i] = s / Lc[i][i]; }
+#pragma unroll
+                for (int i = NU - 1; i >= 0; i--) { double s = kc[i]; for (int q = i + 1; q < NU; q++) s -= Lc[q][i] * kc[q]; kc[i] = s / Lc[i][i]; }
+                if (c < NS) { for (int a = 0; a < NU; a++) G[sc.KT + (k * NS + c) * NU + a] = kc[a]; }
+                else { for (int a = 0; a < NU; a++) G[sc.KF + k * NU + a] = kc[a]; }
+                if (k >= 1) {
+#pragma unroll
+                    for (int r = 0; r < NS; r++) {
+                        double s = mc[r];
+#pragma unroll
+                        for (int a = 0; a < NU; a++) s += L[L_SR + a * 44 + r] * kc[a];
+                        if (c < NS) L[L_PM + r * 36 + c] = s; else L[L_PV + r] = s;
+                    }
+                }
+            }
+        LANES_END
+        if (L[L_FLAG] == 0.0) return false;
+    }
+    return true;
+}
+
+// forward sweep: dZ[N][44]
+BMPC_D inline void wave_forward(Wave &W, const Scr &sc) {
+    const int N = W.N; const double h = W.h;
+    double *L = W.L, *G = W.G;
+    LANES_BEGIN
+        if (lane < 36) L[L_DS + lane] = 0.0;
+    LANES_END
+    for (int k = 0; k < N; k++) {
+        LANES_BEGIN
+            if (lane < NU) { double s = G[sc.KF + k * NU + lane]; for (int b = 0; b < NS; b++) s += G[sc.KT + (k * NS + b) * NU + lane] * L[L_DS + b]; L[L_DU + lane] = s; }
+            for (int id = lane; id < KREC; id += 64) L[L_K0 + id] = G[sc.KIN + k * KREC + id];
+        LANES_END
+        LANES_BEGIN
+            if (lane < NS) {
+                const int r = lane; double v = G[sc.RDY + k * 36 + r];
+                const double *ds = L + L_DS, *du = L + L_DU;
+                if (r < 28 || (r >= SPHI && r <= SJPHI)) {
+                    const int f = r < 28 ? r / 7 : r - 28, i = r < 28 ? r % 7 : 7;
+                    for (int fc = 0; fc < 4; fc++) v += chain_cf(h, f, fc) * ds[srow(fc, i)];
+                    v += chain_cf(h, f, 4) * du[i];
+                } else {
+                    const int a = r - SIOTA; v += ds[r];
+                    for (int y = 0; y < 14; y++) v += G[sc.AES + k * 42 + a * 14 + y] * ds[y];
+                }
+                L[L_DSN + r] = v;
+            }
+        LANES_END
+        LANES_BEGIN
+            if (lane < NZ) {
+                const int z = lane; const double *dn = L + L_DSN, *K0 = L + L_K0; double v;
+                if (z < 7) v = dn[SJ + z]; else if (z == ZJPHI) v = dn[SJPHI];
+                else if (z < ZPOS) v = dn[z - ZQ];
+                else if (z < ZIW) { const int c = z - ZPOS; v = G[sc.RLV + k * 12 + c]; for (int i = 0; i < 7; i++) v += K0[KW + c * 7 + i] * dn[SQ + i]; }
+                else if (z < ZV) { const int c = z - ZIW; v = dn[SIOTA + c]; for (int i = 0; i < 7; i++) v += 0.5 * h * (K0[KD + (3 + c) * 7 + i] * dn[SQ + i] + K0[KA + c * 7 + i] * dn[SDQ + i]); }
+                else if (z < ZPHI) { const int c6 = z - ZV; v = G[sc.RLV + k * 12 + 3 + c6]; for (int y = 0; y < 14; y++) v += gv_at(K0, c6, y) * dn[y]; }
+                else v = dn[SPHI + z - ZPHI];
+                G[sc.DZ + k * NZ + z] = v;
+            }
+            if (lane < 36) L[L_DS + lane] = lane < NS ? L[L_DSN + lane] : 0.0;
+        LANES_END
+    }
+}
+
+// ----------------------------------------------------------------------------------------
+// main driver for one problem
+// ----------------------------------------------------------------------------------------
+BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
+    const int N = W.N, S = W.S;
+    double *L = W.L, *G = W.G;
+    const POff po = make_poff(S);
+    Scr sc = make_scr(N);
+    const Opts &o = W.o;
+    const int np = po.size, nw = N * NZ, ni = N * NI, ne = N * NE;
+#ifdef BMPC_EMU
+    LaneRegs LRs[64];
+#else
+    LaneRegs LRs[1];
+#endif
+    // ---- coalesced load of the parameter vector into LDS and of x0 into the scratch slab ----
+    LANES_BEGIN
+        for (int id = lane; id < np; id += 64) L[L_PAR + id] = pr.p[id];
+        for (int id = lane; id < nw; id += 64) G[sc.Z + id] = pr.x0[id];
+    LANES_END
+    const double *PAR = L + L_PAR;
+    double mu = o.mu_init; const double mu_min = o.tol * o.mu_min_fac;
+    double rho = 1.0, delta_last = 0.0;
+    double fval = wave_eval(W, po, sc, sc.Z, sc.G, sc.HIN);
+    LANES_BEGIN
+        for (int id = lane; id < ni; id += 64) { const double hv = G[sc.HIN + id]; const double t = (-hv > o.slack_push) ? -hv : o.slack_push; G[sc.T + id] = t; G[sc.NUm + id] = mu / t; }
+    LANES_END
+    int it = 0, status = 1; double E0 = 0;
+    for (it = 0; it <= o.max_iter; it++) {
+        wave_adjoint(W, po, sc, sc.NUm, false, 0.0);
+        // ---- KKT error (Ipopt-style scaling), deterministic reductions ----
+        LANES_BEGIN
+            double ed = 0, ep = 0, cmax = -1e300, cmin = 1e300, sl = 0, sn = 0;
+            for (int id = lane; id < N * NU; id += 64) { const double v = BMPC_FABS(G[sc.RJ + id]); ed = v > ed ? v : ed; }
+            for (int id = lane; id < ne; id += 64) { const double v = BMPC_FABS(G[sc.G + id]); ep = v > ep ? v : ep; sl += BMPC_FABS(G[sc.LAM + id]); }
+            for (int id = lane; id < ni; id += 64) {
+                const double t = G[sc.T + id], nu = G[sc.NUm + id], v = BMPC_FABS(G[sc.HIN + id] + t), c = nu * t;
+                ep = v > ep ? v : ep; cmax = c > cmax ? c : cmax; cmin = c < cmin ? c : cmin; sn += nu;
+            }
+            L[L_RED + lane] = ed; L[L_RED + 64 + lane] = ep; L[L_RED + 128 + lane] = cmax; L[L_RED + 192 + lane] = cmin;
+            L[L_RED + 256 + lane] = sl; L[L_RED + 320 + lane] = sn;
+        LANES_END
+        const double ed = red_max(L + L_RED), ep = red_max(L + L_RED + 64), cmax = red_max(L + L_RED + 128), cmin = red_min(L + L_RED + 192),
+                     sl = red_sum(L + L_RED + 256), sn = red_sum(L + L_RED + 320);
+        const double sd = BMPC_FMAX(100.0, (sl + sn) / (N * (NE + NI))) / 100.0, scl = BMPC_FMAX(100.0, sn / (N * NI)) / 100.0;
+        E0 = BMPC_FMAX(BMPC_FMAX(ed / sd, ep), BMPC_FMAX(cmax, -cmin) / scl);
+        if (E0 <= o.tol) { status = 0; break; }
+        if (it == o.max_iter) break;
+        for (;;) {   // monotone barrier update (Fiacco-McCormick, Ipopt constants)
+            const double ec = BMPC_FMAX(cmax - mu, mu - cmin);
+            const double Emu = BMPC_FMAX(BMPC_FMAX(ed / sd, ep), ec / scl);
+            if (Emu <= 10.0 * mu && mu > mu_min) mu = BMPC_FMAX(mu_min, BMPC_FMIN(0.2 * mu, BMPC_POW15(mu))); else break;
+        }
+        // ---- Newton system: QP gradient, lifted residuals, Riccati ----
+        wave_adjoint(W, po, sc, sc.NUm, true, mu);
+        wave_prepare_rlv(W, sc);
+        double delta = 0.0; bool ok = false;
+        for (int tries = 0; tries < 40; tries++) {
+            if (wave_backward(W, po, sc, mu, delta, LRs)) { ok = true; break; }
+            if (delta == 0.0) delta = delta_last > 0 ? BMPC_FMAX(1e-20, delta_last / 3.0) : 1e-4;
+            else delta *= (delta_last > 0 ? 8.0 : 100.0);
+            if (delta > 1e20) break;
+        }
+        if (!ok) { status = 3; break; }
+        if (delta > 0) delta_last = delta;
+        wave_forward(W, sc);
+        // ---- slack / multiplier directions, fraction to the boundary, merit ingredients ----
+        const double tau = BMPC_FMAX(0.99, 1.0 - mu);
+        LANES_BEGIN
+            double ap = 1.0, ad = 1.0, dbar = 0, nhd = 0, th = 0, bar = 0;
+            for (int id = lane; id < ni; id += 64) {
+                const int k = id / NI, i = id - k * NI;
+                const double t = G[sc.T + id], nu = G[sc.NUm + id], r = G[sc.HIN + id] + t;
+                const double hd = ineq_dir(G + sc.DZ + k * NZ, G + sc.REF + k * RREC, i);
+                const double dt = -r - hd, dnu = mu / t - nu - nu / t * dt;
+                G[sc.DT + id] = dt; G[sc.DNU + id] = dnu;
+                if (dt < 0) { const double a = -tau * t / dt; ap = a < ap ? a : ap; }
+                if (dnu < 0) { const double a = -tau * nu / dnu; ad = a < ad ? a : ad; }
+                dbar += -mu * dt / t; nhd += (mu + nu * r) / t * hd; th += BMPC_FABS(r); bar -= mu * BMPC_LOG(t);
+            }
+            double ghd = 0;
+            for (int id = lane; id < nw; id += 64) ghd += G[sc.GH + id] * G[sc.DZ + id];
+            for (int id = lane; id < ne; id += 64) th += BMPC_FABS(G[sc.G + id]);
+            L[L_RED + lane] = ap; L[L_RED + 64 + lane] = ad; L[L_RED + 128 + lane] = dbar; L[L_RED + 192 + lane] = ghd - nhd;
+            L[L_RED + 256 + lane] = th; L[L_RED + 320 + lane] = bar;
+        LANES_END
+        const double ap = red_min(L + L_RED), ad = red_min(L + L_RED + 64), dbar = red_sum(L + L_RED + 128), gfd = red_sum(L + L_RED + 192),
+                     theta = red_sum(L + L_RED + 256), bar = red_sum(L + L_RED + 320);
+        const double dphi = gfd + dbar;
+        if (theta > 1e-14) { const double rt = dphi / (0.9 * theta); if (rho < rt) rho = rt + 1.0; }
+        const double D = dphi - rho * theta, phi0 = fval + bar + rho * theta;
+        double alpha = ap, ft = 0;
+        for (int ls = 0; ls < 30; ls++) {
+            LANES_BEGIN
+                for (int id = lane; id < nw; id += 64) G[sc.ZT + id] = G[sc.Z + id] + alpha * G[sc.DZ + id];
+                for (int id = lane; id < ni; id += 64) G[sc.TT + id] = G[sc.T + id] + alpha * G[sc.DT + id];
+            LANES_END
+            ft = wave_eval(W, po, sc, sc.ZT, sc.GT, sc.HT);
+            LANES_BEGIN
+                double th = 0, br = 0;
+                for (int id = lane; id < ne; id += 64) th += BMPC_FABS(G[sc.GT + id]);
+                for (int id = lane; id < ni; id += 64) { const double t = G[sc.TT + id]; th += BMPC_FABS(G[sc.HT + id] + t); br -= mu * BMPC_LOG(t); }
+                L[L_RED + lane] = th; L[L_RED + 64 + lane] = br;
+            LANES_END
+            const double tht = red_sum(L + L_RED), brt = red_sum(L + L_RED + 64);
+            const double phi = ft + brt + rho * tht;
+            if (phi <= phi0 + 1e-4 * alpha * D + 1e-13 * BMPC_FABS(phi0)) break;
+            alpha *= 0.5;
+        }
+        // accept the last trial (swap primary / trial slabs), update multipliers
+        { int t_; t_ = sc.Z; sc.Z = sc.ZT; sc.ZT = t_; t_ = sc.T; sc.T = sc.TT; sc.TT = t_; t_ = sc.G; sc.G = sc.GT; sc.GT = t_; t_ = sc.HIN; sc.HIN = sc.HT; sc.HT = t_; }
+        fval = ft;
+        LANES_BEGIN
+            for (int id = lane; id < ni; id += 64) {
+                const double t = G[sc.T + id]; double v = G[sc.NUm + id] + ad * G[sc.DNU + id];
+                const double lo = mu / (1e10 * t), hi = 1e10 * mu / t;
+                v = v < lo ? lo : (v > hi ? hi : v);
+                G[sc.NUm + id] = v;
+            }
+        LANES_END
+    }
+    // ---- outputs in the reference's conventions (casadi nlpsol: x, g, lam_g, lam_x, f) ----
+    LANES_BEGIN
+        if (pr.x) for (int id = lane; id < nw; id += 64) pr.x[id] = G[sc.Z + id];
+        for (int id = lane; id < N * NG; id += 64) {
+            const int k = id / NG, i = id - k * NG;
+            const double *Zn = G + sc.Z + k * NZ, *rr = G + sc.REF + k * RREC, *nu = G + sc.NUm + k * NI;
+            double gv, lv;
+            if (i < NE) { gv = G[sc.G + k * NE + i]; lv = G[sc.LAM + k * NE + i]; }
+            else if (i == 36) { gv = Zn[ZPHI] - PAR[po.phimax]; lv = nu[IPHIMAX]; }
+            else if (i == 37) { gv = Zn[ZDPHI] - PAR[po.dphimax]; lv = nu[IDPHIMAX]; }
+            else { const int m = i - 38; const double c = rr[RC + m], wd = rr[RWD + m]; gv = c * c - wd * wd; lv = wd > 0 ? (nu[ITUBE + 2 * m] + nu[ITUBE + 2 * m + 1]) / (2 * wd) : 0.0; }
+            if (pr.g) pr.g[id] = gv;
+            if (pr.lam_g) pr.lam_g[id] = lv;
+        }
+        if (pr.lam_x) for (int id = lane; id < nw; id += 64) {
+            const int k = id / NZ, z = id - k * NZ; const double *nu = G + sc.NUm + k * NI; double v = 0;
+            if (z < 8) v = nu[IJU + z] - nu[IJL + z]; else if (z < ZDQ) v = nu[IQU + z - ZQ] - nu[IQL + z - ZQ];
+            else if (z < ZDDQ) v = nu[IDQU + z - ZDQ] - nu[IDQL + z - ZDQ]; else if (z == ZPHI) v = -nu[IPHI0];
+            pr.lam_x[id] = v;
+        }
+        if (lane == 0) {
+            if (pr.f) *pr.f = fval; if (pr.iters) *pr.iters = it; if (pr.status) *pr.status = status; if (pr.kkt) *pr.kkt = E0;
+        }
+    LANES_END
+}
+
+}  // namespace bmpc

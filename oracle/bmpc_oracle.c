@@ -1060,3 +1060,25 @@ int bmpc_oracle_solve(int N, int S, double h, const bmpc_oracle_opts *opts, int 
     }
     return 0;
 }
+
+/* debug: reduced QP data and Riccati gains at (x, t, nu, mu) */
+int bmpc_oracle_debug_qp(int N, int S, double h, const double *p, const double *x, const double *t, const double *nu, double mu, int exact,
+                         double delta, double *Qt, double *qt, double *Xt, double *A, double *rdyn, double *T, double *rloc, double *Kg,
+                         double *kff, double *dZ) {
+    Cfg C; C.N = N; C.S = S; C.h = h; C.np = 141 + 91 * S; bmpc_oracle_default_opts(&C.o); C.o.exact_hessian = exact;
+    Par P; par_view(p, S, &P);
+    Work *W = work_alloc(N);
+    memcpy(W->Z, x, sizeof(double) * N * NZ); memcpy(W->t, t, sizeof(double) * N * NI); memcpy(W->nu, nu, sizeof(double) * N * NI);
+    eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
+    adjoint(&C, &P, W, W->Z, W->nu, W->lam, W->Rj, W->gradZ);
+    double *sg = (double *)malloc(N * NI * sizeof(double)), *nuh = (double *)malloc(N * NI * sizeof(double));
+    for (int i = 0; i < N * NI; i++) { sg[i] = nu[i] / t[i]; nuh[i] = (mu + nu[i] * (W->hin[i] + t[i])) / t[i]; }
+    build_qp(&C, &P, W, sg, nuh);
+    memcpy(Qt, W->Qt, sizeof(double) * N * NS * NS); memcpy(qt, W->qt, sizeof(double) * N * NS); memcpy(Xt, W->Xt, sizeof(double) * N * NS * NS);
+    memcpy(A, W->A, sizeof(double) * N * NS * NW); memcpy(rdyn, W->rdyn, sizeof(double) * N * NS);
+    memcpy(T, W->T, sizeof(double) * N * NZ * NS); memcpy(rloc, W->rloc, sizeof(double) * N * NZ);
+    int ok = riccati(&C, W, delta);
+    memcpy(Kg, W->Kg, sizeof(double) * N * NU * NS); memcpy(kff, W->kff, sizeof(double) * N * NU); memcpy(dZ, W->dZ, sizeof(double) * N * NZ);
+    free(sg); free(nuh); work_free(W);
+    return ok ? 0 : 3;
+}

@@ -1,0 +1,86 @@
+// TEST-ONLY lane emulator of the wave program (boundmpc_amd/csrc/bmpc_wave.inl).
+//
+// Compiles the SAME kernel text with g++ and executes each phase as a loop over the 64 lanes
+// in a caller-chosen order.  It exists so the kernel's indexing, phase structure and numerics
+// can be unit-tested in a container without a GPU (pytest -m "not gpu"), and so that
+// intra-phase cross-lane dependences show up as order-dependent results.  It is NOT part of
+// the product: boundmpc_amd never builds, loads or falls back to it.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define BMPC_EMU 1
+#define BMPC_HD
+#define BMPC_D
+#define BMPC_SINCOS(x, s, c) (*(s) = std::sin(x), *(c) = std::cos(x))
+#define BMPC_EXP(x) std::exp(x)
+#define BMPC_LOG(x) std::log(x)
+#define BMPC_SQRT(x) std::sqrt(x)
+#define BMPC_FABS(x) std::fabs(x)
+#define BMPC_FMAX(a, b) std::fmax(a, b)
+#define BMPC_FMIN(a, b) std::fmin(a, b)
+#define BMPC_POW15(x) ((x) * std::sqrt(x))
+#define LANES_BEGIN for (int li_ = 0; li_ < 64; ++li_) { const int lane = W.order[li_]; (void)lane;
+#define LANES_END }
+#define LIDX lane
+
+#include "../../boundmpc_amd/csrc/bmpc_wave.inl"
+
+extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, int B, const double *p, const double *x0, double *x, double *g,
+                              double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, int lane_order, int nthreads) {
+    if (S > bmpc::SMAX || S < 2 || N < 1 || N > 32) return 1;
+    const bmpc::Scr sc = bmpc::make_scr(N);
+    const int np = 141 + 91 * S, nw = N * bmpc::NZ, ng = N * bmpc::NG;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+    {
+        std::vector<double> lds(bmpc::L_SIZE, 0.0), scr(sc.size, 0.0);
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < B; b++) {
+            bmpc::Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = scr.data();
+            for (int i = 0; i < 64; i++) W.order[i] = lane_order == 0 ? i : (lane_order == 1 ? 63 - i : (i * 37 + 11) % 64);
+            bmpc::Problem pr;
+            pr.p = p + (size_t)b * np; pr.x0 = x0 + (size_t)b * nw;
+            pr.x = x ? x + (size_t)b * nw : nullptr; pr.g = g ? g + (size_t)b * ng : nullptr;
+            pr.lam_g = lam_g ? lam_g + (size_t)b * ng : nullptr; pr.lam_x = lam_x ? lam_x + (size_t)b * nw : nullptr;
+            pr.f = f ? f + b : nullptr; pr.kkt = kkt ? kkt + b : nullptr; pr.iters = iters ? iters + b : nullptr; pr.status = status ? status + b : nullptr;
+            bmpc::wave_solve(W, pr);
+        }
+    }
+    return 0;
+}
+// debug: one Newton direction at (x, t, nu, mu); dumps the scratch slab
+extern "C" int bmpc_emu_newton(int N, int S, double h, const bmpc::Opts *opts, const double *p, const double *x, const double *t, const double *nu,
+                               double mu, double delta, double *scratch_out, double *lds_out) {
+    using namespace bmpc;
+    const Scr sc = make_scr(N); const POff po = make_poff(S);
+    std::vector<double> lds(L_SIZE, 0.0), scr(sc.size, 0.0);
+    Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = scr.data();
+    for (int i = 0; i < 64; i++) W.order[i] = i;
+    for (int i = 0; i < po.size; i++) W.L[L_PAR + i] = p[i];
+    for (int i = 0; i < N * NZ; i++) W.G[sc.Z + i] = x[i];
+    for (int i = 0; i < N * NI; i++) { W.G[sc.T + i] = t[i]; W.G[sc.NUm + i] = nu[i]; }
+    wave_eval(W, po, sc, sc.Z, sc.G, sc.HIN);
+    wave_adjoint(W, po, sc, sc.NUm, false, 0.0);
+    wave_adjoint(W, po, sc, sc.NUm, true, mu);
+    wave_prepare_rlv(W, sc);
+    LaneRegs LRs[64];
+    bool ok = wave_backward(W, po, sc, mu, delta, LRs);
+    if (ok) wave_forward(W, sc);
+    memcpy(scratch_out, scr.data(), sizeof(double) * sc.size);
+    memcpy(lds_out, lds.data(), sizeof(double) * L_SIZE);
+    return ok ? 0 : 3;
+}
+extern "C" void bmpc_emu_scr_offsets(int N, int *out) {
+    const bmpc::Scr s = bmpc::make_scr(N);
+    int v[] = {s.Z, s.ZT, s.T, s.TT, s.NUm, s.LAM, s.G, s.GT, s.HIN, s.HT, s.DZ, s.DT, s.DNU, s.GH, s.GVP, s.RJ, s.KIN, s.REF, s.KT, s.KF, s.RDY, s.AES, s.RLV, s.size};
+    for (unsigned i = 0; i < sizeof(v) / sizeof(int); i++) out[i] = v[i];
+}
+extern "C" int bmpc_emu_lds_doubles() { return bmpc::L_SIZE; }
+extern "C" int bmpc_emu_scratch_doubles(int N) { return bmpc::make_scr(N).size; }

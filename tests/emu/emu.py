@@ -1,0 +1,60 @@
+"""TEST-ONLY: ctypes binding of the CPU lane emulator of the wave program (tests/emu/bmpc_emu.cpp).
+Not part of the product; see the header of bmpc_emu.cpp."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libbmpc_emu.so")
+_SRC = [os.path.join(_HERE, "bmpc_emu.cpp"), os.path.join(_HERE, "..", "..", "boundmpc_amd", "csrc", "bmpc_wave.inl")]
+
+
+class Opts(ctypes.Structure):
+    _fields_ = [("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("mu_init", ctypes.c_double),
+                ("mu_min_fac", ctypes.c_double), ("slack_push", ctypes.c_double),
+                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_LIB) or any(os.path.getmtime(_LIB) < os.path.getmtime(s) for s in _SRC):
+        subprocess.check_call(["g++", "-O2", "-fopenmp", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas",
+                               "-o", _LIB, _SRC[0]])
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = ctypes.CDLL(_LIB)
+    return _lib
+
+
+def default_opts(**kw):
+    o = Opts(1e-6, 500, 0.1, 0.1, 1e-2, 1, 0)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def solve(p, x0, N, S, h, opts=None, lane_order=0, nthreads=0):
+    p = np.ascontiguousarray(np.atleast_2d(p), dtype=np.float64)
+    x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
+    B = p.shape[0]
+    out = dict(x=np.zeros((B, N * 44)), g=np.zeros((B, N * 43)), lam_g=np.zeros((B, N * 43)), lam_x=np.zeros((B, N * 44)),
+               f=np.zeros(B), iters=np.zeros(B, dtype=np.int32), status=np.zeros(B, dtype=np.int32), kkt=np.zeros(B))
+    o = opts if opts is not None else default_opts()
+    rc = lib().bmpc_emu_solve(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(B), _p(p), _p(x0),
+                              _p(out["x"]), _p(out["g"]), _p(out["lam_g"]), _p(out["lam_x"]), _p(out["f"]), _p(out["iters"]),
+                              _p(out["status"]), _p(out["kkt"]), ctypes.c_int(lane_order), ctypes.c_int(nthreads))
+    assert rc == 0
+    return out
