@@ -1,0 +1,58 @@
+"""ctypes binding of the C ABI in include/boundmpc_hip.h (libboundmpc_hip.so).
+
+There is deliberately NO CPU fallback: if the HIP extension is missing or no GPU is present
+the import / create call raises."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libboundmpc_hip.so")
+
+SYMBOLS = ["bmpc_default_options", "bmpc_error_string", "bmpc_create", "bmpc_destroy", "bmpc_num_vars", "bmpc_num_cons",
+           "bmpc_num_params", "bmpc_get_bounds", "bmpc_solve_batch", "bmpc_solve_batch_host", "bmpc_set_timing",
+           "bmpc_last_kernel_ms", "bmpc_launch_info"]
+
+
+class Options(ctypes.Structure):
+    _fields_ = [("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("mu_init", ctypes.c_double),
+                ("mu_min_fac", ctypes.c_double), ("slack_push", ctypes.c_double),
+                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int)]
+
+
+class BoundMPCHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BoundMPCHipError(
+            f"HIP extension {LIB_PATH} is missing - build it with `python -m boundmpc_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+    lib.bmpc_default_options.argtypes = [ctypes.POINTER(Options)]
+    lib.bmpc_error_string.restype = ctypes.c_char_p
+    lib.bmpc_error_string.argtypes = [ci]
+    lib.bmpc_create.argtypes = [ci, ci, cd, ctypes.POINTER(Options), ctypes.POINTER(vp)]
+    lib.bmpc_destroy.argtypes = [vp]
+    for n in ("bmpc_num_vars", "bmpc_num_cons", "bmpc_num_params"):
+        getattr(lib, n).argtypes = [vp]
+    lib.bmpc_get_bounds.argtypes = [vp, vp, vp, vp, vp]
+    lib.bmpc_solve_batch.argtypes = [vp, ci] + [vp] * 11
+    lib.bmpc_solve_batch_host.argtypes = [vp, ci] + [vp] * 10
+    lib.bmpc_set_timing.argtypes = [vp, ci]
+    lib.bmpc_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.bmpc_launch_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_longlong)]
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise BoundMPCHipError(f"{what} failed: {load().bmpc_error_string(rc).decode()} (code {rc})")

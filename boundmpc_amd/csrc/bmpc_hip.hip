@@ -1,0 +1,183 @@
+// bmpc_hip.hip -- gfx950 kernel + C ABI (include/boundmpc_hip.h) of the batched BoundMPC OCP solver.
+// One problem per 64-lane wavefront (one wave per workgroup); persistent workgroups pull problems
+// from an atomic work queue so per-problem iteration counts load-balance; per-wave LDS working
+// set + per-wave global scratch slab (see bmpc_wave.inl for the algorithm and the lane maps).
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/boundmpc_hip.h"
+
+#define BMPC_HD __host__ __device__
+#define BMPC_D __device__ __forceinline__
+#define BMPC_SINCOS(x, s, c) sincos(x, s, c)
+#define BMPC_EXP(x) exp(x)
+#define BMPC_LOG(x) log(x)
+#define BMPC_SQRT(x) sqrt(x)
+#define BMPC_FABS(x) fabs(x)
+#define BMPC_FMAX(a, b) fmax(a, b)
+#define BMPC_FMIN(a, b) fmin(a, b)
+#define BMPC_POW15(x) ((x) * sqrt(x))
+#define LANES_BEGIN { const int lane = threadIdx.x; (void)lane;
+#define LANES_END } __syncthreads();
+#define LIDX 0
+
+#include "bmpc_wave.inl"
+
+struct KArgs {
+    int N, S, B; double h; bmpc::Opts o;
+    const double *p, *x0; double *x, *g, *lam_g, *lam_x, *f, *kkt; int *iters, *status;
+    double *scratch; long long scr_stride; int *counter;
+};
+
+__global__ void __launch_bounds__(64) bmpc_solve_kernel(KArgs a) {
+    __shared__ double lds[bmpc::L_SIZE];
+    bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = a.scratch + (long long)blockIdx.x * a.scr_stride;
+    const int np = 141 + 91 * a.S, nw = a.N * bmpc::NZ, ng = a.N * bmpc::NG;
+    for (;;) {
+        int b = 0;
+        if (threadIdx.x == 0) b = atomicAdd(a.counter, 1);
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (b >= a.B) break;             // every wave reaches this exit: the queue is finite
+        bmpc::Problem pr;
+        pr.p = a.p + (long long)b * np; pr.x0 = a.x0 + (long long)b * nw;
+        pr.x = a.x ? a.x + (long long)b * nw : nullptr; pr.g = a.g ? a.g + (long long)b * ng : nullptr;
+        pr.lam_g = a.lam_g ? a.lam_g + (long long)b * ng : nullptr; pr.lam_x = a.lam_x ? a.lam_x + (long long)b * nw : nullptr;
+        pr.f = a.f ? a.f + b : nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr;
+        pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status ? a.status + b : nullptr;
+        bmpc::wave_solve(W, pr);
+        __syncthreads();
+    }
+}
+
+struct bmpc_handle {
+    int N, S; double h; bmpc_options o;
+    int grid; long long scr_stride; double *scratch; int *counter;
+    int timing; hipEvent_t ev0, ev1; int have_ev;
+};
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "boundmpc_hip: %s failed: %s\n", #x, hipGetErrorString(e_)); return BMPC_ERR_HIP; } } while (0)
+
+extern "C" int bmpc_default_options(bmpc_options *o) {
+    if (!o) return BMPC_ERR_ARG;
+    o->tol = 1e-6; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0;
+    return BMPC_OK;
+}
+extern "C" const char *bmpc_error_string(int c) {
+    switch (c) { case BMPC_OK: return "ok"; case BMPC_ERR_ARG: return "invalid argument"; case BMPC_ERR_HIP: return "HIP runtime error";
+                 case BMPC_ERR_NOGPU: return "no HIP device available"; default: return "unknown error"; }
+}
+extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bmpc_handle **out) {
+    if (!out || N < 1 || N > 32 || S < 2 || S > bmpc::SMAX || !(dt > 0)) return BMPC_ERR_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BMPC_ERR_NOGPU;
+    bmpc_handle *h = new (std::nothrow) bmpc_handle();
+    if (!h) return BMPC_ERR_ARG;
+    h->N = N; h->S = S; h->h = dt; h->timing = 0; h->have_ev = 0;
+    if (opts) h->o = *opts; else bmpc_default_options(&h->o);
+    int dev = 0; HIPCHK(hipGetDevice(&dev));
+    hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, dev));
+    int per_cu = 0;
+    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel, 64, 0));
+    if (per_cu < 1) per_cu = 1;
+    h->grid = per_cu * prop.multiProcessorCount;
+    h->scr_stride = bmpc::make_scr(N).size;
+    HIPCHK(hipMalloc(&h->scratch, sizeof(double) * (size_t)h->scr_stride * h->grid));
+    HIPCHK(hipMalloc(&h->counter, sizeof(int)));
+    *out = h;
+    return BMPC_OK;
+}
+extern "C" int bmpc_destroy(bmpc_handle *h) {
+    if (!h) return BMPC_ERR_ARG;
+    if (h->have_ev) { hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); }
+    hipFree(h->scratch); hipFree(h->counter);
+    delete h;
+    return BMPC_OK;
+}
+extern "C" int bmpc_num_vars(const bmpc_handle *h) { return h ? h->N * bmpc::NZ : -1; }
+extern "C" int bmpc_num_cons(const bmpc_handle *h) { return h ? h->N * bmpc::NG : -1; }
+extern "C" int bmpc_num_params(const bmpc_handle *h) { return h ? 141 + 91 * h->S : -1; }
+
+extern "C" int bmpc_get_bounds(const bmpc_handle *h, double *lbx, double *ubx, double *lbg, double *ubg) {
+    if (!h) return BMPC_ERR_ARG;
+    // casadi_ocp_formulation.py:92-153 (variables) and :272-349 (constraints); limits RobotModel.py:20-43
+    const double qd[7] = {165, 115, 165, 115, 165, 115, 170}, dqd[7] = {85, 85, 100, 75, 130, 135, 135};
+    const double inf = INFINITY, pi = 3.14159265358979323846;
+    for (int k = 0; k < h->N; k++) {
+        double *l = lbx ? lbx + k * 44 : nullptr, *u = ubx ? ubx + k * 44 : nullptr;
+        for (int i = 0; i < 44; i++) {
+            double lo = -inf, hi = inf;
+            if (i < 8) { lo = -35.0; hi = 35.0; }
+            else if (i < 15) { hi = qd[i - 8] * pi / 180; lo = -hi; }
+            else if (i < 22) { hi = dqd[i - 15] * pi / 180; lo = -hi; }
+            else if (i == 41) { lo = 0.0; }
+            if (l) l[i] = lo; if (u) u[i] = hi;
+        }
+        for (int i = 0; i < 43; i++) { if (lbg) lbg[k * 43 + i] = i < 36 ? 0.0 : -inf; if (ubg) ubg[k * 43 + i] = 0.0; }
+    }
+    return BMPC_OK;
+}
+
+extern "C" int bmpc_solve_batch(bmpc_handle *h, int B, const double *p, const double *x0, double *x, double *g, double *lam_g, double *lam_x,
+                                double *f, int *iters, int *status, double *kkt, void *hip_stream) {
+    if (!h || B < 0 || (B > 0 && (!p || !x0 || !x))) return BMPC_ERR_ARG;
+    if (B == 0) return BMPC_OK;
+    hipStream_t st = (hipStream_t)hip_stream;
+    KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
+    a.o.tol = h->o.tol; a.o.max_iter = h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
+    a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0;
+    a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = lam_g; a.lam_x = lam_x; a.f = f; a.kkt = kkt; a.iters = iters; a.status = status;
+    a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter;
+    HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), st));
+    const int grid = B < h->grid ? B : h->grid;
+    if (h->timing) {
+        if (!h->have_ev) { HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1)); h->have_ev = 1; }
+        HIPCHK(hipEventRecord(h->ev0, st));
+    }
+    hipLaunchKernelGGL(bmpc_solve_kernel, dim3(grid), dim3(64), 0, st, a);
+    HIPCHK(hipGetLastError());
+    if (h->timing) HIPCHK(hipEventRecord(h->ev1, st));
+    return BMPC_OK;
+}
+
+extern "C" int bmpc_solve_batch_host(bmpc_handle *h, int B, const double *p, const double *x0, double *x, double *g, double *lam_g, double *lam_x,
+                                     double *f, int *iters, int *status, double *kkt) {
+    if (!h || B < 0 || (B > 0 && (!p || !x0 || !x))) return BMPC_ERR_ARG;
+    if (B == 0) return BMPC_OK;
+    const size_t np = 141 + 91 * h->S, nw = (size_t)h->N * 44, ng = (size_t)h->N * 43;
+    double *dp = nullptr, *dx0 = nullptr, *dx = nullptr, *dg = nullptr, *dlg = nullptr, *dlx = nullptr, *df = nullptr, *dk = nullptr; int *dit = nullptr, *dst = nullptr;
+    int rc = BMPC_OK;
+#define TRY(x) do { if (rc == BMPC_OK && (x) != hipSuccess) rc = BMPC_ERR_HIP; } while (0)
+    TRY(hipMalloc(&dp, B * np * 8)); TRY(hipMalloc(&dx0, B * nw * 8)); TRY(hipMalloc(&dx, B * nw * 8)); TRY(hipMalloc(&dg, B * ng * 8));
+    TRY(hipMalloc(&dlg, B * ng * 8)); TRY(hipMalloc(&dlx, B * nw * 8)); TRY(hipMalloc(&df, B * 8)); TRY(hipMalloc(&dk, B * 8));
+    TRY(hipMalloc(&dit, B * 4)); TRY(hipMalloc(&dst, B * 4));
+    TRY(hipMemcpy(dp, p, B * np * 8, hipMemcpyHostToDevice)); TRY(hipMemcpy(dx0, x0, B * nw * 8, hipMemcpyHostToDevice));
+    if (rc == BMPC_OK) rc = bmpc_solve_batch(h, B, dp, dx0, dx, dg, dlg, dlx, df, dit, dst, dk, nullptr);
+    TRY(hipDeviceSynchronize());
+    TRY(hipMemcpy(x, dx, B * nw * 8, hipMemcpyDeviceToHost));
+    if (g) TRY(hipMemcpy(g, dg, B * ng * 8, hipMemcpyDeviceToHost));
+    if (lam_g) TRY(hipMemcpy(lam_g, dlg, B * ng * 8, hipMemcpyDeviceToHost));
+    if (lam_x) TRY(hipMemcpy(lam_x, dlx, B * nw * 8, hipMemcpyDeviceToHost));
+    if (f) TRY(hipMemcpy(f, df, B * 8, hipMemcpyDeviceToHost));
+    if (kkt) TRY(hipMemcpy(kkt, dk, B * 8, hipMemcpyDeviceToHost));
+    if (iters) TRY(hipMemcpy(iters, dit, B * 4, hipMemcpyDeviceToHost));
+    if (status) TRY(hipMemcpy(status, dst, B * 4, hipMemcpyDeviceToHost));
+#undef TRY
+    hipFree(dp); hipFree(dx0); hipFree(dx); hipFree(dg); hipFree(dlg); hipFree(dlx); hipFree(df); hipFree(dk); hipFree(dit); hipFree(dst);
+    return rc;
+}
+
+extern "C" int bmpc_set_timing(bmpc_handle *h, int enable) { if (!h) return BMPC_ERR_ARG; h->timing = enable ? 1 : 0; return BMPC_OK; }
+extern "C" int bmpc_last_kernel_ms(bmpc_handle *h, float *ms) {
+    if (!h || !ms || !h->have_ev) return BMPC_ERR_ARG;
+    HIPCHK(hipEventSynchronize(h->ev1));
+    HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return BMPC_OK;
+}
+extern "C" int bmpc_launch_info(const bmpc_handle *h, int *grid, int *lds_bytes, long long *scratch_bytes) {
+    if (!h) return BMPC_ERR_ARG;
+    if (grid) *grid = h->grid; if (lds_bytes) *lds_bytes = (int)(bmpc::L_SIZE * sizeof(double)); if (scratch_bytes) *scratch_bytes = h->scr_stride * 8;
+    return BMPC_OK;
+}

@@ -1,0 +1,138 @@
+"""Batched OCP solver handle and the CasADi-`nlpsol`-compatible single-problem shim.
+
+`BatchedOCPSolver` is the torch-facing wrapper of the C ABI (PyTorch-ROCm tensors are used
+for device memory and streams only).  `NlpSolverShim` mirrors the call convention of the
+object the reference creates at casadi_ocp_formulation.py:389 and calls at
+BoundMPC.py:446-456, so that `BoundMPC.step()` reads like the reference's."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+NZ, NG = 44, 43
+
+
+class BatchedOCPSolver:
+    def __init__(self, N, S, dt, tol=1e-6, max_iter=500, mu_init=0.1, slack_push=1e-2, exact_hessian=True):
+        self._lib = _lib.load()
+        o = _lib.Options()
+        self._lib.bmpc_default_options(ctypes.byref(o))
+        o.tol, o.max_iter, o.mu_init, o.slack_push, o.exact_hessian = tol, int(max_iter), mu_init, slack_push, int(exact_hessian)
+        self._h = ctypes.c_void_p()
+        _lib.check(self._lib.bmpc_create(int(N), int(S), float(dt), ctypes.byref(o), ctypes.byref(self._h)), "bmpc_create")
+        self.N, self.S, self.dt = int(N), int(S), float(dt)
+        self.n_w, self.n_g, self.n_p = N * NZ, N * NG, 141 + 91 * S
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.bmpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- structural constants (casadi_ocp_formulation.py:384-391) ----
+    def bounds(self):
+        lbx, ubx, lbg, ubg = np.zeros(self.n_w), np.zeros(self.n_w), np.zeros(self.n_g), np.zeros(self.n_g)
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(self._lib.bmpc_get_bounds(self._h, vp(lbx), vp(ubx), vp(lbg), vp(ubg)), "bmpc_get_bounds")
+        return lbx, ubx, lbg, ubg
+
+    def launch_info(self):
+        g, l, s = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
+        self._lib.bmpc_launch_info(self._h, ctypes.byref(g), ctypes.byref(l), ctypes.byref(s))
+        return dict(grid=g.value, lds_bytes=l.value, scratch_bytes=s.value)
+
+    def set_timing(self, on=True):
+        self._lib.bmpc_set_timing(self._h, int(on))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        _lib.check(self._lib.bmpc_last_kernel_ms(self._h, ctypes.byref(ms)), "bmpc_last_kernel_ms")
+        return ms.value
+
+    # ---- batched device solve ----
+    def solve_batch(self, p, x0, out=None, want=("g", "lam_g", "lam_x", "f", "iters", "status", "kkt"), stream=None):
+        """p [B][n_p], x0 [B][n_w]: CUDA(ROCm) float64 contiguous tensors.  Returns dict of tensors.
+        Asynchronous on `stream` (default: torch's current stream)."""
+        import torch
+        if not (p.is_cuda and x0.is_cuda and p.dtype == torch.float64 and x0.dtype == torch.float64):
+            raise ValueError("p and x0 must be float64 tensors on the GPU")
+        p, x0 = p.contiguous(), x0.contiguous()
+        B = p.shape[0]
+        if p.shape != (B, self.n_p) or x0.shape != (B, self.n_w):
+            raise ValueError(f"shape mismatch: p {tuple(p.shape)} x0 {tuple(x0.shape)}")
+        o = out if out is not None else {}
+        dev = p.device
+
+        def buf(name, shape, dtype):
+            if name not in o or o[name] is None:
+                o[name] = torch.empty(shape, dtype=dtype, device=dev)
+            return o[name]
+        x = buf("x", (B, self.n_w), torch.float64)
+        ptr = {k: None for k in ("g", "lam_g", "lam_x", "f", "iters", "status", "kkt")}
+        if "g" in want: ptr["g"] = buf("g", (B, self.n_g), torch.float64)
+        if "lam_g" in want: ptr["lam_g"] = buf("lam_g", (B, self.n_g), torch.float64)
+        if "lam_x" in want: ptr["lam_x"] = buf("lam_x", (B, self.n_w), torch.float64)
+        if "f" in want: ptr["f"] = buf("f", (B,), torch.float64)
+        if "iters" in want: ptr["iters"] = buf("iters", (B,), torch.int32)
+        if "status" in want: ptr["status"] = buf("status", (B,), torch.int32)
+        if "kkt" in want: ptr["kkt"] = buf("kkt", (B,), torch.float64)
+        st = stream if stream is not None else torch.cuda.current_stream(dev)
+        dp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(self._lib.bmpc_solve_batch(self._h, B, dp(p), dp(x0), dp(x), dp(ptr["g"]), dp(ptr["lam_g"]), dp(ptr["lam_x"]),
+                                              dp(ptr["f"]), dp(ptr["iters"]), dp(ptr["status"]), dp(ptr["kkt"]),
+                                              ctypes.c_void_p(st.cuda_stream)), "bmpc_solve_batch")
+        return o
+
+    # ---- host-buffer solve (numpy in/out) ----
+    def solve_host(self, p, x0):
+        p = np.ascontiguousarray(np.atleast_2d(p), dtype=np.float64)
+        x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
+        B = p.shape[0]
+        if p.shape != (B, self.n_p) or x0.shape != (B, self.n_w):
+            raise ValueError(f"shape mismatch: p {p.shape} x0 {x0.shape}")
+        out = dict(x=np.zeros((B, self.n_w)), g=np.zeros((B, self.n_g)), lam_g=np.zeros((B, self.n_g)), lam_x=np.zeros((B, self.n_w)),
+                   f=np.zeros(B), iters=np.zeros(B, dtype=np.int32), status=np.zeros(B, dtype=np.int32), kkt=np.zeros(B))
+        vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        _lib.check(self._lib.bmpc_solve_batch_host(self._h, B, vp(p), vp(x0), vp(out["x"]), vp(out["g"]), vp(out["lam_g"]),
+                                                   vp(out["lam_x"]), vp(out["f"]), vp(out["iters"]), vp(out["status"]), vp(out["kkt"])),
+                   "bmpc_solve_batch_host")
+        return out
+
+
+_STATUS = {0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 3: "Error_In_Step_Computation"}
+
+
+class NlpSolverShim:
+    """Stands where `ca.nlpsol('solver','ipopt',prob,opts)` stands in the reference
+    (casadi_ocp_formulation.py:389): `sol = solver(x0=, lbx=, ubx=, lbg=, ubg=, p=)` returns a
+    dict with 'x','f','g','lam_x','lam_g' (column vectors like CasADi DMs); `stats()` returns
+    'iter_count', 'success', 'return_status' (BoundMPC.py:446-474)."""
+
+    def __init__(self, batched: BatchedOCPSolver):
+        self._s = batched
+        self._stats = {"iter_count": 0, "success": False, "return_status": "not run"}
+        self._lbx, self._ubx, self._lbg, self._ubg = batched.bounds()
+
+    def generate_dependencies(self, *a, **k):   # BoundMPC.py:155-157 -- nothing to generate
+        return None
+
+    def __call__(self, x0=None, lbx=None, ubx=None, lbg=None, ubg=None, p=None, lam_x0=None, lam_g0=None):
+        # the bound vectors are structural constants of the formulation; refuse silently different ones
+        for given, mine, nm in ((lbx, self._lbx, "lbx"), (ubx, self._ubx, "ubx"), (lbg, self._lbg, "lbg"), (ubg, self._ubg, "ubg")):
+            if given is not None and not np.array_equal(np.asarray(given, dtype=float).ravel(), mine):
+                raise ValueError(f"{nm} differs from the formulation's structural bounds (casadi_ocp_formulation.py:92-153,272-349)")
+        out = self._s.solve_host(np.asarray(p, dtype=float).ravel()[None, :], np.asarray(x0, dtype=float).ravel()[None, :])
+        st = int(out["status"][0])
+        self._stats = {"iter_count": int(out["iters"][0]), "success": st == 0, "return_status": _STATUS.get(st, f"status_{st}"),
+                       "kkt_error": float(out["kkt"][0])}
+        col = lambda a: np.asarray(a[0]).reshape(-1, 1)
+        return {"x": col(out["x"]), "f": float(out["f"][0]), "g": col(out["g"]), "lam_x": col(out["lam_x"]), "lam_g": col(out["lam_g"])}
+
+    def stats(self):
+        return dict(self._stats)

@@ -1,0 +1,88 @@
+/*
+ * boundmpc_hip.h -- C ABI of the MI355X-native batched BoundMPC OCP solver.
+ *
+ * Drop-in boundary.  In the reference (Thieso/BoundMPC) the per-step optimisation is one
+ * CasADi `nlpsol('solver','ipopt',...)` Function object created at
+ *   bound_mpc/bound_mpc/BoundMPC/casadi_ocp_formulation.py:389
+ * and invoked only at
+ *   bound_mpc/bound_mpc/BoundMPC/BoundMPC.py:446-453   sol = solver(x0=, lbx=, ubx=, lbg=, ubg=, p=)
+ *   bound_mpc/bound_mpc/BoundMPC/BoundMPC.py:456        stats = solver.stats()
+ * The reference defines no C ABI for it (it is a Python object backed by CasADi/Ipopt/MUMPS);
+ * the entry points below carry exactly the information that call carries, batched:
+ *
+ *   bmpc_create        <-> setup_optimization_problem(N, 7, nr_segs, dt, ...)  (casadi_ocp_formulation.py:9-11)
+ *                          + the Ipopt option dict (BoundMPC.py:120-148: tol, max_iter)
+ *   bmpc_get_bounds    <-> the lbu, ubu, lbg, ubg lists returned there (casadi_ocp_formulation.py:384-391)
+ *   bmpc_solve_batch   <-> solver(x0=, lbx=, ubx=, lbg=, ubg=, p=) -> {'x','f','g','lam_x','lam_g'}  (BoundMPC.py:446-453)
+ *                          and solver.stats() -> iter_count / success (BoundMPC.py:456-457), one record per problem
+ *   bmpc_destroy       <-> garbage collection of the Function object
+ *
+ * All arithmetic is fp64.  Layouts (row-major, one problem per row):
+ *   p      [B][n_p]   n_p = 141 + 91*S  parameter vector, layout of casadi_ocp_formulation.py:361-376
+ *   x0, x  [B][44*N]  stage variables z_k = [u(7) u_phi | q dq ddq | p(6) | v(6) | phi dphi ddphi] (:90-153)
+ *   g      [B][43*N]  constraints in the reference's order/form (:272-349)
+ *   lam_g  [B][43*N]  multipliers of g (sign: L = f + lam_g.g), lam_x [B][44*N] multipliers of lbx <= x <= ubx
+ *   f, kkt [B], iters [B], status [B]  (0 converged, 1 max_iter reached, 3 numerical failure)
+ * lbx/ubx/lbg/ubg are structural constants of the formulation (robot limits, 36 equalities
+ * + 7 inequalities per stage) and do not cross the ABI per call; bmpc_get_bounds returns them.
+ *
+ * Ownership: the caller owns every buffer; the library owns the handle and its device
+ * scratch.  Errors are integer return codes (no exceptions cross the ABI); per-problem
+ * failure is data (status[]), as in the reference (BoundMPC.py:465-489).
+ * Thread-safety: one in-flight bmpc_solve_batch per handle.
+ */
+#ifndef BOUNDMPC_HIP_H
+#define BOUNDMPC_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bmpc_handle bmpc_handle;
+
+typedef struct {
+    double tol;         /* KKT tolerance, Ipopt-style scaled error (reference: 'tol': 10e-6, BoundMPC.py:121); default 1e-6 */
+    int max_iter;       /* reference: 500 (BoundMPC.py:122) */
+    double mu_init;     /* initial barrier parameter (Ipopt default 0.1) */
+    double mu_min_fac;  /* final barrier = tol * mu_min_fac */
+    double slack_push;  /* minimum initial slack of an inequality row (Ipopt bound_push 1e-2) */
+    int exact_hessian;  /* 1: exact Lagrangian Hessian (reference uses CasADi's exact Hessian); 0: Gauss-Newton */
+    int verbose;
+} bmpc_options;
+
+enum { BMPC_OK = 0, BMPC_ERR_ARG = 1, BMPC_ERR_HIP = 2, BMPC_ERR_NOGPU = 4 };
+
+int bmpc_default_options(bmpc_options *o);
+const char *bmpc_error_string(int code);
+
+/* N horizon (1..32), S path segments in the window (2..4), dt sampling time */
+int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bmpc_handle **out);
+int bmpc_destroy(bmpc_handle *h);
+
+int bmpc_num_vars(const bmpc_handle *h);    /* 44 N */
+int bmpc_num_cons(const bmpc_handle *h);    /* 43 N */
+int bmpc_num_params(const bmpc_handle *h);  /* 141 + 91 S */
+
+/* HOST pointers, lengths 44N, 44N, 43N, 43N */
+int bmpc_get_bounds(const bmpc_handle *h, double *lbx, double *ubx, double *lbg, double *ubg);
+
+/* DEVICE pointers (e.g. torch-ROCm tensor.data_ptr()); g, lam_g, lam_x, f, iters, status, kkt may be NULL.
+ * hip_stream: hipStream_t to launch on (NULL = default stream).  Asynchronous w.r.t. the host. */
+int bmpc_solve_batch(bmpc_handle *h, int B, const double *p, const double *x0, double *x, double *g, double *lam_g, double *lam_x,
+                     double *f, int *iters, int *status, double *kkt, void *hip_stream);
+
+/* HOST pointers; copies in/out and synchronises (convenience for the single-problem solver(...) call) */
+int bmpc_solve_batch_host(bmpc_handle *h, int B, const double *p, const double *x0, double *x, double *g, double *lam_g, double *lam_x,
+                          double *f, int *iters, int *status, double *kkt);
+
+/* Timing of the solver kernel with HIP events on the launch stream: enable, solve, then read the
+ * duration of the last launch (synchronises on the stop event). */
+int bmpc_set_timing(bmpc_handle *h, int enable);
+int bmpc_last_kernel_ms(bmpc_handle *h, float *ms);
+
+/* launch geometry actually used: resident workgroups (one wave each), LDS bytes per workgroup, scratch bytes per workgroup */
+int bmpc_launch_info(const bmpc_handle *h, int *grid, int *lds_bytes, long long *scratch_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
