@@ -1,0 +1,191 @@
+"""Host-side mirror of the reference interface (boundmpc_amd.robot_model / reference_path / bound_mpc)
+against golden vectors generated from the reference's own numeric code.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from boundmpc_amd import bound_mpc as bm
+from boundmpc_amd import workload
+from boundmpc_amd.bound_mpc import BoundMPC, integrate_joint
+from boundmpc_amd.reference_path import ReferencePath
+from boundmpc_amd.robot_model import RobotModel
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_robot_model_g1():
+    d = np.load(os.path.join(G, "g1_kinematics.npz"))
+    rm = RobotModel()
+    for i in range(0, 256, 4):
+        q, dq, ddq = d["q"][i], d["dq"][i], d["ddq"][i]
+        np.testing.assert_allclose(rm.fk(q), d["fk"][i], atol=5e-15)
+        np.testing.assert_allclose(rm.jacobian_fk(q), d["jacobian_fk"][i], atol=5e-15)
+        np.testing.assert_allclose(rm.djacobian_fk(q, dq), d["djacobian_fk"][i], atol=2e-14)
+        np.testing.assert_allclose(rm.ddjacobian_fk(q, dq, ddq), d["ddjacobian_fk"][i], atol=2e-13)
+        np.testing.assert_allclose(rm.hom_transform_endeffector(q), d["hom"][i], atol=5e-15)
+        np.testing.assert_allclose(rm.velocity_ee(q, dq), d["velocity_ee"][i], atol=2e-14)
+        np.testing.assert_allclose(rm.omega_ee(q, dq), d["omega_ee"][i], atol=2e-14)
+    lim = d["limits"]
+    np.testing.assert_array_equal(lim, np.array([rm.q_lim_lower, rm.q_lim_upper, rm.dq_lim_lower, rm.dq_lim_upper]))
+
+
+def test_integrator_g2():
+    d = np.load(os.path.join(G, "g2_integrator.npz"))
+    h = float(d["h"])
+    for i in range(d["jm2"].shape[0]):
+        x, dx, ddx = bm.integrate_chain(d["q0"][i], d["dq0"][i], d["ddq0"][i], d["jm2"][i][:, 0], d["jm2"][i][:, 1], h)
+        np.testing.assert_allclose(x, d["ang2"][i], atol=1e-15, rtol=1e-15)
+        np.testing.assert_allclose(dx, d["vel2"][i], atol=1e-15, rtol=1e-15)
+        np.testing.assert_allclose(ddx, d["acc2"][i], atol=1e-15, rtol=1e-15)
+
+
+def test_tube_coefficients_g3():
+    d = np.load(os.path.join(G, "g3_tubes.npz"))
+    for i in range(len(d["phi1"])):
+        c = np.array(bm.compute_bound_params(d["phi1"][i], d["e0"][i], d["e1"][i], d["s"][i], d["emax"][i]))
+        ref = d["coef_a4_a3_a2_a1_a0"][i]
+        np.testing.assert_allclose(c, ref, rtol=1e-11, atol=1e-11 * np.abs(ref).max())
+
+
+def test_lie_helpers_g5():
+    d = np.load(os.path.join(G, "g5_lie.npz"))
+    for i in range(len(d["axis"])):
+        np.testing.assert_allclose(bm.jac_SO3_inv_right(d["axis"][i]), d["jac_right"][i], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(bm.jac_SO3_inv_left(d["axis"][i]), d["jac_left"][i], rtol=1e-12, atol=1e-12)
+        out = bm.compute_initial_rot_errors(d["pr"][i], d["pr_ref"][i], d["dp_ref"][i], d["br1"][i], d["br2"][i])
+        np.testing.assert_allclose(np.array(out), d["init_rot_errors"][i], atol=1e-13)
+        np.testing.assert_allclose(bm.integrate_rotation_reference(d["pr"][i], d["omega"][i], d["phi0"][i], d["phi1"][i]),
+                                   d["rot_ref_int"][i], atol=1e-13)
+
+
+def _path_from(d):
+    mk = lambda k: [np.array(v) for v in d[k]]
+    return (mk("p_via"), mk("r_via"), [mk("p_lower"), mk("p_upper")], [mk("r_lower"), mk("r_upper")], mk("bp1_in"), mk("br1_in"),
+            list(d["s_in"]), list(d["e_p_min_in"]), list(d["e_r_min_in"]), list(d["e_p_max_in"]), list(d["e_r_max_in"]))
+
+
+@pytest.mark.parametrize("which", [1, 2])
+def test_reference_path_g4(which):
+    d = np.load(os.path.join(G, f"g4_refpath_exp{which}.npz"))
+    rp = ReferencePath(*_path_from(d), 4)
+    assert rp.phi_max == float(d["phi_max"])
+    for i, ph in enumerate(d["phis"]):
+        pd, dn, dpd, _, psw = rp.get_parameters(ph)
+        al, au, b1, b2, r1, r2 = rp.get_limits()
+        epm, erm, epx, erx, ss = rp.get_bound_params()
+        got = dict(pd=pd, dpd_normed=dn, dpd=dpd, phi_switch=psw, asymm_lower=al, asymm_upper=au, bp1=b1, bp2=b2, br1=r1, br2=r2,
+                   e_p_min=epm, e_r_min=erm, e_p_max=epx, e_r_max=erx, s=ss)
+        for k, v in got.items():
+            np.testing.assert_allclose(np.array(v, dtype=float), d[k][i], atol=1e-14, err_msg=f"{k} at phi={ph}")
+        assert rp.sector == int(d["sector"][i])
+
+
+class _Stub:
+    """Stands where the solver stands; answers with a prescribed solution and records (x0, p)."""
+
+    def __init__(self):
+        self.ans = None
+        self.last = None
+
+    def generate_dependencies(self, *a, **k):
+        pass
+
+    def __call__(self, x0=None, lbx=None, ubx=None, lbg=None, ubg=None, p=None):
+        self.last = (np.array(x0, dtype=float), np.array(p, dtype=float))
+        x = np.asarray(self.ans, dtype=float)
+        return {"x": x.reshape(-1, 1), "g": np.zeros((len(lbg), 1)), "f": 0.0, "lam_x": 0 * x, "lam_g": np.zeros(len(lbg))}
+
+    def stats(self):
+        return {"iter_count": 0, "success": True, "return_status": "stub"}
+
+
+@pytest.mark.parametrize("which", [1, 2])
+def test_pack_and_postprocess_closed_loop_g6_g7(which):
+    """Drive the host mirror tick by tick with the fixture's states and solutions: the packed (x0, p), the
+    traj_data dict and the advanced path/rotation-reference state must equal what the reference's own
+    step()/compute_return_data produced (fixtures G6 for tick 0 and G7 for every tick)."""
+    d6 = np.load(os.path.join(G, f"g6_pack_exp{which}_tick0.npz"))
+    d7 = np.load(os.path.join(G, f"g7_closedloop_exp{which}.npz"))
+    stub = _Stub()
+    mpc = BoundMPC(*_path_from(d6), p0=d6["p0fk"].copy(), params=workload.Params(weights=d6["weights_f64"], build=True), solver=stub)
+    x_phi_d = np.array([mpc.phi_max[0], 0, 0])
+    mask = d6["p_defined_mask"]
+    assert abs(mpc.phi_max[0] - float(d6["phi_max_f64"])) < 1e-15
+    ticks = min(len(d7["x"]), 60)
+    for i in range(ticks):
+        stub.ans = d7["x"][i]
+        traj, ref, err, _, _ = mpc.step(d7["q"][i], d7["dq"][i], d7["ddq"][i], d7["p_lie"][i], d7["v"][i], x_phi_d, d7["jerk"][i])
+        x0, p = stub.last
+        if i == 0:
+            np.testing.assert_allclose(p[mask], d6["p_f64"][mask], atol=1e-13)
+            np.testing.assert_array_equal(x0, d6["x0_f64"])
+        np.testing.assert_allclose(p[mask], d7["p"][i][mask], atol=2e-12, err_msg=f"p tick {i}")
+        np.testing.assert_allclose(x0, d7["x0"][i], atol=1e-14, err_msg=f"x0 tick {i}")
+        for k in ("p", "v", "a", "q", "dq", "ddq", "dddq", "phi", "dphi", "ddphi", "dddphi"):
+            np.testing.assert_allclose(np.array(traj[k]), d7["traj_" + k][i], atol=1e-12, err_msg=f"traj {k} tick {i}")
+        assert abs(mpc.phi_current[0] - d7["phi_current"][i]) < 1e-13
+        np.testing.assert_allclose(mpc.pr_ref, d7["pr_ref"][i], atol=1e-12)
+        np.testing.assert_allclose(mpc.iw_ref, d7["iw_ref"][i], atol=1e-12)
+        assert mpc.ref_path.sector == d7["sector"][i]
+    rm = RobotModel()
+    i = 5
+    jm = np.concatenate((d7["jerk"][i][:, None], d7["traj_dddq"][i][:, :2]), axis=1)
+    ns = integrate_joint(rm, jm, d7["q"][i], d7["dq"][i], d7["ddq"][i], 0.1)
+    np.testing.assert_allclose(ns[0], d7["q"][i + 1], atol=1e-15)
+    np.testing.assert_allclose(ns[4], d7["v"][i + 1], atol=1e-14)
+
+
+def test_float32_rounded_parameters_g6():
+    """The ROS service rounds dt and weights through float32 (MPCParams.srv:4-5); packing with those values
+    reproduces the reference's packing with the same values."""
+    d6 = np.load(os.path.join(G, "g6_pack_exp1_tick0.npz"))
+    stub = _Stub()
+    prm = workload.Params(dt=float(d6["dt_f32"]), weights=d6["weights_f32"], build=False)
+    mpc = BoundMPC(*_path_from(d6), p0=d6["p0fk"].copy(), params=prm, solver=stub)
+    w0, p, _ = mpc.pack(d6["q0"], np.zeros(7), np.zeros(7), d6["p0fk"], np.zeros(6), np.array([mpc.phi_max[0], 0, 0]), np.zeros(7))
+    m = d6["p_defined_mask"]
+    np.testing.assert_allclose(p[m], d6["p_f32"][m], atol=1e-13)
+    np.testing.assert_array_equal(np.array(w0), d6["x0_f32"])
+
+
+def test_failure_fallback_semantics():
+    """Solver failure is data, not an exception: error_count increments and the previous plan is replayed
+    (BoundMPC.py:465-489); after N consecutive failures step returns five Nones (:498-506)."""
+    d6 = np.load(os.path.join(G, "g6_pack_exp1_tick0.npz"))
+    d7 = np.load(os.path.join(G, "g7_closedloop_exp1.npz"))
+
+    class Failing(_Stub):
+        fail = False
+
+        def __call__(self, **k):
+            out = super().__call__(**k)
+            if self.fail:
+                out["g"] = np.ones_like(out["g"])       # gross violation of the equalities
+            return out
+
+        def stats(self):
+            return {"iter_count": 3, "success": not self.fail, "return_status": "Maximum_Iterations_Exceeded" if self.fail else "ok"}
+    stub = Failing()
+    mpc = BoundMPC(*_path_from(d6), p0=d6["p0fk"].copy(), params=workload.Params(weights=d6["weights_f64"]), solver=stub)
+    x_phi_d = np.array([mpc.phi_max[0], 0, 0])
+    stub.ans = d7["x"][0]
+    args = lambda i: (d7["q"][i], d7["dq"][i], d7["ddq"][i], d7["p_lie"][i], d7["v"][i], x_phi_d, d7["jerk"][i])
+    traj, *_ = mpc.step(*args(0))
+    assert mpc.error_count == 0 and traj["q"].shape == (7, 10)
+    stub.fail = True
+    for n in range(1, 10):
+        traj, _, _, _, iters = mpc.step(*args(1))
+        assert mpc.error_count == n and traj["q"].shape == (7, 10 - n) and iters == 3
+    assert mpc.step(*args(1)) == (None, None, None, None, None)
+
+
+def test_workload_generator_reproducible_and_exp1():
+    P, X, q0 = workload.make_batch(8, seed=0, workers=1)
+    P2, X2, _ = workload.make_batch(8, seed=0, workers=1)
+    np.testing.assert_array_equal(P, P2)
+    np.testing.assert_array_equal(X, X2)
+    assert P.shape == (8, 505) and X.shape == (8, 440) and np.isfinite(P).all()
+    d6 = np.load(os.path.join(G, "g6_pack_exp1_tick0.npz"))
+    p, x0 = workload.pack_cold(workload.Q0_EXP1)
+    np.testing.assert_allclose(p[d6["p_defined_mask"]], d6["p_f64"][d6["p_defined_mask"]], atol=1e-13)

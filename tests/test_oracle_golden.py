@@ -76,3 +76,132 @@ def test_g6_cold_start_and_feasibility(which):
     assert np.abs(g[:, :36]).max() < 1e-14
     assert (g[:, 36:] <= 1e-12).all()
     assert np.isfinite(f)
+
+
+# ---------------------------------------------------------------------------------------------
+# C oracle (oracle/bmpc_oracle.c) against the numpy restatement and by complex-step derivatives
+# ---------------------------------------------------------------------------------------------
+from oracle import c_oracle  # noqa: E402
+
+
+def _perturbed_point(which, N=10, seed=1, scale=0.03):
+    d = np.load(os.path.join(G, f"g6_pack_exp{which}_tick0.npz"))
+    p, x0 = d["p_f64"], d["x0_f64"]
+    rng = np.random.default_rng(seed)
+    x = x0 + rng.normal(size=x0.shape) * scale
+    x.reshape(N, 44)[:, 41] = np.abs(x.reshape(N, 44)[:, 41]) + np.linspace(0.1, 2.5, N)   # spread phi over segments
+    return p, x, rng
+
+
+@pytest.mark.parametrize("which", [1, 2])
+def test_c_oracle_values_match_numpy(which):
+    p, x, _ = _perturbed_point(which)
+    f, g = nlp.nlp_eval(x, p, 10, 4, 0.1)
+    fc, gc = c_oracle.eval_fg(p, x, 10, 4, 0.1)
+    assert abs(f - fc) <= 1e-12 * abs(f)
+    np.testing.assert_allclose(gc, g, atol=1e-13)
+
+
+def test_c_oracle_kinematic_derivatives():
+    rng = np.random.default_rng(5)
+    for _ in range(4):
+        q, dq = rng.uniform(-1.5, 1.5, 7), rng.uniform(-1, 1, 7)
+        mp, mv, mw = rng.normal(size=3), rng.normal(size=3), rng.normal(size=3)
+        pos, v, J, D, W = c_oracle.kin(q, dq, mp, mv, mw)
+        Jn = nlp.jacobian(q)
+        np.testing.assert_allclose(J, Jn, atol=1e-14)
+        Dn = np.zeros((6, 7))
+        for i in range(7):
+            qc = q.astype(complex); qc[i] += 1e-30j
+            Dn[:, i] = (nlp.jacobian(qc) @ dq).imag / 1e-30
+        np.testing.assert_allclose(D, Dn, atol=1e-13)
+
+        def S(y):
+            Jy = nlp.jacobian(y[:7])
+            return mp @ nlp.fk_pos(y[:7]) + mv @ (Jy[:3] @ y[7:]) + mw @ (Jy[3:] @ y[7:])
+
+        def grad(y):
+            g = np.zeros(14)
+            for i in range(14):
+                yc = y.astype(complex); yc[i] += 1e-30j
+                g[i] = S(yc).imag / 1e-30
+            return g
+        y = np.concatenate([q, dq])
+        H = np.zeros((14, 14))
+        for i in range(14):
+            e = np.zeros(14); e[i] = 1e-5
+            H[:, i] = (grad(y + e) - grad(y - e)) / 2e-5
+        np.testing.assert_allclose(W, H, atol=2e-9)
+
+
+def test_c_oracle_adjoint_is_lagrangian_gradient():
+    """Multipliers from the adjoint sweep zero the Lagrangian gradient w.r.t. every state variable; the jerk part
+    equals Rj -- checked against a complex-step gradient of the numpy Lagrangian (first derivatives of f, g and of
+    the internal inequality rows are therefore all correct)."""
+    N, S, h = 10, 4, 0.1
+    p, x, rng = _perturbed_point(1)
+    nu = rng.uniform(0.1, 2, N * 57)
+    lam, rj, _ = c_oracle.adjoint(p, x, nu, N, S, h)
+
+    def L(xc):
+        f, g = nlp.nlp_eval(xc, p, N, S, h)
+        return f + lam @ g.reshape(N, 43)[:, :36].reshape(-1) + nu @ nlp.internal_ineq(xc, p, N, S)
+    gl = np.zeros(x.size)
+    xc = x.astype(complex)
+    for i in range(x.size):
+        xc[i] += 1e-30j; gl[i] = L(xc).imag / 1e-30; xc[i] = x[i]
+    gl = gl.reshape(N, 44)
+    scale = max(1.0, np.abs(lam).max())
+    assert np.abs(gl[:, 8:]).max() < 1e-11 * scale
+    np.testing.assert_allclose(gl[:, :8], rj.reshape(N, 8), atol=1e-11 * scale)
+
+
+@pytest.mark.parametrize("which", [1, 2])
+def test_c_oracle_solution_is_kkt_point(which):
+    """Solve tick 0 from the reference's cold start and certify the result with quantities computed by the
+    independent numpy restatement: equality residuals, inequality feasibility, complementarity and the
+    Lagrangian gradient (complex step) with the reported multipliers lam_g / lam_x in CasADi's sign convention."""
+    N, S, h = 10, 4, 0.1
+    d = np.load(os.path.join(G, f"g6_pack_exp{which}_tick0.npz"))
+    p, x0 = d["p_f64"], d["x0_f64"]
+    out = c_oracle.solve(p, x0, N, S, h, c_oracle.default_opts(tol=1e-8))
+    assert out["status"][0] == 0 and out["iters"][0] < 60
+    x, lam_g, lam_x = out["x"][0], out["lam_g"][0], out["lam_x"][0]
+    f, g = nlp.nlp_eval(x, p, N, S, h)
+    np.testing.assert_allclose(out["g"][0], g, atol=1e-12)
+    assert abs(out["f"][0] - f) < 1e-9 * abs(f)
+    g2 = g.reshape(N, 43)
+    assert np.abs(g2[:, :36]).max() < 1e-8
+    assert g2[:, 36:].max() < 1e-8
+    lbx, ubx, _, _ = nlp.bounds(N)
+    assert (x >= lbx - 1e-9).all() and (x <= ubx + 1e-9).all()
+    lg = lam_g.reshape(N, 43)
+    assert (lg[:, 36:] >= 0).all()
+    assert np.abs(lg[:, 36:] * g2[:, 36:]).max() < 1e-6          # complementarity of the inequality rows
+    gf, Jg = nlp.jac_g_complex_step(x, p, N, S, h)
+    r = gf + Jg.T @ lam_g + lam_x
+    assert np.abs(r).max() < 2e-6 * max(1.0, np.abs(lam_g).max() / 100)
+
+
+def test_c_oracle_reproduces_closed_loop_fixture():
+    """The committed closed-loop fixture (reference host code + oracle solver) is reproducible."""
+    d = np.load(os.path.join(G, "g7_closedloop_exp1.npz"))
+    idx = np.arange(0, len(d["x"]), 7)
+    out = c_oracle.solve(d["p"][idx], d["x0"][idx], 10, 4, 0.1)
+    assert (out["status"] == 0).all()
+    np.testing.assert_array_equal(out["iters"], d["iters"][idx])
+    np.testing.assert_allclose(out["x"], d["x"][idx], atol=1e-9)
+
+
+def test_scipy_independent_solution_if_present():
+    """An independent NLP method (scipy SLSQP on the numpy restatement, reference-form constraints) lands on
+    the same minimiser.  Fixture g8 is produced by oracle/solve_scipy.py (minutes of CPU)."""
+    fn = os.path.join(G, "g8_scipy_exp1_tick0.npz")
+    if not os.path.exists(fn):
+        pytest.skip("g8 fixture not generated")
+    d = np.load(fn)
+    out = c_oracle.solve(d["p"], d["x0"], 10, 4, 0.1, c_oracle.default_opts(tol=1e-8))
+    z, zs = out["x"][0].reshape(10, 44), d["x"].reshape(10, 44)
+    rms_q = np.sqrt(np.mean((z[:, 8:15] - zs[:, 8:15]) ** 2))
+    assert rms_q < 1e-4, rms_q                                    # the north-star tolerance (rad RMS)
+    assert abs(out["f"][0] - float(d["f"])) < 1e-5 * abs(float(d["f"]))
