@@ -30,6 +30,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own HIP runtime; import it FIRST so that this process has exactly one libamdhip64
+    # (loading the system runtime before torch's leaves the second one without devices).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise BoundMPCHipError(
             f"HIP extension {LIB_PATH} is missing - build it with `python -m boundmpc_amd.build` "

@@ -129,7 +129,7 @@ class BoundMPC:
         if solver is None:
             # the product path: HIP batched solver behind the nlpsol call convention; raises without a GPU
             from .solver import BatchedOCPSolver, NlpSolverShim
-            self.batched = BatchedOCPSolver(self.N, S, self.dt, tol=getattr(params, "tol", 1e-6),
+            self.batched = BatchedOCPSolver(self.N, S, self.dt, tol=getattr(params, "tol", 1e-8),
                                             max_iter=getattr(params, "max_iter", 500))
             solver = NlpSolverShim(self.batched)
             self.lbu, self.ubu, self.lbg, self.ubg = (a.tolist() for a in self.batched.bounds())

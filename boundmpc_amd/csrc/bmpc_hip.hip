@@ -20,6 +20,7 @@
 #define BMPC_FMAX(a, b) fmax(a, b)
 #define BMPC_FMIN(a, b) fmin(a, b)
 #define BMPC_POW15(x) ((x) * sqrt(x))
+#define BMPC_POW(x, y) pow(x, y)
 #define LANES_BEGIN { const int lane = threadIdx.x; (void)lane;
 #define LANES_END } __syncthreads();
 #define LIDX 0
@@ -62,7 +63,7 @@ struct bmpc_handle {
 
 extern "C" int bmpc_default_options(bmpc_options *o) {
     if (!o) return BMPC_ERR_ARG;
-    o->tol = 1e-6; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0;
+    o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0;
     return BMPC_OK;
 }
 extern "C" const char *bmpc_error_string(int c) {

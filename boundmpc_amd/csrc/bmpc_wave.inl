@@ -62,7 +62,7 @@ BMPC_HD inline POff make_poff(int S) {
 enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV = L_RED + 6 * 64, L_PR = L_PV + 36, L_QT = L_PR + 36,
        L_RD = L_QT + 36, L_DS = L_RD + 36, L_DSN = L_DS + 36, L_DU = L_DSN + 36, L_MV = L_DU + 8, L_AE = L_MV + 44, L_K0 = L_AE + 42,
        L_K1 = L_K0 + KREC, L_KV = L_K1 + KREC, L_XT = L_KV + KREC, L_NC = L_XT + 15 * 14, L_WY = L_NC + 160, L_WV = L_WY + 196, L_TOT = L_WV + 196,
-       L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_SIZE = L_FLAG + 8 };
+       L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_SIZE = L_FILT + 64 };
 // node-cost work area inside L_NC
 enum { NC_HPP = 0, NC_HRR = 9, NC_HPF = 18, NC_HRF = 21, NC_SC = 24 /* hff,hdd,hddd,cv */, NC_A1 = 28 /* Hpp*Jp 3x7 */, NC_A2 = 49 /* Hrr*Ehat 3x14 */,
        NC_GL = 91 /* 44 */, NC_RL = 135 /* 9 */, NC_GY = 144 /* 14 */ };
@@ -964,6 +964,14 @@ BMPC_D inline bool wave_backward(Wave &W, const POff &po, const Scr &sc, double 
             }
         LANES_END
         if (L[L_FLAG] == 0.0) return false;
+        if (k >= 1) {   // keep the value-function Hessian symmetric against round-off
+            LANES_BEGIN
+                for (int id = lane; id < NS * NS; id += 64) {
+                    const int a = id / NS, b = id - a * NS;
+                    if (a < b) { const double v = 0.5 * (L[L_PM + a * 36 + b] + L[L_PM + b * 36 + a]); L[L_PM + a * 36 + b] = v; L[L_PM + b * 36 + a] = v; }
+                }
+            LANES_END
+        }
     }
     return true;
 }
@@ -1033,7 +1041,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     LANES_END
     const double *PAR = L + L_PAR;
     double mu = o.mu_init; const double mu_min = o.tol * o.mu_min_fac;
-    double rho = 1.0, delta_last = 0.0;
+    double delta_last = 0.0, filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0;
     double fval = wave_eval(W, po, sc, sc.Z, sc.G, sc.HIN);
     LANES_BEGIN
         for (int id = lane; id < ni; id += 64) { const double hv = G[sc.HIN + id]; const double t = (-hv > o.slack_push) ? -hv : o.slack_push; G[sc.T + id] = t; G[sc.NUm + id] = mu / t; }
@@ -1057,6 +1065,9 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                      sl = red_sum(L + L_RED + 256), sn = red_sum(L + L_RED + 320);
         const double sd = BMPC_FMAX(100.0, (sl + sn) / (N * (NE + NI))) / 100.0, scl = BMPC_FMAX(100.0, sn / (N * NI)) / 100.0;
         E0 = BMPC_FMAX(BMPC_FMAX(ed / sd, ep), BMPC_FMAX(cmax, -cmin) / scl);
+#ifdef BMPC_EMU
+        if (o.verbose) fprintf(stderr, "it %3d f %.8e dual %.2e prim %.2e compl %.2e mu %.1e\n", it, fval, ed, ep, BMPC_FMAX(cmax, -cmin), mu);
+#endif
         if (E0 <= o.tol) { status = 0; break; }
         if (it == o.max_iter) break;
         for (;;) {   // monotone barrier update (Fiacco-McCormick, Ipopt constants)
@@ -1099,11 +1110,12 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         LANES_END
         const double ap = red_min(L + L_RED), ad = red_min(L + L_RED + 64), dbar = red_sum(L + L_RED + 128), gfd = red_sum(L + L_RED + 192),
                      theta = red_sum(L + L_RED + 256), bar = red_sum(L + L_RED + 320);
-        const double dphi = gfd + dbar;
-        if (theta > 1e-14) { const double rt = dphi / (0.9 * theta); if (rho < rt) rho = rt + 1.0; }
-        const double D = dphi - rho * theta, phi0 = fval + bar + rho * theta;
-        double alpha = ap, ft = 0;
-        for (int ls = 0; ls < 30; ls++) {
+        // ---- filter line search (Waechter & Biegler 2006, Ipopt constants) on theta and phi = f - mu sum log t ----
+        const double dphi = gfd + dbar, phi0 = fval + bar;
+        if (mu != filt_mu) { nfilt = 0; filt_mu = mu; }
+        if (theta_min < 0) { theta_min = 1e-4 * BMPC_FMAX(1.0, theta); theta_max = 1e4 * BMPC_FMAX(1.0, theta); }
+        double alpha = ap, ft = 0; bool accepted = false, armijo_step = false;
+        for (int ls = 0; ls < 14; ls++) {
             LANES_BEGIN
                 for (int id = lane; id < nw; id += 64) G[sc.ZT + id] = G[sc.Z + id] + alpha * G[sc.DZ + id];
                 for (int id = lane; id < ni; id += 64) G[sc.TT + id] = G[sc.T + id] + alpha * G[sc.DT + id];
@@ -1115,10 +1127,28 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                 for (int id = lane; id < ni; id += 64) { const double t = G[sc.TT + id]; th += BMPC_FABS(G[sc.HT + id] + t); br -= mu * BMPC_LOG(t); }
                 L[L_RED + lane] = th; L[L_RED + 64 + lane] = br;
             LANES_END
-            const double tht = red_sum(L + L_RED), brt = red_sum(L + L_RED + 64);
-            const double phi = ft + brt + rho * tht;
-            if (phi <= phi0 + 1e-4 * alpha * D + 1e-13 * BMPC_FABS(phi0)) break;
+            const double tht = red_sum(L + L_RED), phit = ft + red_sum(L + L_RED + 64);
+            bool ok = (phit - phit == 0.0) && tht <= theta_max;
+            for (int j = 0; j < nfilt && ok; j++) if (!(tht < L[L_FILT + 2 * j] || phit < L[L_FILT + 2 * j + 1])) ok = false;
+            armijo_step = false;
+            if (ok) {
+                if (theta <= theta_min && dphi < 0 && alpha * BMPC_POW(-dphi, 2.3) > BMPC_POW(theta, 1.1)) {
+                    armijo_step = true;
+                    ok = phit <= phi0 + 1e-8 * alpha * dphi + 1e-13 * BMPC_FABS(phi0);
+                } else ok = (tht <= (1 - 1e-5) * theta) || (phit <= phi0 - 1e-8 * theta);
+            }
+            if (ok) { accepted = true; break; }
             alpha *= 0.5;
+        }
+#ifdef BMPC_EMU
+        if (o.verbose) fprintf(stderr, "   alpha_p %.3e (max %.3e) alpha_d %.3e delta %.1e acc %d arm %d nfilt %d theta %.3e dphi %.3e\n", alpha, ap, ad, delta, (int)accepted, (int)armijo_step, nfilt, theta, dphi);
+#endif
+        if (!accepted) nfilt = 0;          // smallest step taken, filter reset
+        else if (!armijo_step && nfilt < 32) {
+            LANES_BEGIN
+                if (lane == 0) { L[L_FILT + 2 * nfilt] = (1 - 1e-5) * theta; L[L_FILT + 2 * nfilt + 1] = phi0 - 1e-8 * theta; }
+            LANES_END
+            nfilt++;
         }
         // accept the last trial (swap primary / trial slabs), update multipliers
         { int t_; t_ = sc.Z; sc.Z = sc.ZT; sc.ZT = t_; t_ = sc.T; sc.T = sc.TT; sc.TT = t_; t_ = sc.G; sc.G = sc.GT; sc.GT = t_; t_ = sc.HIN; sc.HIN = sc.HT; sc.HT = t_; }

@@ -40,7 +40,7 @@ extern "C" {
 typedef struct bmpc_handle bmpc_handle;
 
 typedef struct {
-    double tol;         /* KKT tolerance, Ipopt-style scaled error (reference: 'tol': 10e-6, BoundMPC.py:121); default 1e-6 */
+    double tol;         /* KKT tolerance, Ipopt-style scaled error (reference: 'tol': 10e-6, BoundMPC.py:121); default 1e-8 */
     int max_iter;       /* reference: 500 (BoundMPC.py:122) */
     double mu_init;     /* initial barrier parameter (Ipopt default 0.1) */
     double mu_min_fac;  /* final barrier = tol * mu_min_fac */

@@ -57,7 +57,7 @@ static const double DQ_LIM_DEG[7] = {85, 85, 100, 75, 130, 135, 135};
 #define PI 3.14159265358979323846
 
 typedef struct {
-    double tol;          /* KKT tolerance (default 1e-6; reference Ipopt tol 1e-5, BoundMPC.py:121) */
+    double tol;          /* KKT tolerance (default 1e-8; reference Ipopt tol 1e-5, BoundMPC.py:121) */
     int max_iter;        /* BoundMPC.py:122 -> 500 */
     double mu_init;      /* 0.1 */
     double mu_min_fac;   /* mu_min = tol * mu_min_fac (0.1) */
@@ -870,6 +870,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
     const bmpc_oracle_opts *o = &C->o;
     memcpy(W->Z, x0, sizeof(double) * N * NZ);
     double mu = o->mu_init, mu_min = o->tol * o->mu_min_fac, rho = 1.0, delta_last = 0.0;
+    double filt_th[32], filt_ph[32], filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0;
     W->f = eval_values(C, P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
     for (int i = 0; i < N * NI; i++) { W->t[i] = fmax(-W->hin[i], o->slack_push); W->nu[i] = mu / W->t[i]; }
     double *sg = (double *)malloc(N * NI * sizeof(double)), *nuh = (double *)malloc(N * NI * sizeof(double));
@@ -882,7 +883,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         double ed, ep, ec0, ecm, sd, sc;
         kkt_errors(C, W, 0.0, &ed, &ep, &ec0, &sd, &sc);
         E0 = fmax(fmax(ed / sd, ep), ec0 / sc);
-        if (o->verbose) fprintf(stderr, "it %3d f %.8e dual %.2e prim %.2e compl %.2e mu %.1e rho %.1e\n", it, W->f, ed, ep, ec0, mu, rho);
+        if (o->verbose) fprintf(stderr, "it %3d f %.8e dual %.2e prim %.2e compl %.2e mu %.1e\n", it, W->f, ed, ep, ec0, mu);
         if (E0 <= o->tol) { status = 0; break; }
         if (it == o->max_iter) break;
         for (;;) {
@@ -918,30 +919,39 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
                 dbar += -mu * W->dt[id] / W->t[id];
             }
         }
-        /* l1 merit function */
-        adjoint(C, P, W, W->Z, zero_nu, gt, ht, gf); /* gf = grad f ; gt/ht scratch (lam, Rj overwritten below again) */
+        /* filter line search (Waechter & Biegler 2006, Ipopt constants) on theta = ||c||_1 + ||h+t||_1 and
+         * the barrier objective phi = f - mu sum log t */
+        adjoint(C, P, W, W->Z, zero_nu, gt, ht, gf); /* gf = grad f ; gt/ht scratch */
         double gfd = 0; for (int i = 0; i < N * NZ; i++) gfd += gf[i] * W->dZ[i];
         double theta = 0, bar = 0;
         for (int i = 0; i < N * NE; i++) theta += fabs(W->g[i]);
         for (int i = 0; i < N * NI; i++) { theta += fabs(W->hin[i] + W->t[i]); bar -= mu * log(W->t[i]); }
-        double dphi = gfd + dbar;
-        if (theta > 1e-14) { double rt = dphi / (0.9 * theta); if (rho < rt) rho = rt + 1.0; }
-        double D = dphi - rho * theta, phi0 = W->f + bar + rho * theta;
-        double alpha = ap; int accepted = 0; double ft = 0;
-        for (int ls = 0; ls < 30; ls++) {
+        const double dphi = gfd + dbar, phi0 = W->f + bar;
+        if (mu != filt_mu) { nfilt = 0; filt_mu = mu; }
+        if (theta_min < 0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
+        double alpha = ap; int accepted = 0, armijo_step = 0; double ft = 0;
+        for (int ls = 0; ls < 14; ls++) {
             for (int i = 0; i < N * NZ; i++) W->Zt[i] = W->Z[i] + alpha * W->dZ[i];
             for (int i = 0; i < N * NI; i++) W->tt[i] = W->t[i] + alpha * W->dt[i];
             ft = eval_values(C, P, W->Zt, W->Kp, W->Kv, W->R, gt, ht);
             double th = 0, br = 0;
             for (int i = 0; i < N * NE; i++) th += fabs(gt[i]);
             for (int i = 0; i < N * NI; i++) { th += fabs(ht[i] + W->tt[i]); br -= mu * log(W->tt[i]); }
-            double phi = ft + br + rho * th;
-            if (phi <= phi0 + 1e-4 * alpha * D + 1e-13 * fabs(phi0)) { accepted = 1; break; }
+            const double phit = ft + br;
+            int ok = isfinite(phit) && th <= theta_max;
+            for (int j = 0; j < nfilt && ok; j++) if (!(th < filt_th[j] || phit < filt_ph[j])) ok = 0;
+            armijo_step = 0;
+            if (ok) {
+                if (theta <= theta_min && dphi < 0 && alpha * pow(-dphi, 2.3) > pow(theta, 1.1)) {
+                    armijo_step = 1;
+                    ok = phit <= phi0 + 1e-8 * alpha * dphi + 1e-13 * fabs(phi0);
+                } else ok = (th <= (1 - 1e-5) * theta) || (phit <= phi0 - 1e-8 * theta);
+            }
+            if (ok) { accepted = 1; break; }
             alpha *= 0.5;
         }
-        if (!accepted) { /* take the smallest step anyway; status reports it if convergence fails */
-            if (o->verbose) fprintf(stderr, "   line search failed (D=%.3e)\n", D);
-        }
+        if (!accepted) { nfilt = 0; if (o->verbose) fprintf(stderr, "   line search failed: smallest step taken, filter reset\n"); }
+        else if (!armijo_step && nfilt < 32) { filt_th[nfilt] = (1 - 1e-5) * theta; filt_ph[nfilt] = phi0 - 1e-8 * theta; nfilt++; }
         memcpy(W->Z, W->Zt, sizeof(double) * N * NZ); memcpy(W->t, W->tt, sizeof(double) * N * NI);
         memcpy(W->g, gt, sizeof(double) * N * NE); memcpy(W->hin, ht, sizeof(double) * N * NI);
         W->f = ft;
@@ -950,7 +960,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
             double lo = mu / (1e10 * W->t[i]), hi = 1e10 * mu / W->t[i];
             W->nu[i] = fmin(fmax(v, lo), hi);
         }
-        if (o->verbose) fprintf(stderr, "   alpha_p %.3e (max %.3e) alpha_d %.3e delta %.1e\n", alpha, ap, ad, delta);
+        if (o->verbose) fprintf(stderr, "   alpha_p %.3e (max %.3e) alpha_d %.3e delta %.1e acc %d arm %d nfilt %d theta %.3e dphi %.3e\n", alpha, ap, ad, delta, accepted, armijo_step, nfilt, theta, dphi);
     }
     info->iters = it; info->status = status; info->f = W->f; info->kkt = E0; info->mu = mu;
     free(sg); free(nuh); free(gf); free(zero_nu); free(hdir); free(gt); free(ht);
@@ -960,7 +970,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
  * exported API (ctypes)
  * ---------------------------------------------------------------------------------------- */
 void bmpc_oracle_default_opts(bmpc_oracle_opts *o) {
-    o->tol = 1e-6; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0;
+    o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0;
 }
 
 static void write_outputs(const Cfg *C, const Par *P, Work *W, double *x, double *g, double *lam_g, double *lam_x) {

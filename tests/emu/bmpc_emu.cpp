@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <cstdio>
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
@@ -24,6 +25,7 @@
 #define BMPC_FMAX(a, b) std::fmax(a, b)
 #define BMPC_FMIN(a, b) std::fmin(a, b)
 #define BMPC_POW15(x) ((x) * std::sqrt(x))
+#define BMPC_POW(x, y) std::pow(x, y)
 #define LANES_BEGIN for (int li_ = 0; li_ < 64; ++li_) { const int lane = W.order[li_]; (void)lane;
 #define LANES_END }
 #define LIDX lane

@@ -31,7 +31,7 @@ def test_options_and_error_strings():
     lib = _lib.load()
     o = _lib.Options()
     assert lib.bmpc_default_options(ctypes.byref(o)) == 0
-    assert o.tol == 1e-6 and o.max_iter == 500 and o.exact_hessian == 1
+    assert o.tol == 1e-8 and o.max_iter == 500 and o.exact_hessian == 1
     assert lib.bmpc_error_string(0) == b"ok" and lib.bmpc_error_string(4) == b"no HIP device available"
     h = ctypes.c_void_p()
     assert lib.bmpc_create(0, 4, 0.1, None, ctypes.byref(h)) == 1      # invalid N

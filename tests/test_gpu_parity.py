@@ -46,7 +46,7 @@ def test_tick0_against_oracle_and_numpy_kkt(solver, which):
     p, x0 = d["p_f64"], d["x0_f64"]
     out = solver.solve_host(p, x0)
     ref = c_oracle.solve(p, x0, 10, 4, 0.1)
-    assert out["status"][0] == 0 and out["iters"][0] == ref["iters"][0]
+    assert out["status"][0] == 0 and abs(int(out["iters"][0]) - int(ref["iters"][0])) <= 1
     assert _rms_q(out["x"], ref["x"]) < TOL_Q_RMS
     np.testing.assert_allclose(out["x"], ref["x"], atol=1e-7)
     np.testing.assert_allclose(out["lam_g"], ref["lam_g"], rtol=1e-6, atol=1e-6)
@@ -100,7 +100,7 @@ def test_random_batch_1024_against_oracle_and_properties(solver):
     assert _rms_q(x[ok], ref["x"][ok]) < TOL_Q_RMS
     g = o["g"].cpu().numpy()[ok].reshape(-1, 10, 43)
     assert np.abs(g[:, :, :36]).max() < 1e-5 and g[:, :, 36:].max() < 1e-5
-    assert (o["kkt"].cpu().numpy()[ok] <= 1e-6).all()
+    assert (o["kkt"].cpu().numpy()[ok] <= 1e-8).all()
     # determinism
     o2 = solver.solve_batch(p, x0, out={})
     torch.cuda.synchronize()
