@@ -6,7 +6,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libboundmpc_hip.so")
+LIB_PATH = os.environ.get("BOUNDMPC_HIP_LIB") or os.path.join(HERE, "csrc", "libboundmpc_hip.so")   # override: A/B builds of the same source
 
 SYMBOLS = ["bmpc_default_options", "bmpc_error_string", "bmpc_create", "bmpc_destroy", "bmpc_num_vars", "bmpc_num_cons",
            "bmpc_num_params", "bmpc_get_bounds", "bmpc_solve_batch", "bmpc_solve_batch_host", "bmpc_set_timing",

@@ -16,6 +16,7 @@
 #define BMPC_EXP(x) exp(x)
 #define BMPC_LOG(x) log(x)
 #define BMPC_SQRT(x) sqrt(x)
+#define BMPC_RSQRT(x) rsqrt(x)
 #define BMPC_FABS(x) fabs(x)
 #define BMPC_FMAX(a, b) fmax(a, b)
 #define BMPC_FMIN(a, b) fmin(a, b)
@@ -24,19 +25,38 @@
 #define LANES_BEGIN { const int lane = threadIdx.x; (void)lane;
 #define LANES_END } __syncthreads();
 #define LIDX 0
+#define BMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+#ifdef BMPC_MARKS
+// diagnostic compile only (-S): textual markers in the ISA at the phase stamps, to count static instructions per phase
+#define BMPC_PROF(W, id) asm volatile("s_nop 0 ; BMPCMARK " #id ::: "memory");
+#endif
+#ifdef BMPC_PROFILE
+// diagnostic build only (libboundmpc_hip_prof.so): per-phase cycle stamps of lane 0, never in the product library
+#undef BMPC_PROF
+#define BMPC_PROF(W, id) { long long now_ = clock64(); if (threadIdx.x == 0) { ((long long *)((W).L + bmpc::L_PROF))[id] += now_ - (W).tprev; } (W).tprev = now_; }
+#endif
 
 #include "bmpc_wave.inl"
 
 struct KArgs {
     int N, S, B; double h; bmpc::Opts o;
     const double *p, *x0; double *x, *g, *lam_g, *lam_x, *f, *kkt; int *iters, *status;
-    double *scratch; long long scr_stride; int *counter;
+    double *scratch; long long scr_stride; int *counter; unsigned long long *prof;
 };
 
-__global__ void __launch_bounds__(64) bmpc_solve_kernel(KArgs a) {
+#ifndef BMPC_WAVES_PER_EU
+#define BMPC_WAVES_PER_EU 1
+#endif
+__global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs a) {
     __shared__ double lds[bmpc::L_SIZE];
     bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = a.scratch + (long long)blockIdx.x * a.scr_stride;
     const int np = 141 + 91 * a.S, nw = a.N * bmpc::NZ, ng = a.N * bmpc::NG;
+#ifdef BMPC_PROFILE
+    if (threadIdx.x < 16) ((long long *)(lds + bmpc::L_PROF))[threadIdx.x] = 0;
+    __syncthreads();
+    W.tprev = clock64();
+#endif
     for (;;) {
         int b = 0;
         if (threadIdx.x == 0) b = atomicAdd(a.counter, 1);
@@ -51,11 +71,14 @@ __global__ void __launch_bounds__(64) bmpc_solve_kernel(KArgs a) {
         bmpc::wave_solve(W, pr);
         __syncthreads();
     }
+#ifdef BMPC_PROFILE
+    if (threadIdx.x < 16 && a.prof) atomicAdd(a.prof + threadIdx.x, (unsigned long long)((long long *)(lds + bmpc::L_PROF))[threadIdx.x]);
+#endif
 }
 
 struct bmpc_handle {
     int N, S; double h; bmpc_options o;
-    int grid; long long scr_stride; double *scratch; int *counter;
+    int grid; long long scr_stride; double *scratch; int *counter; unsigned long long *prof;
     int timing; hipEvent_t ev0, ev1; int have_ev;
 };
 
@@ -87,13 +110,15 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     h->scr_stride = bmpc::make_scr(N).size;
     HIPCHK(hipMalloc(&h->scratch, sizeof(double) * (size_t)h->scr_stride * h->grid));
     HIPCHK(hipMalloc(&h->counter, sizeof(int)));
+    HIPCHK(hipMalloc(&h->prof, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(h->prof, 0, 16 * sizeof(unsigned long long)));
     *out = h;
     return BMPC_OK;
 }
 extern "C" int bmpc_destroy(bmpc_handle *h) {
     if (!h) return BMPC_ERR_ARG;
     if (h->have_ev) { hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); }
-    hipFree(h->scratch); hipFree(h->counter);
+    hipFree(h->scratch); hipFree(h->counter); hipFree(h->prof);
     delete h;
     return BMPC_OK;
 }
@@ -130,7 +155,7 @@ extern "C" int bmpc_solve_batch(bmpc_handle *h, int B, const double *p, const do
     a.o.tol = h->o.tol; a.o.max_iter = h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
     a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = lam_g; a.lam_x = lam_x; a.f = f; a.kkt = kkt; a.iters = iters; a.status = status;
-    a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter;
+    a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter; a.prof = h->prof;
     HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), st));
     const int grid = B < h->grid ? B : h->grid;
     if (h->timing) {
@@ -177,6 +202,20 @@ extern "C" int bmpc_last_kernel_ms(bmpc_handle *h, float *ms) {
     HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
     return BMPC_OK;
 }
+#ifdef BMPC_MARKS
+// diagnostic compile only (-S): textual markers in the ISA at the phase stamps, to count static instructions per phase
+#define BMPC_PROF(W, id) asm volatile("s_nop 0 ; BMPCMARK " #id ::: "memory");
+#endif
+#ifdef BMPC_PROFILE
+// diagnostic build only: accumulated lane-0 cycle counts per phase (16 slots), then reset
+extern "C" int bmpc_get_profile(bmpc_handle *h, unsigned long long *out) {
+    if (!h || !out) return BMPC_ERR_ARG;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, h->prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->prof, 0, 16 * sizeof(unsigned long long)));
+    return BMPC_OK;
+}
+#endif
 extern "C" int bmpc_launch_info(const bmpc_handle *h, int *grid, int *lds_bytes, long long *scratch_bytes) {
     if (!h) return BMPC_ERR_ARG;
     if (grid) *grid = h->grid; if (lds_bytes) *lds_bytes = (int)(bmpc::L_SIZE * sizeof(double)); if (scratch_bytes) *scratch_bytes = h->scr_stride * 8;

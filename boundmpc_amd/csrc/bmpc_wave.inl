@@ -25,6 +25,13 @@
 // integrator-chain sparsity of F); inequality rows = one lane per row (57 per node).
 #pragma once
 
+#ifndef BMPC_PROF
+#define BMPC_PROF(W, id)
+#endif
+#ifndef BMPC_SCHED_FENCE
+#define BMPC_SCHED_FENCE()   // GPU build: stops the scheduler from hoisting LDS loads across this point (bounds live ranges)
+#endif
+
 namespace bmpc {
 
 // ----------------------------------------------------------------------------------------
@@ -62,7 +69,10 @@ BMPC_HD inline POff make_poff(int S) {
 enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV = L_RED + 6 * 64, L_PR = L_PV + 36, L_QT = L_PR + 36,
        L_RD = L_QT + 36, L_DS = L_RD + 36, L_DSN = L_DS + 36, L_DU = L_DSN + 36, L_MV = L_DU + 8, L_AE = L_MV + 44, L_K0 = L_AE + 42,
        L_K1 = L_K0 + KREC, L_KV = L_K1 + KREC, L_XT = L_KV + KREC, L_NC = L_XT + 15 * 14, L_WY = L_NC + 160, L_WV = L_WY + 196, L_TOT = L_WV + 196,
-       L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_SIZE = L_FILT + 64 };
+       L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 16, L_ST = L_KV1 + KREC, L_SIZE = L_ST + 432 };
+// staging area inside L_ST: per-stage inputs of the sequential sweeps, loaded from the scratch slab in ONE burst per stage
+enum { ST_REF = 0, ST_Z = 80, ST_SG = 124, ST_NU = 184, ST_G = 244, ST_LAM0 = 280, ST_LAM1 = 316, ST_GH = 352, ST_RLVM = 396, ST_RLV0 = 408, ST_RLVP = 420,
+       /* forward sweep view */ ST_KT = 0, ST_KF = 280, ST_RDY = 288, ST_AES = 324, ST_RLVF = 366 };
 // node-cost work area inside L_NC
 enum { NC_HPP = 0, NC_HRR = 9, NC_HPF = 18, NC_HRF = 21, NC_SC = 24 /* hff,hdd,hddd,cv */, NC_A1 = 28 /* Hpp*Jp 3x7 */, NC_A2 = 49 /* Hrr*Ehat 3x14 */,
        NC_GL = 91 /* 44 */, NC_RL = 135 /* 9 */, NC_GY = 144 /* 14 */ };
@@ -73,7 +83,7 @@ struct Opts {
 
 // global scratch layout (doubles) for horizon N
 struct Scr {
-    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, size;
+    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, NUH, size;
 };
 BMPC_HD inline Scr make_scr(int N) {
     Scr s; int c = 0;
@@ -81,7 +91,7 @@ BMPC_HD inline Scr make_scr(int N) {
     s.LAM = c; c += N * NE; s.G = c; c += N * NE; s.GT = c; c += N * NE; s.HIN = c; c += N * NI; s.HT = c; c += N * NI;
     s.DZ = c; c += N * NZ; s.DT = c; c += N * NI; s.DNU = c; c += N * NI; s.GH = c; c += N * NZ; s.GVP = c; c += N * 8;
     s.RJ = c; c += N * NU; s.KIN = c; c += 2 * N * KREC; s.REF = c; c += N * RREC; s.KT = c; c += N * NS * NU; s.KF = c; c += N * NU;
-    s.RDY = c; c += N * 36; s.AES = c; c += N * 42; s.RLV = c; c += N * 12;
+    s.RDY = c; c += N * 36; s.AES = c; c += N * 42; s.RLV = c; c += N * 12; s.SG = c; c += N * NI; s.NUH = c; c += N * NI;
     s.size = (c + 15) & ~15;
     return s;
 }
@@ -96,6 +106,7 @@ struct Wave {
     int N, S; double h; Opts o;
     double *L;             // LDS base (L_SIZE doubles)
     double *G;             // scratch base
+    long long tprev;       // diagnostic build only (BMPC_PROFILE): last phase stamp
 #ifdef BMPC_EMU
     int order[64];
 #endif
@@ -387,9 +398,19 @@ struct LaneRegs { double mc[44]; double kc[8]; };
 // ----------------------------------------------------------------------------------------
 // wave-uniform deterministic reductions through LDS (RED has 6 x 64 slots)
 // ----------------------------------------------------------------------------------------
-BMPC_D inline double red_sum(const double *r) { double s = 0; for (int i = 0; i < 64; i++) s += r[i]; return s; }
-BMPC_D inline double red_max(const double *r) { double s = r[0]; for (int i = 1; i < 64; i++) s = r[i] > s ? r[i] : s; return s; }
-BMPC_D inline double red_min(const double *r) { double s = r[0]; for (int i = 1; i < 64; i++) s = r[i] < s ? r[i] : s; return s; }
+// fixed-order pairwise trees over the 64 slots (order identical in the emulator -> bitwise reproducible)
+BMPC_D inline double red_sum(const double *r) {
+    double a[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = ((r[i] + r[i + 8]) + (r[i + 16] + r[i + 24])) + ((r[i + 32] + r[i + 40]) + (r[i + 48] + r[i + 56]));
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+BMPC_D inline double red_max(const double *r) { double s = r[0];
+#pragma unroll
+    for (int i = 1; i < 64; i++) s = BMPC_FMAX(s, r[i]); return s; }
+BMPC_D inline double red_min(const double *r) { double s = r[0];
+#pragma unroll
+    for (int i = 1; i < 64; i++) s = BMPC_FMIN(s, r[i]); return s; }
 
 // ========================================================================================
 //                                   the wave program
@@ -471,12 +492,11 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, int oZ, i
 
 // mu_q, mu_dq of stage kk (node kk -> kk+1) from lam_kk and the predicted-point record, into L_MU[0..15]
 // (lanes 0..7; chain 7 = path parameter)
-BMPC_D inline void stage_mu(Wave &W, const Scr &sc, int kk, int lane) {
-    double *L = W.L, *G = W.G; const double h = W.h;
+BMPC_D inline void stage_mu(Wave &W, const double *lam, const double *kp, int lane) {
+    double *L = W.L; const double h = W.h;
     if (lane < 8) {
-        const double *lam = G + sc.LAM + kk * NE;
         if (lane < 7) {
-            const int i = lane; const double *kp = G + sc.KIN + kk * KREC;
+            const int i = lane;
             double s = lam[GQ + i], s2 = lam[GDQ + i];
             for (int c = 0; c < 3; c++) {
                 const double mv = lam[GV + c], mw = lam[GW + c] + 0.5 * h * lam[GIW + c];
@@ -498,11 +518,7 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
         if (lane < N) {
             const int k = lane;
             double nuv[NI], vprev[6];
-            for (int i = 0; i < NI; i++) {
-                const double nu = G[oNU + k * NI + i];
-                if (use_hat) { const double t = G[sc.T + k * NI + i]; nuv[i] = (mu + nu * (G[sc.HIN + k * NI + i] + t)) / t; }
-                else nuv[i] = nu;
-            }
+            for (int i = 0; i < NI; i++) nuv[i] = G[(use_hat ? sc.NUH : oNU) + k * NI + i];
             for (int c = 0; c < 6; c++) vprev[c] = ndv(PAR, po, Zs, k, ZV + c, po.v0 + c);
             double gz[NZ], gvp[6];
             node_grad(PAR, po, h, Zs + k * NZ, vprev, G + sc.REF + k * RREC, nuv, gz, gvp);
@@ -514,20 +530,26 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
         for (int id = lane; id < (N - 1) * 6; id += 64) { const int k = id / 6, c = id - k * 6; G[sc.GH + k * NZ + ZV + c] += G[sc.GVP + (k + 1) * 8 + c]; }
     LANES_END
     if (use_hat) return;   // QP gradient only
+    // sequential sweep; lam_{k+1} lives in LDS (ping-pong ST_LAM0/ST_LAM1), records of stage k+1 are staged in one burst
     for (int k = N - 1; k >= 0; k--) {
+        double *lam1 = L + L_ST + (((N - 1 - k) & 1) ? ST_LAM0 : ST_LAM1);     // lam_{k+1} (written one step earlier)
+        double *lam0 = L + L_ST + (((N - 1 - k) & 1) ? ST_LAM1 : ST_LAM0);     // lam_k (written now)
+        LANES_BEGIN
+            if (lane < NZ) L[L_ST + ST_GH + lane] = G[sc.GH + k * NZ + lane];
+            if (k < N - 1) for (int id = lane; id < KREC; id += 64) { L[L_K0 + id] = G[sc.KIN + (k + 1) * KREC + id]; L[L_KV + id] = G[sc.KIN + (N + k + 1) * KREC + id]; }
+        LANES_END
         if (k < N - 1) {
             LANES_BEGIN
-                stage_mu(W, sc, k + 1, lane);
+                stage_mu(W, lam1, L + L_K0, lane);
             LANES_END
         }
         LANES_BEGIN
             if (lane < NZ) {
                 const int z = lane;
-                double tot = G[sc.GH + k * NZ + z];
+                double tot = L[L_ST + ST_GH + z];
                 if (k < N - 1) {
-                    const double *lam1 = G + sc.LAM + (k + 1) * NE, *kv = G + sc.KIN + (N + k + 1) * KREC;
-                    // field / chain of this component
-                    int f = -1, i = 0;
+                    const double *kv = L + L_KV;
+                    int f = -1, i = 0;   // field / chain of this component
                     if (z < 7) { f = 3; i = z; } else if (z == ZJPHI) { f = 3; i = 7; }
                     else if (z < ZDQ) { f = 0; i = z - ZQ; } else if (z < ZDDQ) { f = 1; i = z - ZDQ; } else if (z < ZPOS) { f = 2; i = z - ZDDQ; }
                     else if (z >= ZPHI) { f = z - ZPHI; i = 7; }
@@ -545,22 +567,26 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
                 else if (z == ZJPHI) G[sc.RJ + k * NU + 7] = tot;
                 else {
                     const int e = z < ZPOS ? z - ZQ : (z < ZPHI ? GPOS + (z - ZPOS) : GPHI + (z - ZPHI));
-                    G[sc.LAM + k * NE + e] = tot;
+                    G[sc.LAM + k * NE + e] = tot; lam0[e] = tot;
                 }
             } else if (lane < NZ + 8 && k < N - 1) {   // jerk of node k+2 enters stage k+1
-                const int i = lane - NZ; const double *lam1 = G + sc.LAM + (k + 1) * NE;
+                const int i = lane - NZ;
                 const double mdd = i < 7 ? lam1[GDDQ + i] : lam1[GDDPHI];
                 G[sc.RJ + (k + 1) * NU + i] += h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd;
             }
         LANES_END
     }
+    const double *lamz = L + L_ST + (((N - 1) & 1) ? ST_LAM1 : ST_LAM0);   // lam_0
     LANES_BEGIN
-        stage_mu(W, sc, 0, lane);
+        for (int id = lane; id < KREC; id += 64) L[L_K0 + id] = G[sc.KIN + id];
+    LANES_END
+    LANES_BEGIN
+        stage_mu(W, lamz, L + L_K0, lane);
     LANES_END
     LANES_BEGIN
         if (lane < 8) {
-            const int i = lane; const double *lam0 = G + sc.LAM;
-            const double mdd = i < 7 ? lam0[GDDQ + i] : lam0[GDDPHI];
+            const int i = lane;
+            const double mdd = i < 7 ? lamz[GDDQ + i] : lamz[GDDPHI];
             G[sc.RJ + i] += h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd;
         }
     LANES_END
@@ -575,16 +601,12 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
     const int N = W.N; const double h = W.h; const int ex = W.o.exact_hessian;
     double *L = W.L, *G = W.G;
     const double *PAR = L + L_PAR, *w = PAR + po.w;
-    const double *Zn = G + sc.Z + k * NZ, *rr = G + sc.REF + k * RREC, *gk = G + sc.G + k * NE;
-    const double *tk = G + sc.T + k * NI, *nuk = G + sc.NUm + k * NI;
-    double *NC = L + L_NC, *K0 = L + L_K0, *KV1 = L + L_KV, *WY = L + L_WY, *WV = L + L_WV;
+    const double *ST = L + L_ST;   // staged by wave_backward for this stage
+    const double *rr = ST + ST_REF, *gk = ST + ST_G, *sgk = ST + ST_SG, *nuk = ST + ST_NU;
+    double *NC = L + L_NC, *K0 = L + L_K0, *KV1 = L + L_KV1, *WY = L + L_WY, *WV = L + L_WV;
     const bool has_next = k < N - 1;
     // phase 1: stage records, small Hessian blocks, lifted residuals
     LANES_BEGIN
-        for (int id = lane; id < KREC; id += 64) {
-            K0[id] = G[sc.KIN + k * KREC + id];
-            KV1[id] = has_next ? G[sc.KIN + (N + k + 1) * KREC + id] : 0.0;
-        }
         if (lane < 14) NC[NC_GY + lane] = lane < 7 ? gk[GQ + lane] : gk[GDQ + lane - 7];
         if (lane >= 16 && lane < 16 + 9) {   // H_pp (a,b) and H_rr (a,b)
             const int a = (lane - 16) / 3, b = (lane - 16) % 3;
@@ -597,7 +619,7 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
             }
             double hp = 2 * w[0] * sp, hr = 2 * w[1] * sr;
             for (int m = 0; m < 5; m++) {
-                const double su = nuk[ITUBE + 2 * m] / tk[ITUBE + 2 * m], sl = nuk[ITUBE + 2 * m + 1] / tk[ITUBE + 2 * m + 1];
+                const double su = sgk[ITUBE + 2 * m], sl = sgk[ITUBE + 2 * m + 1];
                 const double gg = (su + sl) * rr[RGC + m * 4 + a] * rr[RGC + m * 4 + b];
                 if (m == 1 || m == 2) hp += gg; else hr += gg;
             }
@@ -622,7 +644,7 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
                 hp += 2 * w[0] * sig1 * (epo[a] - depo * d[a]); hr += 2 * w[1] * sig1 * (jl - dhero * l2[a]);
             }
             for (int m = 0; m < 5; m++) {
-                const double su = nuk[ITUBE + 2 * m] / tk[ITUBE + 2 * m], sl = nuk[ITUBE + 2 * m + 1] / tk[ITUBE + 2 * m + 1];
+                const double su = sgk[ITUBE + 2 * m], sl = sgk[ITUBE + 2 * m + 1];
                 const double gpu_ = rr[RGC + m * 4 + 3] - rr[RW1 + m], gpl_ = -rr[RGC + m * 4 + 3] - rr[RW1 + m];
                 const double gg = su * rr[RGC + m * 4 + a] * gpu_ - sl * rr[RGC + m * 4 + a] * gpl_;
                 if (m == 1 || m == 2) hp += gg; else hr += gg;
@@ -642,16 +664,16 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
                 srr += ero * (sig2 * erd + 2 * sig1 * (-rr[RRR + r] + dh[r] * rr[RV2RR]));
             }
             for (int c = 0; c < 6; c++) dpdp += d[c] * d[c];
-            double hff = 2 * w[0] * sp + 2 * w[1] * sr + 2 * w[6] + nuk[IPHI0] / tk[IPHI0] + nuk[IPHIMAX] / tk[IPHIMAX];
+            double hff = 2 * w[0] * sp + 2 * w[1] * sr + 2 * w[6] + sgk[IPHI0] + sgk[IPHIMAX];
             if (ex) hff += 2 * w[0] * spp + 2 * w[1] * srr;
             for (int m = 0; m < 5; m++) {
-                const double su = nuk[ITUBE + 2 * m] / tk[ITUBE + 2 * m], sl = nuk[ITUBE + 2 * m + 1] / tk[ITUBE + 2 * m + 1];
+                const double su = sgk[ITUBE + 2 * m], sl = sgk[ITUBE + 2 * m + 1];
                 const double gpu_ = rr[RGC + m * 4 + 3] - rr[RW1 + m], gpl_ = -rr[RGC + m * 4 + 3] - rr[RW1 + m];
                 hff += su * gpu_ * gpu_ + sl * gpl_ * gpl_;
                 if (ex) hff += nuk[ITUBE + 2 * m] * (rr[RC2 + m] - rr[RW2 + m]) + nuk[ITUBE + 2 * m + 1] * (-rr[RC2 + m] - rr[RW2 + m]);
             }
             NC[NC_SC + 0] = hff;
-            NC[NC_SC + 1] = 2 * w[2] * dpdp + 2 * w[7] + nuk[IDPHIMAX] / tk[IDPHIMAX];
+            NC[NC_SC + 1] = 2 * w[2] * dpdp + 2 * w[7] + sgk[IDPHIMAX];
             NC[NC_SC + 2] = 2 * w[5] * dpdp + 2 * w[8];
             NC[NC_SC + 3] = 2 * w[2] + 2 * w[5] / (h * h) * (has_next ? 2.0 : 1.0);
         }
@@ -659,7 +681,7 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
     // phase 2: lifted residuals r (pos 3, v 6), A1 = Hpp Jp, A2 = Hrr Ehat, multipliers for the kinematic curvature
     LANES_BEGIN
         if (lane < 9) {
-            NC[NC_RL + lane] = G[sc.RLV + k * 12 + lane];
+            NC[NC_RL + lane] = ST[ST_RLV0 + lane];
         } else if (lane >= 16 && lane < 16 + 21) {
             const int c = (lane - 16) / 7, i = (lane - 16) % 7; double s = 0;
             for (int b = 0; b < 3; b++) s += NC[NC_HPP + c * 3 + b] * K0[KW + b * 7 + i];
@@ -671,28 +693,28 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
             NC[NC_A2 + c * 14 + y] = 0.5 * h * s;
         }
         if (lane >= 48 && lane < 60) {         // curvature multipliers: [0..2] mu_p, [3..5] mu_v, [6..8] mu_w (predicted point), [9..11] mu_w (node variables)
-            const int c = (lane - 48) % 3, g = (lane - 48) / 3; const double *lam = G + sc.LAM + k * NE;
+            const int c = (lane - 48) % 3, g = (lane - 48) / 3; const double *lam = ST + ST_LAM0;
             double v = 0;
             if (g == 0) v = lam[GPOS + c]; else if (g == 1) v = lam[GV + c]; else if (g == 2) v = lam[GW + c] + 0.5 * h * lam[GIW + c];
-            else v = has_next ? 0.5 * h * G[sc.LAM + (k + 1) * NE + GIW + c] : 0.0;
+            else v = has_next ? 0.5 * h * ST[ST_LAM1 + GIW + c] : 0.0;
             L[L_MU + 4 + 0 + (lane - 48)] = v;   // L_MU[4..15]
         }
     LANES_END
     // phase 3: Z-space gradient gl = g^ + H r + cross terms (44), kinematic curvature W (14x14)
     LANES_BEGIN
         if (lane < NZ) {
-            const int z = lane; double g = G[sc.GH + k * NZ + z];
+            const int z = lane; double g = ST[ST_GH + z];
             const double *rl = NC + NC_RL, cv = NC[NC_SC + 3], *d = rr + RDP;
             if (z >= ZPOS && z < ZPOS + 3) { for (int b = 0; b < 3; b++) g += NC[NC_HPP + (z - ZPOS) * 3 + b] * rl[b]; }
             else if (z == ZPHI) { for (int b = 0; b < 3; b++) g += NC[NC_HPF + b] * rl[b]; }
             else if (z >= ZV && z < ZV + 6) {
                 const int c = z - ZV; g += cv * rl[3 + c];
-                if (k >= 1) g += -2 * w[5] / (h * h) * G[sc.RLV + (k - 1) * 12 + 3 + c];
-                if (has_next) g += -2 * w[5] / (h * h) * G[sc.RLV + (k + 1) * 12 + 3 + c];
+                if (k >= 1) g += -2 * w[5] / (h * h) * ST[ST_RLVM + 3 + c];
+                if (has_next) g += -2 * w[5] / (h * h) * ST[ST_RLVP + 3 + c];
             } else if (z == ZDPHI) { for (int c = 0; c < 6; c++) g += -2 * w[2] * d[c] * rl[3 + c]; }
             else if (z == ZDDPHI) {
                 for (int c = 0; c < 6; c++) g += -2 * w[5] / h * d[c] * rl[3 + c];
-                if (k >= 1) for (int c = 0; c < 6; c++) g += 2 * w[5] / h * d[c] * G[sc.RLV + (k - 1) * 12 + 3 + c];
+                if (k >= 1) for (int c = 0; c < 6; c++) g += 2 * w[5] / h * d[c] * ST[ST_RLVM + 3 + c];
             }
             NC[NC_GL + z] = g;
         }
@@ -707,6 +729,7 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
             WY[a * 14 + b] = v; WY[b * 14 + a] = v; WV[a * 14 + b] = v2; WV[b * 14 + a] = v2;
         }
     LANES_END
+    BMPC_PROF(W, 14);
     // (RLV of all nodes is produced by wave_prepare_rlv() before the backward sweep.)
     // phase 4: add Q~ into PM and q~ into PV
     LANES_BEGIN
@@ -731,8 +754,8 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
             const int ra = a < 14 ? a : SIOTA + a - 14, rb = b < 14 ? b : SIOTA + b - 14;
             if (a == b) {
                 double dg = delta;
-                if (a < 7) dg += 2 * w[10] + nuk[IQU + a] / tk[IQU + a] + nuk[IQL + a] / tk[IQL + a];
-                else if (a < 14) dg += 2 * w[11] + nuk[IDQU + a - 7] / tk[IDQU + a - 7] + nuk[IDQL + a - 7] / tk[IDQL + a - 7];
+                if (a < 7) dg += 2 * w[10] + sgk[IQU + a] + sgk[IQL + a];
+                else if (a < 14) dg += 2 * w[11] + sgk[IDQU + a - 7] + sgk[IDQL + a - 7];
                 L[L_PM + ra * 36 + ra] += v + dg;
             } else { L[L_PM + ra * 36 + rb] += v; L[L_PM + rb * 36 + ra] += v; }
         }
@@ -774,11 +797,11 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
             const int r = lane - 20;   // diagonal of ddq (7), j (7), phi, dphi, ddphi, jphi
             int idx; double v;
             if (r < 7) { idx = SDDQ + r; v = 2 * w[12]; }
-            else if (r < 14) { const int i = r - 7; idx = SJ + i; v = 2 * w[13] + nuk[IJU + i] / tk[IJU + i] + nuk[IJL + i] / tk[IJL + i]; }
+            else if (r < 14) { const int i = r - 7; idx = SJ + i; v = 2 * w[13] + sgk[IJU + i] + sgk[IJL + i]; }
             else if (r == 14) { idx = SPHI; v = NC[NC_SC + 0]; }
             else if (r == 15) { idx = SDPHI; v = NC[NC_SC + 1]; }
             else if (r == 16) { idx = SDDPHI; v = NC[NC_SC + 2]; }
-            else { idx = SJPHI; v = 2 * w[9] + nuk[IJU + 7] / tk[IJU + 7] + nuk[IJL + 7] / tk[IJL + 7]; }
+            else { idx = SJPHI; v = 2 * w[9] + sgk[IJU + 7] + sgk[IJL + 7]; }
             L[L_PM + idx * 36 + idx] += v + delta;
         }
     LANES_END
@@ -819,13 +842,27 @@ BMPC_D inline bool wave_backward(Wave &W, const POff &po, const Scr &sc, double 
         if (lane < 36) L[L_PV + lane] = 0.0;
     LANES_END
     for (int k = N - 1; k >= 0; k--) {
-        wave_node_cost(W, po, sc, k, mu, delta);          // PM/PV now hold the value function of node k+1
-        // ---- stage data: rdyn, iota coupling AE (3x14), acceleration cross block XT (15x14) ----
-        LANES_BEGIN   // L_K0 holds Kp[k] (loaded by wave_node_cost); load Kp[k-1] and Kv[k]
-            if (k >= 1) for (int id = lane; id < KREC; id += 64) { L[L_K1 + id] = G[sc.KIN + (k - 1) * KREC + id]; L[L_KV + id] = G[sc.KIN + (N + k) * KREC + id]; }
+        BMPC_PROF(W, 6);
+        LANES_BEGIN   // ---- all inputs of this stage from the scratch slab in one burst (coalesced, lane-strided) ----
+            const bool hn = k < N - 1, hp = k >= 1;
+            for (int id = lane; id < KREC; id += 64) {
+                L[L_K0 + id] = G[sc.KIN + k * KREC + id];
+                L[L_KV1 + id] = hn ? G[sc.KIN + (N + k + 1) * KREC + id] : 0.0;
+                if (hp) { L[L_K1 + id] = G[sc.KIN + (k - 1) * KREC + id]; L[L_KV + id] = G[sc.KIN + (N + k) * KREC + id]; }
+            }
+            for (int id = lane; id < RREC; id += 64) L[L_ST + ST_REF + id] = G[sc.REF + k * RREC + id];
+            if (lane < NZ) { L[L_ST + ST_Z + lane] = G[sc.Z + k * NZ + lane]; L[L_ST + ST_GH + lane] = G[sc.GH + k * NZ + lane]; }
+            if (lane < NI) { L[L_ST + ST_SG + lane] = G[sc.SG + k * NI + lane]; L[L_ST + ST_NU + lane] = G[sc.NUm + k * NI + lane]; }
+            if (lane < NE) { L[L_ST + ST_G + lane] = G[sc.G + k * NE + lane]; L[L_ST + ST_LAM0 + lane] = G[sc.LAM + k * NE + lane];
+                             L[L_ST + ST_LAM1 + lane] = hn ? G[sc.LAM + (k + 1) * NE + lane] : 0.0; }
+            if (lane < 12) { L[L_ST + ST_RLV0 + lane] = G[sc.RLV + k * 12 + lane]; L[L_ST + ST_RLVM + lane] = hp ? G[sc.RLV + (k - 1) * 12 + lane] : 0.0;
+                             L[L_ST + ST_RLVP + lane] = hn ? G[sc.RLV + (k + 1) * 12 + lane] : 0.0; }
         LANES_END
+        wave_node_cost(W, po, sc, k, mu, delta);          // PM/PV now hold the value function of node k+1
+        BMPC_PROF(W, 5);
+        // ---- stage data: rdyn, iota coupling AE (3x14), acceleration cross block XT (15x14) ----
         LANES_BEGIN
-            const double *K0 = L + L_K0, *K1 = L + L_K1, *KVk = L + L_KV, *gk = G + sc.G + k * NE;
+            const double *K0 = L + L_K0, *K1 = L + L_K1, *KVk = L + L_KV, *gk = L + L_ST + ST_G;
             if (lane < NS) {
                 const int r = lane; double v = 0;
                 if (r < SJ) v = gk[r];                       // q, dq, ddq defects share the ordering
@@ -842,7 +879,7 @@ BMPC_D inline bool wave_backward(Wave &W, const POff &po, const Scr &sc, double 
                 L[L_AE + lane] = v; G[sc.AES + k * 42 + lane] = v;
             }
             if (k >= 1) {
-                const double *dpn = G + sc.REF + k * RREC + RDP;
+                const double *dpn = L + L_ST + ST_REF + RDP;
                 for (int id = lane; id < 15 * 14; id += 64) {
                     const int r = id / 14, c = id - r * 14; double v = 0;
                     for (int c6 = 0; c6 < 6; c6++) {
@@ -853,6 +890,7 @@ BMPC_D inline bool wave_backward(Wave &W, const POff &po, const Scr &sc, double 
                 }
             }
         LANES_END
+        BMPC_PROF(W, 11);
         LANES_BEGIN   // PR = PV + P' rdyn   (symmetric P': read columns)
             if (lane < NS) { double s = L[L_PV + lane]; for (int c = 0; c < NS; c++) s += L[L_PM + c * 36 + lane] * L[L_RD + c]; L[L_PR + lane] = s; }
         LANES_END
@@ -876,6 +914,7 @@ BMPC_D inline bool wave_backward(Wave &W, const POff &po, const Scr &sc, double 
                     for (int r = 0; r < NS; r++) {
                         const double *row = L + L_PM + r * 36;
                         t1[r] = cf0 * row[i0] + cf1 * row[i1] + cf2 * row[i2] + cf3 * row[i3] + ae0 * row[SIOTA] + ae1 * row[SIOTA + 1] + ae2 * row[SIOTA + 2];
+                        if ((r % 5) == 4) BMPC_SCHED_FENCE();
                     }
                     if (k >= 1 && c < 14) {   // + X S : rows y+ (14) and ddphi+
 #pragma unroll
@@ -899,6 +938,7 @@ BMPC_D inline bool wave_backward(Wave &W, const POff &po, const Scr &sc, double 
                     mc[rddq] = h * h / 2 * t1[rq] + h * t1[rdq] + t1[rddq];
                     mc[rj] = h * h * h / 8 * t1[rq] + h * h / 3 * t1[rdq] + h / 2 * t1[rddq];
                     mc[NS + i] = h * h * h / 24 * t1[rq] + h * h / 6 * t1[rdq] + h / 2 * t1[rddq] + t1[rj];
+                    BMPC_SCHED_FENCE();
                 }
                 mc[SIOTA] = t1[SIOTA]; mc[SIOTA + 1] = t1[SIOTA + 1]; mc[SIOTA + 2] = t1[SIOTA + 2];
                 if (k >= 1) {   // + S^T X^T F  (rows y_k)
@@ -926,18 +966,20 @@ BMPC_D inline bool wave_backward(Wave &W, const POff &po, const Scr &sc, double 
                 for (int a = 0; a < NU; a++) L[L_SR + a * 44 + c] = mc[NS + a];
             }
         LANES_END
+        BMPC_PROF(W, 12);
         // ---- 8x8 Cholesky (every lane, identical data), gains, Schur complement ----
         LANES_BEGIN
             double *mc = LR[LIDX].mc, *kc = LR[LIDX].kc;
-            double Lc[NU][NU]; bool pd = true;
+            double Lc[NU][NU], dinv[NU]; bool pd = true;
 #pragma unroll
             for (int i = 0; i < NU; i++) {
 #pragma unroll
                 for (int j = 0; j <= i; j++) {
                     double s = L[L_SR + i * 44 + NS + j];
+#pragma unroll
                     for (int q = 0; q < j; q++) s -= Lc[i][q] * Lc[j][q];
-                    if (i == j) { if (!(s > 1e-13)) { pd = false; s = 1.0; } Lc[i][i] = BMPC_SQRT(s); }
-                    else Lc[i][j] = s / Lc[j][j];
+                    if (i == j) { if (!(s > 1e-13)) { pd = false; s = 1.0; } dinv[i] = BMPC_RSQRT(s); Lc[i][i] = s * dinv[i]; }
+                    else Lc[i][j] = s * dinv[j];
                 }
             }
             if (lane == 0) L[L_FLAG] = pd ? 1.0 : 0.0;
@@ -947,9 +989,15 @@ BMPC_D inline bool wave_backward(Wave &W, const POff &po, const Scr &sc, double 
 #pragma unroll
                 for (int a = 0; a < NU; a++) kc[a] = -mc[NS + a];
 #pragma unroll
-                for (int i = 0; i < NU; i++) { double s = kc[i]; for (int q = 0; q < i; q++) s -= Lc[i][q] * kc[q]; kc[i] = s / Lc[i][i]; }
+                for (int i = 0; i < NU; i++) { double s = kc[i];
 #pragma unroll
-                for (int i = NU - 1; i >= 0; i--) { double s = kc[i]; for (int q = i + 1; q < NU; q++) s -= Lc[q][i] * kc[q]; kc[i] = s / Lc[i][i]; }
+                    for (int q = 0; q < i; q++) s -= Lc[i][q] * kc[q];
+                    kc[i] = s * dinv[i]; }
+#pragma unroll
+                for (int i = NU - 1; i >= 0; i--) { double s = kc[i];
+#pragma unroll
+                    for (int q = i + 1; q < NU; q++) s -= Lc[q][i] * kc[q];
+                    kc[i] = s * dinv[i]; }
                 if (c < NS) { for (int a = 0; a < NU; a++) G[sc.KT + (k * NS + c) * NU + a] = kc[a]; }
                 else { for (int a = 0; a < NU; a++) G[sc.KF + k * NU + a] = kc[a]; }
                 if (k >= 1) {
@@ -958,20 +1006,14 @@ BMPC_D inline bool wave_backward(Wave &W, const POff &po, const Scr &sc, double 
                         double s = mc[r];
 #pragma unroll
                         for (int a = 0; a < NU; a++) s += L[L_SR + a * 44 + r] * kc[a];
-                        if (c < NS) L[L_PM + r * 36 + c] = s; else L[L_PV + r] = s;
+                        if (c < NS) { if (r >= c) { L[L_PM + r * 36 + c] = s; L[L_PM + c * 36 + r] = s; } } else L[L_PV + r] = s;
+                        if ((r % 4) == 3) BMPC_SCHED_FENCE();
                     }
                 }
             }
         LANES_END
+        BMPC_PROF(W, 13);
         if (L[L_FLAG] == 0.0) return false;
-        if (k >= 1) {   // keep the value-function Hessian symmetric against round-off
-            LANES_BEGIN
-                for (int id = lane; id < NS * NS; id += 64) {
-                    const int a = id / NS, b = id - a * NS;
-                    if (a < b) { const double v = 0.5 * (L[L_PM + a * 36 + b] + L[L_PM + b * 36 + a]); L[L_PM + a * 36 + b] = v; L[L_PM + b * 36 + a] = v; }
-                }
-            LANES_END
-        }
     }
     return true;
 }
@@ -984,13 +1026,31 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc) {
         if (lane < 36) L[L_DS + lane] = 0.0;
     LANES_END
     for (int k = 0; k < N; k++) {
-        LANES_BEGIN
-            if (lane < NU) { double s = G[sc.KF + k * NU + lane]; for (int b = 0; b < NS; b++) s += G[sc.KT + (k * NS + b) * NU + lane] * L[L_DS + b]; L[L_DU + lane] = s; }
+        LANES_BEGIN   // one burst: gains, feed-forward, defects, iota coupling, lifted residuals, kinematics record
+            for (int id = lane; id < NS * NU; id += 64) L[L_ST + ST_KT + id] = G[sc.KT + k * NS * NU + id];
+            if (lane < NU) L[L_ST + ST_KF + lane] = G[sc.KF + k * NU + lane];
+            if (lane < 36) L[L_ST + ST_RDY + lane] = G[sc.RDY + k * 36 + lane];
+            if (lane < 42) L[L_ST + ST_AES + lane] = G[sc.AES + k * 42 + lane];
+            if (lane < 12) L[L_ST + ST_RLVF + lane] = G[sc.RLV + k * 12 + lane];
             for (int id = lane; id < KREC; id += 64) L[L_K0 + id] = G[sc.KIN + k * KREC + id];
         LANES_END
         LANES_BEGIN
+            {   // du = kff + K ds: lane (g, a) sums rows b = g, g+8, ... of K^T, 8 partials per jerk
+                const int a = lane & 7, g = lane >> 3; double s = 0;
+                for (int b = g; b < NS; b += 8) s += L[L_ST + ST_KT + b * NU + a] * L[L_DS + b];
+                L[L_RED + lane] = s;
+            }
+        LANES_END
+        LANES_BEGIN
+            if (lane < NU) {
+                double s = L[L_ST + ST_KF + lane];
+                for (int g = 0; g < 8; g++) s += L[L_RED + g * 8 + lane];
+                L[L_DU + lane] = s;
+            }
+        LANES_END
+        LANES_BEGIN
             if (lane < NS) {
-                const int r = lane; double v = G[sc.RDY + k * 36 + r];
+                const int r = lane; double v = L[L_ST + ST_RDY + r];
                 const double *ds = L + L_DS, *du = L + L_DU;
                 if (r < 28 || (r >= SPHI && r <= SJPHI)) {
                     const int f = r < 28 ? r / 7 : r - 28, i = r < 28 ? r % 7 : 7;
@@ -998,19 +1058,19 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc) {
                     v += chain_cf(h, f, 4) * du[i];
                 } else {
                     const int a = r - SIOTA; v += ds[r];
-                    for (int y = 0; y < 14; y++) v += G[sc.AES + k * 42 + a * 14 + y] * ds[y];
+                    for (int y = 0; y < 14; y++) v += L[L_ST + ST_AES + a * 14 + y] * ds[y];
                 }
                 L[L_DSN + r] = v;
             }
         LANES_END
         LANES_BEGIN
             if (lane < NZ) {
-                const int z = lane; const double *dn = L + L_DSN, *K0 = L + L_K0; double v;
+                const int z = lane; const double *dn = L + L_DSN, *K0 = L + L_K0, *rlv = L + L_ST + ST_RLVF; double v;
                 if (z < 7) v = dn[SJ + z]; else if (z == ZJPHI) v = dn[SJPHI];
                 else if (z < ZPOS) v = dn[z - ZQ];
-                else if (z < ZIW) { const int c = z - ZPOS; v = G[sc.RLV + k * 12 + c]; for (int i = 0; i < 7; i++) v += K0[KW + c * 7 + i] * dn[SQ + i]; }
+                else if (z < ZIW) { const int c = z - ZPOS; v = rlv[c]; for (int i = 0; i < 7; i++) v += K0[KW + c * 7 + i] * dn[SQ + i]; }
                 else if (z < ZV) { const int c = z - ZIW; v = dn[SIOTA + c]; for (int i = 0; i < 7; i++) v += 0.5 * h * (K0[KD + (3 + c) * 7 + i] * dn[SQ + i] + K0[KA + c * 7 + i] * dn[SDQ + i]); }
-                else if (z < ZPHI) { const int c6 = z - ZV; v = G[sc.RLV + k * 12 + 3 + c6]; for (int y = 0; y < 14; y++) v += gv_at(K0, c6, y) * dn[y]; }
+                else if (z < ZPHI) { const int c6 = z - ZV; v = rlv[3 + c6]; for (int y = 0; y < 14; y++) v += gv_at(K0, c6, y) * dn[y]; }
                 else v = dn[SPHI + z - ZPHI];
                 G[sc.DZ + k * NZ + z] = v;
             }
@@ -1042,13 +1102,17 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     const double *PAR = L + L_PAR;
     double mu = o.mu_init; const double mu_min = o.tol * o.mu_min_fac;
     double delta_last = 0.0, filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0;
+    BMPC_PROF(W, 15);
     double fval = wave_eval(W, po, sc, sc.Z, sc.G, sc.HIN);
+    BMPC_PROF(W, 0);
     LANES_BEGIN
         for (int id = lane; id < ni; id += 64) { const double hv = G[sc.HIN + id]; const double t = (-hv > o.slack_push) ? -hv : o.slack_push; G[sc.T + id] = t; G[sc.NUm + id] = mu / t; }
     LANES_END
     int it = 0, status = 1; double E0 = 0;
     for (it = 0; it <= o.max_iter; it++) {
+        BMPC_PROF(W, 10);
         wave_adjoint(W, po, sc, sc.NUm, false, 0.0);
+        BMPC_PROF(W, 1);
         // ---- KKT error (Ipopt-style scaling), deterministic reductions ----
         LANES_BEGIN
             double ed = 0, ep = 0, cmax = -1e300, cmin = 1e300, sl = 0, sn = 0;
@@ -1075,9 +1139,18 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
             const double Emu = BMPC_FMAX(BMPC_FMAX(ed / sd, ep), ec / scl);
             if (Emu <= 10.0 * mu && mu > mu_min) mu = BMPC_FMAX(mu_min, BMPC_FMIN(0.2 * mu, BMPC_POW15(mu))); else break;
         }
+        LANES_BEGIN   // barrier ratios once per iteration: sigma = nu/t, nu_hat = (mu + nu (h+t))/t
+            for (int id = lane; id < ni; id += 64) {
+                const double t = G[sc.T + id], nu = G[sc.NUm + id], ti = 1.0 / t;
+                G[sc.SG + id] = nu * ti; G[sc.NUH + id] = (mu + nu * (G[sc.HIN + id] + t)) * ti;
+            }
+        LANES_END
         // ---- Newton system: QP gradient, lifted residuals, Riccati ----
+        BMPC_PROF(W, 2);
         wave_adjoint(W, po, sc, sc.NUm, true, mu);
+        BMPC_PROF(W, 3);
         wave_prepare_rlv(W, sc);
+        BMPC_PROF(W, 4);
         double delta = 0.0; bool ok = false;
         for (int tries = 0; tries < 40; tries++) {
             if (wave_backward(W, po, sc, mu, delta, LRs)) { ok = true; break; }
@@ -1087,7 +1160,9 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         }
         if (!ok) { status = 3; break; }
         if (delta > 0) delta_last = delta;
+        BMPC_PROF(W, 6);
         wave_forward(W, sc);
+        BMPC_PROF(W, 7);
         // ---- slack / multiplier directions, fraction to the boundary, merit ingredients ----
         const double tau = BMPC_FMAX(0.99, 1.0 - mu);
         LANES_BEGIN
@@ -1096,11 +1171,11 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                 const int k = id / NI, i = id - k * NI;
                 const double t = G[sc.T + id], nu = G[sc.NUm + id], r = G[sc.HIN + id] + t;
                 const double hd = ineq_dir(G + sc.DZ + k * NZ, G + sc.REF + k * RREC, i);
-                const double dt = -r - hd, dnu = mu / t - nu - nu / t * dt;
+                const double sgm = G[sc.SG + id], dt = -r - hd, dnu = (G[sc.NUH + id] - sgm * r) - nu - sgm * dt;
                 G[sc.DT + id] = dt; G[sc.DNU + id] = dnu;
                 if (dt < 0) { const double a = -tau * t / dt; ap = a < ap ? a : ap; }
                 if (dnu < 0) { const double a = -tau * nu / dnu; ad = a < ad ? a : ad; }
-                dbar += -mu * dt / t; nhd += (mu + nu * r) / t * hd; th += BMPC_FABS(r); bar -= mu * BMPC_LOG(t);
+                dbar += -(G[sc.NUH + id] - sgm * r) * dt; nhd += G[sc.NUH + id] * hd; th += BMPC_FABS(r); bar -= mu * BMPC_LOG(t);
             }
             double ghd = 0;
             for (int id = lane; id < nw; id += 64) ghd += G[sc.GH + id] * G[sc.DZ + id];
@@ -1110,6 +1185,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         LANES_END
         const double ap = red_min(L + L_RED), ad = red_min(L + L_RED + 64), dbar = red_sum(L + L_RED + 128), gfd = red_sum(L + L_RED + 192),
                      theta = red_sum(L + L_RED + 256), bar = red_sum(L + L_RED + 320);
+        BMPC_PROF(W, 8);
         // ---- filter line search (Waechter & Biegler 2006, Ipopt constants) on theta and phi = f - mu sum log t ----
         const double dphi = gfd + dbar, phi0 = fval + bar;
         if (mu != filt_mu) { nfilt = 0; filt_mu = mu; }
@@ -1120,7 +1196,9 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                 for (int id = lane; id < nw; id += 64) G[sc.ZT + id] = G[sc.Z + id] + alpha * G[sc.DZ + id];
                 for (int id = lane; id < ni; id += 64) G[sc.TT + id] = G[sc.T + id] + alpha * G[sc.DT + id];
             LANES_END
+            BMPC_PROF(W, 9);
             ft = wave_eval(W, po, sc, sc.ZT, sc.GT, sc.HT);
+            BMPC_PROF(W, 0);
             LANES_BEGIN
                 double th = 0, br = 0;
                 for (int id = lane; id < ne; id += 64) th += BMPC_FABS(G[sc.GT + id]);

@@ -21,6 +21,7 @@
 #define BMPC_EXP(x) std::exp(x)
 #define BMPC_LOG(x) std::log(x)
 #define BMPC_SQRT(x) std::sqrt(x)
+#define BMPC_RSQRT(x) (1.0 / std::sqrt(x))
 #define BMPC_FABS(x) std::fabs(x)
 #define BMPC_FMAX(a, b) std::fmax(a, b)
 #define BMPC_FMIN(a, b) std::fmin(a, b)

@@ -1,0 +1,38 @@
+"""Diagnostic (GPU box): per-phase cycle shares of the solver kernel from the -DBMPC_PROFILE build
+(libboundmpc_hip_prof.so, built here on the fly; never used by the product)."""
+import ctypes, os, subprocess, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from boundmpc_amd import workload, _lib
+
+csrc = os.path.join(ROOT, "boundmpc_amd", "csrc")
+prof_lib = os.path.join(ROOT, "gpurun_out", "libboundmpc_hip_prof.so")
+os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DBMPC_PROFILE",
+                       "-Wno-unused-variable", "-Wno-unused-value", "-Wno-duplicate-decl-specifier", "-o", prof_lib,
+                       os.path.join(csrc, "bmpc_hip.hip")])
+lib = ctypes.CDLL(prof_lib)
+vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+lib.bmpc_create.argtypes = [ci, ci, cd, vp, ctypes.POINTER(vp)]
+lib.bmpc_solve_batch.argtypes = [vp, ci] + [vp] * 11
+lib.bmpc_get_profile.argtypes = [vp, vp]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+P, X, _ = workload.make_batch(B, seed=0, N=N)
+h = vp()
+assert lib.bmpc_create(N, 4, 0.1, None, ctypes.byref(h)) == 0
+p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
+x = torch.empty_like(x0); it = torch.empty(B, dtype=torch.int32, device="cuda")
+prof = np.zeros(16, dtype=np.uint64)
+for rep in range(2):
+    t = time.time()
+    assert lib.bmpc_solve_batch(h, B, vp(p.data_ptr()), vp(x0.data_ptr()), vp(x.data_ptr()), None, None, None, None, vp(it.data_ptr()), None, None, None) == 0
+    torch.cuda.synchronize(); dt = time.time() - t
+    lib.bmpc_get_profile(h, vp(prof.ctypes.data))
+names = ["eval", "adjoint", "kkt+mu", "qp-gradient", "prepare-rlv", "bwd:node-assemble", "bwd:stage-in(+tail)", "forward", "step-dirs", "ls-trial", "nu-update", "bwd:stage-data", "bwd:M-columns", "bwd:chol+schur", "bwd:node-blocks+curv", "load"]
+tot = float(prof.sum()); its = float(it.sum().item())
+print(f"B={B} N={N} wall {dt*1e3:.1f} ms, total iterations {its:.0f}, cycles/iteration (lane-0 stamps, profile build) {tot/its:.0f}")
+for n, c in zip(names, prof):
+    if c: print(f"  {n:14s} {100.0*float(c)/tot:5.1f} %   {float(c)/its:9.0f} cycles/iter")
