@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
     bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = a.scratch + (long long)blockIdx.x * a.scr_stride;
     const int np = 141 + 91 * a.S, nw = a.N * bmpc::NZ, ng = a.N * bmpc::NG;
 #ifdef BMPC_PROFILE
-    if (threadIdx.x < 16) ((long long *)(lds + bmpc::L_PROF))[threadIdx.x] = 0;
+    if (threadIdx.x < 32) ((long long *)(lds + bmpc::L_PROF))[threadIdx.x] = 0;
     __syncthreads();
     W.tprev = clock64();
 #endif
@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
         __syncthreads();
     }
 #ifdef BMPC_PROFILE
-    if (threadIdx.x < 16 && a.prof) atomicAdd(a.prof + threadIdx.x, (unsigned long long)((long long *)(lds + bmpc::L_PROF))[threadIdx.x]);
+    if (threadIdx.x < 32 && a.prof) atomicAdd(a.prof + threadIdx.x, (unsigned long long)((long long *)(lds + bmpc::L_PROF))[threadIdx.x]);
 #endif
 }
 
@@ -110,8 +110,8 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     h->scr_stride = bmpc::make_scr(N).size;
     HIPCHK(hipMalloc(&h->scratch, sizeof(double) * (size_t)h->scr_stride * h->grid));
     HIPCHK(hipMalloc(&h->counter, sizeof(int)));
-    HIPCHK(hipMalloc(&h->prof, 16 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(h->prof, 0, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(&h->prof, 32 * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(h->prof, 0, 32 * sizeof(unsigned long long)));
     *out = h;
     return BMPC_OK;
 }
@@ -211,8 +211,8 @@ extern "C" int bmpc_last_kernel_ms(bmpc_handle *h, float *ms) {
 extern "C" int bmpc_get_profile(bmpc_handle *h, unsigned long long *out) {
     if (!h || !out) return BMPC_ERR_ARG;
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(out, h->prof, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIPCHK(hipMemset(h->prof, 0, 16 * sizeof(unsigned long long)));
+    HIPCHK(hipMemcpy(out, h->prof, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemset(h->prof, 0, 32 * sizeof(unsigned long long)));
     return BMPC_OK;
 }
 #endif

@@ -20,9 +20,9 @@
 // trapezoidal omega coupling eliminated node-locally), l1-merit backtracking line search.
 //
 // Lane maps: evaluation = one lane per kinematic evaluation point (2N points); adjoint /
-// forward sweeps = one lane per state component; Riccati = one lane per COLUMN of the
-// 43x43 stage matrix, column held in registers (two in-register passes of F^T P F exploit the
-// integrator-chain sparsity of F); inequality rows = one lane per row (57 per node).
+// forward sweeps = one lane per state component; Riccati = one lane per PAIR of integrator chains
+// (8 x 8 pairs = 64 lanes): the stage map is I_8 (x) CF, so every 4x4 block of the value-function
+// Hessian transforms independently; inequality rows = one lane per row (57 per node).
 #pragma once
 
 #ifndef BMPC_PROF
@@ -69,7 +69,14 @@ BMPC_HD inline POff make_poff(int S) {
 enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV = L_RED + 6 * 64, L_PR = L_PV + 36, L_QT = L_PR + 36,
        L_RD = L_QT + 36, L_DS = L_RD + 36, L_DSN = L_DS + 36, L_DU = L_DSN + 36, L_MV = L_DU + 8, L_AE = L_MV + 44, L_K0 = L_AE + 42,
        L_K1 = L_K0 + KREC, L_KV = L_K1 + KREC, L_XT = L_KV + KREC, L_NC = L_XT + 15 * 14, L_WY = L_NC + 160, L_WV = L_WY + 196, L_TOT = L_WV + 196,
-       L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 16, L_ST = L_KV1 + KREC, L_SIZE = L_ST + 432 };
+       L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_BLK = L_ST + 432, L_SIZE = L_BLK + 8 };
+// Block (chain-pair) Riccati storage, overlaid on the L_PM..L_RED region (column scheme retired):
+//   PB  [16 planes (f*4+g)][64 pairs (i*8+l)]  value-function Hessian blocks P[(f,i)][(g,l)]
+//   PCI [3][4][8]  P[(f,i)][iota_a] ;  PII [3][3] ;  GS [8][36] jerk rows of M (col 35 = m_j) ; R8 [8][8] ; KS [8][36] gains (col 35 = kff)
+//   MCI [3][5][8]  C^T P_c,iota, then M_c,iota in place ;  PE [3][14] = P_ii E ;  KHP [2][72] prefix vectors of the kinematic curvature
+enum { L_PB = L_PM, L_PCI = L_PB + 1024, L_PII = L_PCI + 96, L_GS = L_PII + 12, L_R8 = L_GS + 288, L_KS = L_R8 + 64, L_MCI = L_KS + 288,
+       L_PE = L_MCI + 120, L_BLK_END = L_PE + 42, L_KHP = L_WV /* 144 of the 196 */ };
+static_assert((int)L_BLK_END <= (int)L_PV, "block Riccati storage must fit into the retired PM/SR/RED region");
 // staging area inside L_ST: per-stage inputs of the sequential sweeps, loaded from the scratch slab in ONE burst per stage
 enum { ST_REF = 0, ST_Z = 80, ST_SG = 124, ST_NU = 184, ST_G = 244, ST_LAM0 = 280, ST_LAM1 = 316, ST_GH = 352, ST_RLVM = 396, ST_RLV0 = 408, ST_RLVP = 420,
        /* forward sweep view */ ST_KT = 0, ST_KF = 280, ST_RDY = 288, ST_AES = 324, ST_RLVF = 366 };
@@ -393,7 +400,7 @@ BMPC_D inline double chain_cf(double h, int fr, int fc) {
 }
 BMPC_D inline int srow(int f, int i) { return i < 7 ? f * 7 + i : 28 + f; }   // reduced-state index of (field, chain)
 
-struct LaneRegs { double mc[44]; double kc[8]; };
+struct LaneRegs { double mc[16]; double pf[20]; };   // pf: software prefetch of the next stage's inputs (global -> registers -> LDS)   // a lane's 4x4 state block of M, kept in registers between the M and the Schur phases
 
 // ----------------------------------------------------------------------------------------
 // wave-uniform deterministic reductions through LDS (RED has 6 x 64 slots)
@@ -592,44 +599,84 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
     LANES_END
 }
 
-// ----------------------------------------------------------------------------------------
-// Node cost: reduced Hessian/gradient of node k+1 (index k) ADDED into PM / PV.
-// Q~ = T^T H T + W  (T eliminates the lifted pos / v variables and the omega part of iw),
-// q~ = T^T (g^ + H r) - W g_y + acceleration cross gradients.  delta = Hessian regularisation.
-// ----------------------------------------------------------------------------------------
-BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k, double mu, double delta) {
+// ========================================================================================
+// Block ("chain-pair") form of the node cost and of the Riccati stage.
+// The stage map of the chain part is the Kronecker product I_8 (x) CF of the 4-state integrator chain, so the
+// congruence F^T P' F acts independently on every 4x4 block P'[(.,i)][(.,l)] of a pair of chains (i,l):
+// ONE LANE PER PAIR (64 pairs = 64 lanes), 16 LDS reads + ~200 FMAs per lane and stage.  A lane always evaluates
+// the canonical pair (min,max) and transposes, so the stored matrix is symmetric bit for bit.
+// ========================================================================================
+BMPC_D inline int pbi(int f, int g, int i, int l) { return (f * 4 + g) * 64 + i * 8 + l; }   // plane-major: lane-contiguous
+BMPC_D inline int pci(int a, int f, int i) { return a * 32 + f * 8 + i; }
+BMPC_D inline int mci(int a, int f, int i) { return a * 40 + f * 8 + i; }                      // f = 0..4
+
+// curvature entries from a kinematics record + its prefix vectors hp = [Wlt 8x3 | Vge 7x3 | Wgt 7x3]
+BMPC_D inline double kh_qq(const double *rec, const double *hp, const double *mu_p, const double *mu_v, const double *mu_w, int i, int l) {
+    double ai[3], al[3], wl[3], t[3], t2[3], u[3], Wil[3];
+    ldA(rec, i, ai); ldA(rec, l, al); ldW(rec, l, wl);
+    const double *Wi = hp + 3 * i, *Wl = hp + 3 * l, *Vl = hp + 24 + 3 * l, *Gl = hp + 45 + 3 * l;
+    cross3(ai, wl, t); double val = dot3(mu_p, t);
+    cross3(Wi, t, u); val += dot3(mu_v, u);
+    cross3(al, Vl, t2); cross3(ai, t2, u); val += dot3(mu_v, u);
+    for (int c = 0; c < 3; c++) Wil[c] = Wl[c] - Wi[c];
+    cross3(Wil, wl, t2); cross3(ai, t2, u); val += dot3(mu_v, u);
+    cross3(al, Gl, t2); cross3(ai, t2, u); val += dot3(mu_w, u);
+    return val;
+}
+BMPC_D inline double kh_qdq(const double *rec, const double *mu_v, const double *mu_w, int i, int j) {   // d2/(dq_i d dq_j)
+    const int lo = i <= j ? i : j, hi = i <= j ? j : i;
+    double alo[3], whi[3], t[3]; ldA(rec, lo, alo); ldW(rec, hi, whi);
+    cross3(alo, whi, t); double val = dot3(mu_v, t);
+    if (i < j) { double aj[3]; ldA(rec, j, aj); cross3(alo, aj, t); val += dot3(mu_w, t); }
+    return val;
+}
+BMPC_D inline void kh_prefix(const double *rec, double *hp) {   // sequential over the 7 joints (one lane)
+    double wl[3] = {0, 0, 0};
+    for (int j = 0; j < 7; j++) { for (int c = 0; c < 3; c++) { hp[3 * j + c] = wl[c]; wl[c] += rec[KDQ + j] * rec[KA + c * 7 + j]; } }
+    for (int c = 0; c < 3; c++) hp[21 + c] = wl[c];
+    double vg[3] = {0, 0, 0}, wg[3] = {0, 0, 0};
+    for (int j = 6; j >= 0; j--) {
+        for (int c = 0; c < 3; c++) { hp[45 + 3 * j + c] = wg[c]; vg[c] += rec[KDQ + j] * rec[KW + c * 7 + j]; hp[24 + 3 * j + c] = vg[c];
+                                      wg[c] += rec[KDQ + j] * rec[KA + c * 7 + j]; }
+    }
+}
+
+// Node cost in block form: Q~ of node k+1 (index k) added into PB / PCI / PII, q~ into PV.
+BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, int k, double mu, double delta) {
     const int N = W.N; const double h = W.h; const int ex = W.o.exact_hessian;
-    double *L = W.L, *G = W.G;
+    double *L = W.L;
     const double *PAR = L + L_PAR, *w = PAR + po.w;
-    const double *ST = L + L_ST;   // staged by wave_backward for this stage
+    const double *ST = L + L_ST;
     const double *rr = ST + ST_REF, *gk = ST + ST_G, *sgk = ST + ST_SG, *nuk = ST + ST_NU;
-    double *NC = L + L_NC, *K0 = L + L_K0, *KV1 = L + L_KV1, *WY = L + L_WY, *WV = L + L_WV;
+    double *NC = L + L_NC, *K0 = L + L_K0, *KV1 = L + L_KV1, *WY = L + L_WY, *KHP = L + L_KHP;
     const bool has_next = k < N - 1;
-    // phase 1: stage records, small Hessian blocks, lifted residuals
+    // phase 1: small Hessian blocks over (pos, iw, phi)
     LANES_BEGIN
         if (lane < 14) NC[NC_GY + lane] = lane < 7 ? gk[GQ + lane] : gk[GDQ + lane - 7];
-        if (lane >= 16 && lane < 16 + 9) {   // H_pp (a,b) and H_rr (a,b)
+        if (lane >= 16 && lane < 16 + 9) {
             const int a = (lane - 16) / 3, b = (lane - 16) % 3;
             const double sig = rr[RSIG], *d = rr + RDP, *dh = rr + RDH, *l2 = rr + RL2, *jacl = PAR + po.jacl;
             double sp = 0, sr = 0;
+#pragma unroll
             for (int r = 0; r < 3; r++) {
                 const double jpa = (r == a ? sig : 0.0) + (1 - sig) * d[r] * d[a], jpb = (r == b ? sig : 0.0) + (1 - sig) * d[r] * d[b];
                 const double jra = sig * jacl[a * 3 + r] + (1 - sig) * dh[r] * l2[a], jrb = sig * jacl[b * 3 + r] + (1 - sig) * dh[r] * l2[b];
                 sp += jpa * jpb; sr += jra * jrb;
             }
             double hp = 2 * w[0] * sp, hr = 2 * w[1] * sr;
+#pragma unroll
             for (int m = 0; m < 5; m++) {
-                const double su = sgk[ITUBE + 2 * m], sl = sgk[ITUBE + 2 * m + 1];
-                const double gg = (su + sl) * rr[RGC + m * 4 + a] * rr[RGC + m * 4 + b];
+                const double gg = (sgk[ITUBE + 2 * m] + sgk[ITUBE + 2 * m + 1]) * rr[RGC + m * 4 + a] * rr[RGC + m * 4 + b];
                 if (m == 1 || m == 2) hp += gg; else hr += gg;
             }
             NC[NC_HPP + a * 3 + b] = hp; NC[NC_HRR + a * 3 + b] = hr;
         }
-        if (lane >= 32 && lane < 35) {       // H_{pos,phi}, H_{iw,phi}
+        if (lane >= 32 && lane < 35) {
             const int a = lane - 32;
             const double sig = rr[RSIG], sig1 = rr[RSIG1], *d = rr + RDP, *dh = rr + RDH, *l2 = rr + RL2, *jacl = PAR + po.jacl;
             const double dde = dot3(d, rr + REP), dd = dot3(d, d);
             double sp = 0, sr = 0, epo[3], ero[3];
+#pragma unroll
             for (int r = 0; r < 3; r++) {
                 const double eperp = rr[REP + r] - dde * d[r], erd = rr[RER + r] - rr[RERPAR + r];
                 epo[r] = sig * rr[REP + r] + (1 - sig) * dde * d[r]; ero[r] = sig * rr[RER + r] + (1 - sig) * rr[RERPAR + r];
@@ -643,6 +690,7 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
                 double jl = 0; for (int r = 0; r < 3; r++) jl += ero[r] * jacl[a * 3 + r];
                 hp += 2 * w[0] * sig1 * (epo[a] - depo * d[a]); hr += 2 * w[1] * sig1 * (jl - dhero * l2[a]);
             }
+#pragma unroll
             for (int m = 0; m < 5; m++) {
                 const double su = sgk[ITUBE + 2 * m], sl = sgk[ITUBE + 2 * m + 1];
                 const double gpu_ = rr[RGC + m * 4 + 3] - rr[RW1 + m], gpl_ = -rr[RGC + m * 4 + 3] - rr[RW1 + m];
@@ -651,10 +699,11 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
             }
             NC[NC_HPF + a] = hp; NC[NC_HRF + a] = hr;
         }
-        if (lane == 40) {                     // scalar blocks: H_phiphi, H_dphidphi, H_ddphiddphi, c_v
+        if (lane == 40) {
             const double sig = rr[RSIG], sig1 = rr[RSIG1], sig2 = rr[RSIG2], *d = rr + RDP, *dh = rr + RDH;
             const double dde = dot3(d, rr + REP), dd = dot3(d, d);
             double sp = 0, sr = 0, spp = 0, srr = 0, dpdp = 0;
+#pragma unroll
             for (int r = 0; r < 3; r++) {
                 const double eperp = rr[REP + r] - dde * d[r], erd = rr[RER + r] - rr[RERPAR + r];
                 const double epo = sig * rr[REP + r] + (1 - sig) * dde * d[r], ero = sig * rr[RER + r] + (1 - sig) * rr[RERPAR + r];
@@ -666,6 +715,7 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
             for (int c = 0; c < 6; c++) dpdp += d[c] * d[c];
             double hff = 2 * w[0] * sp + 2 * w[1] * sr + 2 * w[6] + sgk[IPHI0] + sgk[IPHIMAX];
             if (ex) hff += 2 * w[0] * spp + 2 * w[1] * srr;
+#pragma unroll
             for (int m = 0; m < 5; m++) {
                 const double su = sgk[ITUBE + 2 * m], sl = sgk[ITUBE + 2 * m + 1];
                 const double gpu_ = rr[RGC + m * 4 + 3] - rr[RW1 + m], gpl_ = -rr[RGC + m * 4 + 3] - rr[RW1 + m];
@@ -678,29 +728,44 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
             NC[NC_SC + 3] = 2 * w[2] + 2 * w[5] / (h * h) * (has_next ? 2.0 : 1.0);
         }
     LANES_END
-    // phase 2: lifted residuals r (pos 3, v 6), A1 = Hpp Jp, A2 = Hrr Ehat, multipliers for the kinematic curvature
+    BMPC_PROF(W, 16);
+    // phase 2: A1 = Hpp Jp, A2 = (h/2) Hrr Ehat, curvature multipliers, prefix vectors of the curvature records
     LANES_BEGIN
-        if (lane < 9) {
-            NC[NC_RL + lane] = ST[ST_RLV0 + lane];
-        } else if (lane >= 16 && lane < 16 + 21) {
+        if (ex) {   // hp = [Wlt 8x3 | Vge 7x3 | Wgt 7x3] per record: one lane per (record, joint, component), three short sums each
+            const int rec = lane >> 5, jj = (lane >> 2) & 7, c = lane & 3;
+            if (c < 3) {
+                const double *R_ = rec ? KV1 : K0; double *hp = KHP + rec * 72;
+                double wlt = 0, vge = 0, wgt = 0;
+#pragma unroll
+                for (int m = 0; m < 7; m++) {
+                    const double dqm = R_[KDQ + m], am = R_[KA + c * 7 + m], wm = R_[KW + c * 7 + m];
+                    wlt += (m < jj ? dqm : 0.0) * am; vge += (m >= jj ? dqm : 0.0) * wm; wgt += (m > jj ? dqm : 0.0) * am;
+                }
+                hp[3 * jj + c] = wlt;
+                if (jj < 7) { hp[24 + 3 * jj + c] = vge; hp[45 + 3 * jj + c] = wgt; }
+            }
+        }
+        if (lane < 9) NC[NC_RL + lane] = ST[ST_RLV0 + lane];
+        else if (lane >= 16 && lane < 16 + 21) {
             const int c = (lane - 16) / 7, i = (lane - 16) % 7; double s = 0;
             for (int b = 0; b < 3; b++) s += NC[NC_HPP + c * 3 + b] * K0[KW + b * 7 + i];
             NC[NC_A1 + c * 7 + i] = s;
         }
-        if (lane < 42) {                       // uses a second slot of lanes 0..41 for A2 (distinct outputs from the branch above)
+        if (lane < 42) {
             const int c = lane / 14, y = lane % 14; double s = 0;
             for (int b = 0; b < 3; b++) s += NC[NC_HRR + c * 3 + b] * (y < 7 ? K0[KD + (3 + b) * 7 + y] : K0[KA + b * 7 + y - 7]);
             NC[NC_A2 + c * 14 + y] = 0.5 * h * s;
         }
-        if (lane >= 48 && lane < 60) {         // curvature multipliers: [0..2] mu_p, [3..5] mu_v, [6..8] mu_w (predicted point), [9..11] mu_w (node variables)
+        if (lane >= 48 && lane < 60) {
             const int c = (lane - 48) % 3, g = (lane - 48) / 3; const double *lam = ST + ST_LAM0;
             double v = 0;
             if (g == 0) v = lam[GPOS + c]; else if (g == 1) v = lam[GV + c]; else if (g == 2) v = lam[GW + c] + 0.5 * h * lam[GIW + c];
             else v = has_next ? 0.5 * h * ST[ST_LAM1 + GIW + c] : 0.0;
-            L[L_MU + 4 + 0 + (lane - 48)] = v;   // L_MU[4..15]
+            L[L_MU + 4 + (lane - 48)] = v;
         }
     LANES_END
-    // phase 3: Z-space gradient gl = g^ + H r + cross terms (44), kinematic curvature W (14x14)
+    BMPC_PROF(W, 17);
+    // phase 3: Z-space gradient gl = g^ + H r + cross terms
     LANES_BEGIN
         if (lane < NZ) {
             const int z = lane; double g = ST[ST_GH + z];
@@ -718,56 +783,88 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
             }
             NC[NC_GL + z] = g;
         }
-        for (int id = lane; id < 105; id += 64) {   // upper triangle of the 14x14 curvature block
-            int a = 0, rem = id; while (rem >= 14 - a) { rem -= 14 - a; a++; }
-            const int b = a + rem;
-            double v = 0, v2 = 0;
-            if (ex) {
-                v = kin_hess_entry(K0, L + L_MU + 4, L + L_MU + 7, L + L_MU + 10, a, b);
-                if (has_next) { const double z3[3] = {0, 0, 0}; v2 = kin_hess_entry(KV1, z3, z3, L + L_MU + 13, a, b); }
-            }
-            WY[a * 14 + b] = v; WY[b * 14 + a] = v; WV[a * 14 + b] = v2; WV[b * 14 + a] = v2;
-        }
     LANES_END
-    BMPC_PROF(W, 14);
-    // (RLV of all nodes is produced by wave_prepare_rlv() before the backward sweep.)
-    // phase 4: add Q~ into PM and q~ into PV
+    BMPC_PROF(W, 18);
+    // phase 4: one lane per chain pair adds its block of Q~ (and writes the predicted-point curvature to WY for q~)
     LANES_BEGIN
-        const double *A1 = NC + NC_A1, *A2 = NC + NC_A2, cv = NC[NC_SC + 3], *d = rr + RDP, *gl = NC + NC_GL;
-        // (a) 17 x 17 block over (q, dq, iota): entries id = a*17+b, a<=b handled once and mirrored
-        for (int id = lane; id < 17 * 17; id += 64) {
-            const int a = id / 17, b = id - a * 17;
-            if (a > b) continue;
-            double v = 0;
-            if (b < 14) {
-                if (b < 7) for (int c = 0; c < 3; c++) v += K0[KW + c * 7 + a] * A1[c * 7 + b];                       // Jp^T Hpp Jp (q-q)
-                for (int c = 0; c < 3; c++) v += 0.5 * h * (a < 7 ? K0[KD + (3 + c) * 7 + a] : K0[KA + c * 7 + a - 7]) * A2[c * 14 + b];   // Ehat^T Hrr Ehat
-                double gv = 0;
-                for (int c6 = 0; c6 < 6; c6++) {
-                    const double ga = a < 7 ? K0[KD + c6 * 7 + a] : (c6 < 3 ? K0[KW + c6 * 7 + a - 7] : K0[KA + (c6 - 3) * 7 + a - 7]);
-                    const double gb = b < 7 ? K0[KD + c6 * 7 + b] : (c6 < 3 ? K0[KW + c6 * 7 + b - 7] : K0[KA + (c6 - 3) * 7 + b - 7]);
-                    gv += ga * gb;
+        const int i = lane >> 3, l = lane & 7, ci = i < l ? i : l, cl = i < l ? l : i; const bool tr = i > l;
+        const double *A1 = NC + NC_A1, *A2 = NC + NC_A2, cv = NC[NC_SC + 3], *d = rr + RDP;
+        if (cl < 7) {
+            double e[2][2];
+#pragma unroll
+            for (int f = 0; f < 2; f++) {
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    const int a = f * 7 + ci, b = g * 7 + cl;
+                    double v = 0;
+                    if (f == 0 && g == 0) for (int c = 0; c < 3; c++) v += K0[KW + c * 7 + ci] * A1[c * 7 + cl];
+                    for (int c = 0; c < 3; c++) v += 0.5 * h * (f == 0 ? K0[KD + (3 + c) * 7 + ci] : K0[KA + c * 7 + ci]) * A2[c * 14 + b];
+                    double gv = 0;
+                    for (int c6 = 0; c6 < 6; c6++) {
+                        const double ga = f == 0 ? K0[KD + c6 * 7 + ci] : (c6 < 3 ? K0[KW + c6 * 7 + ci] : K0[KA + (c6 - 3) * 7 + ci]);
+                        const double gb = g == 0 ? K0[KD + c6 * 7 + cl] : (c6 < 3 ? K0[KW + c6 * 7 + cl] : K0[KA + (c6 - 3) * 7 + cl]);
+                        gv += ga * gb;
+                    }
+                    v += cv * gv;
+                    double wp = 0, wn = 0;
+                    if (ex && !(f == 1 && g == 1)) {
+                        const double z3[3] = {0, 0, 0};
+                        if (f == 0 && g == 0) { wp = kh_qq(K0, KHP, L + L_MU + 4, L + L_MU + 7, L + L_MU + 10, ci, cl);
+                                                if (has_next) wn = kh_qq(KV1, KHP + 72, z3, z3, L + L_MU + 13, ci, cl); }
+                        else { const int qi = f == 0 ? ci : cl, dj = f == 0 ? cl : ci;
+                               wp = kh_qdq(K0, L + L_MU + 7, L + L_MU + 10, qi, dj);
+                               if (has_next) wn = kh_qdq(KV1, z3, L + L_MU + 13, qi, dj); }
+                    }
+                    WY[a * 14 + b] = wp; WY[b * 14 + a] = wp;
+                    e[f][g] = v + wp + wn;
                 }
-                v += cv * gv + WY[a * 14 + b] + WV[a * 14 + b];
-            } else if (a < 14) { v = A2[(b - 14) * 14 + a]; }                                                       // (y, iota)
-            else { v = NC[NC_HRR + (a - 14) * 3 + (b - 14)]; }                                                        // (iota, iota)
-            const int ra = a < 14 ? a : SIOTA + a - 14, rb = b < 14 ? b : SIOTA + b - 14;
-            if (a == b) {
-                double dg = delta;
-                if (a < 7) dg += 2 * w[10] + sgk[IQU + a] + sgk[IQL + a];
-                else if (a < 14) dg += 2 * w[11] + sgk[IDQU + a - 7] + sgk[IDQL + a - 7];
-                L[L_PM + ra * 36 + ra] += v + dg;
-            } else { L[L_PM + ra * 36 + rb] += v; L[L_PM + rb * 36 + ra] += v; }
+            }
+            if (ci == cl) {
+                e[1][0] = e[0][1];
+                e[0][0] += 2 * w[10] + sgk[IQU + ci] + sgk[IQL + ci] + delta;
+                e[1][1] += 2 * w[11] + sgk[IDQU + ci] + sgk[IDQL + ci] + delta;
+                L[L_PB + pbi(2, 2, i, l)] += 2 * w[12] + delta;
+                L[L_PB + pbi(3, 3, i, l)] += 2 * w[13] + sgk[IJU + ci] + sgk[IJL + ci] + delta;
+            }
+#pragma unroll
+            for (int f = 0; f < 2; f++)
+#pragma unroll
+                for (int g = 0; g < 2; g++) L[L_PB + pbi(f, g, i, l)] += tr ? e[g][f] : e[f][g];
+        } else if (ci < 7) {          // coupling of (q, dq) of chain ci with (phi, dphi, ddphi)
+#pragma unroll
+            for (int f = 0; f < 2; f++) {
+                double vf = 0, vd = 0, vdd = 0;
+                if (f == 0) for (int c = 0; c < 3; c++) vf += K0[KW + c * 7 + ci] * NC[NC_HPF + c];
+                for (int c = 0; c < 3; c++) vf += 0.5 * h * (f == 0 ? K0[KD + (3 + c) * 7 + ci] : K0[KA + c * 7 + ci]) * NC[NC_HRF + c];
+                for (int c6 = 0; c6 < 6; c6++) {
+                    const double ga = f == 0 ? K0[KD + c6 * 7 + ci] : (c6 < 3 ? K0[KW + c6 * 7 + ci] : K0[KA + (c6 - 3) * 7 + ci]);
+                    vd += -2 * w[2] * d[c6] * ga; vdd += -2 * w[5] / h * d[c6] * ga;
+                }
+                if (!tr) { L[L_PB + pbi(f, 0, i, l)] += vf; L[L_PB + pbi(f, 1, i, l)] += vd; L[L_PB + pbi(f, 2, i, l)] += vdd; }
+                else     { L[L_PB + pbi(0, f, i, l)] += vf; L[L_PB + pbi(1, f, i, l)] += vd; L[L_PB + pbi(2, f, i, l)] += vdd; }
+            }
+        } else {                      // path-parameter chain with itself
+            L[L_PB + pbi(0, 0, 7, 7)] += NC[NC_SC + 0] + delta; L[L_PB + pbi(1, 1, 7, 7)] += NC[NC_SC + 1] + delta;
+            L[L_PB + pbi(2, 2, 7, 7)] += NC[NC_SC + 2] + delta;
+            L[L_PB + pbi(3, 3, 7, 7)] += 2 * w[9] + sgk[IJU + 7] + sgk[IJL + 7] + delta;
         }
-        if (lane < NS) {   // gradient q~
+        // iota couplings
+        if (lane < 14) { const int f = lane / 7, ii = lane % 7; for (int a = 0; a < 3; a++) L[L_PCI + pci(a, f, ii)] += A2[a * 14 + lane]; }
+        else if (lane >= 16 && lane < 19) L[L_PCI + pci(lane - 16, 0, 7)] += NC[NC_HRF + lane - 16];
+        else if (lane >= 24 && lane < 33) { const int a = (lane - 24) / 3, b = (lane - 24) % 3; L[L_PII + a * 3 + b] += NC[NC_HRR + a * 3 + b] + (a == b ? delta : 0.0); }
+    LANES_END
+    BMPC_PROF(W, 19);
+    // phase 5: gradient q~
+    LANES_BEGIN
+        const double *gl = NC + NC_GL;
+        if (lane < NS) {
             const int r = lane; double v;
             if (r < 14) {
                 const int a = r; v = gl[a < 7 ? ZQ + a : ZDQ + a - 7];
                 if (a < 7) for (int c = 0; c < 3; c++) v += K0[KW + c * 7 + a] * gl[ZPOS + c];
                 for (int c = 0; c < 3; c++) v += 0.5 * h * (a < 7 ? K0[KD + (3 + c) * 7 + a] : K0[KA + c * 7 + a - 7]) * gl[ZIW + c];
                 for (int c6 = 0; c6 < 6; c6++) v += (a < 7 ? K0[KD + c6 * 7 + a] : (c6 < 3 ? K0[KW + c6 * 7 + a - 7] : K0[KA + (c6 - 3) * 7 + a - 7])) * gl[ZV + c6];
-                double s = 0; for (int b = 0; b < 14; b++) s += WY[a * 14 + b] * NC[NC_GY + b];
-                v -= s;
+                if (ex) { double sW = 0; for (int b = 0; b < 14; b++) sW += WY[a * 14 + b] * NC[NC_GY + b]; v -= sW; }
             } else if (r < SJ) v = gl[ZDDQ + r - SDDQ];
             else if (r < SPHI) v = gl[ZJ + r - SJ];
             else if (r == SPHI) v = gl[ZPHI]; else if (r == SDPHI) v = gl[ZDPHI]; else if (r == SDDPHI) v = gl[ZDDPHI];
@@ -776,35 +873,7 @@ BMPC_D inline void wave_node_cost(Wave &W, const POff &po, const Scr &sc, int k,
             L[L_PV + r] += v;
         }
     LANES_END
-    LANES_BEGIN
-        const double *A2 = NC + NC_A2, *d = rr + RDP, *gl = NC + NC_GL;
-        // (b) couplings with phi, dphi, ddphi and the remaining diagonal
-        if (lane < 17) {
-            const int a = lane, ra = a < 14 ? a : SIOTA + a - 14;
-            double vf = 0, vd = 0, vdd = 0;
-            if (a < 14) {
-                if (a < 7) for (int c = 0; c < 3; c++) vf += K0[KW + c * 7 + a] * NC[NC_HPF + c];
-                for (int c = 0; c < 3; c++) vf += 0.5 * h * (a < 7 ? K0[KD + (3 + c) * 7 + a] : K0[KA + c * 7 + a - 7]) * NC[NC_HRF + c];
-                for (int c6 = 0; c6 < 6; c6++) {
-                    const double ga = a < 7 ? K0[KD + c6 * 7 + a] : (c6 < 3 ? K0[KW + c6 * 7 + a - 7] : K0[KA + (c6 - 3) * 7 + a - 7]);
-                    vd += -2 * w[2] * d[c6] * ga; vdd += -2 * w[5] / h * d[c6] * ga;
-                }
-            } else vf = NC[NC_HRF + a - 14];
-            L[L_PM + ra * 36 + SPHI] += vf; L[L_PM + SPHI * 36 + ra] += vf;
-            L[L_PM + ra * 36 + SDPHI] += vd; L[L_PM + SDPHI * 36 + ra] += vd;
-            L[L_PM + ra * 36 + SDDPHI] += vdd; L[L_PM + SDDPHI * 36 + ra] += vdd;
-        } else if (lane >= 20 && lane < 20 + 18) {
-            const int r = lane - 20;   // diagonal of ddq (7), j (7), phi, dphi, ddphi, jphi
-            int idx; double v;
-            if (r < 7) { idx = SDDQ + r; v = 2 * w[12]; }
-            else if (r < 14) { const int i = r - 7; idx = SJ + i; v = 2 * w[13] + sgk[IJU + i] + sgk[IJL + i]; }
-            else if (r == 14) { idx = SPHI; v = NC[NC_SC + 0]; }
-            else if (r == 15) { idx = SDPHI; v = NC[NC_SC + 1]; }
-            else if (r == 16) { idx = SDDPHI; v = NC[NC_SC + 2]; }
-            else { idx = SJPHI; v = 2 * w[9] + sgk[IJU + 7] + sgk[IJL + 7]; }
-            L[L_PM + idx * 36 + idx] += v + delta;
-        }
-    LANES_END
+    BMPC_PROF(W, 20);
 }
 
 // lifted residuals r_pos (3), r_v (6) of every node: r = g_lifted - G g_y   (needed across neighbouring nodes)
@@ -830,42 +899,60 @@ BMPC_D inline double gv_at(const double *rec, int c6, int y) {
     return y < 7 ? rec[KD + c6 * 7 + y] : (c6 < 3 ? rec[KW + c6 * 7 + y - 7] : rec[KA + (c6 - 3) * 7 + y - 7]);
 }
 
+// issue the global loads of stage k's inputs into per-lane registers (consumed one stage later by the commit phase)
+BMPC_D inline void wave_backward_prefetch(Wave &W, const Scr &sc, int k, LaneRegs *LR) {
+    const int N = W.N; double *G = W.G;
+    LANES_BEGIN
+        double *pf = LR[LIDX].pf;
+        const bool hn = k < N - 1, hp = k >= 1, lo = lane < KREC - 64;
+        pf[0] = G[sc.KIN + k * KREC + lane]; pf[1] = lo ? G[sc.KIN + k * KREC + 64 + lane] : 0.0;
+        pf[2] = hn ? G[sc.KIN + (N + k + 1) * KREC + lane] : 0.0; pf[3] = (hn && lo) ? G[sc.KIN + (N + k + 1) * KREC + 64 + lane] : 0.0;
+        pf[4] = hp ? G[sc.KIN + (k - 1) * KREC + lane] : 0.0; pf[5] = (hp && lo) ? G[sc.KIN + (k - 1) * KREC + 64 + lane] : 0.0;
+        pf[6] = hp ? G[sc.KIN + (N + k) * KREC + lane] : 0.0; pf[7] = (hp && lo) ? G[sc.KIN + (N + k) * KREC + 64 + lane] : 0.0;
+        pf[8] = G[sc.REF + k * RREC + lane]; pf[9] = lane < RREC - 64 ? G[sc.REF + k * RREC + 64 + lane] : 0.0;
+        pf[10] = lane < NZ ? G[sc.Z + k * NZ + lane] : 0.0; pf[11] = lane < NZ ? G[sc.GH + k * NZ + lane] : 0.0;
+        pf[12] = lane < NI ? G[sc.SG + k * NI + lane] : 0.0; pf[13] = lane < NI ? G[sc.NUm + k * NI + lane] : 0.0;
+        pf[14] = lane < NE ? G[sc.G + k * NE + lane] : 0.0; pf[15] = lane < NE ? G[sc.LAM + k * NE + lane] : 0.0;
+        pf[16] = (lane < NE && hn) ? G[sc.LAM + (k + 1) * NE + lane] : 0.0;
+        pf[17] = lane < 12 ? G[sc.RLV + k * 12 + lane] : 0.0; pf[18] = (lane < 12 && hp) ? G[sc.RLV + (k - 1) * 12 + lane] : 0.0;
+        pf[19] = (lane < 12 && hn) ? G[sc.RLV + (k + 1) * 12 + lane] : 0.0;
+    LANES_END
+}
+
 // ----------------------------------------------------------------------------------------
-// Riccati backward sweep.  Returns false (wave-uniform) if some stage's M_jj is not positive definite.
+// Riccati backward sweep, block form.  Returns false (wave-uniform) if a stage's 8x8 jerk block is not positive definite.
 // ----------------------------------------------------------------------------------------
-BMPC_D inline bool wave_backward(Wave &W, const POff &po, const Scr &sc, double mu, double delta, LaneRegs *LR) {
-    const int N = W.N; const double h = W.h;
+BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, double mu, double delta, LaneRegs *LR) {
+    const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
     double *L = W.L, *G = W.G;
     const double *PAR = L + L_PAR, *w = PAR + po.w;
     LANES_BEGIN
-        for (int id = lane; id < 35 * 36; id += 64) L[L_PM + id] = 0.0;
+        for (int id = lane; id < 1024 + 96 + 12; id += 64) L[L_PB + id] = 0.0;
         if (lane < 36) L[L_PV + lane] = 0.0;
     LANES_END
+    wave_backward_prefetch(W, sc, N - 1, LR);
     for (int k = N - 1; k >= 0; k--) {
         BMPC_PROF(W, 6);
-        LANES_BEGIN   // ---- all inputs of this stage from the scratch slab in one burst (coalesced, lane-strided) ----
-            const bool hn = k < N - 1, hp = k >= 1;
-            for (int id = lane; id < KREC; id += 64) {
-                L[L_K0 + id] = G[sc.KIN + k * KREC + id];
-                L[L_KV1 + id] = hn ? G[sc.KIN + (N + k + 1) * KREC + id] : 0.0;
-                if (hp) { L[L_K1 + id] = G[sc.KIN + (k - 1) * KREC + id]; L[L_KV + id] = G[sc.KIN + (N + k) * KREC + id]; }
-            }
-            for (int id = lane; id < RREC; id += 64) L[L_ST + ST_REF + id] = G[sc.REF + k * RREC + id];
-            if (lane < NZ) { L[L_ST + ST_Z + lane] = G[sc.Z + k * NZ + lane]; L[L_ST + ST_GH + lane] = G[sc.GH + k * NZ + lane]; }
-            if (lane < NI) { L[L_ST + ST_SG + lane] = G[sc.SG + k * NI + lane]; L[L_ST + ST_NU + lane] = G[sc.NUm + k * NI + lane]; }
-            if (lane < NE) { L[L_ST + ST_G + lane] = G[sc.G + k * NE + lane]; L[L_ST + ST_LAM0 + lane] = G[sc.LAM + k * NE + lane];
-                             L[L_ST + ST_LAM1 + lane] = hn ? G[sc.LAM + (k + 1) * NE + lane] : 0.0; }
-            if (lane < 12) { L[L_ST + ST_RLV0 + lane] = G[sc.RLV + k * 12 + lane]; L[L_ST + ST_RLVM + lane] = hp ? G[sc.RLV + (k - 1) * 12 + lane] : 0.0;
-                             L[L_ST + ST_RLVP + lane] = hn ? G[sc.RLV + (k + 1) * 12 + lane] : 0.0; }
+        LANES_BEGIN   // ---- commit the prefetched inputs of this stage (registers -> LDS) ----
+            const double *pf = LR[LIDX].pf;
+            L[L_K0 + lane] = pf[0]; L[L_KV1 + lane] = pf[2]; L[L_K1 + lane] = pf[4]; L[L_KV + lane] = pf[6];
+            if (lane < KREC - 64) { L[L_K0 + 64 + lane] = pf[1]; L[L_KV1 + 64 + lane] = pf[3]; L[L_K1 + 64 + lane] = pf[5]; L[L_KV + 64 + lane] = pf[7]; }
+            L[L_ST + ST_REF + lane] = pf[8]; if (lane < RREC - 64) L[L_ST + ST_REF + 64 + lane] = pf[9];
+            if (lane < NZ) { L[L_ST + ST_Z + lane] = pf[10]; L[L_ST + ST_GH + lane] = pf[11]; }
+            if (lane < NI) { L[L_ST + ST_SG + lane] = pf[12]; L[L_ST + ST_NU + lane] = pf[13]; }
+            if (lane < NE) { L[L_ST + ST_G + lane] = pf[14]; L[L_ST + ST_LAM0 + lane] = pf[15]; L[L_ST + ST_LAM1 + lane] = pf[16]; }
+            if (lane < 12) { L[L_ST + ST_RLV0 + lane] = pf[17]; L[L_ST + ST_RLVM + lane] = pf[18]; L[L_ST + ST_RLVP + lane] = pf[19]; }
         LANES_END
-        wave_node_cost(W, po, sc, k, mu, delta);          // PM/PV now hold the value function of node k+1
+        if (k >= 1) wave_backward_prefetch(W, sc, k - 1, LR);   // loads for the NEXT stage fly while this stage computes
+        BMPC_PROF(W, 24);
+        wave_node_cost_blk(W, po, sc, k, mu, delta);     // PB/PCI/PII/PV now hold the value function of node k+1
         BMPC_PROF(W, 5);
         // ---- stage data: rdyn, iota coupling AE (3x14), acceleration cross block XT (15x14) ----
         LANES_BEGIN
             const double *K0 = L + L_K0, *K1 = L + L_K1, *KVk = L + L_KV, *gk = L + L_ST + ST_G;
             if (lane < NS) {
                 const int r = lane; double v = 0;
-                if (r < SJ) v = gk[r];                       // q, dq, ddq defects share the ordering
+                if (r < SJ) v = gk[r];
                 else if (r >= SPHI && r <= SDDPHI) v = gk[GPHI + r - SPHI];
                 else if (r >= SIOTA) {
                     const int c = r - SIOTA; v = gk[GIW + c];
@@ -891,129 +978,211 @@ BMPC_D inline bool wave_backward(Wave &W, const POff &po, const Scr &sc, double 
             }
         LANES_END
         BMPC_PROF(W, 11);
-        LANES_BEGIN   // PR = PV + P' rdyn   (symmetric P': read columns)
-            if (lane < NS) { double s = L[L_PV + lane]; for (int c = 0; c < NS; c++) s += L[L_PM + c * 36 + lane] * L[L_RD + c]; L[L_PR + lane] = s; }
-        LANES_END
-        // ---- M = F^T P' F (+ cross terms), one COLUMN per lane, held in registers ----
+        // ---- S0: PR = P' rdyn + p ; C^T P_c,iota ; P_ii E ----
         LANES_BEGIN
-            double *mc = LR[LIDX].mc;
-            if (lane <= NW) {
-                const int c = lane;
-                double t1[NS];
-                // column structure of F
-                int f = -1, ci = 0, io = -1;
-                if (c < 28) { f = c / 7; ci = c % 7; } else if (c < 32) { f = c - 28; ci = 7; } else if (c < 35) { io = c - 32; } else if (c < NW) { f = 4; ci = c - 35; }
-                if (c < NW) {
-                    double cf0 = 0, cf1 = 0, cf2 = 0, cf3 = 0, ae0 = 0, ae1 = 0, ae2 = 0; int i0 = 0, i1 = 0, i2 = 0, i3 = 0;
-                    if (f >= 0) {
-                        cf0 = chain_cf(h, 0, f); cf1 = chain_cf(h, 1, f); cf2 = chain_cf(h, 2, f); cf3 = chain_cf(h, 3, f);
-                        i0 = srow(0, ci); i1 = srow(1, ci); i2 = srow(2, ci); i3 = srow(3, ci);
-                        if (ci < 7 && f <= 1) { ae0 = L[L_AE + 0 * 14 + f * 7 + ci]; ae1 = L[L_AE + 1 * 14 + f * 7 + ci]; ae2 = L[L_AE + 2 * 14 + f * 7 + ci]; }
-                    } else { cf0 = 1.0; i0 = SIOTA + io; }
+            if (lane < NS) {
+                const int r = lane; double sacc = L[L_PV + r];
+                if (r < 32) {
+                    const int f = r < 28 ? r / 7 : r - 28, i = r < 28 ? r % 7 : 7;
+                    for (int l = 0; l < 8; l++)
 #pragma unroll
-                    for (int r = 0; r < NS; r++) {
-                        const double *row = L + L_PM + r * 36;
-                        t1[r] = cf0 * row[i0] + cf1 * row[i1] + cf2 * row[i2] + cf3 * row[i3] + ae0 * row[SIOTA] + ae1 * row[SIOTA + 1] + ae2 * row[SIOTA + 2];
-                        if ((r % 5) == 4) BMPC_SCHED_FENCE();
-                    }
-                    if (k >= 1 && c < 14) {   // + X S : rows y+ (14) and ddphi+
-#pragma unroll
-                        for (int r = 0; r < 14; r++) t1[r] += L[L_XT + r * 14 + c];
-                        t1[SDDPHI] += L[L_XT + 14 * 14 + c];
-                    }
+                        for (int g = 0; g < 4; g++) sacc += L[L_PB + pbi(f, g, i, l)] * L[L_RD + srow(g, l)];
+                    for (int a = 0; a < 3; a++) sacc += L[L_PCI + pci(a, f, i)] * L[L_RD + SIOTA + a];
                 } else {
+                    const int a = r - SIOTA;
+                    for (int l = 0; l < 8; l++)
 #pragma unroll
-                    for (int r = 0; r < NS; r++) t1[r] = L[L_PR + r];
+                        for (int g = 0; g < 4; g++) sacc += L[L_PCI + pci(a, g, l)] * L[L_RD + srow(g, l)];
+                    for (int b = 0; b < 3; b++) sacc += L[L_PII + a * 3 + b] * L[L_RD + SIOTA + b];
                 }
-                // second pass: mc = F^T t1
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int rq = srow(0, i), rdq = srow(1, i), rddq = srow(2, i), rj = srow(3, i);
-                    double a_q = t1[rq], a_dq = h * t1[rq] + t1[rdq];
-                    if (i < 7) {
-                        a_q += L[L_AE + i] * t1[SIOTA] + L[L_AE + 14 + i] * t1[SIOTA + 1] + L[L_AE + 28 + i] * t1[SIOTA + 2];
-                        a_dq += L[L_AE + 7 + i] * t1[SIOTA] + L[L_AE + 21 + i] * t1[SIOTA + 1] + L[L_AE + 35 + i] * t1[SIOTA + 2];
-                    }
-                    mc[rq] = a_q; mc[rdq] = a_dq;
-                    mc[rddq] = h * h / 2 * t1[rq] + h * t1[rdq] + t1[rddq];
-                    mc[rj] = h * h * h / 8 * t1[rq] + h * h / 3 * t1[rdq] + h / 2 * t1[rddq];
-                    mc[NS + i] = h * h * h / 24 * t1[rq] + h * h / 6 * t1[rdq] + h / 2 * t1[rddq] + t1[rj];
-                    BMPC_SCHED_FENCE();
-                }
-                mc[SIOTA] = t1[SIOTA]; mc[SIOTA + 1] = t1[SIOTA + 1]; mc[SIOTA + 2] = t1[SIOTA + 2];
-                if (k >= 1) {   // + S^T X^T F  (rows y_k)
-                    if (c < NW) {
-                        if (f >= 0 && ci < 7) {
-                            const double c0 = chain_cf(h, 0, f), c1 = chain_cf(h, 1, f);
-#pragma unroll
-                            for (int y = 0; y < 14; y++) mc[y] += c0 * L[L_XT + ci * 14 + y] + c1 * L[L_XT + (7 + ci) * 14 + y];
-                        } else if (f >= 0) {
-                            const double c2 = chain_cf(h, 2, f);
-#pragma unroll
-                            for (int y = 0; y < 14; y++) mc[y] += c2 * L[L_XT + 14 * 14 + y];
-                        }
-                    } else {    // gradient column: X^T rdyn
-#pragma unroll
-                        for (int y = 0; y < 14; y++) {
-                            double s = L[L_XT + 14 * 14 + y] * L[L_RD + SDDPHI];
-                            for (int r = 0; r < 14; r++) s += L[L_XT + r * 14 + y] * L[L_RD + r];
-                            mc[y] += s;
-                        }
-                    }
-                }
-                // publish the jerk rows (M_js | M_jj | m_j)
-#pragma unroll
-                for (int a = 0; a < NU; a++) L[L_SR + a * 44 + c] = mc[NS + a];
+                L[L_PR + r] = sacc;
             }
+            if (lane < 40) {   // U[(f',i)][a] = sum_f CF[f][f'] P[(f,i)][iota_a]
+                const int fp = lane >> 3, i = lane & 7;
+                for (int a = 0; a < 3; a++) {
+                    double u = 0;
+#pragma unroll
+                    for (int f = 0; f < 4; f++) u += chain_cf(h, f, fp) * L[L_PCI + pci(a, f, i)];
+                    L[L_MCI + mci(a, fp, i)] = u;
+                }
+            }
+            if (lane < 42) { const int a = lane / 14, y = lane % 14; double sacc = 0; for (int b = 0; b < 3; b++) sacc += L[L_PII + a * 3 + b] * L[L_AE + b * 14 + y]; L[L_PE + lane] = sacc; }
+        LANES_END
+        BMPC_PROF(W, 21);
+        // ---- S0b: M_c,iota = U + E^T P_ii ; gradient column m = F^T PR + S^T X^T rdyn ----
+        LANES_BEGIN
+            if (lane < 40) {
+                const int fp = lane >> 3, i = lane & 7;
+                if (fp <= 1 && i < 7) for (int a = 0; a < 3; a++) { double sacc = 0; for (int b = 0; b < 3; b++) sacc += L[L_AE + b * 14 + fp * 7 + i] * L[L_PII + b * 3 + a]; L[L_MCI + mci(a, fp, i)] += sacc; }
+                double v = 0;
+#pragma unroll
+                for (int f = 0; f < 4; f++) v += chain_cf(h, f, fp) * L[L_PR + srow(f, i)];
+                if (fp <= 1 && i < 7) {
+                    const int y = fp * 7 + i;
+                    for (int a = 0; a < 3; a++) v += L[L_AE + a * 14 + y] * L[L_PR + SIOTA + a];
+                    if (k >= 1) { double sx = L[L_XT + 14 * 14 + y] * L[L_RD + SDDPHI]; for (int r = 0; r < 14; r++) sx += L[L_XT + r * 14 + y] * L[L_RD + r]; v += sx; }
+                }
+                if (fp < 4) L[L_MV + srow(fp, i)] = v; else L[L_GS + i * 36 + 35] = v;
+            } else if (lane < 43) L[L_MV + SIOTA + lane - 40] = L[L_PR + SIOTA + lane - 40];
+        LANES_END
+        LANES_BEGIN   // jerk rows of the iota columns: M[u_i][iota_a] = M_c,iota[(4,i)][a]
+            if (lane < 24) { const int i = lane & 7, a = lane >> 3; L[L_GS + i * 36 + SIOTA + a] = L[L_MCI + mci(a, 4, i)]; }
+        LANES_END
+        BMPC_PROF(W, 22);
+        // ---- S1: one lane per chain pair: 5x5 block of M = F^T P' F (+ iota and acceleration cross terms) ----
+        LANES_BEGIN
+            const int i = lane >> 3, l = lane & 7, ci = i < l ? i : l, cl = i < l ? l : i; const bool tr = i > l;
+            double B[4][4], T[4][5], M5[5][5];
+#pragma unroll
+            for (int f = 0; f < 4; f++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) B[f][g] = L[L_PB + pbi(f, g, ci, cl)];
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                T[f][0] = B[f][0]; T[f][1] = h * B[f][0] + B[f][1]; T[f][2] = h2 / 2 * B[f][0] + h * B[f][1] + B[f][2];
+                T[f][3] = h3 / 8 * B[f][0] + h2 / 3 * B[f][1] + h / 2 * B[f][2];
+                T[f][4] = h3 / 24 * B[f][0] + h2 / 6 * B[f][1] + h / 2 * B[f][2] + B[f][3];
+            }
+#pragma unroll
+            for (int g = 0; g < 5; g++) {
+                M5[0][g] = T[0][g]; M5[1][g] = h * T[0][g] + T[1][g]; M5[2][g] = h2 / 2 * T[0][g] + h * T[1][g] + T[2][g];
+                M5[3][g] = h3 / 8 * T[0][g] + h2 / 3 * T[1][g] + h / 2 * T[2][g];
+                M5[4][g] = h3 / 24 * T[0][g] + h2 / 6 * T[1][g] + h / 2 * T[2][g] + T[3][g];
+            }
+            // ---- all remaining operands are loaded up front (clamped indices, 0/1 masks instead of branches) so that
+            //      the LDS latency is paid once per phase, not once per term ----
+            const double ml = cl < 7 ? 1.0 : 0.0, mi = ci < 7 ? 1.0 : 0.0, mx = k >= 1 ? 1.0 : 0.0;
+            const int cic = ci < 7 ? ci : 0, clc = cl < 7 ? cl : 0;
+            double Ei[2][3], El[2][3], Ui[5][3], Ul[5][3], PEl[2][3], Xl[2][3], Xi[2][3];
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    El[g][a] = ml * L[L_AE + a * 14 + g * 7 + clc]; Ei[g][a] = mi * L[L_AE + a * 14 + g * 7 + cic];
+                    PEl[g][a] = ml * L[L_PE + a * 14 + g * 7 + clc];
+                }
+#pragma unroll
+            for (int f = 0; f < 5; f++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) { Ui[f][a] = L[L_MCI + mci(a, f, ci)]; Ul[f][a] = L[L_MCI + mci(a, f, cl)]; }
+            // acceleration cross block rows for chain ci / cl: X[q+_c], X[dq+_c] (chains < 7) or X[ddphi+] (chain 7)
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const int yl = g * 7 + clc, yi = g * 7 + cic;
+                Xl[g][0] = mx * ml * mi * L[L_XT + cic * 14 + yl]; Xl[g][1] = mx * ml * mi * L[L_XT + (7 + cic) * 14 + yl];
+                Xl[g][2] = mx * ml * (1.0 - mi) * L[L_XT + 14 * 14 + yl];
+                Xi[g][0] = mx * mi * ml * L[L_XT + clc * 14 + yi]; Xi[g][1] = mx * mi * ml * L[L_XT + (7 + clc) * 14 + yi];
+                Xi[g][2] = mx * mi * (1.0 - ml) * L[L_XT + 14 * 14 + yi];
+            }
+            // iota coupling: + Mci E + (Mci E)^T - E^T Pii E ; acceleration cross term: + F^T X S + S^T X^T F
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+#pragma unroll
+                for (int f = 0; f < 5; f++)
+                    M5[f][g] += Ui[f][0] * El[g][0] + Ui[f][1] * El[g][1] + Ui[f][2] * El[g][2]
+                              + chain_cf(h, 0, f) * Xl[g][0] + chain_cf(h, 1, f) * Xl[g][1] + chain_cf(h, 2, f) * Xl[g][2];
+#pragma unroll
+            for (int f = 0; f < 2; f++) {
+#pragma unroll
+                for (int g = 0; g < 5; g++)
+                    M5[f][g] += Ul[g][0] * Ei[f][0] + Ul[g][1] * Ei[f][1] + Ul[g][2] * Ei[f][2]
+                              + chain_cf(h, 0, g) * Xi[f][0] + chain_cf(h, 1, g) * Xi[f][1] + chain_cf(h, 2, g) * Xi[f][2];
+#pragma unroll
+                for (int g = 0; g < 2; g++) M5[f][g] -= Ei[f][0] * PEl[g][0] + Ei[f][1] * PEl[g][1] + Ei[f][2] * PEl[g][2];
+            }
+            if (ci == cl) {   // exact symmetry of the diagonal pairs
+#pragma unroll
+                for (int f = 0; f < 5; f++)
+#pragma unroll
+                    for (int g = 0; g < f; g++) M5[f][g] = M5[g][f];
+            }
+            double *mc = LR[LIDX].mc;
+#pragma unroll
+            for (int f = 0; f < 4; f++)
+#pragma unroll
+                for (int g = 0; g < 4; g++) mc[f * 4 + g] = M5[f][g];
+            // publish the jerk rows: GS[u_l][(f,i)] = own[f][4], R8[i][l] = M[u_i][u_l]
+#pragma unroll
+            for (int f = 0; f < 4; f++) L[L_GS + l * 36 + srow(f, i)] = tr ? M5[4][f] : M5[f][4];
+            L[L_R8 + i * 8 + l] = M5[4][4];
         LANES_END
         BMPC_PROF(W, 12);
-        // ---- 8x8 Cholesky (every lane, identical data), gains, Schur complement ----
+        // ---- S2: 8x8 Cholesky (identical data in every lane), gains ----
         LANES_BEGIN
-            double *mc = LR[LIDX].mc, *kc = LR[LIDX].kc;
             double Lc[NU][NU], dinv[NU]; bool pd = true;
 #pragma unroll
-            for (int i = 0; i < NU; i++) {
+            for (int a = 0; a < NU; a++) {
 #pragma unroll
-                for (int j = 0; j <= i; j++) {
-                    double s = L[L_SR + i * 44 + NS + j];
+                for (int b = 0; b <= a; b++) {
+                    double sacc = L[L_R8 + a * 8 + b];
 #pragma unroll
-                    for (int q = 0; q < j; q++) s -= Lc[i][q] * Lc[j][q];
-                    if (i == j) { if (!(s > 1e-13)) { pd = false; s = 1.0; } dinv[i] = BMPC_RSQRT(s); Lc[i][i] = s * dinv[i]; }
-                    else Lc[i][j] = s * dinv[j];
+                    for (int q = 0; q < b; q++) sacc -= Lc[a][q] * Lc[b][q];
+                    if (a == b) { if (!(sacc > 1e-13)) { pd = false; sacc = 1.0; } dinv[a] = BMPC_RSQRT(sacc); Lc[a][a] = sacc * dinv[a]; }
+                    else Lc[a][b] = sacc * dinv[b];
                 }
             }
             if (lane == 0) L[L_FLAG] = pd ? 1.0 : 0.0;
-            if (pd && lane <= NW && lane != NS + 0 && !(lane > NS && lane < NW)) {
-                // lanes 0..34 (state columns) and lane 43 (gradient column): solve R k = -M_j,col
-                const int c = lane;
+            if (pd && lane < 36) {
+                const int c = lane; double kc[NU];
 #pragma unroll
-                for (int a = 0; a < NU; a++) kc[a] = -mc[NS + a];
+                for (int a = 0; a < NU; a++) kc[a] = -L[L_GS + a * 36 + c];
 #pragma unroll
-                for (int i = 0; i < NU; i++) { double s = kc[i];
+                for (int a = 0; a < NU; a++) { double sacc = kc[a];
 #pragma unroll
-                    for (int q = 0; q < i; q++) s -= Lc[i][q] * kc[q];
-                    kc[i] = s * dinv[i]; }
+                    for (int q = 0; q < a; q++) sacc -= Lc[a][q] * kc[q];
+                    kc[a] = sacc * dinv[a]; }
 #pragma unroll
-                for (int i = NU - 1; i >= 0; i--) { double s = kc[i];
+                for (int a = NU - 1; a >= 0; a--) { double sacc = kc[a];
 #pragma unroll
-                    for (int q = i + 1; q < NU; q++) s -= Lc[q][i] * kc[q];
-                    kc[i] = s * dinv[i]; }
+                    for (int q = a + 1; q < NU; q++) sacc -= Lc[q][a] * kc[q];
+                    kc[a] = sacc * dinv[a]; }
+#pragma unroll
+                for (int a = 0; a < NU; a++) L[L_KS + a * 36 + c] = kc[a];
                 if (c < NS) { for (int a = 0; a < NU; a++) G[sc.KT + (k * NS + c) * NU + a] = kc[a]; }
                 else { for (int a = 0; a < NU; a++) G[sc.KF + k * NU + a] = kc[a]; }
-                if (k >= 1) {
-#pragma unroll
-                    for (int r = 0; r < NS; r++) {
-                        double s = mc[r];
-#pragma unroll
-                        for (int a = 0; a < NU; a++) s += L[L_SR + a * 44 + r] * kc[a];
-                        if (c < NS) { if (r >= c) { L[L_PM + r * 36 + c] = s; L[L_PM + c * 36 + r] = s; } } else L[L_PV + r] = s;
-                        if ((r % 4) == 3) BMPC_SCHED_FENCE();
-                    }
-                }
             }
         LANES_END
-        BMPC_PROF(W, 13);
+        BMPC_PROF(W, 23);
         if (L[L_FLAG] == 0.0) return false;
+        // ---- S3: Schur complement, block lanes write the value function of node k ----
+        if (k >= 1) {
+            LANES_BEGIN
+                const int i = lane >> 3, l = lane & 7, ci = i < l ? i : l, cl = i < l ? l : i; const bool tr = i > l;
+                const double *mc = LR[LIDX].mc;
+                double C[4][4];
+#pragma unroll
+                for (int f = 0; f < 4; f++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        double sacc = mc[f * 4 + g];
+#pragma unroll
+                        for (int a = 0; a < NU; a++) sacc += L[L_GS + a * 36 + srow(f, ci)] * L[L_KS + a * 36 + srow(g, cl)];
+                        C[f][g] = sacc;
+                    }
+                if (ci == cl) {
+#pragma unroll
+                    for (int f = 0; f < 4; f++)
+#pragma unroll
+                        for (int g = 0; g < f; g++) C[f][g] = C[g][f];
+                }
+#pragma unroll
+                for (int f = 0; f < 4; f++)
+#pragma unroll
+                    for (int g = 0; g < 4; g++) L[L_PB + pbi(f, g, i, l)] = tr ? C[g][f] : C[f][g];
+                if (lane < 32) {   // chain x iota
+                    const int f = lane >> 3, ii = lane & 7;
+                    for (int b = 0; b < 3; b++) { double sacc = L[L_MCI + mci(b, f, ii)]; for (int a = 0; a < NU; a++) sacc += L[L_GS + a * 36 + srow(f, ii)] * L[L_KS + a * 36 + SIOTA + b]; L[L_PCI + pci(b, f, ii)] = sacc; }
+                } else if (lane < 32 + 6) {   // iota x iota, upper triangle mirrored
+                    const int t = lane - 32; const int b = t < 3 ? 0 : (t < 5 ? 1 : 2), c = t < 3 ? t : (t < 5 ? t - 2 : 2);
+                    double sacc = L[L_PII + b * 3 + c]; for (int a = 0; a < NU; a++) sacc += L[L_GS + a * 36 + SIOTA + b] * L[L_KS + a * 36 + SIOTA + c];
+                    L[L_PII + b * 3 + c] = sacc; L[L_PII + c * 3 + b] = sacc;
+                }
+            LANES_END
+            LANES_BEGIN
+                if (lane < NS) { double sacc = L[L_MV + lane]; for (int a = 0; a < NU; a++) sacc += L[L_GS + a * 36 + lane] * L[L_KS + a * 36 + 35]; L[L_PV + lane] = sacc; }
+            LANES_END
+        }
+        BMPC_PROF(W, 13);
     }
     return true;
 }
@@ -1153,7 +1322,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         BMPC_PROF(W, 4);
         double delta = 0.0; bool ok = false;
         for (int tries = 0; tries < 40; tries++) {
-            if (wave_backward(W, po, sc, mu, delta, LRs)) { ok = true; break; }
+            if (wave_backward_blk(W, po, sc, mu, delta, LRs)) { ok = true; break; }
             if (delta == 0.0) delta = delta_last > 0 ? BMPC_FMAX(1e-20, delta_last / 3.0) : 1e-4;
             else delta *= (delta_last > 0 ? 8.0 : 100.0);
             if (delta > 1e20) break;

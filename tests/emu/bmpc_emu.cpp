@@ -71,10 +71,11 @@ extern "C" int bmpc_emu_newton(int N, int S, double h, const bmpc::Opts *opts, c
     for (int i = 0; i < N * NI; i++) { W.G[sc.T + i] = t[i]; W.G[sc.NUm + i] = nu[i]; }
     wave_eval(W, po, sc, sc.Z, sc.G, sc.HIN);
     wave_adjoint(W, po, sc, sc.NUm, false, 0.0);
+    for (int i = 0; i < N * NI; i++) { const double tt = W.G[sc.T + i], nn = W.G[sc.NUm + i]; W.G[sc.SG + i] = nn / tt; W.G[sc.NUH + i] = (mu + nn * (W.G[sc.HIN + i] + tt)) / tt; }
     wave_adjoint(W, po, sc, sc.NUm, true, mu);
     wave_prepare_rlv(W, sc);
     LaneRegs LRs[64];
-    bool ok = wave_backward(W, po, sc, mu, delta, LRs);
+    bool ok = wave_backward_blk(W, po, sc, mu, delta, LRs);
     if (ok) wave_forward(W, sc);
     memcpy(scratch_out, scr.data(), sizeof(double) * sc.size);
     memcpy(lds_out, lds.data(), sizeof(double) * L_SIZE);
@@ -82,7 +83,7 @@ extern "C" int bmpc_emu_newton(int N, int S, double h, const bmpc::Opts *opts, c
 }
 extern "C" void bmpc_emu_scr_offsets(int N, int *out) {
     const bmpc::Scr s = bmpc::make_scr(N);
-    int v[] = {s.Z, s.ZT, s.T, s.TT, s.NUm, s.LAM, s.G, s.GT, s.HIN, s.HT, s.DZ, s.DT, s.DNU, s.GH, s.GVP, s.RJ, s.KIN, s.REF, s.KT, s.KF, s.RDY, s.AES, s.RLV, s.size};
+    int v[] = {s.Z, s.ZT, s.T, s.TT, s.NUm, s.LAM, s.G, s.GT, s.HIN, s.HT, s.DZ, s.DT, s.DNU, s.GH, s.GVP, s.RJ, s.KIN, s.REF, s.KT, s.KF, s.RDY, s.AES, s.RLV, s.SG, s.NUH, s.size};
     for (unsigned i = 0; i < sizeof(v) / sizeof(int); i++) out[i] = v[i];
 }
 extern "C" int bmpc_emu_lds_doubles() { return bmpc::L_SIZE; }
