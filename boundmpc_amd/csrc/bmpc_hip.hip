@@ -48,6 +48,7 @@ struct KArgs {
 #ifndef BMPC_WAVES_PER_EU
 #define BMPC_WAVES_PER_EU 1
 #endif
+template <bool ZLDS>
 __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs a) {
     __shared__ double lds[bmpc::L_SIZE];
     bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = a.scratch + (long long)blockIdx.x * a.scr_stride;
@@ -68,7 +69,7 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
         pr.lam_g = a.lam_g ? a.lam_g + (long long)b * ng : nullptr; pr.lam_x = a.lam_x ? a.lam_x + (long long)b * nw : nullptr;
         pr.f = a.f ? a.f + b : nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr;
         pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status ? a.status + b : nullptr;
-        bmpc::wave_solve(W, pr);
+        bmpc::wave_solve<ZLDS>(W, pr);
         __syncthreads();
     }
 #ifdef BMPC_PROFILE
@@ -104,7 +105,8 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     int dev = 0; HIPCHK(hipGetDevice(&dev));
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, dev));
     int per_cu = 0;
-    HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel, 64, 0));
+    if (N <= 11) { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel<true>, 64, 0)); }
+    else { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel<false>, 64, 0)); }
     if (per_cu < 1) per_cu = 1;
     h->grid = per_cu * prop.multiProcessorCount;
     h->scr_stride = bmpc::make_scr(N).size;
@@ -162,7 +164,8 @@ extern "C" int bmpc_solve_batch(bmpc_handle *h, int B, const double *p, const do
         if (!h->have_ev) { HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1)); h->have_ev = 1; }
         HIPCHK(hipEventRecord(h->ev0, st));
     }
-    hipLaunchKernelGGL(bmpc_solve_kernel, dim3(grid), dim3(64), 0, st, a);
+    if (h->N <= 11) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL(bmpc_solve_kernel<false>, dim3(grid), dim3(64), 0, st, a);
     HIPCHK(hipGetLastError());
     if (h->timing) HIPCHK(hipEventRecord(h->ev1, st));
     return BMPC_OK;

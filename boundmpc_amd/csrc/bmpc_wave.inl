@@ -69,7 +69,8 @@ BMPC_HD inline POff make_poff(int S) {
 enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV = L_RED + 6 * 64, L_PR = L_PV + 36, L_QT = L_PR + 36,
        L_RD = L_QT + 36, L_DS = L_RD + 36, L_DSN = L_DS + 36, L_DU = L_DSN + 36, L_MV = L_DU + 8, L_AE = L_MV + 44, L_K0 = L_AE + 42,
        L_K1 = L_K0 + KREC, L_KV = L_K1 + KREC, L_XT = L_KV + KREC, L_NC = L_XT + 15 * 14, L_WY = L_NC + 160, L_WV = L_WY + 196, L_TOT = L_WV + 196,
-       L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_BLK = L_ST + 432, L_SIZE = L_BLK + 8 };
+       L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_ZL = L_ST + 432, L_SIZE = L_ZL + 484 };
+enum { L_KKP = L_WY };   // inequality part of the KKT error (4 x 64 slots), parked in the node-cost work area between sweeps (WY 196 + WV 196)   // L_ZL: iterate Z (N <= 11)
 // Block (chain-pair) Riccati storage, overlaid on the L_PM..L_RED region (column scheme retired):
 //   PB  [16 planes (f*4+g)][64 pairs (i*8+l)]  value-function Hessian blocks P[(f,i)][(g,l)]
 //   PCI [3][4][8]  P[(f,i)][iota_a] ;  PII [3][3] ;  GS [8][36] jerk rows of M (col 35 = m_j) ; R8 [8][8] ; KS [8][36] gains (col 35 = kff)
@@ -90,7 +91,7 @@ struct Opts {
 
 // global scratch layout (doubles) for horizon N
 struct Scr {
-    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, NUH, size;
+    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, size;
 };
 BMPC_HD inline Scr make_scr(int N) {
     Scr s; int c = 0;
@@ -98,7 +99,7 @@ BMPC_HD inline Scr make_scr(int N) {
     s.LAM = c; c += N * NE; s.G = c; c += N * NE; s.GT = c; c += N * NE; s.HIN = c; c += N * NI; s.HT = c; c += N * NI;
     s.DZ = c; c += N * NZ; s.DT = c; c += N * NI; s.DNU = c; c += N * NI; s.GH = c; c += N * NZ; s.GVP = c; c += N * 8;
     s.RJ = c; c += N * NU; s.KIN = c; c += 2 * N * KREC; s.REF = c; c += N * RREC; s.KT = c; c += N * NS * NU; s.KF = c; c += N * NU;
-    s.RDY = c; c += N * 36; s.AES = c; c += N * 42; s.RLV = c; c += N * 12; s.SG = c; c += N * NI; s.NUH = c; c += N * NI;
+    s.RDY = c; c += N * 36; s.AES = c; c += N * 42; s.RLV = c; c += N * 12; s.SG = c; c += N * NI; s.TI = c; c += N * NI; s.SR = c; c += N * NI;
     s.size = (c + 15) & ~15;
     return s;
 }
@@ -114,6 +115,7 @@ struct Wave {
     double *L;             // LDS base (L_SIZE doubles)
     double *G;             // scratch base
     long long tprev;       // diagnostic build only (BMPC_PROFILE): last phase stamp
+    double *Zc, *Zt, *Dz;  // iterate, trial iterate, Newton direction [N][44]: LDS-resident for N <= 11, else in the scratch slab
 #ifdef BMPC_EMU
     int order[64];
 #endif
@@ -425,10 +427,10 @@ BMPC_D inline double red_min(const double *r) { double s = r[0];
 
 // Evaluate at Zs: kinematic records, node references, equality residuals Gd[N][36], inequality
 // values Hd[N][57]; returns the objective (wave-uniform).
-BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, int oZ, int oG, int oH) {
+BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, const double *Zs, int oG, int oH) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
     double *L = W.L, *G = W.G;
-    const double *PAR = L + L_PAR, *Zs = G + oZ;
+    const double *PAR = L + L_PAR;
     LANES_BEGIN
         if (lane < 2 * N) {
             const int k = lane < N ? lane : lane - N;
@@ -520,12 +522,12 @@ BMPC_D inline void stage_mu(Wave &W, const double *lam, const double *kp, int la
 BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU, bool use_hat, double mu) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
     double *L = W.L, *G = W.G;
-    const double *PAR = L + L_PAR, *Zs = G + sc.Z;
+    const double *PAR = L + L_PAR, *Zs = W.Zc;
     LANES_BEGIN
         if (lane < N) {
             const int k = lane;
             double nuv[NI], vprev[6];
-            for (int i = 0; i < NI; i++) nuv[i] = G[(use_hat ? sc.NUH : oNU) + k * NI + i];
+            for (int i = 0; i < NI; i++) nuv[i] = use_hat ? mu * G[sc.TI + k * NI + i] + G[sc.SR + k * NI + i] : G[oNU + k * NI + i];
             for (int c = 0; c < 6; c++) vprev[c] = ndv(PAR, po, Zs, k, ZV + c, po.v0 + c);
             double gz[NZ], gvp[6];
             node_grad(PAR, po, h, Zs + k * NZ, vprev, G + sc.REF + k * RREC, nuv, gz, gvp);
@@ -910,7 +912,7 @@ BMPC_D inline void wave_backward_prefetch(Wave &W, const Scr &sc, int k, LaneReg
         pf[4] = hp ? G[sc.KIN + (k - 1) * KREC + lane] : 0.0; pf[5] = (hp && lo) ? G[sc.KIN + (k - 1) * KREC + 64 + lane] : 0.0;
         pf[6] = hp ? G[sc.KIN + (N + k) * KREC + lane] : 0.0; pf[7] = (hp && lo) ? G[sc.KIN + (N + k) * KREC + 64 + lane] : 0.0;
         pf[8] = G[sc.REF + k * RREC + lane]; pf[9] = lane < RREC - 64 ? G[sc.REF + k * RREC + 64 + lane] : 0.0;
-        pf[10] = lane < NZ ? G[sc.Z + k * NZ + lane] : 0.0; pf[11] = lane < NZ ? G[sc.GH + k * NZ + lane] : 0.0;
+        pf[10] = 0.0; pf[11] = lane < NZ ? G[sc.GH + k * NZ + lane] : 0.0;
         pf[12] = lane < NI ? G[sc.SG + k * NI + lane] : 0.0; pf[13] = lane < NI ? G[sc.NUm + k * NI + lane] : 0.0;
         pf[14] = lane < NE ? G[sc.G + k * NE + lane] : 0.0; pf[15] = lane < NE ? G[sc.LAM + k * NE + lane] : 0.0;
         pf[16] = (lane < NE && hn) ? G[sc.LAM + (k + 1) * NE + lane] : 0.0;
@@ -938,7 +940,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
             L[L_K0 + lane] = pf[0]; L[L_KV1 + lane] = pf[2]; L[L_K1 + lane] = pf[4]; L[L_KV + lane] = pf[6];
             if (lane < KREC - 64) { L[L_K0 + 64 + lane] = pf[1]; L[L_KV1 + 64 + lane] = pf[3]; L[L_K1 + 64 + lane] = pf[5]; L[L_KV + 64 + lane] = pf[7]; }
             L[L_ST + ST_REF + lane] = pf[8]; if (lane < RREC - 64) L[L_ST + ST_REF + 64 + lane] = pf[9];
-            if (lane < NZ) { L[L_ST + ST_Z + lane] = pf[10]; L[L_ST + ST_GH + lane] = pf[11]; }
+            if (lane < NZ) L[L_ST + ST_GH + lane] = pf[11];
             if (lane < NI) { L[L_ST + ST_SG + lane] = pf[12]; L[L_ST + ST_NU + lane] = pf[13]; }
             if (lane < NE) { L[L_ST + ST_G + lane] = pf[14]; L[L_ST + ST_LAM0 + lane] = pf[15]; L[L_ST + ST_LAM1 + lane] = pf[16]; }
             if (lane < 12) { L[L_ST + ST_RLV0 + lane] = pf[17]; L[L_ST + ST_RLVM + lane] = pf[18]; L[L_ST + ST_RLVP + lane] = pf[19]; }
@@ -1187,34 +1189,46 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
     return true;
 }
 
-// forward sweep: dZ[N][44]
-BMPC_D inline void wave_forward(Wave &W, const Scr &sc) {
+// forward sweep: dZ[N][44].  The inputs of stage k+1 (gains, defects, kinematics record) are prefetched into registers
+// while stage k computes.
+BMPC_D inline void wave_forward_prefetch(Wave &W, const Scr &sc, int k, LaneRegs *LR) {
+    double *G = W.G;
+    LANES_BEGIN
+        double *pf = LR[LIDX].pf;
+#pragma unroll
+        for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; pf[u] = id < NS * NU ? G[sc.KT + k * NS * NU + id] : 0.0; }
+        pf[5] = lane < NU ? G[sc.KF + k * NU + lane] : 0.0;
+        pf[6] = lane < 36 ? G[sc.RDY + k * 36 + lane] : 0.0;
+        pf[7] = lane < 42 ? G[sc.AES + k * 42 + lane] : 0.0;
+        pf[8] = lane < 12 ? G[sc.RLV + k * 12 + lane] : 0.0;
+        pf[9] = G[sc.KIN + k * KREC + lane]; pf[10] = lane < KREC - 64 ? G[sc.KIN + k * KREC + 64 + lane] : 0.0;
+    LANES_END
+}
+BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
     const int N = W.N; const double h = W.h;
-    double *L = W.L, *G = W.G;
+    double *L = W.L;
     LANES_BEGIN
         if (lane < 36) L[L_DS + lane] = 0.0;
     LANES_END
+    wave_forward_prefetch(W, sc, 0, LR);
     for (int k = 0; k < N; k++) {
-        LANES_BEGIN   // one burst: gains, feed-forward, defects, iota coupling, lifted residuals, kinematics record
-            for (int id = lane; id < NS * NU; id += 64) L[L_ST + ST_KT + id] = G[sc.KT + k * NS * NU + id];
-            if (lane < NU) L[L_ST + ST_KF + lane] = G[sc.KF + k * NU + lane];
-            if (lane < 36) L[L_ST + ST_RDY + lane] = G[sc.RDY + k * 36 + lane];
-            if (lane < 42) L[L_ST + ST_AES + lane] = G[sc.AES + k * 42 + lane];
-            if (lane < 12) L[L_ST + ST_RLVF + lane] = G[sc.RLV + k * 12 + lane];
-            for (int id = lane; id < KREC; id += 64) L[L_K0 + id] = G[sc.KIN + k * KREC + id];
+        LANES_BEGIN   // commit the prefetched stage inputs
+            const double *pf = LR[LIDX].pf;
+#pragma unroll
+            for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; if (id < NS * NU) L[L_ST + ST_KT + id] = pf[u]; }
+            if (lane < NU) L[L_ST + ST_KF + lane] = pf[5];
+            if (lane < 36) L[L_ST + ST_RDY + lane] = pf[6];
+            if (lane < 42) L[L_ST + ST_AES + lane] = pf[7];
+            if (lane < 12) L[L_ST + ST_RLVF + lane] = pf[8];
+            L[L_K0 + lane] = pf[9]; if (lane < KREC - 64) L[L_K0 + 64 + lane] = pf[10];
         LANES_END
-        LANES_BEGIN
-            {   // du = kff + K ds: lane (g, a) sums rows b = g, g+8, ... of K^T, 8 partials per jerk
-                const int a = lane & 7, g = lane >> 3; double s = 0;
-                for (int b = g; b < NS; b += 8) s += L[L_ST + ST_KT + b * NU + a] * L[L_DS + b];
-                L[L_RED + lane] = s;
-            }
-        LANES_END
-        LANES_BEGIN
+        if (k + 1 < N) wave_forward_prefetch(W, sc, k + 1, LR);
+        LANES_BEGIN   // du = kff + K ds
             if (lane < NU) {
-                double s = L[L_ST + ST_KF + lane];
-                for (int g = 0; g < 8; g++) s += L[L_RED + g * 8 + lane];
-                L[L_DU + lane] = s;
+                double sacc = L[L_ST + ST_KF + lane];
+#pragma unroll
+                for (int b = 0; b < NS; b++) sacc += L[L_ST + ST_KT + b * NU + lane] * L[L_DS + b];
+                L[L_DU + lane] = sacc;
             }
         LANES_END
         LANES_BEGIN
@@ -1223,10 +1237,12 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc) {
                 const double *ds = L + L_DS, *du = L + L_DU;
                 if (r < 28 || (r >= SPHI && r <= SJPHI)) {
                     const int f = r < 28 ? r / 7 : r - 28, i = r < 28 ? r % 7 : 7;
+#pragma unroll
                     for (int fc = 0; fc < 4; fc++) v += chain_cf(h, f, fc) * ds[srow(fc, i)];
                     v += chain_cf(h, f, 4) * du[i];
                 } else {
                     const int a = r - SIOTA; v += ds[r];
+#pragma unroll
                     for (int y = 0; y < 14; y++) v += L[L_ST + ST_AES + a * 14 + y] * ds[y];
                 }
                 L[L_DSN + r] = v;
@@ -1237,11 +1253,17 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc) {
                 const int z = lane; const double *dn = L + L_DSN, *K0 = L + L_K0, *rlv = L + L_ST + ST_RLVF; double v;
                 if (z < 7) v = dn[SJ + z]; else if (z == ZJPHI) v = dn[SJPHI];
                 else if (z < ZPOS) v = dn[z - ZQ];
-                else if (z < ZIW) { const int c = z - ZPOS; v = rlv[c]; for (int i = 0; i < 7; i++) v += K0[KW + c * 7 + i] * dn[SQ + i]; }
-                else if (z < ZV) { const int c = z - ZIW; v = dn[SIOTA + c]; for (int i = 0; i < 7; i++) v += 0.5 * h * (K0[KD + (3 + c) * 7 + i] * dn[SQ + i] + K0[KA + c * 7 + i] * dn[SDQ + i]); }
-                else if (z < ZPHI) { const int c6 = z - ZV; v = rlv[3 + c6]; for (int y = 0; y < 14; y++) v += gv_at(K0, c6, y) * dn[y]; }
+                else if (z < ZIW) { const int c = z - ZPOS; v = rlv[c];
+#pragma unroll
+                    for (int i = 0; i < 7; i++) v += K0[KW + c * 7 + i] * dn[SQ + i]; }
+                else if (z < ZV) { const int c = z - ZIW; v = dn[SIOTA + c];
+#pragma unroll
+                    for (int i = 0; i < 7; i++) v += 0.5 * h * (K0[KD + (3 + c) * 7 + i] * dn[SQ + i] + K0[KA + c * 7 + i] * dn[SDQ + i]); }
+                else if (z < ZPHI) { const int c6 = z - ZV; v = rlv[3 + c6];
+#pragma unroll
+                    for (int y = 0; y < 14; y++) v += gv_at(K0, c6, y) * dn[y]; }
                 else v = dn[SPHI + z - ZPHI];
-                G[sc.DZ + k * NZ + z] = v;
+                W.Dz[k * NZ + z] = v;
             }
             if (lane < 36) L[L_DS + lane] = lane < NS ? L[L_DSN + lane] : 0.0;
         LANES_END
@@ -1251,6 +1273,9 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc) {
 // ----------------------------------------------------------------------------------------
 // main driver for one problem
 // ----------------------------------------------------------------------------------------
+// ZLDS: the iterate / trial iterate / direction live in LDS (horizons N <= 11); a compile-time switch so that the compiler
+// knows the address space of every access (a run-time select would degrade them to FLAT instructions).
+template <bool ZLDS>
 BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     const int N = W.N, S = W.S;
     double *L = W.L, *G = W.G;
@@ -1263,39 +1288,63 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
 #else
     LaneRegs LRs[1];
 #endif
-    // ---- coalesced load of the parameter vector into LDS and of x0 into the scratch slab ----
+    // ---- coalesced load of the parameter vector into LDS and of x0 into the iterate ----
+    constexpr bool zlds = ZLDS;
+    if (ZLDS) { W.Zc = L + L_ZL; W.Zt = L + L_PB; W.Dz = L + L_PB + 512; } else { W.Zc = G + sc.Z; W.Zt = G + sc.ZT; W.Dz = G + sc.DZ; }
     LANES_BEGIN
         for (int id = lane; id < np; id += 64) L[L_PAR + id] = pr.p[id];
-        for (int id = lane; id < nw; id += 64) G[sc.Z + id] = pr.x0[id];
+        for (int id = lane; id < nw; id += 64) W.Zc[id] = pr.x0[id];
     LANES_END
     const double *PAR = L + L_PAR;
     double mu = o.mu_init; const double mu_min = o.tol * o.mu_min_fac;
     double delta_last = 0.0, filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0;
     BMPC_PROF(W, 15);
-    double fval = wave_eval(W, po, sc, sc.Z, sc.G, sc.HIN);
+    double fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN);
     BMPC_PROF(W, 0);
-    LANES_BEGIN
-        for (int id = lane; id < ni; id += 64) { const double hv = G[sc.HIN + id]; const double t = (-hv > o.slack_push) ? -hv : o.slack_push; G[sc.T + id] = t; G[sc.NUm + id] = mu / t; }
-    LANES_END
+    // Row pass "A" (57 rows per node, lane-strided, three rows in flight per lane): multipliers nu, barrier ratios
+    // sigma = nu/t, 1/t, sigma*(h+t), and the inequality part of the KKT error.  first = initialisation of t, nu.
+    double ad = 1.0;
+    for (int it_first = 1; it_first >= 1; it_first--) {
+        LANES_BEGIN
+            double ep = 0, cmax = -1e300, cmin = 1e300, sn = 0;
+            for (int base = lane; base < ni; base += 192) {
+                double hv[3], tv[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) { const int id = base + 64 * u; hv[u] = id < ni ? G[sc.HIN + id] : -1.0; }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int id = base + 64 * u;
+                    if (id < ni) {
+                        const double t = (-hv[u] > o.slack_push) ? -hv[u] : o.slack_push, ti = 1.0 / t, nu = mu * ti, r = hv[u] + t;
+                        G[sc.T + id] = t; G[sc.NUm + id] = nu; G[sc.SG + id] = nu * ti; G[sc.TI + id] = ti; G[sc.SR + id] = nu * ti * r;
+                        const double v = BMPC_FABS(r), c = nu * t;
+                        ep = v > ep ? v : ep; cmax = c > cmax ? c : cmax; cmin = c < cmin ? c : cmin; sn += nu;
+                    }
+                }
+            }
+            L[L_KKP + lane] = ep; L[L_KKP + 64 + lane] = cmax; L[L_KKP + 128 + lane] = cmin; L[L_KKP + 192 + lane] = sn;
+        LANES_END
+    }
     int it = 0, status = 1; double E0 = 0;
     for (it = 0; it <= o.max_iter; it++) {
         BMPC_PROF(W, 10);
         wave_adjoint(W, po, sc, sc.NUm, false, 0.0);
         BMPC_PROF(W, 1);
-        // ---- KKT error (Ipopt-style scaling), deterministic reductions ----
+        // ---- KKT error (Ipopt-style scaling), deterministic reductions; the inequality part comes from row pass A ----
         LANES_BEGIN
-            double ed = 0, ep = 0, cmax = -1e300, cmin = 1e300, sl = 0, sn = 0;
+            double ed = 0, ep = L[L_KKP + lane], sl = 0;
             for (int id = lane; id < N * NU; id += 64) { const double v = BMPC_FABS(G[sc.RJ + id]); ed = v > ed ? v : ed; }
-            for (int id = lane; id < ne; id += 64) { const double v = BMPC_FABS(G[sc.G + id]); ep = v > ep ? v : ep; sl += BMPC_FABS(G[sc.LAM + id]); }
-            for (int id = lane; id < ni; id += 64) {
-                const double t = G[sc.T + id], nu = G[sc.NUm + id], v = BMPC_FABS(G[sc.HIN + id] + t), c = nu * t;
-                ep = v > ep ? v : ep; cmax = c > cmax ? c : cmax; cmin = c < cmin ? c : cmin; sn += nu;
+            for (int base = lane; base < ne; base += 192) {
+                double gv[3], lv[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) { const int id = base + 64 * u; gv[u] = id < ne ? G[sc.G + id] : 0.0; lv[u] = id < ne ? G[sc.LAM + id] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 3; u++) { const double v = BMPC_FABS(gv[u]); ep = v > ep ? v : ep; sl += BMPC_FABS(lv[u]); }
             }
-            L[L_RED + lane] = ed; L[L_RED + 64 + lane] = ep; L[L_RED + 128 + lane] = cmax; L[L_RED + 192 + lane] = cmin;
-            L[L_RED + 256 + lane] = sl; L[L_RED + 320 + lane] = sn;
+            L[L_RED + lane] = ed; L[L_RED + 64 + lane] = ep; L[L_RED + 128 + lane] = sl;
         LANES_END
-        const double ed = red_max(L + L_RED), ep = red_max(L + L_RED + 64), cmax = red_max(L + L_RED + 128), cmin = red_min(L + L_RED + 192),
-                     sl = red_sum(L + L_RED + 256), sn = red_sum(L + L_RED + 320);
+        const double ed = red_max(L + L_RED), ep = red_max(L + L_RED + 64), cmax = red_max(L + L_KKP + 64), cmin = red_min(L + L_KKP + 128),
+                     sl = red_sum(L + L_RED + 128), sn = red_sum(L + L_KKP + 192);
         const double sd = BMPC_FMAX(100.0, (sl + sn) / (N * (NE + NI))) / 100.0, scl = BMPC_FMAX(100.0, sn / (N * NI)) / 100.0;
         E0 = BMPC_FMAX(BMPC_FMAX(ed / sd, ep), BMPC_FMAX(cmax, -cmin) / scl);
 #ifdef BMPC_EMU
@@ -1308,12 +1357,6 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
             const double Emu = BMPC_FMAX(BMPC_FMAX(ed / sd, ep), ec / scl);
             if (Emu <= 10.0 * mu && mu > mu_min) mu = BMPC_FMAX(mu_min, BMPC_FMIN(0.2 * mu, BMPC_POW15(mu))); else break;
         }
-        LANES_BEGIN   // barrier ratios once per iteration: sigma = nu/t, nu_hat = (mu + nu (h+t))/t
-            for (int id = lane; id < ni; id += 64) {
-                const double t = G[sc.T + id], nu = G[sc.NUm + id], ti = 1.0 / t;
-                G[sc.SG + id] = nu * ti; G[sc.NUH + id] = (mu + nu * (G[sc.HIN + id] + t)) * ti;
-            }
-        LANES_END
         // ---- Newton system: QP gradient, lifted residuals, Riccati ----
         BMPC_PROF(W, 2);
         wave_adjoint(W, po, sc, sc.NUm, true, mu);
@@ -1330,30 +1373,59 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         if (!ok) { status = 3; break; }
         if (delta > 0) delta_last = delta;
         BMPC_PROF(W, 6);
-        wave_forward(W, sc);
+        wave_forward(W, sc, LRs);
         BMPC_PROF(W, 7);
-        // ---- slack / multiplier directions, fraction to the boundary, merit ingredients ----
+        // ---- row pass "B": slack / multiplier directions, fraction to the boundary, merit ingredients ----
         const double tau = BMPC_FMAX(0.99, 1.0 - mu);
         LANES_BEGIN
-            double ap = 1.0, ad = 1.0, dbar = 0, nhd = 0, th = 0, bar = 0;
-            for (int id = lane; id < ni; id += 64) {
-                const int k = id / NI, i = id - k * NI;
-                const double t = G[sc.T + id], nu = G[sc.NUm + id], r = G[sc.HIN + id] + t;
-                const double hd = ineq_dir(G + sc.DZ + k * NZ, G + sc.REF + k * RREC, i);
-                const double sgm = G[sc.SG + id], dt = -r - hd, dnu = (G[sc.NUH + id] - sgm * r) - nu - sgm * dt;
-                G[sc.DT + id] = dt; G[sc.DNU + id] = dnu;
-                if (dt < 0) { const double a = -tau * t / dt; ap = a < ap ? a : ap; }
-                if (dnu < 0) { const double a = -tau * nu / dnu; ad = a < ad ? a : ad; }
-                dbar += -(G[sc.NUH + id] - sgm * r) * dt; nhd += G[sc.NUH + id] * hd; th += BMPC_FABS(r); bar -= mu * BMPC_LOG(t);
+            double ap = 1.0, adl = 1.0, dbar = 0, nhd = 0, th = 0, bar = 0;
+            for (int base = lane; base < ni; base += 192) {
+                double tv[3], nv[3], hv[3], sg[3], tiv[3], sr[3], hd[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int id = base + 64 * u; const bool v = id < ni;
+                    tv[u] = v ? G[sc.T + id] : 1.0; nv[u] = v ? G[sc.NUm + id] : 1.0; hv[u] = v ? G[sc.HIN + id] : -1.0;
+                    sg[u] = v ? G[sc.SG + id] : 0.0; tiv[u] = v ? G[sc.TI + id] : 0.0; sr[u] = v ? G[sc.SR + id] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int id = base + 64 * u; const int k = id / NI, i = id - k * NI;
+                    hd[u] = id < ni ? ineq_dir(W.Dz + k * NZ, G + sc.REF + k * RREC, i) : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int id = base + 64 * u;
+                    if (id < ni) {
+                        const double t = tv[u], nu = nv[u], r = hv[u] + t, mti = mu * tiv[u], nuh = mti + sr[u];
+                        const double dt = -r - hd[u], dnu = mti - nu - sg[u] * dt;
+                        G[sc.DT + id] = dt; G[sc.DNU + id] = dnu;
+                        if (dt < 0) { const double a = -tau * t / dt; ap = a < ap ? a : ap; }
+                        if (dnu < 0) { const double a = -tau * nu / dnu; adl = a < adl ? a : adl; }
+                        dbar += -mti * dt; nhd += nuh * hd[u]; th += BMPC_FABS(r); bar -= mu * BMPC_LOG(t);
+                    }
+                }
             }
             double ghd = 0;
-            for (int id = lane; id < nw; id += 64) ghd += G[sc.GH + id] * G[sc.DZ + id];
-            for (int id = lane; id < ne; id += 64) th += BMPC_FABS(G[sc.G + id]);
-            L[L_RED + lane] = ap; L[L_RED + 64 + lane] = ad; L[L_RED + 128 + lane] = dbar; L[L_RED + 192 + lane] = ghd - nhd;
+            for (int base = lane; base < nw; base += 192) {
+                double gv[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) { const int id = base + 64 * u; gv[u] = id < nw ? G[sc.GH + id] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 3; u++) { const int id = base + 64 * u; if (id < nw) ghd += gv[u] * W.Dz[id]; }
+            }
+            for (int base = lane; base < ne; base += 192) {
+                double gv[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) { const int id = base + 64 * u; gv[u] = id < ne ? G[sc.G + id] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 3; u++) th += BMPC_FABS(gv[u]);
+            }
+            L[L_RED + lane] = ap; L[L_RED + 64 + lane] = adl; L[L_RED + 128 + lane] = dbar; L[L_RED + 192 + lane] = ghd - nhd;
             L[L_RED + 256 + lane] = th; L[L_RED + 320 + lane] = bar;
         LANES_END
-        const double ap = red_min(L + L_RED), ad = red_min(L + L_RED + 64), dbar = red_sum(L + L_RED + 128), gfd = red_sum(L + L_RED + 192),
+        const double ap = red_min(L + L_RED), dbar = red_sum(L + L_RED + 128), gfd = red_sum(L + L_RED + 192),
                      theta = red_sum(L + L_RED + 256), bar = red_sum(L + L_RED + 320);
+        ad = red_min(L + L_RED + 64);
         BMPC_PROF(W, 8);
         // ---- filter line search (Waechter & Biegler 2006, Ipopt constants) on theta and phi = f - mu sum log t ----
         const double dphi = gfd + dbar, phi0 = fval + bar;
@@ -1362,29 +1434,47 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         double alpha = ap, ft = 0; bool accepted = false, armijo_step = false;
         for (int ls = 0; ls < 14; ls++) {
             LANES_BEGIN
-                for (int id = lane; id < nw; id += 64) G[sc.ZT + id] = G[sc.Z + id] + alpha * G[sc.DZ + id];
-                for (int id = lane; id < ni; id += 64) G[sc.TT + id] = G[sc.T + id] + alpha * G[sc.DT + id];
+                for (int id = lane; id < nw; id += 64) W.Zt[id] = W.Zc[id] + alpha * W.Dz[id];
+                for (int base = lane; base < ni; base += 192) {
+                    double tv[3], dv[3];
+#pragma unroll
+                    for (int u = 0; u < 3; u++) { const int id = base + 64 * u; tv[u] = id < ni ? G[sc.T + id] : 0.0; dv[u] = id < ni ? G[sc.DT + id] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 3; u++) { const int id = base + 64 * u; if (id < ni) G[sc.TT + id] = tv[u] + alpha * dv[u]; }
+                }
             LANES_END
             BMPC_PROF(W, 9);
-            ft = wave_eval(W, po, sc, sc.ZT, sc.GT, sc.HT);
+            ft = wave_eval(W, po, sc, W.Zt, sc.GT, sc.HT);
             BMPC_PROF(W, 0);
             LANES_BEGIN
                 double th = 0, br = 0;
-                for (int id = lane; id < ne; id += 64) th += BMPC_FABS(G[sc.GT + id]);
-                for (int id = lane; id < ni; id += 64) { const double t = G[sc.TT + id]; th += BMPC_FABS(G[sc.HT + id] + t); br -= mu * BMPC_LOG(t); }
+                for (int base = lane; base < ne; base += 192) {
+                    double gv[3];
+#pragma unroll
+                    for (int u = 0; u < 3; u++) { const int id = base + 64 * u; gv[u] = id < ne ? G[sc.GT + id] : 0.0; }
+#pragma unroll
+                    for (int u = 0; u < 3; u++) th += BMPC_FABS(gv[u]);
+                }
+                for (int base = lane; base < ni; base += 192) {
+                    double tv[3], hv[3];
+#pragma unroll
+                    for (int u = 0; u < 3; u++) { const int id = base + 64 * u; tv[u] = id < ni ? G[sc.TT + id] : 1.0; hv[u] = id < ni ? G[sc.HT + id] : -1.0; }
+#pragma unroll
+                    for (int u = 0; u < 3; u++) { const int id = base + 64 * u; if (id < ni) { th += BMPC_FABS(hv[u] + tv[u]); br -= mu * BMPC_LOG(tv[u]); } }
+                }
                 L[L_RED + lane] = th; L[L_RED + 64 + lane] = br;
             LANES_END
             const double tht = red_sum(L + L_RED), phit = ft + red_sum(L + L_RED + 64);
-            bool ok = (phit - phit == 0.0) && tht <= theta_max;
-            for (int j = 0; j < nfilt && ok; j++) if (!(tht < L[L_FILT + 2 * j] || phit < L[L_FILT + 2 * j + 1])) ok = false;
+            bool okk = (phit - phit == 0.0) && tht <= theta_max;
+            for (int j = 0; j < nfilt && okk; j++) if (!(tht < L[L_FILT + 2 * j] || phit < L[L_FILT + 2 * j + 1])) okk = false;
             armijo_step = false;
-            if (ok) {
+            if (okk) {
                 if (theta <= theta_min && dphi < 0 && alpha * BMPC_POW(-dphi, 2.3) > BMPC_POW(theta, 1.1)) {
                     armijo_step = true;
-                    ok = phit <= phi0 + 1e-8 * alpha * dphi + 1e-13 * BMPC_FABS(phi0);
-                } else ok = (tht <= (1 - 1e-5) * theta) || (phit <= phi0 - 1e-8 * theta);
+                    okk = phit <= phi0 + 1e-8 * alpha * dphi + 1e-13 * BMPC_FABS(phi0);
+                } else okk = (tht <= (1 - 1e-5) * theta) || (phit <= phi0 - 1e-8 * theta);
             }
-            if (ok) { accepted = true; break; }
+            if (okk) { accepted = true; break; }
             alpha *= 0.5;
         }
 #ifdef BMPC_EMU
@@ -1397,24 +1487,46 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
             LANES_END
             nfilt++;
         }
-        // accept the last trial (swap primary / trial slabs), update multipliers
-        { int t_; t_ = sc.Z; sc.Z = sc.ZT; sc.ZT = t_; t_ = sc.T; sc.T = sc.TT; sc.TT = t_; t_ = sc.G; sc.G = sc.GT; sc.GT = t_; t_ = sc.HIN; sc.HIN = sc.HT; sc.HT = t_; }
+        // accept the last trial: iterate (LDS copy or slab swap), slab swaps for t / g / h; then row pass "A" with the multiplier update
+        if (zlds) {
+            LANES_BEGIN
+                for (int id = lane; id < nw; id += 64) W.Zc[id] = W.Zt[id];
+            LANES_END
+        } else { double *t_ = W.Zc; W.Zc = W.Zt; W.Zt = t_; }
+        { int t_; t_ = sc.T; sc.T = sc.TT; sc.TT = t_; t_ = sc.G; sc.G = sc.GT; sc.GT = t_; t_ = sc.HIN; sc.HIN = sc.HT; sc.HT = t_; }
         fval = ft;
         LANES_BEGIN
-            for (int id = lane; id < ni; id += 64) {
-                const double t = G[sc.T + id]; double v = G[sc.NUm + id] + ad * G[sc.DNU + id];
-                const double lo = mu / (1e10 * t), hi = 1e10 * mu / t;
-                v = v < lo ? lo : (v > hi ? hi : v);
-                G[sc.NUm + id] = v;
+            double ep = 0, cmax = -1e300, cmin = 1e300, sn = 0;
+            for (int base = lane; base < ni; base += 192) {
+                double tv[3], nv[3], dv[3], hv[3];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int id = base + 64 * u; const bool v = id < ni;
+                    tv[u] = v ? G[sc.T + id] : 1.0; nv[u] = v ? G[sc.NUm + id] : 0.0; dv[u] = v ? G[sc.DNU + id] : 0.0; hv[u] = v ? G[sc.HIN + id] : -1.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int id = base + 64 * u;
+                    if (id < ni) {
+                        const double t = tv[u], ti = 1.0 / t; double nu = nv[u] + ad * dv[u];
+                        const double lo = mu * ti * 1e-10, hi = 1e10 * mu * ti;
+                        nu = nu < lo ? lo : (nu > hi ? hi : nu);
+                        const double r = hv[u] + t, sgm = nu * ti;
+                        G[sc.NUm + id] = nu; G[sc.SG + id] = sgm; G[sc.TI + id] = ti; G[sc.SR + id] = sgm * r;
+                        const double v = BMPC_FABS(r), c = nu * t;
+                        ep = v > ep ? v : ep; cmax = c > cmax ? c : cmax; cmin = c < cmin ? c : cmin; sn += nu;
+                    }
+                }
             }
+            L[L_KKP + lane] = ep; L[L_KKP + 64 + lane] = cmax; L[L_KKP + 128 + lane] = cmin; L[L_KKP + 192 + lane] = sn;
         LANES_END
     }
     // ---- outputs in the reference's conventions (casadi nlpsol: x, g, lam_g, lam_x, f) ----
     LANES_BEGIN
-        if (pr.x) for (int id = lane; id < nw; id += 64) pr.x[id] = G[sc.Z + id];
+        if (pr.x) for (int id = lane; id < nw; id += 64) pr.x[id] = W.Zc[id];
         for (int id = lane; id < N * NG; id += 64) {
             const int k = id / NG, i = id - k * NG;
-            const double *Zn = G + sc.Z + k * NZ, *rr = G + sc.REF + k * RREC, *nu = G + sc.NUm + k * NI;
+            const double *Zn = W.Zc + k * NZ, *rr = G + sc.REF + k * RREC, *nu = G + sc.NUm + k * NI;
             double gv, lv;
             if (i < NE) { gv = G[sc.G + k * NE + i]; lv = G[sc.LAM + k * NE + i]; }
             else if (i == 36) { gv = Zn[ZPHI] - PAR[po.phimax]; lv = nu[IPHIMAX]; }

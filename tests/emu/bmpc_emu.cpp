@@ -53,7 +53,7 @@ extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, in
             pr.x = x ? x + (size_t)b * nw : nullptr; pr.g = g ? g + (size_t)b * ng : nullptr;
             pr.lam_g = lam_g ? lam_g + (size_t)b * ng : nullptr; pr.lam_x = lam_x ? lam_x + (size_t)b * nw : nullptr;
             pr.f = f ? f + b : nullptr; pr.kkt = kkt ? kkt + b : nullptr; pr.iters = iters ? iters + b : nullptr; pr.status = status ? status + b : nullptr;
-            bmpc::wave_solve(W, pr);
+            if (N <= 11) bmpc::wave_solve<true>(W, pr); else bmpc::wave_solve<false>(W, pr);
         }
     }
     return 0;
@@ -67,23 +67,25 @@ extern "C" int bmpc_emu_newton(int N, int S, double h, const bmpc::Opts *opts, c
     Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = scr.data();
     for (int i = 0; i < 64; i++) W.order[i] = i;
     for (int i = 0; i < po.size; i++) W.L[L_PAR + i] = p[i];
-    for (int i = 0; i < N * NZ; i++) W.G[sc.Z + i] = x[i];
+    const bool zl = N <= 11; W.Zc = zl ? W.L + L_ZL : W.G + sc.Z; W.Zt = zl ? W.L + L_PB : W.G + sc.ZT; W.Dz = zl ? W.L + L_PB + 512 : W.G + sc.DZ;
+    for (int i = 0; i < N * NZ; i++) W.Zc[i] = x[i];
     for (int i = 0; i < N * NI; i++) { W.G[sc.T + i] = t[i]; W.G[sc.NUm + i] = nu[i]; }
-    wave_eval(W, po, sc, sc.Z, sc.G, sc.HIN);
+    wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN);
     wave_adjoint(W, po, sc, sc.NUm, false, 0.0);
-    for (int i = 0; i < N * NI; i++) { const double tt = W.G[sc.T + i], nn = W.G[sc.NUm + i]; W.G[sc.SG + i] = nn / tt; W.G[sc.NUH + i] = (mu + nn * (W.G[sc.HIN + i] + tt)) / tt; }
+    for (int i = 0; i < N * NI; i++) { const double tt = W.G[sc.T + i], nn = W.G[sc.NUm + i]; W.G[sc.SG + i] = nn / tt; W.G[sc.TI + i] = 1.0 / tt; W.G[sc.SR + i] = nn / tt * (W.G[sc.HIN + i] + tt); }
     wave_adjoint(W, po, sc, sc.NUm, true, mu);
     wave_prepare_rlv(W, sc);
     LaneRegs LRs[64];
     bool ok = wave_backward_blk(W, po, sc, mu, delta, LRs);
-    if (ok) wave_forward(W, sc);
+    if (ok) wave_forward(W, sc, LRs);
+    if (ok) for (int i = 0; i < N * NZ; i++) W.G[sc.DZ + i] = W.Dz[i];
     memcpy(scratch_out, scr.data(), sizeof(double) * sc.size);
     memcpy(lds_out, lds.data(), sizeof(double) * L_SIZE);
     return ok ? 0 : 3;
 }
 extern "C" void bmpc_emu_scr_offsets(int N, int *out) {
     const bmpc::Scr s = bmpc::make_scr(N);
-    int v[] = {s.Z, s.ZT, s.T, s.TT, s.NUm, s.LAM, s.G, s.GT, s.HIN, s.HT, s.DZ, s.DT, s.DNU, s.GH, s.GVP, s.RJ, s.KIN, s.REF, s.KT, s.KF, s.RDY, s.AES, s.RLV, s.SG, s.NUH, s.size};
+    int v[] = {s.Z, s.ZT, s.T, s.TT, s.NUm, s.LAM, s.G, s.GT, s.HIN, s.HT, s.DZ, s.DT, s.DNU, s.GH, s.GVP, s.RJ, s.KIN, s.REF, s.KT, s.KF, s.RDY, s.AES, s.RLV, s.SG, s.TI, s.SR, s.size};
     for (unsigned i = 0; i < sizeof(v) / sizeof(int); i++) out[i] = v[i];
 }
 extern "C" int bmpc_emu_lds_doubles() { return bmpc::L_SIZE; }
