@@ -22,8 +22,11 @@
 #define BMPC_FMIN(a, b) fmin(a, b)
 #define BMPC_POW15(x) ((x) * sqrt(x))
 #define BMPC_POW(x, y) pow(x, y)
-#define LANES_BEGIN { const int lane = threadIdx.x; (void)lane;
-#define LANES_END } __syncthreads();
+#define LANES_BEGIN { int lane_ = threadIdx.x; asm volatile("" : "+v"(lane_)); const int lane = lane_; (void)lane;   // opaque per phase: stops LICM from hoisting per-lane address arithmetic out of the solver loops (register pressure)
+// The workgroup is ONE wave: its LDS and vector-memory instructions execute in program order, so a phase boundary needs no
+// s_barrier and no s_waitcnt drain (what __syncthreads() would emit: vmcnt(0) lgkmcnt(0), i.e. a full stall on every
+// outstanding prefetch / store).  A wavefront-scope fence keeps the COMPILER from moving memory operations across it.
+#define LANES_END } __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 #define LIDX 0
 #define BMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 

@@ -28,6 +28,10 @@
 #ifndef BMPC_PROF
 #define BMPC_PROF(W, id)
 #endif
+// four independent partial sums: breaks the dependent fp64 FMA chain of a long dot product (use inside fully unrolled loops)
+#define BMPC_ACC4(acc, idx, val) { if (((idx) & 3) == 0) acc##0 += (val); else if (((idx) & 3) == 1) acc##1 += (val); else if (((idx) & 3) == 2) acc##2 += (val); else acc##3 += (val); }
+#define BMPC_ACC4_DECL(acc) double acc##0 = 0, acc##1 = 0, acc##2 = 0, acc##3 = 0
+#define BMPC_ACC4_SUM(acc) ((acc##0 + acc##1) + (acc##2 + acc##3))
 #ifndef BMPC_SCHED_FENCE
 #define BMPC_SCHED_FENCE()   // GPU build: stops the scheduler from hoisting LDS loads across this point (bounds live ranges)
 #endif
@@ -983,21 +987,25 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         // ---- S0: PR = P' rdyn + p ; C^T P_c,iota ; P_ii E ----
         LANES_BEGIN
             if (lane < NS) {
-                const int r = lane; double sacc = L[L_PV + r];
+                const int r = lane; BMPC_ACC4_DECL(pa);
                 if (r < 32) {
                     const int f = r < 28 ? r / 7 : r - 28, i = r < 28 ? r % 7 : 7;
+#pragma unroll
                     for (int l = 0; l < 8; l++)
 #pragma unroll
-                        for (int g = 0; g < 4; g++) sacc += L[L_PB + pbi(f, g, i, l)] * L[L_RD + srow(g, l)];
-                    for (int a = 0; a < 3; a++) sacc += L[L_PCI + pci(a, f, i)] * L[L_RD + SIOTA + a];
+                        for (int g = 0; g < 4; g++) BMPC_ACC4(pa, g, L[L_PB + pbi(f, g, i, l)] * L[L_RD + srow(g, l)]);
+#pragma unroll
+                    for (int a = 0; a < 3; a++) BMPC_ACC4(pa, a, L[L_PCI + pci(a, f, i)] * L[L_RD + SIOTA + a]);
                 } else {
                     const int a = r - SIOTA;
+#pragma unroll
                     for (int l = 0; l < 8; l++)
 #pragma unroll
-                        for (int g = 0; g < 4; g++) sacc += L[L_PCI + pci(a, g, l)] * L[L_RD + srow(g, l)];
-                    for (int b = 0; b < 3; b++) sacc += L[L_PII + a * 3 + b] * L[L_RD + SIOTA + b];
+                        for (int g = 0; g < 4; g++) BMPC_ACC4(pa, g, L[L_PCI + pci(a, g, l)] * L[L_RD + srow(g, l)]);
+#pragma unroll
+                    for (int b = 0; b < 3; b++) BMPC_ACC4(pa, b, L[L_PII + a * 3 + b] * L[L_RD + SIOTA + b]);
                 }
-                L[L_PR + r] = sacc;
+                L[L_PR + r] = L[L_PV + r] + BMPC_ACC4_SUM(pa);
             }
             if (lane < 40) {   // U[(f',i)][a] = sum_f CF[f][f'] P[(f,i)][iota_a]
                 const int fp = lane >> 3, i = lane & 7;
@@ -1225,10 +1233,10 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
         if (k + 1 < N) wave_forward_prefetch(W, sc, k + 1, LR);
         LANES_BEGIN   // du = kff + K ds
             if (lane < NU) {
-                double sacc = L[L_ST + ST_KF + lane];
+                BMPC_ACC4_DECL(da);
 #pragma unroll
-                for (int b = 0; b < NS; b++) sacc += L[L_ST + ST_KT + b * NU + lane] * L[L_DS + b];
-                L[L_DU + lane] = sacc;
+                for (int b = 0; b < NS; b++) BMPC_ACC4(da, b, L[L_ST + ST_KT + b * NU + lane] * L[L_DS + b]);
+                L[L_DU + lane] = L[L_ST + ST_KF + lane] + BMPC_ACC4_SUM(da);
             }
         LANES_END
         LANES_BEGIN
@@ -1241,9 +1249,10 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
                     for (int fc = 0; fc < 4; fc++) v += chain_cf(h, f, fc) * ds[srow(fc, i)];
                     v += chain_cf(h, f, 4) * du[i];
                 } else {
-                    const int a = r - SIOTA; v += ds[r];
+                    const int a = r - SIOTA; v += ds[r]; BMPC_ACC4_DECL(ia);
 #pragma unroll
-                    for (int y = 0; y < 14; y++) v += L[L_ST + ST_AES + a * 14 + y] * ds[y];
+                    for (int y = 0; y < 14; y++) BMPC_ACC4(ia, y, L[L_ST + ST_AES + a * 14 + y] * ds[y]);
+                    v += BMPC_ACC4_SUM(ia);
                 }
                 L[L_DSN + r] = v;
             }
@@ -1256,12 +1265,14 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
                 else if (z < ZIW) { const int c = z - ZPOS; v = rlv[c];
 #pragma unroll
                     for (int i = 0; i < 7; i++) v += K0[KW + c * 7 + i] * dn[SQ + i]; }
-                else if (z < ZV) { const int c = z - ZIW; v = dn[SIOTA + c];
+                else if (z < ZV) { const int c = z - ZIW; BMPC_ACC4_DECL(za);
 #pragma unroll
-                    for (int i = 0; i < 7; i++) v += 0.5 * h * (K0[KD + (3 + c) * 7 + i] * dn[SQ + i] + K0[KA + c * 7 + i] * dn[SDQ + i]); }
-                else if (z < ZPHI) { const int c6 = z - ZV; v = rlv[3 + c6];
+                    for (int i = 0; i < 7; i++) { BMPC_ACC4(za, i, K0[KD + (3 + c) * 7 + i] * dn[SQ + i]); BMPC_ACC4(za, i + 2, K0[KA + c * 7 + i] * dn[SDQ + i]); }
+                    v = dn[SIOTA + c] + 0.5 * h * BMPC_ACC4_SUM(za); }
+                else if (z < ZPHI) { const int c6 = z - ZV; BMPC_ACC4_DECL(va);
 #pragma unroll
-                    for (int y = 0; y < 14; y++) v += gv_at(K0, c6, y) * dn[y]; }
+                    for (int y = 0; y < 14; y++) BMPC_ACC4(va, y, gv_at(K0, c6, y) * dn[y]);
+                    v = rlv[3 + c6] + BMPC_ACC4_SUM(va); }
                 else v = dn[SPHI + z - ZPHI];
                 W.Dz[k * NZ + z] = v;
             }
