@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-end measurement run on the GPU box: parity tests, smoke, the two bench
+# sizes, the rocprofv3 kernel-stats summary of the bench command, the in-kernel
+# phase profile.  Usage: bash tests/gpu_round.sh TAG
+set -e
+TAG=${1:-r01_x}
+cd "${GRAFT_REPO_ROOT:-.}"
+R=$PWD
+mkdir -p gpurun_out
+timeout -k 10 500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_$TAG.log 2>&1
+tail -2 gpurun_out/pytest_gpu_$TAG.log
+timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1
+tail -1 gpurun_out/smoke_$TAG.log
+timeout -k 10 400 python bench.py > gpurun_out/bench_${TAG}_B1024.json 2> gpurun_out/bench_err.log
+cat gpurun_out/bench_${TAG}_B1024.json
+timeout -k 10 300 python bench.py --batch 8192 --no-cpu-baseline > gpurun_out/bench_${TAG}_B8192.json 2>> gpurun_out/bench_err.log
+cat gpurun_out/bench_${TAG}_B8192.json
+export TMPDIR=/tmp
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
+cd $R
+find gpurun_out/prof_$TAG -name '*kernel_stats.csv' -exec cat {} \;
+timeout -k 10 300 python tests/gpu_profile_phases.py > gpurun_out/phases_$TAG.log 2>&1 || true
+tail -40 gpurun_out/phases_$TAG.log
