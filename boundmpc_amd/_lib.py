@@ -10,13 +10,14 @@ LIB_PATH = os.environ.get("BOUNDMPC_HIP_LIB") or os.path.join(HERE, "csrc", "lib
 
 SYMBOLS = ["bmpc_default_options", "bmpc_error_string", "bmpc_create", "bmpc_destroy", "bmpc_num_vars", "bmpc_num_cons",
            "bmpc_num_params", "bmpc_get_bounds", "bmpc_solve_batch", "bmpc_solve_batch_host", "bmpc_set_timing",
-           "bmpc_last_kernel_ms", "bmpc_launch_info"]
+           "bmpc_last_kernel_ms", "bmpc_launch_info", "bmpc_state_len", "bmpc_solve_batch_warm", "bmpc_graph_create",
+           "bmpc_graph_launch", "bmpc_graph_destroy"]
 
 
 class Options(ctypes.Structure):
     _fields_ = [("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("mu_init", ctypes.c_double),
                 ("mu_min_fac", ctypes.c_double), ("slack_push", ctypes.c_double),
-                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int)]
+                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double)]
 
 
 class BoundMPCHipError(RuntimeError):
@@ -49,6 +50,11 @@ def load():
     lib.bmpc_get_bounds.argtypes = [vp, vp, vp, vp, vp]
     lib.bmpc_solve_batch.argtypes = [vp, ci] + [vp] * 11
     lib.bmpc_solve_batch_host.argtypes = [vp, ci] + [vp] * 10
+    lib.bmpc_state_len.argtypes = [vp]
+    lib.bmpc_solve_batch_warm.argtypes = [vp, ci, vp, vp, vp, ci] + [vp] * 9
+    lib.bmpc_graph_create.argtypes = [vp, ci, vp, vp, vp, ci] + [vp] * 8 + [ctypes.POINTER(vp)]
+    lib.bmpc_graph_launch.argtypes = [vp, vp]
+    lib.bmpc_graph_destroy.argtypes = [vp]
     lib.bmpc_set_timing.argtypes = [vp, ci]
     lib.bmpc_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.bmpc_launch_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_longlong)]

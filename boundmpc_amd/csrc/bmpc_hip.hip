@@ -45,6 +45,7 @@
 struct KArgs {
     int N, S, B; double h; bmpc::Opts o;
     const double *p, *x0; double *x, *g, *lam_g, *lam_x, *f, *kkt; int *iters, *status;
+    double *state;           // optional [B][57 N + 2] dual state of a receding-horizon stream (bmpc_solve_batch_warm)
     double *scratch; long long scr_stride; int *counter; unsigned long long *prof;
 };
 
@@ -72,6 +73,7 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
         pr.lam_g = a.lam_g ? a.lam_g + (long long)b * ng : nullptr; pr.lam_x = a.lam_x ? a.lam_x + (long long)b * nw : nullptr;
         pr.f = a.f ? a.f + b : nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr;
         pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status ? a.status + b : nullptr;
+        pr.state = a.state ? a.state + (long long)b * (a.N * bmpc::NI + 2) : nullptr;
         bmpc::wave_solve<ZLDS>(W, pr);
         __syncthreads();
     }
@@ -90,7 +92,7 @@ struct bmpc_handle {
 
 extern "C" int bmpc_default_options(bmpc_options *o) {
     if (!o) return BMPC_ERR_ARG;
-    o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0;
+    o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0; o->mu_warm = 1e-4;
     return BMPC_OK;
 }
 extern "C" const char *bmpc_error_string(int c) {
@@ -151,26 +153,82 @@ extern "C" int bmpc_get_bounds(const bmpc_handle *h, double *lbx, double *ubx, d
     return BMPC_OK;
 }
 
-extern "C" int bmpc_solve_batch(bmpc_handle *h, int B, const double *p, const double *x0, double *x, double *g, double *lam_g, double *lam_x,
-                                double *f, int *iters, int *status, double *kkt, void *hip_stream) {
-    if (!h || B < 0 || (B > 0 && (!p || !x0 || !x))) return BMPC_ERR_ARG;
-    if (B == 0) return BMPC_OK;
-    hipStream_t st = (hipStream_t)hip_stream;
+// fills the kernel arguments and enqueues {reset of the work-queue counter, solver kernel} on `st`
+static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g, double *lam_g,
+                         double *lam_x, double *f, int *iters, int *status, double *kkt, hipStream_t st, bool timed) {
     KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
-    a.o.tol = h->o.tol; a.o.max_iter = h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
-    a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0;
+    a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
+    a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = lam_g; a.lam_x = lam_x; a.f = f; a.kkt = kkt; a.iters = iters; a.status = status;
+    a.state = state;
     a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter; a.prof = h->prof;
     HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), st));
     const int grid = B < h->grid ? B : h->grid;
-    if (h->timing) {
+    if (timed) {
         if (!h->have_ev) { HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1)); h->have_ev = 1; }
         HIPCHK(hipEventRecord(h->ev0, st));
     }
     if (h->N <= 11) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL(bmpc_solve_kernel<false>, dim3(grid), dim3(64), 0, st, a);
     HIPCHK(hipGetLastError());
+    if (timed) HIPCHK(hipEventRecord(h->ev1, st));
+    return BMPC_OK;
+}
+
+extern "C" int bmpc_solve_batch(bmpc_handle *h, int B, const double *p, const double *x0, double *x, double *g, double *lam_g, double *lam_x,
+                                double *f, int *iters, int *status, double *kkt, void *hip_stream) {
+    if (!h || B < 0 || (B > 0 && (!p || !x0 || !x))) return BMPC_ERR_ARG;
+    if (B == 0) return BMPC_OK;
+    return enqueue_solve(h, B, p, x0, nullptr, 0, x, g, lam_g, lam_x, f, iters, status, kkt, (hipStream_t)hip_stream, h->timing != 0);
+}
+
+extern "C" int bmpc_state_len(const bmpc_handle *h) { return h ? h->N * bmpc::NI + 2 : -1; }
+
+extern "C" int bmpc_solve_batch_warm(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g,
+                                     double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, void *hip_stream) {
+    if (!h || B < 0 || max_iter < 0 || (B > 0 && (!p || !x0 || !x || !state))) return BMPC_ERR_ARG;
+    if (B == 0) return BMPC_OK;
+    return enqueue_solve(h, B, p, x0, state, max_iter, x, g, lam_g, lam_x, f, iters, status, kkt, (hipStream_t)hip_stream, h->timing != 0);
+}
+
+// ---- hipGraph-captured step: the memset + kernel pair of one (warm-started) solve, instantiated once, replayed per tick ----
+struct bmpc_graph { bmpc_handle *h; hipGraph_t graph; hipGraphExec_t exec; };
+
+extern "C" int bmpc_graph_create(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g,
+                                 double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, bmpc_graph **out) {
+    if (!h || !out || B < 1 || max_iter < 0 || !p || !x0 || !x) return BMPC_ERR_ARG;
+    hipStream_t cs;
+    HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    bmpc_graph *gr = new (std::nothrow) bmpc_graph();
+    if (!gr) { hipStreamDestroy(cs); return BMPC_ERR_ARG; }
+    gr->h = h; gr->graph = nullptr; gr->exec = nullptr;
+    int rc = BMPC_OK;
+    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = BMPC_ERR_HIP;
+    if (rc == BMPC_OK) {
+        rc = enqueue_solve(h, B, p, x0, state, max_iter, x, g, lam_g, lam_x, f, iters, status, kkt, cs, false);
+        hipError_t e = hipStreamEndCapture(cs, &gr->graph);       // always end the capture, also after an enqueue error
+        if (rc == BMPC_OK && e != hipSuccess) rc = BMPC_ERR_HIP;
+    }
+    if (rc == BMPC_OK && hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0) != hipSuccess) rc = BMPC_ERR_HIP;
+    hipStreamDestroy(cs);
+    if (rc != BMPC_OK) { if (gr->exec) hipGraphExecDestroy(gr->exec); if (gr->graph) hipGraphDestroy(gr->graph); delete gr; return rc; }
+    *out = gr;
+    return BMPC_OK;
+}
+extern "C" int bmpc_graph_launch(bmpc_graph *gr, void *hip_stream) {
+    if (!gr) return BMPC_ERR_ARG;
+    bmpc_handle *h = gr->h; hipStream_t st = (hipStream_t)hip_stream;
+    if (h->timing) {
+        if (!h->have_ev) { HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1)); h->have_ev = 1; }
+        HIPCHK(hipEventRecord(h->ev0, st));
+    }
+    HIPCHK(hipGraphLaunch(gr->exec, st));
     if (h->timing) HIPCHK(hipEventRecord(h->ev1, st));
+    return BMPC_OK;
+}
+extern "C" int bmpc_graph_destroy(bmpc_graph *gr) {
+    if (!gr) return BMPC_ERR_ARG;
+    hipGraphExecDestroy(gr->exec); hipGraphDestroy(gr->graph); delete gr;
     return BMPC_OK;
 }
 

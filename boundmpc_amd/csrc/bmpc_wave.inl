@@ -90,7 +90,7 @@ enum { NC_HPP = 0, NC_HRR = 9, NC_HPF = 18, NC_HRF = 21, NC_SC = 24 /* hff,hdd,h
        NC_GL = 91 /* 44 */, NC_RL = 135 /* 9 */, NC_GY = 144 /* 14 */ };
 
 struct Opts {
-    double tol; int max_iter; double mu_init; double mu_min_fac; double slack_push; int exact_hessian; int verbose;
+    double tol; int max_iter; double mu_init; double mu_min_fac; double slack_push; int exact_hessian; int verbose; double mu_warm;
 };
 
 // global scratch layout (doubles) for horizon N
@@ -112,6 +112,7 @@ struct Problem {           // per-problem global pointers
     const double *p, *x0;
     double *x, *g, *lam_g, *lam_x, *f, *kkt;
     int *iters, *status;
+    double *state;         // optional dual state of a receding-horizon stream: [nu (N*57) | mu | iterations]; mu <= 0: cold start
 };
 
 struct Wave {
@@ -1307,7 +1308,11 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         for (int id = lane; id < nw; id += 64) W.Zc[id] = pr.x0[id];
     LANES_END
     const double *PAR = L + L_PAR;
-    double mu = o.mu_init; const double mu_min = o.tol * o.mu_min_fac;
+    // warm start (oracle/bmpc_oracle.c solve_one): barrier restarts at clamp(stored mu, mu_warm, mu_init); the stored
+    // multiplier of a row bounds its initial slack from below by mu/nu, so active rows keep their multiplier
+    const double mu_state = pr.state ? pr.state[ni] : 0.0;
+    const bool warm = mu_state > 0.0;
+    double mu = warm ? BMPC_FMIN(o.mu_init, BMPC_FMAX(mu_state, o.mu_warm)) : o.mu_init; const double mu_min = o.tol * o.mu_min_fac;
     double delta_last = 0.0, filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0;
     BMPC_PROF(W, 15);
     double fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN);
@@ -1321,12 +1326,16 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
             for (int base = lane; base < ni; base += 192) {
                 double hv[3], tv[3];
 #pragma unroll
-                for (int u = 0; u < 3; u++) { const int id = base + 64 * u; hv[u] = id < ni ? G[sc.HIN + id] : -1.0; }
+                for (int u = 0; u < 3; u++) {
+                    const int id = base + 64 * u; hv[u] = id < ni ? G[sc.HIN + id] : -1.0;
+                    const double ns = (warm && id < ni) ? pr.state[id] : 0.0;
+                    tv[u] = ns > 0.0 ? BMPC_FMIN(mu / ns, o.slack_push) : o.slack_push;
+                }
 #pragma unroll
                 for (int u = 0; u < 3; u++) {
                     const int id = base + 64 * u;
                     if (id < ni) {
-                        const double t = (-hv[u] > o.slack_push) ? -hv[u] : o.slack_push, ti = 1.0 / t, nu = mu * ti, r = hv[u] + t;
+                        const double t = (-hv[u] > tv[u]) ? -hv[u] : tv[u], ti = 1.0 / t, nu = mu * ti, r = hv[u] + t;
                         G[sc.T + id] = t; G[sc.NUm + id] = nu; G[sc.SG + id] = nu * ti; G[sc.TI + id] = ti; G[sc.SR + id] = nu * ti * r;
                         const double v = BMPC_FABS(r), c = nu * t;
                         ep = v > ep ? v : ep; cmax = c > cmax ? c : cmax; cmin = c < cmin ? c : cmin; sn += nu;
@@ -1552,8 +1561,10 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
             else if (z < ZDDQ) v = nu[IDQU + z - ZDQ] - nu[IDQL + z - ZDQ]; else if (z == ZPHI) v = -nu[IPHI0];
             pr.lam_x[id] = v;
         }
+        if (pr.state) for (int id = lane; id < ni; id += 64) pr.state[id] = G[sc.NUm + id];
         if (lane == 0) {
             if (pr.f) *pr.f = fval; if (pr.iters) *pr.iters = it; if (pr.status) *pr.status = status; if (pr.kkt) *pr.kkt = E0;
+            if (pr.state) { pr.state[ni] = mu; pr.state[ni + 1] = (double)it; }
         }
     LANES_END
 }

@@ -14,15 +14,17 @@ NZ, NG = 44, 43
 
 
 class BatchedOCPSolver:
-    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=0.1, slack_push=1e-2, exact_hessian=True):
+    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=0.1, slack_push=1e-2, exact_hessian=True, mu_warm=1e-4):
         self._lib = _lib.load()
         o = _lib.Options()
         self._lib.bmpc_default_options(ctypes.byref(o))
         o.tol, o.max_iter, o.mu_init, o.slack_push, o.exact_hessian = tol, int(max_iter), mu_init, slack_push, int(exact_hessian)
+        o.mu_warm = mu_warm
         self._h = ctypes.c_void_p()
         _lib.check(self._lib.bmpc_create(int(N), int(S), float(dt), ctypes.byref(o), ctypes.byref(self._h)), "bmpc_create")
         self.N, self.S, self.dt = int(N), int(S), float(dt)
         self.n_w, self.n_g, self.n_p = N * NZ, N * NG, 141 + 91 * S
+        self.state_len = int(self._lib.bmpc_state_len(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -55,17 +57,40 @@ class BatchedOCPSolver:
         _lib.check(self._lib.bmpc_last_kernel_ms(self._h, ctypes.byref(ms)), "bmpc_last_kernel_ms")
         return ms.value
 
-    # ---- batched device solve ----
-    def solve_batch(self, p, x0, out=None, want=("g", "lam_g", "lam_x", "f", "iters", "status", "kkt"), stream=None):
-        """p [B][n_p], x0 [B][n_w]: CUDA(ROCm) float64 contiguous tensors.  Returns dict of tensors.
-        Asynchronous on `stream` (default: torch's current stream)."""
+    # ---- dual state of a receding-horizon stream (bmpc_solve_batch_warm) ----
+    def new_state(self, B, device="cuda"):
+        """Zeroed state = cold start on first use."""
+        import torch
+        return torch.zeros((B, self.state_len), dtype=torch.float64, device=device)
+
+    def shift_state(self, state):
+        """Advance the horizon by one stage, as the host does with x0 (BoundMPC.py:372-375): rows of node k+1 -> node k,
+        last node duplicated.  In place."""
+        nu = state[:, :self.N * 57].view(-1, self.N, 57)
+        nu[:, :-1] = nu[:, 1:].clone()
+        return state
+
+    def _check_io(self, p, x0, state):
         import torch
         if not (p.is_cuda and x0.is_cuda and p.dtype == torch.float64 and x0.dtype == torch.float64):
             raise ValueError("p and x0 must be float64 tensors on the GPU")
-        p, x0 = p.contiguous(), x0.contiguous()
         B = p.shape[0]
         if p.shape != (B, self.n_p) or x0.shape != (B, self.n_w):
             raise ValueError(f"shape mismatch: p {tuple(p.shape)} x0 {tuple(x0.shape)}")
+        if state is not None and not (state.is_cuda and state.dtype == torch.float64 and state.is_contiguous()
+                                      and state.shape == (B, self.state_len)):
+            raise ValueError(f"state must be a contiguous float64 GPU tensor of shape ({B}, {self.state_len})")
+        return B
+
+    # ---- batched device solve ----
+    def solve_batch(self, p, x0, out=None, want=("g", "lam_g", "lam_x", "f", "iters", "status", "kkt"), stream=None, state=None, max_iter=0):
+        """p [B][n_p], x0 [B][n_w]: CUDA(ROCm) float64 contiguous tensors.  Returns dict of tensors.
+        Asynchronous on `stream` (default: torch's current stream).  With `state` (see new_state) the solve is warm-started
+        from it and updates it in place; `max_iter` > 0 caps the Newton steps of this call (real-time iteration)."""
+        import torch
+        self._check_io(p, x0, state)
+        p, x0 = p.contiguous(), x0.contiguous()
+        B = p.shape[0]
         o = out if out is not None else {}
         dev = p.device
 
@@ -84,10 +109,22 @@ class BatchedOCPSolver:
         if "kkt" in want: ptr["kkt"] = buf("kkt", (B,), torch.float64)
         st = stream if stream is not None else torch.cuda.current_stream(dev)
         dp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-        _lib.check(self._lib.bmpc_solve_batch(self._h, B, dp(p), dp(x0), dp(x), dp(ptr["g"]), dp(ptr["lam_g"]), dp(ptr["lam_x"]),
-                                              dp(ptr["f"]), dp(ptr["iters"]), dp(ptr["status"]), dp(ptr["kkt"]),
-                                              ctypes.c_void_p(st.cuda_stream)), "bmpc_solve_batch")
+        if state is None and not max_iter:
+            _lib.check(self._lib.bmpc_solve_batch(self._h, B, dp(p), dp(x0), dp(x), dp(ptr["g"]), dp(ptr["lam_g"]), dp(ptr["lam_x"]),
+                                                  dp(ptr["f"]), dp(ptr["iters"]), dp(ptr["status"]), dp(ptr["kkt"]),
+                                                  ctypes.c_void_p(st.cuda_stream)), "bmpc_solve_batch")
+        else:
+            if state is None:
+                raise ValueError("max_iter per call needs a state buffer (new_state)")
+            _lib.check(self._lib.bmpc_solve_batch_warm(self._h, B, dp(p), dp(x0), dp(state), int(max_iter), dp(x), dp(ptr["g"]), dp(ptr["lam_g"]),
+                                                       dp(ptr["lam_x"]), dp(ptr["f"]), dp(ptr["iters"]), dp(ptr["status"]), dp(ptr["kkt"]),
+                                                       ctypes.c_void_p(st.cuda_stream)), "bmpc_solve_batch_warm")
         return o
+
+    def capture_step(self, p, x0, state=None, max_iter=0, want=("iters", "status", "kkt")):
+        """hipGraph-captured step over FIXED buffers: returns a StepGraph whose launch() replays {queue reset, solver kernel};
+        the caller refreshes p / x0 / state in place between launches and reads graph.out."""
+        return StepGraph(self, p, x0, state, max_iter, want)
 
     # ---- host-buffer solve (numpy in/out) ----
     def solve_host(self, p, x0):
@@ -103,6 +140,45 @@ class BatchedOCPSolver:
                                                    vp(out["lam_x"]), vp(out["f"]), vp(out["iters"]), vp(out["status"]), vp(out["kkt"])),
                    "bmpc_solve_batch_host")
         return out
+
+
+class StepGraph:
+    """One solver step captured into a hipGraph (bmpc_graph_create / _launch / _destroy)."""
+
+    def __init__(self, solver, p, x0, state, max_iter, want):
+        import torch
+        B = solver._check_io(p, x0, state)
+        if not (p.is_contiguous() and x0.is_contiguous()):
+            raise ValueError("capture needs contiguous p and x0 (their addresses are baked into the graph)")
+        self._solver, self.p, self.x0, self.state = solver, p, x0, state
+        dev = p.device
+        shapes = dict(g=((B, solver.n_g), torch.float64), lam_g=((B, solver.n_g), torch.float64), lam_x=((B, solver.n_w), torch.float64),
+                      f=((B,), torch.float64), iters=((B,), torch.int32), status=((B,), torch.int32), kkt=((B,), torch.float64))
+        self.out = {"x": torch.empty((B, solver.n_w), dtype=torch.float64, device=dev)}
+        for k in want:
+            self.out[k] = torch.empty(shapes[k][0], dtype=shapes[k][1], device=dev)
+        dp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+        g = lambda k: dp(self.out.get(k))
+        self._g = ctypes.c_void_p()
+        _lib.check(solver._lib.bmpc_graph_create(solver._h, B, dp(p), dp(x0), dp(state), int(max_iter), dp(self.out["x"]), g("g"), g("lam_g"),
+                                                 g("lam_x"), g("f"), g("iters"), g("status"), g("kkt"), ctypes.byref(self._g)), "bmpc_graph_create")
+
+    def launch(self, stream=None):
+        import torch
+        st = stream if stream is not None else torch.cuda.current_stream(self.p.device)
+        _lib.check(self._solver._lib.bmpc_graph_launch(self._g, ctypes.c_void_p(st.cuda_stream)), "bmpc_graph_launch")
+        return self.out
+
+    def close(self):
+        if getattr(self, "_g", None):
+            self._solver._lib.bmpc_graph_destroy(self._g)
+            self._g = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _STATUS = {0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 3: "Error_In_Step_Computation"}

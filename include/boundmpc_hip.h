@@ -47,6 +47,7 @@ typedef struct {
     double slack_push;  /* minimum initial slack of an inequality row (Ipopt bound_push 1e-2) */
     int exact_hessian;  /* 1: exact Lagrangian Hessian (reference uses CasADi's exact Hessian); 0: Gauss-Newton */
     int verbose;
+    double mu_warm;     /* warm start (bmpc_solve_batch_warm): the barrier restarts at clamp(stored mu, mu_warm, mu_init); default 1e-4 */
 } bmpc_options;
 
 enum { BMPC_OK = 0, BMPC_ERR_ARG = 1, BMPC_ERR_HIP = 2, BMPC_ERR_NOGPU = 4 };
@@ -69,6 +70,28 @@ int bmpc_get_bounds(const bmpc_handle *h, double *lbx, double *ubx, double *lbg,
  * hip_stream: hipStream_t to launch on (NULL = default stream).  Asynchronous w.r.t. the host. */
 int bmpc_solve_batch(bmpc_handle *h, int B, const double *p, const double *x0, double *x, double *g, double *lam_g, double *lam_x,
                      double *f, int *iters, int *status, double *kkt, void *hip_stream);
+
+/* Warm-started solve for receding-horizon streams.  The reference warm-starts Ipopt from the previous tick's shifted solution
+ * (x0: BoundMPC.py:322-375, 'warm_start_init_point': 'yes' :134; its lam_g0/lam_x0 hand-over is commented out, :451-452).  This
+ * call takes the same x0 and additionally carries the solver's dual state across ticks:
+ *   state [B][bmpc_state_len(h)] DEVICE doubles, read and updated in place: [nu (N x 57 internal inequality rows) | mu | iterations].
+ *   A row with mu <= 0 (e.g. a zeroed buffer) is a cold start, identical to bmpc_solve_batch.  Otherwise the barrier restarts at
+ *   clamp(stored mu, options.mu_warm, options.mu_init), every slack at max(-h_i(x0), min(mu/nu_i, slack_push)), nu_i = mu/t_i.
+ *   The caller shifts `state` the way it shifts x0 (rows of node k+1 -> node k) when the horizon advances by one stage.
+ * max_iter > 0 overrides options.max_iter for this call (real-time iteration: a fixed number of Newton steps per tick; status 1
+ * is then the normal outcome and the state carries the unfinished iterate's multipliers to the next tick); 0 keeps the option. */
+int bmpc_state_len(const bmpc_handle *h);   /* 57 N + 2 */
+int bmpc_solve_batch_warm(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g,
+                          double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, void *hip_stream);
+
+/* The same step captured once into a hipGraph (work-queue reset + solver kernel) and replayed per tick with hipGraphLaunch: the
+ * buffers are fixed at capture time, the caller refreshes their contents (p, x0, state) between launches.  state may be NULL
+ * (cold starts).  One graph or solve in flight per handle. */
+typedef struct bmpc_graph bmpc_graph;
+int bmpc_graph_create(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g,
+                      double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, bmpc_graph **out);
+int bmpc_graph_launch(bmpc_graph *g, void *hip_stream);
+int bmpc_graph_destroy(bmpc_graph *g);
 
 /* HOST pointers; copies in/out and synchronises (convenience for the single-problem solver(...) call) */
 int bmpc_solve_batch_host(bmpc_handle *h, int B, const double *p, const double *x0, double *x, double *g, double *lam_g, double *lam_x,

@@ -64,6 +64,7 @@ typedef struct {
     double slack_push;   /* 1e-2 */
     int exact_hessian;   /* 1 */
     int verbose;
+    double mu_warm;      /* warm start: barrier restarts at clamp(stored mu, mu_warm, mu_init) */
 } bmpc_oracle_opts;
 
 typedef struct {
@@ -864,15 +865,24 @@ static void kkt_errors(const Cfg *C, const Work *W, double mu, double *ed, doubl
     *sc = fmax(100.0, sn / (N * NI)) / 100.0;
 }
 
-static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, SolveInfo *info) {
+/* `state` (may be NULL): dual state of a receding-horizon stream, [nu (N*57) | mu | iterations of the last call].
+ * mu <= 0 on entry means "no state": cold start.  On exit the final multipliers and barrier are stored.
+ * Warm start: mu0 = clamp(stored mu, mu_warm, mu_init); t = max(-h(x0), min(mu0 / nu_stored, slack_push)),
+ * nu = mu0 / t -- active rows keep their multiplier, inactive rows are re-centred at their new slack. */
+static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, SolveInfo *info, double *state) {
     const int N = C->N;
     Par Pp; par_view(p, C->S, &Pp); const Par *P = &Pp;
     const bmpc_oracle_opts *o = &C->o;
     memcpy(W->Z, x0, sizeof(double) * N * NZ);
-    double mu = o->mu_init, mu_min = o->tol * o->mu_min_fac, rho = 1.0, delta_last = 0.0;
+    const int warm = state && state[N * NI] > 0.0;
+    double mu = warm ? fmin(o->mu_init, fmax(state[N * NI], o->mu_warm)) : o->mu_init;
+    double mu_min = o->tol * o->mu_min_fac, delta_last = 0.0;
     double filt_th[32], filt_ph[32], filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0;
     W->f = eval_values(C, P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
-    for (int i = 0; i < N * NI; i++) { W->t[i] = fmax(-W->hin[i], o->slack_push); W->nu[i] = mu / W->t[i]; }
+    for (int i = 0; i < N * NI; i++) {
+        const double tmin = (warm && state[i] > 0.0) ? fmin(mu / state[i], o->slack_push) : o->slack_push;
+        W->t[i] = fmax(-W->hin[i], tmin); W->nu[i] = mu / W->t[i];
+    }
     double *sg = (double *)malloc(N * NI * sizeof(double)), *nuh = (double *)malloc(N * NI * sizeof(double));
     double *gf = (double *)malloc(N * NZ * sizeof(double)), *zero_nu = (double *)calloc(N * NI, sizeof(double));
     double *hdir = (double *)malloc(NI * sizeof(double)), *gt = (double *)malloc(N * NE * sizeof(double)), *ht = (double *)malloc(N * NI * sizeof(double));
@@ -963,6 +973,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         if (o->verbose) fprintf(stderr, "   alpha_p %.3e (max %.3e) alpha_d %.3e delta %.1e acc %d arm %d nfilt %d theta %.3e dphi %.3e\n", alpha, ap, ad, delta, accepted, armijo_step, nfilt, theta, dphi);
     }
     info->iters = it; info->status = status; info->f = W->f; info->kkt = E0; info->mu = mu;
+    if (state) { memcpy(state, W->nu, sizeof(double) * N * NI); state[N * NI] = mu; state[N * NI + 1] = (double)it; }
     free(sg); free(nuh); free(gf); free(zero_nu); free(hdir); free(gt); free(ht);
 }
 
@@ -970,7 +981,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
  * exported API (ctypes)
  * ---------------------------------------------------------------------------------------- */
 void bmpc_oracle_default_opts(bmpc_oracle_opts *o) {
-    o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0;
+    o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0; o->mu_warm = 1e-4;
 }
 
 static void write_outputs(const Cfg *C, const Par *P, Work *W, double *x, double *g, double *lam_g, double *lam_x) {
@@ -1045,8 +1056,11 @@ int bmpc_oracle_newton_dir(int N, int S, double h, const double *p, const double
     return ok ? 0 : 3;
 }
 
-int bmpc_oracle_solve(int N, int S, double h, const bmpc_oracle_opts *opts, int B, const double *p, const double *x0,
-                      double *x, double *g, double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, int nthreads) {
+int bmpc_oracle_state_len(int N) { return N * NI + 2; }
+
+/* state: NULL or [B][bmpc_oracle_state_len(N)], read (warm start where mu > 0) and written */
+int bmpc_oracle_solve_warm(int N, int S, double h, const bmpc_oracle_opts *opts, int B, const double *p, const double *x0, double *state,
+                           double *x, double *g, double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, int nthreads) {
     Cfg C; C.N = N; C.S = S; C.h = h; C.np = 141 + 91 * S;
     if (opts) C.o = *opts; else bmpc_oracle_default_opts(&C.o);
     const int nw = N * NZ, ng = N * NG;
@@ -1059,7 +1073,7 @@ int bmpc_oracle_solve(int N, int S, double h, const bmpc_oracle_opts *opts, int 
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < B; b++) {
             SolveInfo info; Par P; par_view(p + (size_t)b * C.np, S, &P);
-            solve_one(&C, p + (size_t)b * C.np, x0 + (size_t)b * nw, W, &info);
+            solve_one(&C, p + (size_t)b * C.np, x0 + (size_t)b * nw, W, &info, state ? state + (size_t)b * (N * NI + 2) : NULL);
             /* refresh node data at the final point for the outputs */
             W->f = eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
             write_outputs(&C, &P, W, x ? x + (size_t)b * nw : NULL, g ? g + (size_t)b * ng : NULL,
@@ -1069,6 +1083,11 @@ int bmpc_oracle_solve(int N, int S, double h, const bmpc_oracle_opts *opts, int 
         work_free(W);
     }
     return 0;
+}
+
+int bmpc_oracle_solve(int N, int S, double h, const bmpc_oracle_opts *opts, int B, const double *p, const double *x0,
+                      double *x, double *g, double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, int nthreads) {
+    return bmpc_oracle_solve_warm(N, S, h, opts, B, p, x0, NULL, x, g, lam_g, lam_x, f, iters, status, kkt, nthreads);
 }
 
 /* debug: reduced QP data and Riccati gains at (x, t, nu, mu) */

@@ -17,7 +17,7 @@ NZ, NG, NE, NI = 44, 43, 36, 57
 class Opts(ctypes.Structure):
     _fields_ = [("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("mu_init", ctypes.c_double),
                 ("mu_min_fac", ctypes.c_double), ("slack_push", ctypes.c_double),
-                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int)]
+                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double)]
 
 
 def build(force=False):
@@ -87,8 +87,13 @@ def newton_dir(p, x, t, nu, mu, N, S, h, exact=1, delta=0.0):
     return rc, dZ
 
 
-def solve(p, x0, N, S, h, opts=None, nthreads=0):
-    """Batched CPU solve.  p [B][n_p], x0 [B][44N] -> dict of outputs."""
+def state_len(N):
+    return N * 57 + 2
+
+
+def solve(p, x0, N, S, h, opts=None, nthreads=0, state=None):
+    """Batched CPU solve.  p [B][n_p], x0 [B][44N] -> dict of outputs.  state: None or float64 [B][state_len(N)],
+    dual state of a receding-horizon stream, read (warm start where its mu entry > 0) and updated in place."""
     p = np.ascontiguousarray(np.atleast_2d(p), dtype=np.float64)
     x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
     B = p.shape[0]
@@ -97,7 +102,9 @@ def solve(p, x0, N, S, h, opts=None, nthreads=0):
                lam_x=np.zeros((B, N * NZ)), f=np.zeros(B), iters=np.zeros(B, dtype=np.int32),
                status=np.zeros(B, dtype=np.int32), kkt=np.zeros(B))
     o = opts if opts is not None else default_opts()
-    lib().bmpc_oracle_solve(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(B),
-                            _p(p), _p(x0), _p(out["x"]), _p(out["g"]), _p(out["lam_g"]), _p(out["lam_x"]),
+    if state is not None:
+        assert state.dtype == np.float64 and state.flags.c_contiguous and state.shape == (B, state_len(N))
+    lib().bmpc_oracle_solve_warm(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(B),
+                            _p(p), _p(x0), _p(state) if state is not None else None, _p(out["x"]), _p(out["g"]), _p(out["lam_g"]), _p(out["lam_x"]),
                             _p(out["f"]), _p(out["iters"]), _p(out["status"]), _p(out["kkt"]), ctypes.c_int(nthreads))
     return out

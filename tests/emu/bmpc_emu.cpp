@@ -33,7 +33,7 @@
 
 #include "../../boundmpc_amd/csrc/bmpc_wave.inl"
 
-extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, int B, const double *p, const double *x0, double *x, double *g,
+extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, int B, const double *p, const double *x0, double *state, double *x, double *g,
                               double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, int lane_order, int nthreads) {
     if (S > bmpc::SMAX || S < 2 || N < 1 || N > 32) return 1;
     const bmpc::Scr sc = bmpc::make_scr(N);
@@ -53,6 +53,7 @@ extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, in
             pr.x = x ? x + (size_t)b * nw : nullptr; pr.g = g ? g + (size_t)b * ng : nullptr;
             pr.lam_g = lam_g ? lam_g + (size_t)b * ng : nullptr; pr.lam_x = lam_x ? lam_x + (size_t)b * nw : nullptr;
             pr.f = f ? f + b : nullptr; pr.kkt = kkt ? kkt + b : nullptr; pr.iters = iters ? iters + b : nullptr; pr.status = status ? status + b : nullptr;
+            pr.state = state ? state + (size_t)b * (N * bmpc::NI + 2) : nullptr;
             if (N <= 11) bmpc::wave_solve<true>(W, pr); else bmpc::wave_solve<false>(W, pr);
         }
     }

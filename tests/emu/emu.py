@@ -14,7 +14,7 @@ _SRC = [os.path.join(_HERE, "bmpc_emu.cpp"), os.path.join(_HERE, "..", "..", "bo
 class Opts(ctypes.Structure):
     _fields_ = [("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("mu_init", ctypes.c_double),
                 ("mu_min_fac", ctypes.c_double), ("slack_push", ctypes.c_double),
-                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int)]
+                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double)]
 
 
 def build(force=False):
@@ -36,7 +36,7 @@ def lib():
 
 
 def default_opts(**kw):
-    o = Opts(1e-8, 500, 0.1, 0.1, 1e-2, 1, 0)
+    o = Opts(1e-8, 500, 0.1, 0.1, 1e-2, 1, 0, 1e-4)
     for k, v in kw.items():
         setattr(o, k, v)
     return o
@@ -46,14 +46,14 @@ def _p(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
 
 
-def solve(p, x0, N, S, h, opts=None, lane_order=0, nthreads=0):
+def solve(p, x0, N, S, h, opts=None, lane_order=0, nthreads=0, state=None):
     p = np.ascontiguousarray(np.atleast_2d(p), dtype=np.float64)
     x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
     B = p.shape[0]
     out = dict(x=np.zeros((B, N * 44)), g=np.zeros((B, N * 43)), lam_g=np.zeros((B, N * 43)), lam_x=np.zeros((B, N * 44)),
                f=np.zeros(B), iters=np.zeros(B, dtype=np.int32), status=np.zeros(B, dtype=np.int32), kkt=np.zeros(B))
     o = opts if opts is not None else default_opts()
-    rc = lib().bmpc_emu_solve(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(B), _p(p), _p(x0),
+    rc = lib().bmpc_emu_solve(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(B), _p(p), _p(x0), _p(state) if state is not None else None,
                               _p(out["x"]), _p(out["g"]), _p(out["lam_g"]), _p(out["lam_x"]), _p(out["f"]), _p(out["iters"]),
                               _p(out["status"]), _p(out["kkt"]), ctypes.c_int(lane_order), ctypes.c_int(nthreads))
     assert rc == 0

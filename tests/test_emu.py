@@ -70,3 +70,41 @@ def test_emu_gauss_newton_and_iteration_cap():
     ogn = emu.solve(d["p_f64"], d["x0_f64"], 10, 4, 0.1, emu.default_opts(exact_hessian=0))
     ref = c_oracle.solve(d["p_f64"], d["x0_f64"], 10, 4, 0.1, c_oracle.default_opts(exact_hessian=0))
     assert ogn["status"][0] == ref["status"][0] and abs(int(ogn["iters"][0]) - int(ref["iters"][0])) <= 1
+
+
+def _replay(solve, d, ticks, N=10, **kw):
+    """Warm-started replay of the first closed-loop ticks of a fixture: one stream, dual state carried and shifted."""
+    st = np.zeros((1, c_oracle.state_len(N)))
+    xs, its, sts = [], [], []
+    for t in range(ticks):
+        if t:
+            nu = st[0, :N * 57].reshape(N, 57); nu[:-1] = nu[1:].copy()      # horizon advanced by one stage
+        o = solve(d["p"][t], d["x0"][t], N, 4, 0.1, state=st, **kw)
+        xs.append(o["x"][0].copy()); its.append(int(o["iters"][0])); sts.append(st.copy())
+    return np.array(xs), np.array(its), np.array(sts)
+
+
+def test_emu_warm_started_stream_matches_oracle():
+    d = np.load(os.path.join(G, "g7_closedloop_exp1.npz"))
+    T = 8
+    xo, io, so = _replay(c_oracle.solve, d, T)
+    xe, ie, se = _replay(emu.solve, d, T)
+    assert np.abs(ie - io).max() <= 1
+    assert np.sqrt(np.mean((xe - xo).reshape(T, 10, 44)[:, :, 8:15] ** 2)) < 1e-7
+    # a converged warm-started solve lands on the same minimiser as the cold-started fixture solve
+    assert np.sqrt(np.mean((xo - d["x"][:T]).reshape(T, 10, 44)[:, :, 8:15] ** 2)) < 1e-6
+    assert so[-1][0, -2] > 0 and se[-1][0, -1] == ie[-1]                     # mu stored, iteration count stored
+    # the multipliers carried to the next tick agree where they matter (active rows)
+    act = so[-1][0, :570] > 1e-3
+    np.testing.assert_allclose(se[-1][0, :570][act], so[-1][0, :570][act], rtol=1e-5)
+
+
+def test_emu_real_time_iteration_stream_matches_oracle():
+    """Two Newton steps per tick, state and iterate carried over: status 1 every tick, emulator == oracle."""
+    d = np.load(os.path.join(G, "g7_closedloop_exp1.npz"))
+    T = 6
+    xo, io, so = _replay(c_oracle.solve, d, T, opts=c_oracle.default_opts(max_iter=2))
+    xe, ie, se = _replay(emu.solve, d, T, opts=emu.default_opts(max_iter=2))
+    assert (io == 2).all() and (ie == 2).all()
+    np.testing.assert_allclose(xe, xo, atol=1e-8)
+    np.testing.assert_allclose(se[:, 0, :571], so[:, 0, :571], rtol=1e-6, atol=1e-9)

@@ -175,3 +175,70 @@ def test_bound_mpc_step_closed_loop_drop_in():
         q, dq, ddq, p_lie, v = integrate_joint(rm, jm, q, dq, ddq, mpc.dt)[:5]
         jerk = traj["dddq"][:, 0].copy()
     assert abs(mpc.phi_current[0] - d7["phi_current"][24]) < 1e-6
+
+
+def _streams():
+    """Two recorded closed-loop streams (experiment1 / experiment2 fixtures) as a batch of 2 problems per tick."""
+    d1 = np.load(os.path.join(G, "g7_closedloop_exp1.npz")); d2 = np.load(os.path.join(G, "g7_closedloop_exp2.npz"))
+    return (lambda t: np.stack([d1["p"][t], d2["p"][t]])), (lambda t: np.stack([d1["x0"][t], d2["x0"][t]])), (lambda t: np.stack([d1["x"][t], d2["x"][t]]))
+
+
+@pytest.mark.parametrize("cap", [0, 2])
+def test_warm_started_stream_against_oracle(solver, cap):
+    """bmpc_solve_batch_warm: dual state carried (and shifted) across ticks; converged (cap 0) and real-time-iteration
+    (2 Newton steps per tick) modes against the CPU oracle fed with the same sequence."""
+    import torch
+    from oracle import c_oracle
+    P, X0, XF = _streams()
+    T = 8
+    st_d = solver.new_state(2)
+    st_o = np.zeros((2, c_oracle.state_len(10)))
+    for t in range(T):
+        if t:
+            solver.shift_state(st_d)
+            nu = st_o[:, :570].reshape(2, 10, 57); nu[:, :-1] = nu[:, 1:].copy()
+        o = solver.solve_batch(torch.tensor(P(t), device="cuda"), torch.tensor(X0(t), device="cuda"), state=st_d, max_iter=cap)
+        ref = c_oracle.solve(P(t), X0(t), 10, 4, 0.1, opts=c_oracle.default_opts(max_iter=cap) if cap else None, state=st_o)
+        it = o["iters"].cpu().numpy()
+        assert np.abs(it - ref["iters"]).max() <= (0 if cap else 1)
+        x = o["x"].cpu().numpy()
+        if cap:
+            assert (o["status"].cpu().numpy() == 1).all()
+            np.testing.assert_allclose(x, ref["x"], atol=1e-8)
+            np.testing.assert_allclose(st_d.cpu().numpy()[:, :571], st_o[:, :571], rtol=1e-6, atol=1e-9)
+        else:
+            assert (o["status"].cpu().numpy() == 0).all()
+            assert _rms_q(x, ref["x"]) < TOL_Q_RMS
+            assert _rms_q(x, XF(t)) < 1e-6          # same minimiser as the cold-started fixture solve
+        st_h = st_d.cpu().numpy()
+        assert (st_h[:, 570] > 0).all() and (st_h[:, 571] == it).all()
+    # a zeroed state is a cold start: identical bits to bmpc_solve_batch
+    p, x0 = torch.tensor(P(0), device="cuda"), torch.tensor(X0(0), device="cuda")
+    a = solver.solve_batch(p, x0)["x"].clone()
+    b = solver.solve_batch(p, x0, state=solver.new_state(2))["x"]
+    assert torch.equal(a, b)
+
+
+def test_hip_graph_step_replays_and_matches_direct_launch(solver):
+    """bmpc_graph_create/_launch: the captured {queue reset + kernel} step over fixed buffers, replayed tick after tick with
+    refreshed contents, gives bit-identical results to direct launches of the same sequence."""
+    import torch
+    P, X0, _ = _streams()
+    T = 5
+    p = torch.empty((2, 505), dtype=torch.float64, device="cuda"); x0 = torch.empty((2, 440), dtype=torch.float64, device="cuda")
+    st_g, st_d = solver.new_state(2), solver.new_state(2)
+    graph = solver.capture_step(p, x0, state=st_g, max_iter=3)
+    for t in range(T):
+        if t:
+            solver.shift_state(st_g); solver.shift_state(st_d)
+        p.copy_(torch.tensor(P(t))); x0.copy_(torch.tensor(X0(t)))
+        og = graph.launch()
+        torch.cuda.synchronize()
+        xg, itg = og["x"].clone(), og["iters"].clone()
+        od = solver.solve_batch(p.clone(), x0.clone(), state=st_d, max_iter=3)
+        assert torch.equal(xg, od["x"]) and torch.equal(itg, od["iters"]) and torch.equal(st_g, st_d)
+    graph.close()
+    with pytest.raises(ValueError):
+        solver.solve_batch(p, x0, max_iter=3)                     # per-call cap needs a state buffer
+    with pytest.raises(ValueError):
+        solver.solve_batch(p, x0, state=torch.zeros((2, 5), dtype=torch.float64, device="cuda"))
