@@ -16,6 +16,9 @@
 #define BMPC_EXP(x) exp(x)
 #define BMPC_LOG(x) log(x)
 #define BMPC_SQRT(x) sqrt(x)
+#define BMPC_SIN(x) sin(x)
+#define BMPC_COS(x) cos(x)
+#define BMPC_ATAN2(y, x) atan2(y, x)
 #define BMPC_RSQRT(x) rsqrt(x)
 #define BMPC_FABS(x) fabs(x)
 #define BMPC_FMAX(a, b) fmax(a, b)
@@ -41,6 +44,7 @@
 #endif
 
 #include "bmpc_wave.inl"
+#include "bmpc_stream.inl"
 
 struct KArgs {
     int N, S, B; double h; bmpc::Opts o;
@@ -266,6 +270,70 @@ extern "C" int bmpc_last_kernel_ms(bmpc_handle *h, float *ms) {
     HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
     return BMPC_OK;
 }
+// ---- receding-horizon streams: device-side packing / post-processing, one stream per thread ----
+__global__ void __launch_bounds__(64) bmpc_stream_pack_kernel(int N, int S, int B, const double *path, int path_stride, double *ss, const double *rb,
+                                                             double *p, double *x0, double *dual) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    bmpcs::stream_pack(N, S, path + (long long)b * path_stride, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
+                       p + (long long)b * (141 + 91 * S), x0 + (long long)b * 44 * N, dual ? dual + (long long)b * (57 * N + 2) : nullptr);
+}
+__global__ void __launch_bounds__(64) bmpc_stream_post_kernel(int N, int S, int B, double h, const double *path, int path_stride, double *ss, double *rb,
+                                                             const double *x, const double *g, const int *status, double *traj, int simulate) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    bmpcs::stream_post(N, S, h, path + (long long)b * path_stride, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
+                       x + (long long)b * 44 * N, g + (long long)b * 43 * N, status[b], traj + (long long)b * bmpcs::tr_len(N), simulate);
+}
+extern "C" int bmpc_stream_lengths(const bmpc_handle *h, int *path_entry, int *state, int *robot, int *traj) {
+    if (!h) return BMPC_ERR_ARG;
+    if (path_entry) *path_entry = bmpcs::PT_LEN; if (state) *state = bmpcs::ss_len(h->N); if (robot) *robot = bmpcs::RB_LEN; if (traj) *traj = bmpcs::tr_len(h->N);
+    return BMPC_OK;
+}
+extern "C" int bmpc_stream_pack(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, const double *robot, double *p, double *x0,
+                                double *dual_state, void *hip_stream) {
+    if (!h || B < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !p || !x0))) return BMPC_ERR_ARG;
+    if (B == 0) return BMPC_OK;
+    hipLaunchKernelGGL(bmpc_stream_pack_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, path, path_entries * bmpcs::PT_LEN,
+                       sstate, robot, p, x0, dual_state);
+    HIPCHK(hipGetLastError());
+    return BMPC_OK;
+}
+extern "C" int bmpc_stream_post(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, const double *x, const double *g,
+                                const int *status, double *traj, int simulate, void *hip_stream) {
+    if (!h || B < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !x || !g || !status || !traj))) return BMPC_ERR_ARG;
+    if (B == 0) return BMPC_OK;
+    hipLaunchKernelGGL(bmpc_stream_post_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, h->h, path,
+                       path_entries * bmpcs::PT_LEN, sstate, robot, x, g, status, traj, simulate);
+    HIPCHK(hipGetLastError());
+    return BMPC_OK;
+}
+// one closed-loop tick {pack, solve (warm-started, max_iter), post} captured into a hipGraph
+extern "C" int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, double *p, double *x0,
+                                        double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj,
+                                        int simulate, bmpc_graph **out) {
+    if (!h || !out || B < 1 || max_iter < 0 || path_entries < h->S + 1 || !path || !sstate || !robot || !p || !x0 || !x || !g || !status || !traj) return BMPC_ERR_ARG;
+    hipStream_t cs;
+    HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    bmpc_graph *gr = new (std::nothrow) bmpc_graph();
+    if (!gr) { hipStreamDestroy(cs); return BMPC_ERR_ARG; }
+    gr->h = h; gr->graph = nullptr; gr->exec = nullptr;
+    int rc = BMPC_OK;
+    if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = BMPC_ERR_HIP;
+    if (rc == BMPC_OK) {
+        rc = bmpc_stream_pack(h, B, path, path_entries, sstate, robot, p, x0, dual_state, cs);
+        if (rc == BMPC_OK) rc = enqueue_solve(h, B, p, x0, dual_state, max_iter, x, g, nullptr, nullptr, nullptr, iters, status, kkt, cs, false);
+        if (rc == BMPC_OK) rc = bmpc_stream_post(h, B, path, path_entries, sstate, robot, x, g, status, traj, simulate, cs);
+        hipError_t e = hipStreamEndCapture(cs, &gr->graph);
+        if (rc == BMPC_OK && e != hipSuccess) rc = BMPC_ERR_HIP;
+    }
+    if (rc == BMPC_OK && hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0) != hipSuccess) rc = BMPC_ERR_HIP;
+    hipStreamDestroy(cs);
+    if (rc != BMPC_OK) { if (gr->exec) hipGraphExecDestroy(gr->exec); if (gr->graph) hipGraphDestroy(gr->graph); delete gr; return rc; }
+    *out = gr;
+    return BMPC_OK;
+}
+
 #ifdef BMPC_MARKS
 // diagnostic compile only (-S): textual markers in the ISA at the phase stamps, to count static instructions per phase
 #define BMPC_PROF(W, id) asm volatile("s_nop 0 ; BMPCMARK " #id ::: "memory");

@@ -1,0 +1,396 @@
+// bmpc_stream.inl -- the per-stream host arithmetic of BoundMPC.step() as device code.
+//
+// Two functions, one stream (trajectory) per thread:
+//   stream_pack  (f1 + f3): sliding path window (ReferencePath.update/get_* , ReferencePath.py:178-238), warm-start vector
+//                (cold start BoundMPC.py:316-321, integrated-omega unwrap :326-333, shift :372-375), initial orientation errors
+//                (util_functions.py:11-31), SO(3) Jacobians and dual basis (BoundMPC.py:267-304, lie_functions.py:41-64), tube
+//                quartics (BoundMPC.py:219-265, mpc_utils_casadi.py:130-137), parameter vector p in the layout of
+//                casadi_ocp_formulation.py:361-376 / BoundMPC.py:416-443.
+//   stream_post  (f2 + f3): feasibility rule and fallback to the previous plan (BoundMPC.py:460-506), re-integration of the
+//                joint and path states from the optimal jerks (:513-555), Cartesian trajectory (:568-587), advance of the
+//                path-parameter state and of the rotation reference (:594-611, util_functions.py:88-99), optional kinematic
+//                plant step (util_functions.py:152-161) so that a closed loop runs without leaving the device.
+// Not covered (stays on the host object boundmpc_amd.bound_mpc.BoundMPC): re-planning `update()` (BoundMPC.py:163-217,335-369)
+// and the RViz logging dictionaries.
+//
+// Rotation conversions follow scipy.spatial.transform.Rotation's algorithms (from_rotvec / as_matrix / from_matrix /
+// as_rotvec / as_euler('zyx')) so that the parameters agree with the host mirror to round-off.
+// The same text is compiled by g++ for the CPU tests (tests/emu).
+#pragma once
+
+namespace bmpcs {
+
+// path table entry (one per via-point slot), doubles
+enum { PT_P = 0, PT_IW = 3, PT_DPN = 6, PT_DR = 9, PT_RRV = 12, PT_PLO = 15, PT_PUP = 17, PT_RLO = 19, PT_RUP = 21, PT_BP1 = 23, PT_BP2 = 26,
+       PT_BR1 = 29, PT_BR2 = 32, PT_CUM = 35, PT_EPMIN = 36, PT_ERMIN = 37, PT_EPMAX = 38, PT_ERMAX = 39, PT_S = 40, PT_LEN = 48 };
+// stream state, doubles; the previous solution [N][44] follows at SS_PREV
+enum { SS_SECTOR = 0, SS_HASPREV = 1, SS_ERRCNT = 2, SS_PHI = 3, SS_DPHI = 4, SS_DDPHI = 5, SS_DDDPHI = 6, SS_PRREF = 7, SS_IWREF = 10,
+       SS_PHIMAX = 13, SS_W = 14 /* 15 weights */, SS_NENT = 29, SS_USINGPREV = 30, SS_VALID = 31, SS_PREV = 32 };
+// robot record per tick: the arguments of step(q, dq, ddq, p_lie, v, x_phi_d, jerk)
+enum { RB_Q = 0, RB_DQ = 7, RB_DDQ = 14, RB_P = 21, RB_V = 27, RB_XPHID = 33, RB_JERK = 36, RB_LEN = 43 };
+// trajectory record: [q dq ddq dddq](7 x N each) [p v a](6 x N each) [phi dphi ddphi dddphi](N each) n_valid
+BMPC_HD inline int tr_len(int N) { return 4 * 7 * N + 3 * 6 * N + 4 * N + 4; }
+BMPC_HD inline int ss_len(int N) { return SS_PREV + 44 * N; }
+
+BMPC_HD inline double norm3(const double *a) { return BMPC_SQRT(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+BMPC_HD inline double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+BMPC_HD inline void cross3s(const double *a, const double *b, double *c) {
+    const double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+    c[0] = x; c[1] = y; c[2] = z;
+}
+BMPC_HD inline void mat3_mul(const double *A, const double *B, double *C) {   // row-major 3x3
+    double t[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) t[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+    for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+BMPC_HD inline void mat3_mul_bt(const double *A, const double *B, double *C) {   // A * B^T
+    double t[9];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) t[i * 3 + j] = A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1] + A[i * 3 + 2] * B[j * 3 + 2];
+    for (int i = 0; i < 9; i++) C[i] = t[i];
+}
+// rotation vector -> unit quaternion (x, y, z, w)
+BMPC_HD inline void rotvec_to_quat(const double *v, double *q) {
+    const double ang = norm3(v);
+    double sc;
+    if (ang <= 1e-3) { const double a2 = ang * ang; sc = 0.5 - a2 / 48 + a2 * a2 / 3840; }
+    else sc = BMPC_SIN(ang / 2) / ang;
+    q[0] = sc * v[0]; q[1] = sc * v[1]; q[2] = sc * v[2]; q[3] = BMPC_COS(ang / 2);
+}
+BMPC_HD inline void quat_to_mat(const double *q, double *M) {
+    const double x = q[0], y = q[1], z = q[2], w = q[3];
+    const double x2 = x * x, y2 = y * y, z2 = z * z, w2 = w * w, xy = x * y, zw = z * w, xz = x * z, yw = y * w, yz = y * z, xw = x * w;
+    M[0] = x2 - y2 - z2 + w2; M[3] = 2 * (xy + zw); M[6] = 2 * (xz - yw);
+    M[1] = 2 * (xy - zw); M[4] = -x2 + y2 - z2 + w2; M[7] = 2 * (yz + xw);
+    M[2] = 2 * (xz + yw); M[5] = 2 * (yz - xw); M[8] = -x2 - y2 + z2 + w2;
+}
+BMPC_HD inline void rotvec_to_mat(const double *v, double *M) { double q[4]; rotvec_to_quat(v, q); quat_to_mat(q, M); }
+// rotation matrix -> unit quaternion (largest of the diagonal / trace decides the branch)
+BMPC_HD inline void mat_to_quat(const double *M, double *q) {
+    const double d0 = M[0], d1 = M[4], d2 = M[8], tr = d0 + d1 + d2;
+    int choice = 0; double best = d0;
+    if (d1 > best) { best = d1; choice = 1; }
+    if (d2 > best) { best = d2; choice = 2; }
+    if (tr > best) { best = tr; choice = 3; }
+    if (choice != 3) {
+        const int i = choice, j = (i + 1) % 3, k = (j + 1) % 3;
+        q[i] = 1 - tr + 2 * M[i * 3 + i];
+        q[j] = M[j * 3 + i] + M[i * 3 + j];
+        q[k] = M[k * 3 + i] + M[i * 3 + k];
+        q[3] = M[k * 3 + j] - M[j * 3 + k];
+    } else {
+        q[0] = M[7] - M[5]; q[1] = M[2] - M[6]; q[2] = M[3] - M[1]; q[3] = 1 + tr;
+    }
+    const double n = BMPC_SQRT(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    for (int i = 0; i < 4; i++) q[i] /= n;
+}
+BMPC_HD inline void quat_to_rotvec(const double *qin, double *v) {
+    double q[4] = {qin[0], qin[1], qin[2], qin[3]};
+    if (q[3] < 0) for (int i = 0; i < 4; i++) q[i] = -q[i];
+    const double ang = 2 * BMPC_ATAN2(norm3(q), q[3]);
+    double sc;
+    if (ang <= 1e-3) { const double a2 = ang * ang; sc = 2 + a2 / 12 + 7 * a2 * a2 / 2880; }
+    else sc = ang / BMPC_SIN(ang / 2);
+    v[0] = sc * q[0]; v[1] = sc * q[1]; v[2] = sc * q[2];
+}
+BMPC_HD inline void mat_to_rotvec(const double *M, double *v) { double q[4]; mat_to_quat(M, q); quat_to_rotvec(q, v); }
+// extrinsic z-y-x Euler angles of R = Rx(e2) Ry(e1) Rz(e0)
+BMPC_HD inline void mat_to_euler_zyx(const double *M, double *e) {
+    // through the quaternion, as scipy does, so that a slightly non-orthogonal input is treated alike
+    double q[4], Rn[9]; mat_to_quat(M, q); quat_to_mat(q, Rn);
+    e[1] = BMPC_ATAN2(Rn[2], BMPC_SQRT(Rn[0] * Rn[0] + Rn[1] * Rn[1]));
+    e[0] = BMPC_ATAN2(-Rn[1], Rn[0]);
+    e[2] = BMPC_ATAN2(-Rn[5], Rn[8]);
+}
+// J_r^{-1}, J_l^{-1} of SO(3) with the reference's angle = |axis| + 1e-6 (lie_functions.py:41-64), row-major
+BMPC_HD inline void jac_so3_inv(const double *a, double sign, double *J) {
+    const double th = norm3(a) + 1e-6;
+    const double K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
+    double K2[9]; mat3_mul(K, K, K2);
+    const double c = 1 / (th * th) - (1 + BMPC_COS(th)) / (2 * th * BMPC_SIN(th));
+    for (int i = 0; i < 9; i++) J[i] = (i % 4 == 0 ? 1.0 : 0.0) + sign * 0.5 * K[i] + c * K2[i];
+}
+BMPC_HD inline void mat3_vec(const double *A, const double *x, double *y) {
+    const double a = A[0] * x[0] + A[1] * x[1] + A[2] * x[2], b = A[3] * x[0] + A[4] * x[1] + A[5] * x[2], c = A[6] * x[0] + A[7] * x[1] + A[8] * x[2];
+    y[0] = a; y[1] = b; y[2] = c;
+}
+BMPC_HD inline void unit_or_y(const double *v, double tol, double *out) {
+    const double n = norm3(v);
+    if (n > tol) { out[0] = v[0] / n; out[1] = v[1] / n; out[2] = v[2] / n; } else { out[0] = 0; out[1] = 1; out[2] = 0; }
+}
+// rotate the reference by the constant angular velocity om over (phi1 - phi0)  (util_functions.py:88-99)
+BMPC_HD inline void integrate_rotation_reference(const double *pr_ref, const double *om, double phi0, double phi1, double *out) {
+    double R0[9]; rotvec_to_mat(pr_ref, R0);
+    const double n = norm3(om);
+    if (n > 1e-4) {
+        const double k[3] = {om[0] / n, om[1] / n, om[2] / n};
+        const double K[9] = {0, -k[2], k[1], k[2], 0, -k[0], -k[1], k[0], 0};
+        double K2[9]; mat3_mul(K, K, K2);
+        const double ang = (phi1 - phi0) * n, s = BMPC_SIN(ang), c1 = 1 - BMPC_COS(ang);
+        double E[9];
+        for (int i = 0; i < 9; i++) E[i] = (i % 4 == 0 ? 1.0 : 0.0) + s * K[i] + c1 * K2[i];
+        mat3_mul(E, R0, R0);
+    }
+    mat_to_rotvec(R0, out);
+}
+// hat-function jerk integrator, one step (jerk_trajectory_casadi.py:78-175 closed form)
+BMPC_HD inline void chain_step(double &x, double &dx, double &ddx, double up, double u, double h) {
+    const double xn = x + h * dx + h * h / 2 * ddx + h * h * h / 8 * up + h * h * h / 24 * u;
+    const double dxn = dx + h * ddx + h * h / 3 * up + h * h / 6 * u;
+    const double ddxn = ddx + h / 2 * (up + u);
+    x = xn; dx = dxn; ddx = ddxn;
+}
+
+// iiwa14 geometric chain (RobotModel.py:9-16,62-116,254-563): EE pose [pos; rotvec], J (6x7 row-major), dJ
+struct Fk { double p[6], J[42], dJ[42]; };
+BMPC_HD inline void forward_kinematics(const double *q, const double *dq, Fk &F) {
+    const int ax[7] = {2, 1, 2, -1, 2, 1, 2};
+    const double pre[7] = {0.0, 0.1575 + 0.2025, 0.0, 0.2375 + 0.1825, 0.0, 0.2175 + 0.1825, 0.0};
+    const double tool = 0.081 + (0.071 + 0.145);
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0}, A[7][3], O[7][3];
+    for (int j = 0; j < 7; j++) {
+        for (int c = 0; c < 3; c++) { o[c] += R[c * 3 + 2] * pre[j]; O[j][c] = o[c]; }
+        double cs = BMPC_COS(q[j]), sn = BMPC_SIN(q[j]);
+        if (ax[j] == 2) {
+            for (int c = 0; c < 3; c++) { A[j][c] = R[c * 3 + 2]; const double c0 = R[c * 3], c1 = R[c * 3 + 1]; R[c * 3] = cs * c0 + sn * c1; R[c * 3 + 1] = -sn * c0 + cs * c1; }
+        } else {
+            const double sg = (double)ax[j]; sn *= sg;
+            for (int c = 0; c < 3; c++) { A[j][c] = sg * R[c * 3 + 1]; const double c0 = R[c * 3], c2 = R[c * 3 + 2]; R[c * 3] = cs * c0 - sn * c2; R[c * 3 + 2] = sn * c0 + cs * c2; }
+        }
+    }
+    for (int c = 0; c < 3; c++) F.p[c] = o[c] + R[c * 3 + 2] * tool;
+    mat_to_rotvec(R, F.p + 3);
+    double Wc[7][3];
+    for (int j = 0; j < 7; j++) {
+        const double r[3] = {F.p[0] - O[j][0], F.p[1] - O[j][1], F.p[2] - O[j][2]};
+        cross3s(A[j], r, Wc[j]);
+        for (int c = 0; c < 3; c++) { F.J[c * 7 + j] = Wc[j][c]; F.J[(3 + c) * 7 + j] = A[j][c]; }
+    }
+    for (int i = 0; i < 42; i++) F.dJ[i] = 0.0;
+    for (int i = 0; i < 7; i++) {
+        const double f = dq[i];
+        for (int j = 0; j < 7; j++) {
+            double v[3];
+            if (i <= j) cross3s(A[i], Wc[j], v); else cross3s(A[j], Wc[i], v);
+            for (int c = 0; c < 3; c++) F.dJ[c * 7 + j] += f * v[c];
+            if (i < j) { cross3s(A[i], A[j], v); for (int c = 0; c < 3; c++) F.dJ[(3 + c) * 7 + j] += f * v[c]; }
+        }
+    }
+}
+
+// quartic a4..a0 on [0, L] with f(0)=e0, f(L)=e1, f(L/2)=emax, f'(0)=s, f'(L)=-s  (mpc_utils_casadi.py:130-137 at phi0 = 0)
+BMPC_HD inline void bound_params(double L, double e0, double e1, double s, double emax, double *a4, double *a3, double *a2, double *a1, double *a0) {
+    const double r1 = e1 - e0 - s * L, r2 = emax - e0 - s * L / 2, r3 = -2 * s * L;
+    const double A = 16 * r2 - 5 * r1 + r3, B = -32 * r2 + 14 * r1 - 3 * r3, C = 16 * r2 - 8 * r1 + 2 * r3;
+    const double L2 = L * L;
+    *a4 = C / (L2 * L2); *a3 = B / (L2 * L); *a2 = A / L2; *a1 = s + 0 * e0; *a0 = e0 + 0 * s;
+}
+
+// ------------------------------------------------------------------------------------------
+// f1 + f3: pack one stream.  path [nent][PT_LEN], ss stream state, rb robot record, p [141+91 S], x0 [N][44],
+// dual (may be null): the solver's dual state [57 N + 2], shifted with the plan.
+// ------------------------------------------------------------------------------------------
+BMPC_HD inline void stream_pack(int N, int S, const double *path, double *ss, const double *rb, double *p, double *x0, double *dual) {
+    const int nent = (int)ss[SS_NENT];
+    int sector = (int)ss[SS_SECTOR];
+    const double phi_cur = ss[SS_PHI];
+    // ReferencePath.update: slide the window while phi passed the first switch
+    while (sector + S + 1 < nent && phi_cur > path[(sector + 1) * PT_LEN + PT_CUM]) sector++;
+    ss[SS_SECTOR] = (double)sector;
+    const double *q0 = rb + RB_Q, *p0 = rb + RB_P;
+    // ---- warm-start vector ----
+    const bool has_prev = ss[SS_HASPREV] > 0.5;
+    if (!has_prev) {
+        for (int k = 0; k < N; k++) {
+            double *z = x0 + k * 44;
+            for (int i = 0; i < 44; i++) z[i] = 0.0;
+            for (int i = 0; i < 7; i++) z[8 + i] = q0[i];
+            for (int i = 0; i < 6; i++) z[29 + i] = p0[i];
+        }
+    } else {
+        const double *pv = ss + SS_PREV;
+        for (int i = 0; i < 44 * N; i++) x0[i] = pv[i];
+        const double d[3] = {p0[3] - x0[32], p0[4] - x0[33], p0[5] - x0[34]};
+        if (norm3(d) > 1.5) {                                   // integrated-omega unwrap :326-333
+            const double p1[3] = {x0[32], x0[33], x0[34]};
+            for (int k = 0; k < N - 1; k++) for (int c = 0; c < 3; c++) x0[k * 44 + 32 + c] = p0[3 + c] + (pv[(k + 1) * 44 + 32 + c] - p1[c]);
+            for (int c = 0; c < 3; c++) x0[(N - 1) * 44 + 32 + c] = x0[(N - 2) * 44 + 32 + c];
+        }
+        for (int k = 0; k < N - 1; k++) for (int i = 0; i < 44; i++) x0[k * 44 + i] = x0[(k + 1) * 44 + i];   // shift :372-375
+        if (dual && dual[57 * N] > 0.0) for (int k = 0; k < N - 1; k++) for (int i = 0; i < 57; i++) dual[k * 57 + i] = dual[(k + 1) * 57 + i];
+    }
+    // ---- window views ----
+    const double *e0p = path + sector * PT_LEN;
+    double phi_sw[5];
+    for (int i = 0; i <= S; i++) phi_sw[i] = path[(sector + i) * PT_LEN + PT_CUM];
+    // ---- initial orientation errors per segment (util_functions.py:11-31) ----
+    double dtau[3], par[4][3], o1[4][3], o2[4][3], dn[4][3];
+    {
+        double Ra[9], Rb[9], Rd[9];
+        rotvec_to_mat(p0 + 3, Ra); rotvec_to_mat(ss + SS_PRREF, Rb); mat3_mul_bt(Ra, Rb, Rd);
+        mat_to_rotvec(Rd, dtau);
+    }
+    double Rtau[9]; rotvec_to_mat(dtau, Rtau);
+    for (int i = 0; i < S; i++) {
+        const double *e = path + (sector + i) * PT_LEN;
+        unit_or_y(e + PT_DR, 1e-4, dn[i]);
+        const double *b1 = e + PT_BR1, *b2 = e + PT_BR2;
+        const double F[9] = {b2[0], dn[i][0], b1[0], b2[1], dn[i][1], b1[1], b2[2], dn[i][2], b1[2]};   // columns br2, d, br1
+        double T[9], M[9], Ft[9];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ft[r * 3 + c] = F[c * 3 + r];
+        mat3_mul(Rtau, F, T); mat3_mul(Ft, T, M);
+        double eul[3]; mat_to_euler_zyx(M, eul);
+        for (int c = 0; c < 3; c++) { par[i][c] = eul[1] * dn[i][c]; o1[i][c] = eul[0] * b1[c]; o2[i][c] = eul[2] * b2[c]; }
+    }
+    // ---- SO(3) Jacobians and the dual basis (BoundMPC.py:267-304) ----
+    double jr[9], jl[9], v1[4][3], v2[4][3], v3[4][3];
+    jac_so3_inv(dtau, +1.0, jr); jac_so3_inv(dtau, -1.0, jl);
+    for (int i = 0; i < S; i++) {
+        const double *e = path + (sector + i) * PT_LEN;
+        double Ro[9], Rp[9], rest1[9], rest2[9], rv[3], Jt[9], t1[3], t2[3], t3[3];
+        rotvec_to_mat(o1[i], Ro); rotvec_to_mat(par[i], Rp);
+        mat3_mul_bt(Rtau, Ro, rest1); mat3_mul_bt(rest1, Rp, rest2);
+        mat3_vec(jr, e + PT_BR1, t1);
+        mat_to_rotvec(rest1, rv); jac_so3_inv(rv, +1.0, Jt); mat3_vec(Jt, dn[i], t2);
+        mat_to_rotvec(rest2, rv); jac_so3_inv(rv, +1.0, Jt); mat3_vec(Jt, e + PT_BR2, t3);
+        // rows of inv([t1 t2 t3]) (columns t1, t2, t3): cross products over the determinant
+        double c23[3], c31[3], c12[3];
+        cross3s(t2, t3, c23); cross3s(t3, t1, c31); cross3s(t1, t2, c12);
+        const double det = dot3(t1, c23);
+        for (int c = 0; c < 3; c++) { v1[i][c] = c23[c] / det; v2[i][c] = c31[c] / det; v3[i][c] = c12[c] / det; }
+    }
+    // ---- parameter vector ----
+    int c = 0;
+    for (int i = 0; i < 21; i++) p[c++] = rb[RB_Q + i];                 // q0, dq0, ddq0
+    p[c++] = ss[SS_PHI]; p[c++] = ss[SS_DPHI]; p[c++] = ss[SS_DDPHI];
+    for (int i = 0; i < 12; i++) p[c++] = rb[RB_P + i];                 // p0, v0
+    for (int i = 0; i < 3; i++) p[c++] = ss[SS_IWREF + i];
+    for (int i = 0; i < 3; i++) p[c++] = dtau[i];
+    for (int i = 0; i < S; i++) for (int k = 0; k < 3; k++) p[c++] = par[i][k];
+    for (int i = 0; i < S; i++) for (int k = 0; k < 3; k++) p[c++] = o1[i][k];
+    for (int i = 0; i < S; i++) for (int k = 0; k < 3; k++) p[c++] = o2[i][k];
+    const double phi_max = ss[SS_PHIMAX];
+    const double phimax_p = BMPC_FMIN(phi_cur + 5.0, phi_max);
+    p[c++] = BMPC_FMIN(phi_cur + 5.0, rb[RB_XPHID]); p[c++] = rb[RB_XPHID + 1]; p[c++] = rb[RB_XPHID + 2];
+    for (int i = 0; i < 7; i++) p[c++] = rb[RB_JERK + i];
+    p[c++] = ss[SS_DDDPHI];
+    for (int i = 0; i <= S; i++) p[c++] = phi_sw[i];
+    for (int col = 0; col < 3; col++) for (int r = 0; r < 3; r++) p[c++] = jr[r * 3 + col];      // jac_r.T.ravel()
+    for (int col = 0; col < 3; col++) for (int r = 0; r < 3; r++) p[c++] = jl[r * 3 + col];
+    for (int k = 0; k < 6; k++) for (int i = 0; i < S; i++) p[c++] = path[(sector + i) * PT_LEN + (k < 3 ? PT_P + k : PT_IW + k - 3)];
+    for (int k = 0; k < 6; k++) for (int i = 0; i < S; i++) p[c++] = path[(sector + i) * PT_LEN + (k < 3 ? PT_DPN + k : PT_DR + k - 3)];
+    for (int k = 0; k < 3; k++) for (int i = 0; i < S; i++) p[c++] = dn[i][k];
+    for (int f = 0; f < 4; f++) {
+        const int off = f == 0 ? PT_BP1 : (f == 1 ? PT_BP2 : (f == 2 ? PT_BR1 : PT_BR2));
+        for (int k = 0; k < 3; k++) for (int i = 0; i < S; i++) p[c++] = path[(sector + i) * PT_LEN + off + k];
+    }
+    // tube quartics a4..a0, each [chan 0..8][seg 0..S]; only the first window entry's bound parameters are used (:224-232)
+    {
+        const double pm = e0p[PT_EPMIN], rmn = e0p[PT_ERMIN], px = e0p[PT_EPMAX], rx = e0p[PT_ERMAX], sl = e0p[PT_S];
+        const double e0v[9] = {pm, pm, -pm, -pm, rmn, rmn, -rmn, -rmn, rmn};
+        const double sg[9] = {1, 1, -1, -1, 1, 1, -1, -1, 1};
+        const double ex[9] = {px, px, px, px, rx, rx, rx, rx, rx};
+        double *A4 = p + c, *A3 = A4 + 9 * (S + 1), *A2 = A3 + 9 * (S + 1), *A1 = A2 + 9 * (S + 1), *A0 = A1 + 9 * (S + 1);
+        for (int i = 0; i < S; i++) {
+            const double *e = path + (sector + i) * PT_LEN;
+            const double ab[8] = {e[PT_PUP], e[PT_PUP + 1], -e[PT_PLO], -e[PT_PLO + 1], e[PT_RUP], e[PT_RUP + 1], -e[PT_RLO], -e[PT_RLO + 1]};
+            const double L = phi_sw[i + 1] - phi_sw[i];
+            for (int ch = 0; ch < 9; ch++) {
+                const double scale = ab[ch < 8 ? ch : 7];
+                const int id = ch * (S + 1) + i;
+                bound_params(L, e0v[ch], e0v[ch], sg[ch] * sl * scale, sg[ch] * ex[ch] * scale, A4 + id, A3 + id, A2 + id, A1 + id, A0 + id);
+            }
+        }
+        for (int ch = 0; ch < 9; ch++) {                       // row S (np.empty in the reference) := row S-1
+            const int id = ch * (S + 1) + S;
+            A4[id] = A4[id - 1]; A3[id] = A3[id - 1]; A2[id] = A2[id - 1]; A1[id] = A1[id - 1]; A0[id] = A0[id - 1];
+        }
+        c += 5 * 9 * (S + 1);
+    }
+    for (int i = 0; i < 15; i++) p[c + i] = ss[SS_W + i];
+    if (rb[RB_XPHID] < 1) p[c + 6] *= BMPC_FMIN(1 / (phi_max * phi_max), 2.0);          // :400-403
+    c += 15;
+    p[c++] = phimax_p; p[c++] = ss[SS_W + 4];                                           // phi_max (clipped), dphi_max = weights[4]
+    for (int k = 0; k < 3; k++) for (int i = 0; i < S; i++) p[c++] = v1[i][k];
+    for (int k = 0; k < 3; k++) for (int i = 0; i < S; i++) p[c++] = v2[i][k];
+    for (int k = 0; k < 3; k++) for (int i = 0; i < S; i++) p[c++] = v3[i][k];
+    const bool near_end = phimax_p - phi_cur < 0.05;                                    // :411-413
+    for (int i = 0; i < 7; i++) p[c++] = near_end ? q0[i] : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------
+// f2 + f3: post-process one stream.  x [N][44] solver result, g [N][43], status; traj: trajectory record (tr_len(N));
+// simulate != 0: advance the robot record rb with the kinematic plant step of the node (util_functions.py:152-161).
+// ------------------------------------------------------------------------------------------
+BMPC_HD inline void stream_post(int N, int S, double h, const double *path, double *ss, double *rb, const double *x, const double *g, int status,
+                                double *traj, int simulate) {
+    // feasibility rule :460-465
+    double viol = 0.0;
+    for (int k = 0; k < N; k++) for (int i = 0; i < 43; i++) {
+        const double v = g[k * 43 + i];
+        if (i < 36 && v < -1e-6) viol -= v;
+        if (v > 1e-6) viol += v;
+    }
+    const bool success = status == 0 || viol < 1e-4;
+    int ec = (int)ss[SS_ERRCNT];
+    double *prev = ss + SS_PREV;
+    const double *w = x;                       // plan used for the return data
+    int using_prev = 0;
+    if (!success) {
+        ec += 1;
+        if (ss[SS_HASPREV] > 0.5) { w = prev; using_prev = 1; }
+        else { ec = 0; using_prev = 1; }
+    } else {
+        ec = 0;
+        for (int i = 0; i < 44 * N; i++) prev[i] = x[i];
+        ss[SS_HASPREV] = 1.0;
+    }
+    ss[SS_ERRCNT] = (double)ec; ss[SS_USINGPREV] = (double)using_prev;
+    const int TRN = tr_len(N);
+    if (ec >= N) { ss[SS_VALID] = 0.0; traj[TRN - 4] = 0.0; return; }      // step() returns None :504-506
+    ss[SS_VALID] = 1.0;
+    const int n = N - ec;
+    double *Tq = traj, *Tdq = Tq + 7 * N, *Tddq = Tdq + 7 * N, *Tj = Tddq + 7 * N, *Tp = Tj + 7 * N, *Tv = Tp + 6 * N, *Ta = Tv + 6 * N,
+           *Tphi = Ta + 6 * N, *Tdphi = Tphi + N, *Tddphi = Tdphi + N, *Tjphi = Tddphi + N;
+    double q[7], dq[7], ddq[7], up[7];
+    for (int i = 0; i < 7; i++) { q[i] = rb[RB_Q + i]; dq[i] = rb[RB_DQ + i]; ddq[i] = rb[RB_DDQ + i]; up[i] = rb[RB_JERK + i]; }
+    double ph = ss[SS_PHI], dph = ss[SS_DPHI], ddph = ss[SS_DDPHI], upp = ss[SS_DDDPHI];
+    const double phi_before = ss[SS_PHI];
+    for (int i = 0; i < n; i++) {                                           // :536-555
+        const double *z = w + (ec + i) * 44;
+        for (int j = 0; j < 7; j++) { chain_step(q[j], dq[j], ddq[j], up[j], z[j], h); up[j] = z[j]; }
+        chain_step(ph, dph, ddph, upp, z[7], h); upp = z[7];
+        for (int j = 0; j < 7; j++) { Tq[j * N + i] = q[j]; Tdq[j * N + i] = dq[j]; Tddq[j * N + i] = ddq[j]; Tj[j * N + i] = z[j]; }
+        Tphi[i] = ph; Tdphi[i] = dph; Tddphi[i] = ddph; Tjphi[i] = z[7];
+        Fk F; forward_kinematics(q, dq, F);                                  // :568-587
+        for (int c = 0; c < 6; c++) {
+            double v = 0, a = 0;
+            for (int j = 0; j < 7; j++) { v += F.J[c * 7 + j] * dq[j]; a += F.J[c * 7 + j] * ddq[j] + F.dJ[c * 7 + j] * dq[j]; }
+            Tp[c * N + i] = F.p[c]; Tv[c * N + i] = v; Ta[c * N + i] = a;
+        }
+    }
+    traj[TRN - 4] = (double)n; traj[TRN - 3] = (double)using_prev; traj[TRN - 2] = (double)success; traj[TRN - 1] = viol;
+    // rotation reference and path-parameter state :594-611
+    const int sector = (int)ss[SS_SECTOR];
+    const double *e0 = path + sector * PT_LEN, *e1 = path + (sector + 1) * PT_LEN;
+    const double sw0 = e0[PT_CUM], sw1 = e1[PT_CUM], phi0 = Tphi[0];
+    double prn[3];
+    if (phi0 > sw1) {
+        integrate_rotation_reference(e1 + PT_RRV, e1 + PT_DR, sw1, phi0, prn);
+        for (int c = 0; c < 3; c++) ss[SS_IWREF + c] = e1[PT_IW + c] + (phi0 - sw1) * e1[PT_DR + c];
+    } else {
+        integrate_rotation_reference(ss + SS_PRREF, e0 + PT_DR, phi_before, phi0, prn);
+        for (int c = 0; c < 3; c++) ss[SS_IWREF + c] = e0[PT_IW + c] + (phi0 - sw0) * e0[PT_DR + c];
+    }
+    for (int c = 0; c < 3; c++) ss[SS_PRREF + c] = prn[c];
+    ss[SS_PHI] = phi0; ss[SS_DPHI] = Tdphi[0]; ss[SS_DDPHI] = Tddphi[0]; ss[SS_DDDPHI] = Tjphi[0];
+    if (simulate) {
+        // the node's kinematic simulation: integrate with [jerk_current, first planned jerk], then FK (util_functions.py:152-161)
+        double qs[7], dqs[7], ddqs[7];
+        for (int j = 0; j < 7; j++) { qs[j] = rb[RB_Q + j]; dqs[j] = rb[RB_DQ + j]; ddqs[j] = rb[RB_DDQ + j]; chain_step(qs[j], dqs[j], ddqs[j], rb[RB_JERK + j], Tj[j * N], h); }
+        Fk F; forward_kinematics(qs, dqs, F);
+        for (int j = 0; j < 7; j++) { rb[RB_Q + j] = qs[j]; rb[RB_DQ + j] = dqs[j]; rb[RB_DDQ + j] = ddqs[j]; rb[RB_JERK + j] = Tj[j * N]; }
+        for (int c = 0; c < 6; c++) { double v = 0; for (int j = 0; j < 7; j++) v += F.J[c * 7 + j] * dqs[j]; rb[RB_P + c] = F.p[c]; rb[RB_V + c] = v; }
+    }
+}
+
+}  // namespace bmpcs

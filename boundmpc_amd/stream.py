@@ -1,0 +1,166 @@
+"""Batched receding-horizon streams: the whole tick of `BoundMPC.step()` on the device.
+
+One stream = one trajectory (what one reference `BoundMPC` object is, BoundMPC.py:20-33 -- SURVEY.md 8b: "a
+BoundMPC instance is stateful per trajectory").  The static part of a stream is its *path table* (the arrays
+`ReferencePath.__init__` derives from the via points, ReferencePath.py:10-163), built here on the host once;
+the dynamic part is the *stream state* (phi-state, rotation reference, window sector, error count, previous
+solution).  Per tick the device runs  pack -> solve -> post  (csrc/bmpc_stream.inl + the solver kernel),
+optionally as one captured hipGraph and optionally with the node's kinematic plant simulation, so a closed loop
+needs no host round trip.  Re-planning (`BoundMPC.update`) is not covered.
+"""
+import ctypes
+
+import numpy as np
+from scipy.spatial.transform import Rotation as R
+
+from . import _lib
+
+# csrc/bmpc_stream.inl
+PT = dict(P=0, IW=3, DPN=6, DR=9, RRV=12, PLO=15, PUP=17, RLO=19, RUP=21, BP1=23, BP2=26, BR1=29, BR2=32, CUM=35, EPMIN=36, ERMIN=37,
+          EPMAX=38, ERMAX=39, S=40, LEN=48)
+SS = dict(SECTOR=0, HASPREV=1, ERRCNT=2, PHI=3, DPHI=4, DDPHI=5, DDDPHI=6, PRREF=7, IWREF=10, PHIMAX=13, W=14, NENT=29, USINGPREV=30, VALID=31,
+          PREV=32)
+RB = dict(Q=0, DQ=7, DDQ=14, P=21, V=27, XPHID=33, JERK=36, LEN=43)
+
+
+def path_table(rp, entries=None):
+    """Flatten a host `ReferencePath` (boundmpc_amd.reference_path) into the device table [entries][48]."""
+    M = len(rp.p)
+    assert rp.phi_bias == 0
+    n_rows = entries if entries is not None else M
+    assert n_rows >= M
+    T = np.zeros((n_rows, PT["LEN"]))
+    at = lambda lst, j: lst[min(j, len(lst) - 1)]
+    for j in range(M):
+        e = T[j]
+        e[0:3], e[3:6] = rp.p[j], at(rp.iw, j)
+        dpj = at(rp.dp, j)
+        e[6:9] = dpj / np.linalg.norm(dpj)
+        e[9:12] = at(rp.dr, j)
+        e[12:15] = R.from_matrix(at(rp.r, j)).as_rotvec()
+        e[15:17], e[17:19] = at(rp.p_lower, j), at(rp.p_upper, j)
+        e[19:21], e[21:23] = at(rp.r_lower, j), at(rp.r_upper, j)
+        e[23:26], e[26:29], e[29:32], e[32:35] = at(rp.bp1, j), at(rp.bp2, j), at(rp.br1, j), at(rp.br2, j)
+        e[35] = rp._cum[j]
+        e[36], e[37], e[38], e[39], e[40] = at(rp.e_p_min, j), at(rp.e_r_min, j), at(rp.e_p_max, j), at(rp.e_r_max, j), at(rp.s, j)
+    T[M:] = T[M - 1]
+    return T, M
+
+
+def initial_state(mpc, N):
+    """Stream state of a freshly constructed host `BoundMPC` (before its first step)."""
+    s = np.zeros(SS["PREV"] + 44 * N)
+    s[SS["SECTOR"]] = mpc.ref_path.sector
+    s[SS["PHI"]], s[SS["DPHI"]], s[SS["DDPHI"]], s[SS["DDDPHI"]] = mpc.phi_current[0], mpc.dphi_current[0], mpc.ddphi_current[0], mpc.dddphi_current[0]
+    s[SS["PRREF"]:SS["PRREF"] + 3] = mpc.pr_ref
+    s[SS["IWREF"]:SS["IWREF"] + 3] = mpc.iw_ref
+    s[SS["PHIMAX"]] = mpc.phi_max[0]
+    s[SS["W"]:SS["W"] + 15] = mpc.weights
+    if mpc.prev_solution is not None:
+        s[SS["HASPREV"]] = 1.0
+        s[SS["PREV"]:] = np.asarray(mpc.prev_solution, dtype=float).ravel()
+    s[SS["ERRCNT"]] = mpc.error_count
+    return s
+
+
+def robot_record(q, dq, ddq, p_lie, v, x_phi_d, jerk):
+    return np.concatenate([q, dq, ddq, p_lie, v, x_phi_d, jerk]).astype(float)
+
+
+def unpack_traj(t, N):
+    """Trajectory record -> the reference's traj_data dict (BoundMPC.py:757-770) + flags."""
+    t = np.asarray(t)
+    n = int(t[-4])
+    o, out = 0, {}
+    for k in ("q", "dq", "ddq", "dddq"):
+        out[k] = t[o:o + 7 * N].reshape(7, N)[:, :n]; o += 7 * N
+    for k in ("p", "v", "a"):
+        out[k] = t[o:o + 6 * N].reshape(6, N)[:, :n]; o += 6 * N
+    for k in ("phi", "dphi", "ddphi", "dddphi"):
+        out[k] = t[o:o + N][:n]; o += N
+    return out, dict(n_valid=n, using_previous=bool(t[-3]), success=bool(t[-2]), g_viol=float(t[-1]))
+
+
+class StreamBatch:
+    """B streams on the GPU.  `mpcs`: list of freshly constructed host `boundmpc_amd.bound_mpc.BoundMPC` objects (used only to
+    read their path and initial state; they are not advanced)."""
+
+    def __init__(self, solver, mpcs, device="cuda"):
+        import torch
+        self.solver, self.B, self.N, self.S = solver, len(mpcs), solver.N, solver.S
+        lens = [ctypes.c_int() for _ in range(4)]
+        _lib.check(solver._lib.bmpc_stream_lengths(solver._h, *[ctypes.byref(v) for v in lens]), "bmpc_stream_lengths")
+        self.pt_len, self.ss_len, self.rb_len, self.tr_len = (v.value for v in lens)
+        assert self.pt_len == PT["LEN"] and self.rb_len == RB["LEN"] and self.ss_len == SS["PREV"] + 44 * self.N
+        self.entries = max(len(m.ref_path.p) for m in mpcs)
+        tabs, states = [], []
+        for m in mpcs:
+            assert m.N == self.N and m.nr_segs == self.S and abs(m.dt - solver.dt) < 1e-15
+            T, M = path_table(m.ref_path, self.entries)
+            s = initial_state(m, self.N); s[SS["NENT"]] = M
+            tabs.append(T); states.append(s)
+        t64 = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float64, device=device)
+        self.path, self.state = t64(np.stack(tabs)), t64(np.stack(states))
+        self.robot = torch.zeros((self.B, self.rb_len), dtype=torch.float64, device=device)
+        self.p = torch.empty((self.B, solver.n_p), dtype=torch.float64, device=device)
+        self.x0 = torch.empty((self.B, solver.n_w), dtype=torch.float64, device=device)
+        self.dual = solver.new_state(self.B, device)
+        self.x = torch.empty((self.B, solver.n_w), dtype=torch.float64, device=device)
+        self.g = torch.empty((self.B, solver.n_g), dtype=torch.float64, device=device)
+        self.iters = torch.zeros((self.B,), dtype=torch.int32, device=device)
+        self.status = torch.zeros((self.B,), dtype=torch.int32, device=device)
+        self.kkt = torch.zeros((self.B,), dtype=torch.float64, device=device)
+        self.traj = torch.zeros((self.B, self.tr_len), dtype=torch.float64, device=device)
+        self._graphs = {}
+
+    def set_robot(self, rec):
+        import torch
+        self.robot.copy_(torch.as_tensor(np.ascontiguousarray(rec), dtype=torch.float64))
+
+    def _stream(self, stream):
+        import torch
+        return ctypes.c_void_p((stream if stream is not None else torch.cuda.current_stream(self.path.device)).cuda_stream)
+
+    def pack(self, warm_dual=False, stream=None):
+        dp = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(self.solver._lib.bmpc_stream_pack(self.solver._h, self.B, dp(self.path), self.entries, dp(self.state), dp(self.robot), dp(self.p),
+                                                     dp(self.x0), dp(self.dual) if warm_dual else None, self._stream(stream)), "bmpc_stream_pack")
+
+    def post(self, simulate=True, stream=None):
+        dp = lambda t: ctypes.c_void_p(t.data_ptr())
+        _lib.check(self.solver._lib.bmpc_stream_post(self.solver._h, self.B, dp(self.path), self.entries, dp(self.state), dp(self.robot), dp(self.x),
+                                                     dp(self.g), dp(self.status), dp(self.traj), int(simulate), self._stream(stream)), "bmpc_stream_post")
+
+    def tick(self, max_iter=0, warm_dual=False, simulate=True, stream=None):
+        """pack -> solve -> post as three launches (see tick_graph for the captured form)."""
+        self.pack(warm_dual, stream)
+        out = dict(x=self.x, g=self.g, iters=self.iters, status=self.status, kkt=self.kkt)
+        self.solver.solve_batch(self.p, self.x0, out=out, want=("g", "iters", "status", "kkt"), stream=stream,
+                                state=self.dual if (warm_dual or max_iter) else None, max_iter=max_iter)
+        self.post(simulate, stream)
+
+    def tick_graph(self, max_iter=0, warm_dual=False, simulate=True, stream=None):
+        """The same tick replayed from a hipGraph captured on first use (bmpc_stream_graph_create)."""
+        key = (int(max_iter), bool(warm_dual), bool(simulate))
+        if key not in self._graphs:
+            if max_iter and not warm_dual:
+                raise ValueError("an iteration cap needs the dual state (warm_dual=True)")
+            dp = lambda t: ctypes.c_void_p(t.data_ptr())
+            g = ctypes.c_void_p()
+            _lib.check(self.solver._lib.bmpc_stream_graph_create(
+                self.solver._h, self.B, dp(self.path), self.entries, dp(self.state), dp(self.robot), dp(self.p), dp(self.x0),
+                dp(self.dual) if warm_dual else None, int(max_iter), dp(self.x), dp(self.g), dp(self.iters), dp(self.status), dp(self.kkt),
+                dp(self.traj), int(simulate), ctypes.byref(g)), "bmpc_stream_graph_create")
+            self._graphs[key] = g
+        _lib.check(self.solver._lib.bmpc_graph_launch(self._graphs[key], self._stream(stream)), "bmpc_graph_launch")
+
+    def close(self):
+        for g in self._graphs.values():
+            self.solver._lib.bmpc_graph_destroy(g)
+        self._graphs = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -93,6 +93,32 @@ int bmpc_graph_create(bmpc_handle *h, int B, const double *p, const double *x0, 
 int bmpc_graph_launch(bmpc_graph *g, void *hip_stream);
 int bmpc_graph_destroy(bmpc_graph *g);
 
+/* ---- Receding-horizon streams: the per-tick host arithmetic of BoundMPC.step() as device kernels (one stream per thread) ----
+ * bmpc_stream_pack  <-> BoundMPC.step() pre-solve, BoundMPC.py:310-443 (ReferencePath window ReferencePath.py:178-238, warm start
+ *                       :316-333,372-375, compute_initial_rot_errors util_functions.py:11-31, projection vectors :267-304, tube
+ *                       quartics :219-265): (path table, stream state, robot record) -> p [B][n_p], x0 [B][44N]; also shifts the
+ *                       solver's dual state with the plan (dual_state may be NULL).
+ * bmpc_stream_post  <-> BoundMPC.step() post-solve, BoundMPC.py:460-506 (feasibility rule, fallback to the previous plan) and
+ *                       compute_return_data :513-611 (re-integration, Cartesian trajectory, advance of phi / rotation reference);
+ *                       simulate != 0 additionally advances the robot record like the node's kinematic simulation
+ *                       (util_functions.py:152-161, bound_mpc_node.py:292-372).
+ * All buffers are DEVICE doubles, one row per stream, row lengths from bmpc_stream_lengths:
+ *   path   [B][path_entries][path_entry]  static via-point table (built on the host once per path; layout in
+ *                                          boundmpc_amd/csrc/bmpc_stream.inl, builder boundmpc_amd.stream.path_table)
+ *   sstate [B][state]   phi-state, rotation reference, sector, error count, weights, previous solution
+ *   robot  [B][robot]   q dq ddq p_lie v x_phi_d jerk  = the arguments of step()            (read; written when simulate)
+ *   traj   [B][traj]    q dq ddq dddq (7 x N) | p v a (6 x N) | phi dphi ddphi dddphi (N) | n_valid using_previous success g_viol
+ * Re-planning (BoundMPC.update, BoundMPC.py:163-217) is not covered: rebuild the table and state on the host. */
+int bmpc_stream_lengths(const bmpc_handle *h, int *path_entry, int *state, int *robot, int *traj);
+int bmpc_stream_pack(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, const double *robot, double *p, double *x0,
+                     double *dual_state, void *hip_stream);
+int bmpc_stream_post(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, const double *x, const double *g,
+                     const int *status, double *traj, int simulate, void *hip_stream);
+/* one whole tick {pack, warm-started solve with max_iter (0 = options), post} captured into a hipGraph; launch with bmpc_graph_launch */
+int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, double *p, double *x0,
+                             double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj,
+                             int simulate, bmpc_graph **out);
+
 /* HOST pointers; copies in/out and synchronises (convenience for the single-problem solver(...) call) */
 int bmpc_solve_batch_host(bmpc_handle *h, int B, const double *p, const double *x0, double *x, double *g, double *lam_g, double *lam_x,
                           double *f, int *iters, int *status, double *kkt);

@@ -21,6 +21,9 @@
 #define BMPC_EXP(x) std::exp(x)
 #define BMPC_LOG(x) std::log(x)
 #define BMPC_SQRT(x) std::sqrt(x)
+#define BMPC_SIN(x) std::sin(x)
+#define BMPC_COS(x) std::cos(x)
+#define BMPC_ATAN2(y, x) std::atan2(y, x)
 #define BMPC_RSQRT(x) (1.0 / std::sqrt(x))
 #define BMPC_FABS(x) std::fabs(x)
 #define BMPC_FMAX(a, b) std::fmax(a, b)
@@ -32,6 +35,17 @@
 #define LIDX lane
 
 #include "../../boundmpc_amd/csrc/bmpc_wave.inl"
+#include "../../boundmpc_amd/csrc/bmpc_stream.inl"
+
+// CPU build of the stream functions (same text as the device kernels), one call per stream
+extern "C" void bmpc_emu_stream_lengths(int N, int *out) { out[0] = bmpcs::PT_LEN; out[1] = bmpcs::ss_len(N); out[2] = bmpcs::RB_LEN; out[3] = bmpcs::tr_len(N); }
+extern "C" void bmpc_emu_stream_pack(int N, int S, const double *path, double *ss, const double *rb, double *p, double *x0, double *dual) {
+    bmpcs::stream_pack(N, S, path, ss, rb, p, x0, dual);
+}
+extern "C" void bmpc_emu_stream_post(int N, int S, double h, const double *path, double *ss, double *rb, const double *x, const double *g, int status,
+                                     double *traj, int simulate) {
+    bmpcs::stream_post(N, S, h, path, ss, rb, x, g, status, traj, simulate);
+}
 
 extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, int B, const double *p, const double *x0, double *state, double *x, double *g,
                               double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, int lane_order, int nthreads) {

@@ -58,3 +58,26 @@ def solve(p, x0, N, S, h, opts=None, lane_order=0, nthreads=0, state=None):
                               _p(out["status"]), _p(out["kkt"]), ctypes.c_int(lane_order), ctypes.c_int(nthreads))
     assert rc == 0
     return out
+
+
+# ---- CPU build of the stream functions (boundmpc_amd/csrc/bmpc_stream.inl) ----
+def stream_lengths(N):
+    out = (ctypes.c_int * 4)()
+    lib().bmpc_emu_stream_lengths(ctypes.c_int(N), out)
+    return dict(path_entry=out[0], state=out[1], robot=out[2], traj=out[3])
+
+
+def stream_pack(N, S, path, ss, rb, dual=None):
+    """path [M][48], ss (updated in place), rb -> (p, x0)"""
+    p = np.zeros(141 + 91 * S); x0 = np.zeros(44 * N)
+    assert path.flags.c_contiguous and ss.flags.c_contiguous and rb.flags.c_contiguous
+    lib().bmpc_emu_stream_pack(ctypes.c_int(N), ctypes.c_int(S), _p(path), _p(ss), _p(rb), _p(p), _p(x0), _p(dual) if dual is not None else None)
+    return p, x0
+
+
+def stream_post(N, S, h, path, ss, rb, x, g, status, simulate=True):
+    traj = np.zeros(stream_lengths(N)["traj"])
+    x = np.ascontiguousarray(x, dtype=np.float64); g = np.ascontiguousarray(g, dtype=np.float64)
+    lib().bmpc_emu_stream_post(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), _p(path), _p(ss), _p(rb), _p(x), _p(g), ctypes.c_int(int(status)),
+                               _p(traj), ctypes.c_int(int(simulate)))
+    return traj
