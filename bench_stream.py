@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[4]: warm-started receding-horizon stream, hipGraph-captured step, batch=256 parallel trajectories.
+"""BASELINE.json configs[4] (SURVEY 8d "Config 5"): warm-started receding-horizon stream, hipGraph-captured step,
+batch=256 parallel closed-loop trajectories.
 
-Not the driver's bench line (that is bench.py / configs[1]); this script measures the per-tick latency of the
-solver on a stream.  Workload: 256 trajectories replaying the recorded experiment1 closed loop (tests/golden/
-g7_closedloop_exp1.npz: p and x0 of 155 consecutive ticks, x0 = shifted previous solution as BoundMPC.py:372-375),
-trajectory b started at tick (b mod 100), so a batch mixes all phases of the motion.  Host-side packing is not part of
-the timed region (device-side packing is a later row); the timed region per tick is the replay of the
-captured graph {work-queue reset, solver kernel}, measured with HIP events on the launch stream.
+Not the driver's bench line (that is bench.py / configs[1]).  256 independent closed loops (generator of configs[1], seed 3:
+random q0, own experiment1-pattern path each), same OCP (N=10, h=0.1 s, S=4).  Like the reference node, simulated time
+advances by h per tick while the wall-clock tick rate is what is measured.  Each tick, entirely on the device and replayed
+from ONE captured hipGraph: pack (path window, warm-start shift, parameter vector) -> solver step -> post (feasibility rule,
+re-integration, phi / rotation-reference advance, kinematic plant step).  Timed with HIP events around the graph launch.
 
-Modes: cold (dual cold start every tick = what the reference does with Ipopt), warm (dual state carried, solved to tol),
-rti-K (K Newton steps per tick).  For rti-K the deviation from the converged solution of the same tick is reported."""
+Modes: converged (solve to tol every tick, cold duals = what the reference does with Ipopt), warm (dual state carried),
+rti-K (K Newton steps per tick from the carried primal-dual state).  For every mode the closed-loop result is compared
+with the converged loop: RMS joint deviation over all ticks, and path progress phi after the last tick."""
 import argparse
 import json
 import os
@@ -24,44 +25,49 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=256)
-    ap.add_argument("--ticks", type=int, default=50)
+    ap.add_argument("--ticks", type=int, default=60)
     ap.add_argument("--tol", type=float, default=1e-8)
+    ap.add_argument("--mu-warm", type=float, default=1e-4)
+    ap.add_argument("--max-iter", type=int, default=100, help="iteration cap of the converged modes (reference: 500)")
     args = ap.parse_args()
     import torch
-    from boundmpc_amd import BatchedOCPSolver
-    d = np.load(os.path.join(ROOT, "tests", "golden", "g7_closedloop_exp1.npz"))
+    from boundmpc_amd import BatchedOCPSolver, workload, stream as bstream
     B, T = args.batch, args.ticks
-    off = np.arange(B) % 100
-    assert off.max() + T <= d["p"].shape[0]
-    dev = torch.device("cuda:0")
-    Pall = torch.tensor(d["p"], device=dev); Xall = torch.tensor(d["x0"], device=dev); Xfin = torch.tensor(d["x"], device=dev)
-    idx = torch.tensor(off, device=dev)
-    solver = BatchedOCPSolver(10, 4, 0.1, tol=args.tol)
+    q0s = workload.random_q0(B, seed=3)
+    mpcs, recs = [], []
+    for q0 in q0s:
+        m, p0fk = workload.make_mpc(q0)
+        mpcs.append(m)
+        recs.append(bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([m.phi_max[0], 0.0, 0.0]), np.zeros(7)))
+    recs = np.stack(recs)
+    solver = BatchedOCPSolver(10, 4, 0.1, tol=args.tol, mu_warm=args.mu_warm, max_iter=args.max_iter)
     solver.set_timing(True)
-    p = torch.empty((B, 505), dtype=torch.float64, device=dev); x0 = torch.empty((B, 440), dtype=torch.float64, device=dev)
-    res = []
-    for mode, cap, warm in (("cold", 0, False), ("warm", 0, True), ("rti-3", 3, True), ("rti-2", 2, True), ("rti-1", 1, True)):
-        state = solver.new_state(B) if (warm or cap) else None
-        graph = solver.capture_step(p, x0, state=state, max_iter=cap)
-        ms, its, err = [], [], []
+    res, ref_q = [], None
+    for mode, cap, warm in (("converged", 0, False), ("warm", 0, True), ("rti-5", 5, True), ("rti-3", 3, True), ("rti-2", 2, True), ("rti-1", 1, True)):
+        sb = bstream.StreamBatch(solver, mpcs)
+        sb.set_robot(recs)
+        ms, its, Q, ok = [], [], [], []
         for t in range(T):
-            p.copy_(Pall[idx + t]); x0.copy_(Xall[idx + t])
-            if state is not None:
-                if not warm: state.zero_()
-                elif t: solver.shift_state(state)
-            torch.cuda.synchronize()
-            out = graph.launch()
+            # the first tick of every stream is its cold start: solved to tolerance in all modes
+            sb.tick_graph(max_iter=0 if t == 0 else cap, warm_dual=warm, simulate=True, accept_capped=cap > 0)
             ms.append(solver.last_kernel_ms())
-            its.append(float(out["iters"].double().mean().item()))
-            dq = (out["x"] - Xfin[idx + t]).view(B, 10, 44)[:, :, 8:15]
-            err.append(float(torch.sqrt((dq ** 2).mean()).item()))
-        graph.close()
-        ms = np.array(ms[1:]); its = np.array(its[1:]); err = np.array(err[1:])      # tick 0 is the cold start of the stream
+            its.append(float(sb.iters.double().mean().item()))
+            Q.append(sb.robot[:, :7].clone())
+            ok.append(float((sb.traj[:, -2] > 0.5).double().mean().item()))
+        Q = torch.stack(Q).cpu().numpy()
+        phi = sb.state[:, bstream.SS["PHI"]].cpu().numpy()
+        if ref_q is None:
+            ref_q = Q
+        ms = np.array(ms[1:]); its = np.array(its[1:])
         res.append({"mode": mode, "tick_ms_p50": float(np.percentile(ms, 50)), "tick_ms_p99": float(np.percentile(ms, 99)),
                     "ticks_per_s": float(1e3 / ms.mean()), "solves_per_s": float(B * 1e3 / ms.mean()), "mean_iters": float(its.mean()),
-                    "rms_joint_dev_vs_converged_rad": float(np.sqrt(np.mean(err ** 2)))})
-    print(json.dumps({"metric": "per-tick solver latency, warm-started stream (BASELINE configs[4])", "batch": B, "ticks": T - 1, "tol": args.tol,
-                      "workload": "256 replayed experiment1 closed-loop streams, staggered start, hipGraph-captured step", "results": res}))
+                    "feasible_tick_fraction": float(np.mean(ok)), "rms_joint_dev_vs_converged_loop_rad": float(np.sqrt(np.mean((Q - ref_q) ** 2))),
+                    "max_joint_dev_rad": float(np.abs(Q - ref_q).max()), "mean_phi_after_last_tick": float(phi.mean())})
+        sb.close()
+    print(json.dumps({"metric": "closed-loop tick latency, 256 streams, whole tick in one hipGraph (BASELINE configs[4])", "batch": B, "ticks": T - 1,
+                      "tol": args.tol, "mu_warm": args.mu_warm, "budget_ms": 1.0,
+                      "workload": "256 closed loops, random q0 (seed 3), own experiment1-pattern path, N=10, h=0.1 s; pack+solve+post+plant on device",
+                      "results": res}))
 
 
 if __name__ == "__main__":

@@ -279,11 +279,11 @@ __global__ void __launch_bounds__(64) bmpc_stream_pack_kernel(int N, int S, int 
                        p + (long long)b * (141 + 91 * S), x0 + (long long)b * 44 * N, dual ? dual + (long long)b * (57 * N + 2) : nullptr);
 }
 __global__ void __launch_bounds__(64) bmpc_stream_post_kernel(int N, int S, int B, double h, const double *path, int path_stride, double *ss, double *rb,
-                                                             const double *x, const double *g, const int *status, double *traj, int simulate) {
+                                                             const double *x, const double *g, const int *status, double *traj, int flags) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
     bmpcs::stream_post(N, S, h, path + (long long)b * path_stride, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
-                       x + (long long)b * 44 * N, g + (long long)b * 43 * N, status[b], traj + (long long)b * bmpcs::tr_len(N), simulate);
+                       x + (long long)b * 44 * N, g + (long long)b * 43 * N, status[b], traj + (long long)b * bmpcs::tr_len(N), flags);
 }
 extern "C" int bmpc_stream_lengths(const bmpc_handle *h, int *path_entry, int *state, int *robot, int *traj) {
     if (!h) return BMPC_ERR_ARG;
@@ -300,18 +300,18 @@ extern "C" int bmpc_stream_pack(bmpc_handle *h, int B, const double *path, int p
     return BMPC_OK;
 }
 extern "C" int bmpc_stream_post(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, const double *x, const double *g,
-                                const int *status, double *traj, int simulate, void *hip_stream) {
+                                const int *status, double *traj, int flags, void *hip_stream) {
     if (!h || B < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !x || !g || !status || !traj))) return BMPC_ERR_ARG;
     if (B == 0) return BMPC_OK;
     hipLaunchKernelGGL(bmpc_stream_post_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, h->h, path,
-                       path_entries * bmpcs::PT_LEN, sstate, robot, x, g, status, traj, simulate);
+                       path_entries * bmpcs::PT_LEN, sstate, robot, x, g, status, traj, flags);
     HIPCHK(hipGetLastError());
     return BMPC_OK;
 }
 // one closed-loop tick {pack, solve (warm-started, max_iter), post} captured into a hipGraph
 extern "C" int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, double *p, double *x0,
                                         double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj,
-                                        int simulate, bmpc_graph **out) {
+                                        int flags, bmpc_graph **out) {
     if (!h || !out || B < 1 || max_iter < 0 || path_entries < h->S + 1 || !path || !sstate || !robot || !p || !x0 || !x || !g || !status || !traj) return BMPC_ERR_ARG;
     hipStream_t cs;
     HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
@@ -323,7 +323,7 @@ extern "C" int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *pat
     if (rc == BMPC_OK) {
         rc = bmpc_stream_pack(h, B, path, path_entries, sstate, robot, p, x0, dual_state, cs);
         if (rc == BMPC_OK) rc = enqueue_solve(h, B, p, x0, dual_state, max_iter, x, g, nullptr, nullptr, nullptr, iters, status, kkt, cs, false);
-        if (rc == BMPC_OK) rc = bmpc_stream_post(h, B, path, path_entries, sstate, robot, x, g, status, traj, simulate, cs);
+        if (rc == BMPC_OK) rc = bmpc_stream_post(h, B, path, path_entries, sstate, robot, x, g, status, traj, flags, cs);
         hipError_t e = hipStreamEndCapture(cs, &gr->graph);
         if (rc == BMPC_OK && e != hipSuccess) rc = BMPC_ERR_HIP;
     }

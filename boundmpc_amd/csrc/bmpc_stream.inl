@@ -319,10 +319,11 @@ BMPC_HD inline void stream_pack(int N, int S, const double *path, double *ss, co
 
 // ------------------------------------------------------------------------------------------
 // f2 + f3: post-process one stream.  x [N][44] solver result, g [N][43], status; traj: trajectory record (tr_len(N));
-// simulate != 0: advance the robot record rb with the kinematic plant step of the node (util_functions.py:152-161).
+// flags bit 0: advance the robot record rb with the kinematic plant step of the node (util_functions.py:152-161);
+// bit 1: real-time-iteration mode -- an iteration-capped solve (status 1) counts as a usable plan (not in the reference).
 // ------------------------------------------------------------------------------------------
 BMPC_HD inline void stream_post(int N, int S, double h, const double *path, double *ss, double *rb, const double *x, const double *g, int status,
-                                double *traj, int simulate) {
+                                double *traj, int flags) {
     // feasibility rule :460-465
     double viol = 0.0;
     for (int k = 0; k < N; k++) for (int i = 0; i < 43; i++) {
@@ -330,7 +331,8 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, doub
         if (i < 36 && v < -1e-6) viol -= v;
         if (v > 1e-6) viol += v;
     }
-    const bool success = status == 0 || viol < 1e-4;
+    const bool success = status == 0 || viol < 1e-4 || ((flags & 2) && status == 1);
+    const int simulate = flags & 1;
     int ec = (int)ss[SS_ERRCNT];
     double *prev = ss + SS_PREV;
     const double *w = x;                       // plan used for the return data

@@ -126,22 +126,23 @@ class StreamBatch:
         _lib.check(self.solver._lib.bmpc_stream_pack(self.solver._h, self.B, dp(self.path), self.entries, dp(self.state), dp(self.robot), dp(self.p),
                                                      dp(self.x0), dp(self.dual) if warm_dual else None, self._stream(stream)), "bmpc_stream_pack")
 
-    def post(self, simulate=True, stream=None):
+    def post(self, simulate=True, stream=None, accept_capped=False):
         dp = lambda t: ctypes.c_void_p(t.data_ptr())
         _lib.check(self.solver._lib.bmpc_stream_post(self.solver._h, self.B, dp(self.path), self.entries, dp(self.state), dp(self.robot), dp(self.x),
-                                                     dp(self.g), dp(self.status), dp(self.traj), int(simulate), self._stream(stream)), "bmpc_stream_post")
+                                                     dp(self.g), dp(self.status), dp(self.traj), int(bool(simulate)) | (2 if accept_capped else 0),
+                                                     self._stream(stream)), "bmpc_stream_post")
 
-    def tick(self, max_iter=0, warm_dual=False, simulate=True, stream=None):
+    def tick(self, max_iter=0, warm_dual=False, simulate=True, stream=None, accept_capped=False):
         """pack -> solve -> post as three launches (see tick_graph for the captured form)."""
         self.pack(warm_dual, stream)
         out = dict(x=self.x, g=self.g, iters=self.iters, status=self.status, kkt=self.kkt)
         self.solver.solve_batch(self.p, self.x0, out=out, want=("g", "iters", "status", "kkt"), stream=stream,
                                 state=self.dual if (warm_dual or max_iter) else None, max_iter=max_iter)
-        self.post(simulate, stream)
+        self.post(simulate, stream, accept_capped)
 
-    def tick_graph(self, max_iter=0, warm_dual=False, simulate=True, stream=None):
+    def tick_graph(self, max_iter=0, warm_dual=False, simulate=True, stream=None, accept_capped=False):
         """The same tick replayed from a hipGraph captured on first use (bmpc_stream_graph_create)."""
-        key = (int(max_iter), bool(warm_dual), bool(simulate))
+        key = (int(max_iter), bool(warm_dual), bool(simulate), bool(accept_capped))
         if key not in self._graphs:
             if max_iter and not warm_dual:
                 raise ValueError("an iteration cap needs the dual state (warm_dual=True)")
@@ -150,7 +151,7 @@ class StreamBatch:
             _lib.check(self.solver._lib.bmpc_stream_graph_create(
                 self.solver._h, self.B, dp(self.path), self.entries, dp(self.state), dp(self.robot), dp(self.p), dp(self.x0),
                 dp(self.dual) if warm_dual else None, int(max_iter), dp(self.x), dp(self.g), dp(self.iters), dp(self.status), dp(self.kkt),
-                dp(self.traj), int(simulate), ctypes.byref(g)), "bmpc_stream_graph_create")
+                dp(self.traj), int(bool(simulate)) | (2 if accept_capped else 0), ctypes.byref(g)), "bmpc_stream_graph_create")
             self._graphs[key] = g
         _lib.check(self.solver._lib.bmpc_graph_launch(self._graphs[key], self._stream(stream)), "bmpc_graph_launch")
 

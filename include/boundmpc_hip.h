@@ -100,8 +100,9 @@ int bmpc_graph_destroy(bmpc_graph *g);
  *                       solver's dual state with the plan (dual_state may be NULL).
  * bmpc_stream_post  <-> BoundMPC.step() post-solve, BoundMPC.py:460-506 (feasibility rule, fallback to the previous plan) and
  *                       compute_return_data :513-611 (re-integration, Cartesian trajectory, advance of phi / rotation reference);
- *                       simulate != 0 additionally advances the robot record like the node's kinematic simulation
- *                       (util_functions.py:152-161, bound_mpc_node.py:292-372).
+ *                       flags bit 0 (simulate): additionally advance the robot record like the node's kinematic simulation
+ *                       (util_functions.py:152-161, bound_mpc_node.py:292-372); bit 1 (real-time iteration, not in the
+ *                       reference): an iteration-capped solve (status 1) counts as a usable plan.
  * All buffers are DEVICE doubles, one row per stream, row lengths from bmpc_stream_lengths:
  *   path   [B][path_entries][path_entry]  static via-point table (built on the host once per path; layout in
  *                                          boundmpc_amd/csrc/bmpc_stream.inl, builder boundmpc_amd.stream.path_table)
@@ -113,11 +114,11 @@ int bmpc_stream_lengths(const bmpc_handle *h, int *path_entry, int *state, int *
 int bmpc_stream_pack(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, const double *robot, double *p, double *x0,
                      double *dual_state, void *hip_stream);
 int bmpc_stream_post(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, const double *x, const double *g,
-                     const int *status, double *traj, int simulate, void *hip_stream);
+                     const int *status, double *traj, int flags, void *hip_stream);
 /* one whole tick {pack, warm-started solve with max_iter (0 = options), post} captured into a hipGraph; launch with bmpc_graph_launch */
 int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, double *p, double *x0,
                              double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj,
-                             int simulate, bmpc_graph **out);
+                             int flags, bmpc_graph **out);
 
 /* HOST pointers; copies in/out and synchronises (convenience for the single-problem solver(...) call) */
 int bmpc_solve_batch_host(bmpc_handle *h, int B, const double *p, const double *x0, double *x, double *g, double *lam_g, double *lam_x,
