@@ -17,6 +17,9 @@ def gather_solutions(x_local, B, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return x_local
+    if x_local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal path only (bench.py --rehearse-one-gpu): gloo has no device all-gather, stage through the host
+        return gather_solutions(x_local.cpu(), B, group).to(x_local.device)
     sizes = [shard_range(B, r, world)[1] - shard_range(B, r, world)[0] for r in range(world)]
     nw = x_local.shape[1]
     if len(set(sizes)) == 1:
