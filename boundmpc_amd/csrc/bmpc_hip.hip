@@ -50,6 +50,7 @@ struct KArgs {
     int N, S, B; double h; bmpc::Opts o;
     const double *p, *x0; double *x, *g, *lam_g, *lam_x, *f, *kkt; int *iters, *status;
     double *state;           // optional [B][57 N + 2] dual state of a receding-horizon stream (bmpc_solve_batch_warm)
+    double *latency_us;      // optional [B]: in-kernel duration of each solve (bmpc_set_latency_buffer)
     double *scratch; long long scr_stride; int *counter; unsigned long long *prof;
 };
 
@@ -78,8 +79,10 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
         pr.f = a.f ? a.f + b : nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr;
         pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status ? a.status + b : nullptr;
         pr.state = a.state ? a.state + (long long)b * (a.N * bmpc::NI + 2) : nullptr;
+        const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
         bmpc::wave_solve<ZLDS>(W, pr);
         __syncthreads();
+        if (a.latency_us && threadIdx.x == 0) a.latency_us[b] = (double)((long long)wall_clock64() - t0_) * 0.01;   // constant 100 MHz counter
     }
 #ifdef BMPC_PROFILE
     if (threadIdx.x < 32 && a.prof) atomicAdd(a.prof + threadIdx.x, (unsigned long long)((long long *)(lds + bmpc::L_PROF))[threadIdx.x]);
@@ -90,6 +93,7 @@ struct bmpc_handle {
     int N, S; double h; bmpc_options o;
     int grid; long long scr_stride; double *scratch; int *counter; unsigned long long *prof;
     int timing; hipEvent_t ev0, ev1; int have_ev;
+    double *latency_us;
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "boundmpc_hip: %s failed: %s\n", #x, hipGetErrorString(e_)); return BMPC_ERR_HIP; } } while (0)
@@ -109,7 +113,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BMPC_ERR_NOGPU;
     bmpc_handle *h = new (std::nothrow) bmpc_handle();
     if (!h) return BMPC_ERR_ARG;
-    h->N = N; h->S = S; h->h = dt; h->timing = 0; h->have_ev = 0;
+    h->N = N; h->S = S; h->h = dt; h->timing = 0; h->have_ev = 0; h->latency_us = nullptr;
     if (opts) h->o = *opts; else bmpc_default_options(&h->o);
     int dev = 0; HIPCHK(hipGetDevice(&dev));
     hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, dev));
@@ -164,7 +168,7 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
     a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = lam_g; a.lam_x = lam_x; a.f = f; a.kkt = kkt; a.iters = iters; a.status = status;
-    a.state = state;
+    a.state = state; a.latency_us = h->latency_us;
     a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter; a.prof = h->prof;
     HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), st));
     const int grid = B < h->grid ? B : h->grid;
@@ -263,6 +267,7 @@ extern "C" int bmpc_solve_batch_host(bmpc_handle *h, int B, const double *p, con
     return rc;
 }
 
+extern "C" int bmpc_set_latency_buffer(bmpc_handle *h, double *latency_us) { if (!h) return BMPC_ERR_ARG; h->latency_us = latency_us; return BMPC_OK; }
 extern "C" int bmpc_set_timing(bmpc_handle *h, int enable) { if (!h) return BMPC_ERR_ARG; h->timing = enable ? 1 : 0; return BMPC_OK; }
 extern "C" int bmpc_last_kernel_ms(bmpc_handle *h, float *ms) {
     if (!h || !ms || !h->have_ev) return BMPC_ERR_ARG;

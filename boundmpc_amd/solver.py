@@ -52,6 +52,11 @@ class BatchedOCPSolver:
     def set_timing(self, on=True):
         self._lib.bmpc_set_timing(self._h, int(on))
 
+    def set_latency_buffer(self, buf):
+        """buf: float64 GPU tensor [>= B] that receives each solve's in-kernel duration in microseconds, or None."""
+        self._lat = buf          # keep it alive while registered
+        _lib.check(self._lib.bmpc_set_latency_buffer(self._h, ctypes.c_void_p(buf.data_ptr()) if buf is not None else None), "bmpc_set_latency_buffer")
+
     def last_kernel_ms(self):
         ms = ctypes.c_float()
         _lib.check(self._lib.bmpc_last_kernel_ms(self._h, ctypes.byref(ms)), "bmpc_last_kernel_ms")

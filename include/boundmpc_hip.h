@@ -128,6 +128,9 @@ int bmpc_solve_batch_host(bmpc_handle *h, int B, const double *p, const double *
  * duration of the last launch (synchronises on the stop event). */
 int bmpc_set_timing(bmpc_handle *h, int enable);
 int bmpc_last_kernel_ms(bmpc_handle *h, float *ms);
+/* Per-solve latency: while a DEVICE buffer [>= B] is registered, every solve stores its own in-kernel duration in microseconds
+ * (wall-clock counter read when a wavefront takes the problem from the queue and when it has written the outputs); NULL = off. */
+int bmpc_set_latency_buffer(bmpc_handle *h, double *latency_us);
 
 /* launch geometry actually used: resident workgroups (one wave each), LDS bytes per workgroup, scratch bytes per workgroup */
 int bmpc_launch_info(const bmpc_handle *h, int *grid, int *lds_bytes, long long *scratch_bytes);
