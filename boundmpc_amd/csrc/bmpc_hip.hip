@@ -44,6 +44,7 @@
 #endif
 
 #include "bmpc_wave.inl"
+#define BMPCS_SYNC() __syncthreads()
 #include "bmpc_stream.inl"
 
 struct KArgs {
@@ -275,20 +276,20 @@ extern "C" int bmpc_last_kernel_ms(bmpc_handle *h, float *ms) {
     HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
     return BMPC_OK;
 }
-// ---- receding-horizon streams: device-side packing / post-processing, one stream per thread ----
+// ---- receding-horizon streams: device-side packing / post-processing, one 64-lane wave per stream ----
 __global__ void __launch_bounds__(64) bmpc_stream_pack_kernel(int N, int S, int B, const double *path, int path_stride, double *ss, const double *rb,
                                                              double *p, double *x0, double *dual) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= B) return;
+    __shared__ double sh[bmpcs::SH_LEN];
+    const int b = blockIdx.x;
     bmpcs::stream_pack(N, S, path + (long long)b * path_stride, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
-                       p + (long long)b * (141 + 91 * S), x0 + (long long)b * 44 * N, dual ? dual + (long long)b * (57 * N + 2) : nullptr);
+                       p + (long long)b * (141 + 91 * S), x0 + (long long)b * 44 * N, dual ? dual + (long long)b * (57 * N + 2) : nullptr, sh, threadIdx.x, 64);
 }
 __global__ void __launch_bounds__(64) bmpc_stream_post_kernel(int N, int S, int B, double h, const double *path, int path_stride, double *ss, double *rb,
                                                              const double *x, const double *g, const int *status, double *traj, int flags) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= B) return;
+    __shared__ double sh[bmpcs::SH_LEN];
+    const int b = blockIdx.x;
     bmpcs::stream_post(N, S, h, path + (long long)b * path_stride, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
-                       x + (long long)b * 44 * N, g + (long long)b * 43 * N, status[b], traj + (long long)b * bmpcs::tr_len(N), flags);
+                       x + (long long)b * 44 * N, g + (long long)b * 43 * N, status[b], traj + (long long)b * bmpcs::tr_len(N), flags, sh, threadIdx.x, 64);
 }
 extern "C" int bmpc_stream_lengths(const bmpc_handle *h, int *path_entry, int *state, int *robot, int *traj) {
     if (!h) return BMPC_ERR_ARG;
@@ -299,7 +300,7 @@ extern "C" int bmpc_stream_pack(bmpc_handle *h, int B, const double *path, int p
                                 double *dual_state, void *hip_stream) {
     if (!h || B < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !p || !x0))) return BMPC_ERR_ARG;
     if (B == 0) return BMPC_OK;
-    hipLaunchKernelGGL(bmpc_stream_pack_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, path, path_entries * bmpcs::PT_LEN,
+    hipLaunchKernelGGL(bmpc_stream_pack_kernel, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, path, path_entries * bmpcs::PT_LEN,
                        sstate, robot, p, x0, dual_state);
     HIPCHK(hipGetLastError());
     return BMPC_OK;
@@ -308,7 +309,7 @@ extern "C" int bmpc_stream_post(bmpc_handle *h, int B, const double *path, int p
                                 const int *status, double *traj, int flags, void *hip_stream) {
     if (!h || B < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !x || !g || !status || !traj))) return BMPC_ERR_ARG;
     if (B == 0) return BMPC_OK;
-    hipLaunchKernelGGL(bmpc_stream_post_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, h->h, path,
+    hipLaunchKernelGGL(bmpc_stream_post_kernel, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, h->h, path,
                        path_entries * bmpcs::PT_LEN, sstate, robot, x, g, status, traj, flags);
     HIPCHK(hipGetLastError());
     return BMPC_OK;

@@ -1,6 +1,6 @@
 // bmpc_stream.inl -- the per-stream host arithmetic of BoundMPC.step() as device code.
 //
-// Two functions, one stream (trajectory) per thread:
+// Two functions, one stream (trajectory) per 64-lane wave (phases over cooperating lanes; the CPU test build runs them with one lane):
 //   stream_pack  (f1 + f3): sliding path window (ReferencePath.update/get_* , ReferencePath.py:178-238), warm-start vector
 //                (cold start BoundMPC.py:316-321, integrated-omega unwrap :326-333, shift :372-375), initial orientation errors
 //                (util_functions.py:11-31), SO(3) Jacobians and dual basis (BoundMPC.py:267-304, lie_functions.py:41-64), tube
@@ -186,212 +186,230 @@ BMPC_HD inline void bound_params(double L, double e0, double e1, double s, doubl
 }
 
 // ------------------------------------------------------------------------------------------
+// Both functions are written as PHASES over `nl` cooperating lanes (`lane` = 0..nl-1) with BMPCS_SYNC() between phases:
+// the device kernels run one 64-lane wave per stream (nl = 64, BMPCS_SYNC = workgroup barrier, `sh` in LDS) so that copies are
+// coalesced and the independent pieces (path segments, horizon stages, integrator chains) run side by side; the CPU test
+// build runs the same text with nl = 1.  `sh`: shared workspace of SH_LEN doubles.
+// ------------------------------------------------------------------------------------------
+enum { SH_DTAU = 0, SH_RTAU = 3, SH_JR = 12, SH_JL = 21, SH_PHISW = 30, SH_FLAG = 36 /* 8 */, SH_RED = 44 /* 64 */, SH_LEN = 108 };
+
 // f1 + f3: pack one stream.  path [nent][PT_LEN], ss stream state, rb robot record, p [141+91 S], x0 [N][44],
 // dual (may be null): the solver's dual state [57 N + 2], shifted with the plan.
-// ------------------------------------------------------------------------------------------
-BMPC_HD inline void stream_pack(int N, int S, const double *path, double *ss, const double *rb, double *p, double *x0, double *dual) {
+BMPC_HD inline void stream_pack(int N, int S, const double *path, double *ss, const double *rb, double *p, double *x0, double *dual,
+                                double *sh, int lane, int nl) {
     const int nent = (int)ss[SS_NENT];
-    int sector = (int)ss[SS_SECTOR];
     const double phi_cur = ss[SS_PHI];
-    // ReferencePath.update: slide the window while phi passed the first switch
-    while (sector + S + 1 < nent && phi_cur > path[(sector + 1) * PT_LEN + PT_CUM]) sector++;
-    ss[SS_SECTOR] = (double)sector;
     const double *q0 = rb + RB_Q, *p0 = rb + RB_P;
-    // ---- warm-start vector ----
     const bool has_prev = ss[SS_HASPREV] > 0.5;
-    if (!has_prev) {
-        for (int k = 0; k < N; k++) {
-            double *z = x0 + k * 44;
-            for (int i = 0; i < 44; i++) z[i] = 0.0;
-            for (int i = 0; i < 7; i++) z[8 + i] = q0[i];
-            for (int i = 0; i < 6; i++) z[29 + i] = p0[i];
-        }
-    } else {
-        const double *pv = ss + SS_PREV;
-        for (int i = 0; i < 44 * N; i++) x0[i] = pv[i];
-        const double d[3] = {p0[3] - x0[32], p0[4] - x0[33], p0[5] - x0[34]};
-        if (norm3(d) > 1.5) {                                   // integrated-omega unwrap :326-333
-            const double p1[3] = {x0[32], x0[33], x0[34]};
-            for (int k = 0; k < N - 1; k++) for (int c = 0; c < 3; c++) x0[k * 44 + 32 + c] = p0[3 + c] + (pv[(k + 1) * 44 + 32 + c] - p1[c]);
-            for (int c = 0; c < 3; c++) x0[(N - 1) * 44 + 32 + c] = x0[(N - 2) * 44 + 32 + c];
-        }
-        for (int k = 0; k < N - 1; k++) for (int i = 0; i < 44; i++) x0[k * 44 + i] = x0[(k + 1) * 44 + i];   // shift :372-375
-        if (dual && dual[57 * N] > 0.0) for (int k = 0; k < N - 1; k++) for (int i = 0; i < 57; i++) dual[k * 57 + i] = dual[(k + 1) * 57 + i];
-    }
-    // ---- window views ----
-    const double *e0p = path + sector * PT_LEN;
-    double phi_sw[5];
-    for (int i = 0; i <= S; i++) phi_sw[i] = path[(sector + i) * PT_LEN + PT_CUM];
-    // ---- initial orientation errors per segment (util_functions.py:11-31) ----
-    double dtau[3], par[4][3], o1[4][3], o2[4][3], dn[4][3];
-    {
-        double Ra[9], Rb[9], Rd[9];
+    // ReferencePath.update: slide the window while phi passed the first switch (every lane computes the same sector)
+    int sector = (int)ss[SS_SECTOR];
+    while (sector + S + 1 < nent && phi_cur > path[(sector + 1) * PT_LEN + PT_CUM]) sector++;
+    // ---- phase 0 (one lane): initial orientation error, its rotation matrix, SO(3) Jacobians ----
+    if (lane == 0) {
+        double Ra[9], Rb[9], Rd[9], dtau[3];
         rotvec_to_mat(p0 + 3, Ra); rotvec_to_mat(ss + SS_PRREF, Rb); mat3_mul_bt(Ra, Rb, Rd);
         mat_to_rotvec(Rd, dtau);
+        for (int c = 0; c < 3; c++) sh[SH_DTAU + c] = dtau[c];
+        rotvec_to_mat(dtau, sh + SH_RTAU);
+        jac_so3_inv(dtau, +1.0, sh + SH_JR); jac_so3_inv(dtau, -1.0, sh + SH_JL);
     }
-    double Rtau[9]; rotvec_to_mat(dtau, Rtau);
-    for (int i = 0; i < S; i++) {
-        const double *e = path + (sector + i) * PT_LEN;
-        unit_or_y(e + PT_DR, 1e-4, dn[i]);
-        const double *b1 = e + PT_BR1, *b2 = e + PT_BR2;
-        const double F[9] = {b2[0], dn[i][0], b1[0], b2[1], dn[i][1], b1[1], b2[2], dn[i][2], b1[2]};   // columns br2, d, br1
-        double T[9], M[9], Ft[9];
-        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ft[r * 3 + c] = F[c * 3 + r];
-        mat3_mul(Rtau, F, T); mat3_mul(Ft, T, M);
-        double eul[3]; mat_to_euler_zyx(M, eul);
-        for (int c = 0; c < 3; c++) { par[i][c] = eul[1] * dn[i][c]; o1[i][c] = eul[0] * b1[c]; o2[i][c] = eul[2] * b2[c]; }
-    }
-    // ---- SO(3) Jacobians and the dual basis (BoundMPC.py:267-304) ----
-    double jr[9], jl[9], v1[4][3], v2[4][3], v3[4][3];
-    jac_so3_inv(dtau, +1.0, jr); jac_so3_inv(dtau, -1.0, jl);
-    for (int i = 0; i < S; i++) {
-        const double *e = path + (sector + i) * PT_LEN;
-        double Ro[9], Rp[9], rest1[9], rest2[9], rv[3], Jt[9], t1[3], t2[3], t3[3];
-        rotvec_to_mat(o1[i], Ro); rotvec_to_mat(par[i], Rp);
-        mat3_mul_bt(Rtau, Ro, rest1); mat3_mul_bt(rest1, Rp, rest2);
-        mat3_vec(jr, e + PT_BR1, t1);
-        mat_to_rotvec(rest1, rv); jac_so3_inv(rv, +1.0, Jt); mat3_vec(Jt, dn[i], t2);
-        mat_to_rotvec(rest2, rv); jac_so3_inv(rv, +1.0, Jt); mat3_vec(Jt, e + PT_BR2, t3);
-        // rows of inv([t1 t2 t3]) (columns t1, t2, t3): cross products over the determinant
-        double c23[3], c31[3], c12[3];
-        cross3s(t2, t3, c23); cross3s(t3, t1, c31); cross3s(t1, t2, c12);
-        const double det = dot3(t1, c23);
-        for (int c = 0; c < 3; c++) { v1[i][c] = c23[c] / det; v2[i][c] = c31[c] / det; v3[i][c] = c12[c] / det; }
-    }
-    // ---- parameter vector ----
-    int c = 0;
-    for (int i = 0; i < 21; i++) p[c++] = rb[RB_Q + i];                 // q0, dq0, ddq0
-    p[c++] = ss[SS_PHI]; p[c++] = ss[SS_DPHI]; p[c++] = ss[SS_DDPHI];
-    for (int i = 0; i < 12; i++) p[c++] = rb[RB_P + i];                 // p0, v0
-    for (int i = 0; i < 3; i++) p[c++] = ss[SS_IWREF + i];
-    for (int i = 0; i < 3; i++) p[c++] = dtau[i];
-    for (int i = 0; i < S; i++) for (int k = 0; k < 3; k++) p[c++] = par[i][k];
-    for (int i = 0; i < S; i++) for (int k = 0; k < 3; k++) p[c++] = o1[i][k];
-    for (int i = 0; i < S; i++) for (int k = 0; k < 3; k++) p[c++] = o2[i][k];
+    BMPCS_SYNC();
+    // parameter-vector offsets (casadi_ocp_formulation.py:361-376)
+    const int o_par = 42, o_o1 = o_par + 3 * S, o_o2 = o_o1 + 3 * S, o_xphid = o_o2 + 3 * S, o_jerk = o_xphid + 3, o_sw = o_jerk + 8, o_jr = o_sw + S + 1,
+              o_jl = o_jr + 9, o_pref = o_jl + 9, o_dpref = o_pref + 6 * S, o_dpn = o_dpref + 6 * S, o_b = o_dpn + 3 * S, o_a = o_b + 12 * S,
+              o_w = o_a + 45 * (S + 1), o_pm = o_w + 15, o_v1 = o_pm + 2, o_v2 = o_v1 + 3 * S, o_v3 = o_v2 + 3 * S, o_qd = o_v3 + 3 * S;
     const double phi_max = ss[SS_PHIMAX];
     const double phimax_p = BMPC_FMIN(phi_cur + 5.0, phi_max);
-    p[c++] = BMPC_FMIN(phi_cur + 5.0, rb[RB_XPHID]); p[c++] = rb[RB_XPHID + 1]; p[c++] = rb[RB_XPHID + 2];
-    for (int i = 0; i < 7; i++) p[c++] = rb[RB_JERK + i];
-    p[c++] = ss[SS_DDDPHI];
-    for (int i = 0; i <= S; i++) p[c++] = phi_sw[i];
-    for (int col = 0; col < 3; col++) for (int r = 0; r < 3; r++) p[c++] = jr[r * 3 + col];      // jac_r.T.ravel()
-    for (int col = 0; col < 3; col++) for (int r = 0; r < 3; r++) p[c++] = jl[r * 3 + col];
-    for (int k = 0; k < 6; k++) for (int i = 0; i < S; i++) p[c++] = path[(sector + i) * PT_LEN + (k < 3 ? PT_P + k : PT_IW + k - 3)];
-    for (int k = 0; k < 6; k++) for (int i = 0; i < S; i++) p[c++] = path[(sector + i) * PT_LEN + (k < 3 ? PT_DPN + k : PT_DR + k - 3)];
-    for (int k = 0; k < 3; k++) for (int i = 0; i < S; i++) p[c++] = dn[i][k];
-    for (int f = 0; f < 4; f++) {
-        const int off = f == 0 ? PT_BP1 : (f == 1 ? PT_BP2 : (f == 2 ? PT_BR1 : PT_BR2));
-        for (int k = 0; k < 3; k++) for (int i = 0; i < S; i++) p[c++] = path[(sector + i) * PT_LEN + off + k];
-    }
-    // tube quartics a4..a0, each [chan 0..8][seg 0..S]; only the first window entry's bound parameters are used (:224-232)
-    {
+    // ---- phase 1a: one lane per path segment: orientation-error split, dual basis, tube quartics ----
+    for (int i = lane; i < S; i += nl) {
+        const double *e = path + (sector + i) * PT_LEN, *Rtau = sh + SH_RTAU, *jr = sh + SH_JR;
+        double dn[3], par[3], o1[3], o2[3];
+        unit_or_y(e + PT_DR, 1e-4, dn);
+        const double *b1 = e + PT_BR1, *b2 = e + PT_BR2;
+        {
+            const double F[9] = {b2[0], dn[0], b1[0], b2[1], dn[1], b1[1], b2[2], dn[2], b1[2]};   // columns br2, d, br1
+            double T[9], M[9], Ft[9], eul[3];
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) Ft[r * 3 + c] = F[c * 3 + r];
+            mat3_mul(Rtau, F, T); mat3_mul(Ft, T, M);
+            mat_to_euler_zyx(M, eul);
+            for (int c = 0; c < 3; c++) { par[c] = eul[1] * dn[c]; o1[c] = eul[0] * b1[c]; o2[c] = eul[2] * b2[c]; }
+        }
+        double Ro[9], Rp[9], rest1[9], rest2[9], rv[3], Jt[9], t1[3], t2[3], t3[3];
+        rotvec_to_mat(o1, Ro); rotvec_to_mat(par, Rp);
+        mat3_mul_bt(Rtau, Ro, rest1); mat3_mul_bt(rest1, Rp, rest2);
+        mat3_vec(jr, b1, t1);
+        mat_to_rotvec(rest1, rv); jac_so3_inv(rv, +1.0, Jt); mat3_vec(Jt, dn, t2);
+        mat_to_rotvec(rest2, rv); jac_so3_inv(rv, +1.0, Jt); mat3_vec(Jt, b2, t3);
+        double c23[3], c31[3], c12[3];                     // rows of inv([t1 t2 t3]): cross products over the determinant
+        cross3s(t2, t3, c23); cross3s(t3, t1, c31); cross3s(t1, t2, c12);
+        const double det = dot3(t1, c23);
+        for (int c = 0; c < 3; c++) {
+            p[o_par + 3 * i + c] = par[c]; p[o_o1 + 3 * i + c] = o1[c]; p[o_o2 + 3 * i + c] = o2[c];
+            p[o_dpn + c * S + i] = dn[c];
+            p[o_v1 + c * S + i] = c23[c] / det; p[o_v2 + c * S + i] = c31[c] / det; p[o_v3 + c * S + i] = c12[c] / det;
+        }
+        // tube quartics a4..a0 [chan 0..8][seg 0..S]; only the first window entry's bound parameters are used (:224-232)
+        const double *e0p = path + sector * PT_LEN;
         const double pm = e0p[PT_EPMIN], rmn = e0p[PT_ERMIN], px = e0p[PT_EPMAX], rx = e0p[PT_ERMAX], sl = e0p[PT_S];
         const double e0v[9] = {pm, pm, -pm, -pm, rmn, rmn, -rmn, -rmn, rmn};
         const double sg[9] = {1, 1, -1, -1, 1, 1, -1, -1, 1};
         const double ex[9] = {px, px, px, px, rx, rx, rx, rx, rx};
-        double *A4 = p + c, *A3 = A4 + 9 * (S + 1), *A2 = A3 + 9 * (S + 1), *A1 = A2 + 9 * (S + 1), *A0 = A1 + 9 * (S + 1);
-        for (int i = 0; i < S; i++) {
-            const double *e = path + (sector + i) * PT_LEN;
-            const double ab[8] = {e[PT_PUP], e[PT_PUP + 1], -e[PT_PLO], -e[PT_PLO + 1], e[PT_RUP], e[PT_RUP + 1], -e[PT_RLO], -e[PT_RLO + 1]};
-            const double L = phi_sw[i + 1] - phi_sw[i];
-            for (int ch = 0; ch < 9; ch++) {
-                const double scale = ab[ch < 8 ? ch : 7];
-                const int id = ch * (S + 1) + i;
-                bound_params(L, e0v[ch], e0v[ch], sg[ch] * sl * scale, sg[ch] * ex[ch] * scale, A4 + id, A3 + id, A2 + id, A1 + id, A0 + id);
+        const double ab[8] = {e[PT_PUP], e[PT_PUP + 1], -e[PT_PLO], -e[PT_PLO + 1], e[PT_RUP], e[PT_RUP + 1], -e[PT_RLO], -e[PT_RLO + 1]};
+        const double Ls = path[(sector + i + 1) * PT_LEN + PT_CUM] - e[PT_CUM];
+        double *A4 = p + o_a, *A3 = A4 + 9 * (S + 1), *A2 = A3 + 9 * (S + 1), *A1 = A2 + 9 * (S + 1), *A0 = A1 + 9 * (S + 1);
+        for (int ch = 0; ch < 9; ch++) {
+            const double scale = ab[ch < 8 ? ch : 7];
+            const int id = ch * (S + 1) + i;
+            bound_params(Ls, e0v[ch], e0v[ch], sg[ch] * sl * scale, sg[ch] * ex[ch] * scale, A4 + id, A3 + id, A2 + id, A1 + id, A0 + id);
+            if (i == S - 1) {                              // row S (np.empty in the reference) := row S-1
+                A4[id + 1] = A4[id]; A3[id + 1] = A3[id]; A2[id + 1] = A2[id]; A1[id + 1] = A1[id]; A0[id + 1] = A0[id];
             }
         }
-        for (int ch = 0; ch < 9; ch++) {                       // row S (np.empty in the reference) := row S-1
-            const int id = ch * (S + 1) + S;
-            A4[id] = A4[id - 1]; A3[id] = A3[id - 1]; A2[id] = A2[id - 1]; A1[id] = A1[id - 1]; A0[id] = A0[id - 1];
-        }
-        c += 5 * 9 * (S + 1);
     }
-    for (int i = 0; i < 15; i++) p[c + i] = ss[SS_W + i];
-    if (rb[RB_XPHID] < 1) p[c + 6] *= BMPC_FMIN(1 / (phi_max * phi_max), 2.0);          // :400-403
-    c += 15;
-    p[c++] = phimax_p; p[c++] = ss[SS_W + 4];                                           // phi_max (clipped), dphi_max = weights[4]
-    for (int k = 0; k < 3; k++) for (int i = 0; i < S; i++) p[c++] = v1[i][k];
-    for (int k = 0; k < 3; k++) for (int i = 0; i < S; i++) p[c++] = v2[i][k];
-    for (int k = 0; k < 3; k++) for (int i = 0; i < S; i++) p[c++] = v3[i][k];
-    const bool near_end = phimax_p - phi_cur < 0.05;                                    // :411-413
-    for (int i = 0; i < 7; i++) p[c++] = near_end ? q0[i] : 0.0;
+    // ---- phase 1b (all lanes, strided): everything that is a copy ----
+    for (int id = lane; id < 21; id += nl) p[id] = rb[RB_Q + id];                       // q0, dq0, ddq0
+    for (int id = lane; id < 12; id += nl) p[24 + id] = rb[RB_P + id];                  // p0, v0
+    for (int id = lane; id < 3; id += nl) { p[21 + id] = ss[SS_PHI + id]; p[36 + id] = ss[SS_IWREF + id]; p[39 + id] = sh[SH_DTAU + id]; }
+    for (int id = lane; id < 7; id += nl) { p[o_jerk + id] = rb[RB_JERK + id]; p[o_qd + id] = (phimax_p - phi_cur < 0.05) ? q0[id] : 0.0; }   // :411-413
+    for (int id = lane; id <= S; id += nl) p[o_sw + id] = path[(sector + id) * PT_LEN + PT_CUM];
+    for (int id = lane; id < 9; id += nl) { const int col = id / 3, r = id % 3; p[o_jr + id] = sh[SH_JR + r * 3 + col]; p[o_jl + id] = sh[SH_JL + r * 3 + col]; }
+    for (int id = lane; id < 6 * S; id += nl) {
+        const int k = id / S, i = id % S; const double *e = path + (sector + i) * PT_LEN;
+        p[o_pref + id] = e[k < 3 ? PT_P + k : PT_IW + k - 3]; p[o_dpref + id] = e[k < 3 ? PT_DPN + k : PT_DR + k - 3];
+    }
+    for (int id = lane; id < 12 * S; id += nl) {
+        const int f = id / (3 * S), r = id % (3 * S), k = r / S, i = r % S;
+        p[o_b + id] = path[(sector + i) * PT_LEN + (f == 0 ? PT_BP1 : (f == 1 ? PT_BP2 : (f == 2 ? PT_BR1 : PT_BR2))) + k];
+    }
+    for (int id = lane; id < 15; id += nl) {
+        double wv = ss[SS_W + id];
+        if (id == 6 && rb[RB_XPHID] < 1) wv *= BMPC_FMIN(1 / (phi_max * phi_max), 2.0);      // :400-403
+        p[o_w + id] = wv;
+    }
+    if (lane == 0) {
+        p[o_xphid] = BMPC_FMIN(phi_cur + 5.0, rb[RB_XPHID]); p[o_xphid + 1] = rb[RB_XPHID + 1]; p[o_xphid + 2] = rb[RB_XPHID + 2];
+        p[o_jerk + 7] = ss[SS_DDDPHI];
+        p[o_pm] = phimax_p; p[o_pm + 1] = ss[SS_W + 4];                                     // phi_max (clipped), dphi_max = weights[4]
+    }
+    // ---- warm-start vector: cold start :316-321, or previous plan with omega unwrap :326-333 and shift :372-375 ----
+    if (!has_prev) {
+        for (int id = lane; id < 44 * N; id += nl) {
+            const int i = id % 44;
+            x0[id] = (i >= 8 && i < 15) ? q0[i - 8] : ((i >= 29 && i < 35) ? p0[i - 29] : 0.0);
+        }
+    } else {
+        const double *pv = ss + SS_PREV;
+        const double d[3] = {p0[3] - pv[32], p0[4] - pv[33], p0[5] - pv[34]};
+        const bool unwrap = norm3(d) > 1.5;
+        for (int id = lane; id < 44 * N; id += nl) {
+            const int k = id / 44, i = id % 44;
+            const int kk = k + 1 < N ? k + 1 : N - 1;                      // shift: row k takes (unwrapped) row k+1
+            double v = pv[kk * 44 + i];
+            if (unwrap && i >= 32 && i < 35) { const int ks = kk < N - 1 ? kk : N - 2; v = p0[i - 29] + (pv[(ks + 1) * 44 + i] - pv[i]); }
+            x0[id] = v;
+        }
+        if (dual && dual[57 * N] > 0.0)
+            for (int i = lane; i < 57; i += nl) for (int k = 0; k < N - 1; k++) dual[k * 57 + i] = dual[(k + 1) * 57 + i];
+    }
+    BMPCS_SYNC();
+    if (lane == 0) ss[SS_SECTOR] = (double)sector;
 }
 
-// ------------------------------------------------------------------------------------------
 // f2 + f3: post-process one stream.  x [N][44] solver result, g [N][43], status; traj: trajectory record (tr_len(N));
 // flags bit 0: advance the robot record rb with the kinematic plant step of the node (util_functions.py:152-161);
 // bit 1: real-time-iteration mode -- an iteration-capped solve (status 1) counts as a usable plan (not in the reference).
-// ------------------------------------------------------------------------------------------
 BMPC_HD inline void stream_post(int N, int S, double h, const double *path, double *ss, double *rb, const double *x, const double *g, int status,
-                                double *traj, int flags) {
-    // feasibility rule :460-465
-    double viol = 0.0;
-    for (int k = 0; k < N; k++) for (int i = 0; i < 43; i++) {
-        const double v = g[k * 43 + i];
-        if (i < 36 && v < -1e-6) viol -= v;
-        if (v > 1e-6) viol += v;
+                                double *traj, int flags, double *sh, int lane, int nl) {
+    // ---- phase 0: feasibility rule :460-465 (strided partial sums, fixed-order total) ----
+    {
+        double part = 0.0;
+        for (int id = lane; id < 43 * N; id += nl) {
+            const double v = g[id]; const int i = id % 43;
+            if (i < 36 && v < -1e-6) part -= v;
+            if (v > 1e-6) part += v;
+        }
+        sh[SH_RED + lane] = part;
     }
-    const bool success = status == 0 || viol < 1e-4 || ((flags & 2) && status == 1);
-    const int simulate = flags & 1;
-    int ec = (int)ss[SS_ERRCNT];
+    BMPCS_SYNC();
+    if (lane == 0) {
+        double viol = 0.0;
+        for (int l = 0; l < nl; l++) viol += sh[SH_RED + l];
+        const bool success = status == 0 || viol < 1e-4 || ((flags & 2) && status == 1);
+        int ec = (int)ss[SS_ERRCNT], using_prev = 0, use_prev_plan = 0;
+        if (!success) {
+            ec += 1; using_prev = 1;
+            if (ss[SS_HASPREV] > 0.5) use_prev_plan = 1; else ec = 0;
+        } else ec = 0;
+        sh[SH_FLAG + 0] = success ? 1.0 : 0.0; sh[SH_FLAG + 1] = (double)ec; sh[SH_FLAG + 2] = (double)using_prev; sh[SH_FLAG + 3] = (double)use_prev_plan;
+        sh[SH_FLAG + 4] = viol;
+    }
+    BMPCS_SYNC();
+    const bool success = sh[SH_FLAG + 0] > 0.5;
+    const int ec = (int)sh[SH_FLAG + 1], using_prev = (int)sh[SH_FLAG + 2];
     double *prev = ss + SS_PREV;
-    const double *w = x;                       // plan used for the return data
-    int using_prev = 0;
-    if (!success) {
-        ec += 1;
-        if (ss[SS_HASPREV] > 0.5) { w = prev; using_prev = 1; }
-        else { ec = 0; using_prev = 1; }
-    } else {
-        ec = 0;
-        for (int i = 0; i < 44 * N; i++) prev[i] = x[i];
-        ss[SS_HASPREV] = 1.0;
-    }
-    ss[SS_ERRCNT] = (double)ec; ss[SS_USINGPREV] = (double)using_prev;
+    const double *w = sh[SH_FLAG + 3] > 0.5 ? prev : x;          // plan used for the return data
     const int TRN = tr_len(N);
-    if (ec >= N) { ss[SS_VALID] = 0.0; traj[TRN - 4] = 0.0; return; }      // step() returns None :504-506
-    ss[SS_VALID] = 1.0;
     const int n = N - ec;
     double *Tq = traj, *Tdq = Tq + 7 * N, *Tddq = Tdq + 7 * N, *Tj = Tddq + 7 * N, *Tp = Tj + 7 * N, *Tv = Tp + 6 * N, *Ta = Tv + 6 * N,
            *Tphi = Ta + 6 * N, *Tdphi = Tphi + N, *Tddphi = Tdphi + N, *Tjphi = Tddphi + N;
-    double q[7], dq[7], ddq[7], up[7];
-    for (int i = 0; i < 7; i++) { q[i] = rb[RB_Q + i]; dq[i] = rb[RB_DQ + i]; ddq[i] = rb[RB_DDQ + i]; up[i] = rb[RB_JERK + i]; }
-    double ph = ss[SS_PHI], dph = ss[SS_DPHI], ddph = ss[SS_DDPHI], upp = ss[SS_DDDPHI];
     const double phi_before = ss[SS_PHI];
-    for (int i = 0; i < n; i++) {                                           // :536-555
-        const double *z = w + (ec + i) * 44;
-        for (int j = 0; j < 7; j++) { chain_step(q[j], dq[j], ddq[j], up[j], z[j], h); up[j] = z[j]; }
-        chain_step(ph, dph, ddph, upp, z[7], h); upp = z[7];
-        for (int j = 0; j < 7; j++) { Tq[j * N + i] = q[j]; Tdq[j * N + i] = dq[j]; Tddq[j * N + i] = ddq[j]; Tj[j * N + i] = z[j]; }
-        Tphi[i] = ph; Tdphi[i] = dph; Tddphi[i] = ddph; Tjphi[i] = z[7];
-        Fk F; forward_kinematics(q, dq, F);                                  // :568-587
-        for (int c = 0; c < 6; c++) {
-            double v = 0, a = 0;
-            for (int j = 0; j < 7; j++) { v += F.J[c * 7 + j] * dq[j]; a += F.J[c * 7 + j] * ddq[j] + F.dJ[c * 7 + j] * dq[j]; }
-            Tp[c * N + i] = F.p[c]; Tv[c * N + i] = v; Ta[c * N + i] = a;
+    // ---- phase 1: store the plan; one lane per integrator chain re-integrates it from the optimal jerks :536-555 ----
+    if (success) for (int id = lane; id < 44 * N; id += nl) prev[id] = x[id];
+    if (ec < N) {
+        for (int j = lane; j < 8; j += nl) {
+            double a, da, dda, up;
+            if (j < 7) { a = rb[RB_Q + j]; da = rb[RB_DQ + j]; dda = rb[RB_DDQ + j]; up = rb[RB_JERK + j]; }
+            else { a = ss[SS_PHI]; da = ss[SS_DPHI]; dda = ss[SS_DDPHI]; up = ss[SS_DDDPHI]; }
+            for (int i = 0; i < n; i++) {
+                const double u = w[(ec + i) * 44 + j];
+                chain_step(a, da, dda, up, u, h); up = u;
+                if (j < 7) { Tq[j * N + i] = a; Tdq[j * N + i] = da; Tddq[j * N + i] = dda; Tj[j * N + i] = u; }
+                else { Tphi[i] = a; Tdphi[i] = da; Tddphi[i] = dda; Tjphi[i] = u; }
+            }
         }
     }
-    traj[TRN - 4] = (double)n; traj[TRN - 3] = (double)using_prev; traj[TRN - 2] = (double)success; traj[TRN - 1] = viol;
-    // rotation reference and path-parameter state :594-611
-    const int sector = (int)ss[SS_SECTOR];
-    const double *e0 = path + sector * PT_LEN, *e1 = path + (sector + 1) * PT_LEN;
-    const double sw0 = e0[PT_CUM], sw1 = e1[PT_CUM], phi0 = Tphi[0];
-    double prn[3];
-    if (phi0 > sw1) {
-        integrate_rotation_reference(e1 + PT_RRV, e1 + PT_DR, sw1, phi0, prn);
-        for (int c = 0; c < 3; c++) ss[SS_IWREF + c] = e1[PT_IW + c] + (phi0 - sw1) * e1[PT_DR + c];
-    } else {
-        integrate_rotation_reference(ss + SS_PRREF, e0 + PT_DR, phi_before, phi0, prn);
-        for (int c = 0; c < 3; c++) ss[SS_IWREF + c] = e0[PT_IW + c] + (phi0 - sw0) * e0[PT_DR + c];
+    BMPCS_SYNC();
+    if (lane == 0) {
+        ss[SS_ERRCNT] = (double)ec; ss[SS_USINGPREV] = (double)using_prev; ss[SS_VALID] = ec < N ? 1.0 : 0.0;
+        if (success) ss[SS_HASPREV] = 1.0;
+        traj[TRN - 4] = ec < N ? (double)n : 0.0; traj[TRN - 3] = (double)using_prev; traj[TRN - 2] = success ? 1.0 : 0.0; traj[TRN - 1] = sh[SH_FLAG + 4];
     }
-    for (int c = 0; c < 3; c++) ss[SS_PRREF + c] = prn[c];
-    ss[SS_PHI] = phi0; ss[SS_DPHI] = Tdphi[0]; ss[SS_DDPHI] = Tddphi[0]; ss[SS_DDDPHI] = Tjphi[0];
-    if (simulate) {
-        // the node's kinematic simulation: integrate with [jerk_current, first planned jerk], then FK (util_functions.py:152-161)
-        double qs[7], dqs[7], ddqs[7];
-        for (int j = 0; j < 7; j++) { qs[j] = rb[RB_Q + j]; dqs[j] = rb[RB_DQ + j]; ddqs[j] = rb[RB_DDQ + j]; chain_step(qs[j], dqs[j], ddqs[j], rb[RB_JERK + j], Tj[j * N], h); }
-        Fk F; forward_kinematics(qs, dqs, F);
-        for (int j = 0; j < 7; j++) { rb[RB_Q + j] = qs[j]; rb[RB_DQ + j] = dqs[j]; rb[RB_DDQ + j] = ddqs[j]; rb[RB_JERK + j] = Tj[j * N]; }
-        for (int c = 0; c < 6; c++) { double v = 0; for (int j = 0; j < 7; j++) v += F.J[c * 7 + j] * dqs[j]; rb[RB_P + c] = F.p[c]; rb[RB_V + c] = v; }
+    if (ec >= N) return;                                          // step() returns None :504-506 (uniform over the lanes)
+    // ---- phase 2: roles 0..n-1: Cartesian trajectory of one stage :568-587; role 32: rotation reference and path-parameter
+    //      state :594-611; role 33: the node's kinematic plant step (util_functions.py:152-161) ----
+    for (int role = lane; role < 34; role += nl) {
+        if (role < n) {
+            const int i = role;
+            double q[7], dq[7], ddq[7];
+            for (int j = 0; j < 7; j++) { q[j] = Tq[j * N + i]; dq[j] = Tdq[j * N + i]; ddq[j] = Tddq[j * N + i]; }
+            Fk F; forward_kinematics(q, dq, F);
+            for (int c = 0; c < 6; c++) {
+                double v = 0, a = 0;
+                for (int j = 0; j < 7; j++) { v += F.J[c * 7 + j] * dq[j]; a += F.J[c * 7 + j] * ddq[j] + F.dJ[c * 7 + j] * dq[j]; }
+                Tp[c * N + i] = F.p[c]; Tv[c * N + i] = v; Ta[c * N + i] = a;
+            }
+        } else if (role == 32) {
+            const int sector = (int)ss[SS_SECTOR];
+            const double *e0 = path + sector * PT_LEN, *e1 = path + (sector + 1) * PT_LEN;
+            const double sw0 = e0[PT_CUM], sw1 = e1[PT_CUM], phi0 = Tphi[0];
+            double prn[3];
+            if (phi0 > sw1) {
+                integrate_rotation_reference(e1 + PT_RRV, e1 + PT_DR, sw1, phi0, prn);
+                for (int c = 0; c < 3; c++) ss[SS_IWREF + c] = e1[PT_IW + c] + (phi0 - sw1) * e1[PT_DR + c];
+            } else {
+                integrate_rotation_reference(ss + SS_PRREF, e0 + PT_DR, phi_before, phi0, prn);
+                for (int c = 0; c < 3; c++) ss[SS_IWREF + c] = e0[PT_IW + c] + (phi0 - sw0) * e0[PT_DR + c];
+            }
+            for (int c = 0; c < 3; c++) ss[SS_PRREF + c] = prn[c];
+            ss[SS_PHI] = phi0; ss[SS_DPHI] = Tdphi[0]; ss[SS_DDPHI] = Tddphi[0]; ss[SS_DDDPHI] = Tjphi[0];
+        } else if (role == 33 && (flags & 1)) {
+            // integrate with [jerk_current, first planned jerk], then FK
+            double qs[7], dqs[7], ddqs[7];
+            for (int j = 0; j < 7; j++) { qs[j] = rb[RB_Q + j]; dqs[j] = rb[RB_DQ + j]; ddqs[j] = rb[RB_DDQ + j]; chain_step(qs[j], dqs[j], ddqs[j], rb[RB_JERK + j], Tj[j * N], h); }
+            Fk F; forward_kinematics(qs, dqs, F);
+            for (int j = 0; j < 7; j++) { rb[RB_Q + j] = qs[j]; rb[RB_DQ + j] = dqs[j]; rb[RB_DDQ + j] = ddqs[j]; rb[RB_JERK + j] = Tj[j * N]; }
+            for (int c = 0; c < 6; c++) { double v = 0; for (int j = 0; j < 7; j++) v += F.J[c * 7 + j] * dqs[j]; rb[RB_P + c] = F.p[c]; rb[RB_V + c] = v; }
+        }
     }
 }
 

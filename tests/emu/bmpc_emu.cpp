@@ -35,16 +35,19 @@
 #define LIDX lane
 
 #include "../../boundmpc_amd/csrc/bmpc_wave.inl"
+#define BMPCS_SYNC()
 #include "../../boundmpc_amd/csrc/bmpc_stream.inl"
 
 // CPU build of the stream functions (same text as the device kernels), one call per stream
 extern "C" void bmpc_emu_stream_lengths(int N, int *out) { out[0] = bmpcs::PT_LEN; out[1] = bmpcs::ss_len(N); out[2] = bmpcs::RB_LEN; out[3] = bmpcs::tr_len(N); }
 extern "C" void bmpc_emu_stream_pack(int N, int S, const double *path, double *ss, const double *rb, double *p, double *x0, double *dual) {
-    bmpcs::stream_pack(N, S, path, ss, rb, p, x0, dual);
+    double sh[bmpcs::SH_LEN];
+    bmpcs::stream_pack(N, S, path, ss, rb, p, x0, dual, sh, 0, 1);
 }
 extern "C" void bmpc_emu_stream_post(int N, int S, double h, const double *path, double *ss, double *rb, const double *x, const double *g, int status,
                                      double *traj, int simulate) {
-    bmpcs::stream_post(N, S, h, path, ss, rb, x, g, status, traj, simulate);
+    double sh[bmpcs::SH_LEN];
+    bmpcs::stream_post(N, S, h, path, ss, rb, x, g, status, traj, simulate, sh, 0, 1);
 }
 
 extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, int B, const double *p, const double *x0, double *state, double *x, double *g,

@@ -108,3 +108,15 @@ def test_emu_real_time_iteration_stream_matches_oracle():
     assert (io == 2).all() and (ie == 2).all()
     np.testing.assert_allclose(xe, xo, atol=1e-8)
     np.testing.assert_allclose(se[:, 0, :571], so[:, 0, :571], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("S,N", [(2, 5), (3, 12)])
+def test_emu_other_window_sizes_and_horizons(S, N):
+    """nr_segs != 4 changes the parameter layout (n_p = 141 + 91 S); N > 11 takes the global-memory iterate path."""
+    P, X, _ = workload.make_batch(4, seed=4, N=N, S=S, workers=1)
+    assert P.shape[1] == 141 + 91 * S
+    ref = c_oracle.solve(P, X, N, S, 0.1, nthreads=2)
+    out = emu.solve(P, X, N, S, 0.1, nthreads=2)
+    assert (ref["status"] == 0).all() and (out["status"] == 0).all()
+    assert np.abs(out["iters"] - ref["iters"]).max() <= 1
+    assert np.sqrt(np.mean((out["x"] - ref["x"]).reshape(-1, N, 44)[:, :, 8:15] ** 2)) < 1e-7

@@ -242,3 +242,18 @@ def test_hip_graph_step_replays_and_matches_direct_launch(solver):
         solver.solve_batch(p, x0, max_iter=3)                     # per-call cap needs a state buffer
     with pytest.raises(ValueError):
         solver.solve_batch(p, x0, state=torch.zeros((2, 5), dtype=torch.float64, device="cuda"))
+
+
+@pytest.mark.parametrize("S,N", [(2, 5), (3, 12)])
+def test_other_window_sizes_and_horizons(S, N):
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    from oracle import c_oracle
+    P, X, _ = workload.make_batch(8, seed=4, N=N, S=S, workers=1)
+    s = BatchedOCPSolver(N, S, 0.1)
+    o = s.solve_batch(torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda"))
+    ref = c_oracle.solve(P, X, N, S, 0.1, nthreads=4)
+    assert (o["status"].cpu().numpy() == 0).all()
+    assert np.abs(o["iters"].cpu().numpy() - ref["iters"]).max() <= 1
+    assert _rms_q(o["x"].cpu().numpy(), ref["x"], N) < TOL_Q_RMS
+    s.close()
