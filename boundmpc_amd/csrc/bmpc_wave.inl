@@ -954,7 +954,8 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         BMPC_PROF(W, 24);
         wave_node_cost_blk(W, po, sc, k, mu, delta);     // PB/PCI/PII/PV now hold the value function of node k+1
         BMPC_PROF(W, 5);
-        // ---- stage data: rdyn, iota coupling AE (3x14), acceleration cross block XT (15x14) ----
+        // ---- stage data: rdyn, iota coupling AE (3x14).  The acceleration cross block XT = C^T Gv(K1) (15x14, rank 6) is never
+        //      formed: its consumers contract the two rank-6 factors on the fly (t6 below, chain-pair entries in S1) ----
         LANES_BEGIN
             const double *K0 = L + L_K0, *K1 = L + L_K1, *KVk = L + L_KV, *gk = L + L_ST + ST_G;
             if (lane < NS) {
@@ -971,17 +972,6 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 const int a = lane / 14, y = lane % 14; double v = 0;
                 if (k >= 1) v = 0.5 * h * (y < 7 ? K1[KD + (3 + a) * 7 + y] + KVk[KD + (3 + a) * 7 + y] : K1[KA + a * 7 + y - 7] + KVk[KA + a * 7 + y - 7]);
                 L[L_AE + lane] = v; G[sc.AES + k * 42 + lane] = v;
-            }
-            if (k >= 1) {
-                const double *dpn = L + L_ST + ST_REF + RDP;
-                for (int id = lane; id < 15 * 14; id += 64) {
-                    const int r = id / 14, c = id - r * 14; double v = 0;
-                    for (int c6 = 0; c6 < 6; c6++) {
-                        const double cr = r < 14 ? -2 * w[5] / (h * h) * gv_at(K0, c6, r) : 2 * w[5] / h * dpn[c6];
-                        v += cr * gv_at(K1, c6, c);
-                    }
-                    L[L_XT + id] = v;
-                }
             }
         LANES_END
         BMPC_PROF(W, 11);
@@ -1018,6 +1008,14 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 }
             }
             if (lane < 42) { const int a = lane / 14, y = lane % 14; double sacc = 0; for (int b = 0; b < 3; b++) sacc += L[L_PII + a * 3 + b] * L[L_AE + b * 14 + y]; L[L_PE + lane] = sacc; }
+            if (k >= 1 && lane >= 48 && lane < 54) {   // t6 = C rdyn: the rdyn side of X^T rdyn = Gv(K1)^T (C rdyn)
+                const int c6 = lane - 48; const double *K0 = L + L_K0, *dpn = L + L_ST + ST_REF + RDP;
+                const double *jrow = c6 < 3 ? K0 + KW + c6 * 7 : K0 + KA + (c6 - 3) * 7;
+                BMPC_ACC4_DECL(ta);
+#pragma unroll
+                for (int r = 0; r < 7; r++) { BMPC_ACC4(ta, r, K0[KD + c6 * 7 + r] * L[L_RD + r]); BMPC_ACC4(ta, r + 1, jrow[r] * L[L_RD + 7 + r]); }
+                L[L_XT + c6] = -2 * w[5] / (h * h) * BMPC_ACC4_SUM(ta) + 2 * w[5] / h * dpn[c6] * L[L_RD + SDDPHI];
+            }
         LANES_END
         BMPC_PROF(W, 21);
         // ---- S0b: M_c,iota = U + E^T P_ii ; gradient column m = F^T PR + S^T X^T rdyn ----
@@ -1031,7 +1029,12 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 if (fp <= 1 && i < 7) {
                     const int y = fp * 7 + i;
                     for (int a = 0; a < 3; a++) v += L[L_AE + a * 14 + y] * L[L_PR + SIOTA + a];
-                    if (k >= 1) { double sx = L[L_XT + 14 * 14 + y] * L[L_RD + SDDPHI]; for (int r = 0; r < 14; r++) sx += L[L_XT + r * 14 + y] * L[L_RD + r]; v += sx; }
+                    if (k >= 1) {
+                        const double *K1 = L + L_K1; double sx = 0;
+#pragma unroll
+                        for (int c6 = 0; c6 < 6; c6++) sx += (fp == 0 ? K1[KD + c6 * 7 + i] : (c6 < 3 ? K1[KW + c6 * 7 + i] : K1[KA + (c6 - 3) * 7 + i])) * L[L_XT + c6];
+                        v += sx;
+                    }
                 }
                 if (fp < 4) L[L_MV + srow(fp, i)] = v; else L[L_GS + i * 36 + 35] = v;
             } else if (lane < 43) L[L_MV + SIOTA + lane - 40] = L[L_PR + SIOTA + lane - 40];
@@ -1076,14 +1079,26 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
             for (int f = 0; f < 5; f++)
 #pragma unroll
                 for (int a = 0; a < 3; a++) { Ui[f][a] = L[L_MCI + mci(a, f, ci)]; Ul[f][a] = L[L_MCI + mci(a, f, cl)]; }
-            // acceleration cross block rows for chain ci / cl: X[q+_c], X[dq+_c] (chains < 7) or X[ddphi+] (chain 7)
+            // acceleration cross block entries for chain ci / cl: X[q+_c], X[dq+_c] (chains < 7) or X[ddphi+] (chain 7), contracted
+            // on the fly from the rank-6 factors: X[r][c] = sum_c6 C[c6][r] Gv(K1)[c6][c], C = -2 w_a/h^2 Gv(K0) (rows < 14), 2 w_a/h dpn
+            {
+                const double *K0 = L + L_K0, *K1 = L + L_K1, *dpn = L + L_ST + ST_REF + RDP;
+                const double fx = -2 * w[5] / (h * h) * mx * ml * mi, fphi = 2 * w[5] / h * mx * mi * (1.0 - ml);
+                double xl0[2] = {0, 0}, xl1[2] = {0, 0}, xi0[2] = {0, 0}, xi1[2] = {0, 0}, xi2[2] = {0, 0};
 #pragma unroll
-            for (int g = 0; g < 2; g++) {
-                const int yl = g * 7 + clc, yi = g * 7 + cic;
-                Xl[g][0] = mx * ml * mi * L[L_XT + cic * 14 + yl]; Xl[g][1] = mx * ml * mi * L[L_XT + (7 + cic) * 14 + yl];
-                Xl[g][2] = mx * ml * (1.0 - mi) * L[L_XT + 14 * 14 + yl];
-                Xi[g][0] = mx * mi * ml * L[L_XT + clc * 14 + yi]; Xi[g][1] = mx * mi * ml * L[L_XT + (7 + clc) * 14 + yi];
-                Xi[g][2] = mx * mi * (1.0 - ml) * L[L_XT + 14 * 14 + yi];
+                for (int c6 = 0; c6 < 6; c6++) {
+                    const int jo = c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7;       // J row of the record ([J_v; J_w])
+                    const double a0 = K0[KD + c6 * 7 + cic], a1 = K0[jo + cic], b0 = K0[KD + c6 * 7 + clc], b1 = K0[jo + clc];
+                    const double cl0 = K1[KD + c6 * 7 + clc], cl1 = K1[jo + clc], ci0 = K1[KD + c6 * 7 + cic], ci1 = K1[jo + cic], dp = dpn[c6];
+                    xl0[0] += a0 * cl0; xl0[1] += a0 * cl1; xl1[0] += a1 * cl0; xl1[1] += a1 * cl1;
+                    xi0[0] += b0 * ci0; xi0[1] += b0 * ci1; xi1[0] += b1 * ci0; xi1[1] += b1 * ci1;
+                    xi2[0] += dp * ci0; xi2[1] += dp * ci1;
+                }
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    Xl[g][0] = fx * xl0[g]; Xl[g][1] = fx * xl1[g]; Xl[g][2] = 0.0;
+                    Xi[g][0] = fx * xi0[g]; Xi[g][1] = fx * xi1[g]; Xi[g][2] = fphi * xi2[g];
+                }
             }
             // iota coupling: + Mci E + (Mci E)^T - E^T Pii E ; acceleration cross term: + F^T X S + S^T X^T F
 #pragma unroll
