@@ -1302,6 +1302,7 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
 // ----------------------------------------------------------------------------------------
 // ZLDS: the iterate / trial iterate / direction live in LDS (horizons N <= 11); a compile-time switch so that the compiler
 // knows the address space of every access (a run-time select would degrade them to FLAT instructions).
+constexpr int RU = 9;   // rows of a lane-strided pass kept in flight per lane: one batch of global loads covers 576 rows (N = 10: 570)
 template <bool ZLDS>
 BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     const int N = W.N, S = W.S;
@@ -1338,16 +1339,16 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     for (int it_first = 1; it_first >= 1; it_first--) {
         LANES_BEGIN
             double ep = 0, cmax = -1e300, cmin = 1e300, sn = 0;
-            for (int base = lane; base < ni; base += 192) {
-                double hv[3], tv[3];
+            for (int base = lane; base < ni; base += 64 * RU) {
+                double hv[RU], tv[RU];
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
+                for (int u = 0; u < RU; u++) {
                     const int id = base + 64 * u; hv[u] = id < ni ? G[sc.HIN + id] : -1.0;
                     const double ns = (warm && id < ni) ? pr.state[id] : 0.0;
                     tv[u] = ns > 0.0 ? BMPC_FMIN(mu / ns, o.slack_push) : o.slack_push;
                 }
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
+                for (int u = 0; u < RU; u++) {
                     const int id = base + 64 * u;
                     if (id < ni) {
                         const double t = (-hv[u] > tv[u]) ? -hv[u] : tv[u], ti = 1.0 / t, nu = mu * ti, r = hv[u] + t;
@@ -1369,12 +1370,12 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         LANES_BEGIN
             double ed = 0, ep = L[L_KKP + lane], sl = 0;
             for (int id = lane; id < N * NU; id += 64) { const double v = BMPC_FABS(G[sc.RJ + id]); ed = v > ed ? v : ed; }
-            for (int base = lane; base < ne; base += 192) {
-                double gv[3], lv[3];
+            for (int base = lane; base < ne; base += 64 * RU) {
+                double gv[RU], lv[RU];
 #pragma unroll
-                for (int u = 0; u < 3; u++) { const int id = base + 64 * u; gv[u] = id < ne ? G[sc.G + id] : 0.0; lv[u] = id < ne ? G[sc.LAM + id] : 0.0; }
+                for (int u = 0; u < RU; u++) { const int id = base + 64 * u; gv[u] = id < ne ? G[sc.G + id] : 0.0; lv[u] = id < ne ? G[sc.LAM + id] : 0.0; }
 #pragma unroll
-                for (int u = 0; u < 3; u++) { const double v = BMPC_FABS(gv[u]); ep = v > ep ? v : ep; sl += BMPC_FABS(lv[u]); }
+                for (int u = 0; u < RU; u++) { const double v = BMPC_FABS(gv[u]); ep = v > ep ? v : ep; sl += BMPC_FABS(lv[u]); }
             }
             L[L_RED + lane] = ed; L[L_RED + 64 + lane] = ep; L[L_RED + 128 + lane] = sl;
         LANES_END
@@ -1414,21 +1415,21 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         const double tau = BMPC_FMAX(0.99, 1.0 - mu);
         LANES_BEGIN
             double ap = 1.0, adl = 1.0, dbar = 0, nhd = 0, th = 0, bar = 0;
-            for (int base = lane; base < ni; base += 192) {
-                double tv[3], nv[3], hv[3], sg[3], tiv[3], sr[3], hd[3];
+            for (int base = lane; base < ni; base += 64 * RU) {
+                double tv[RU], nv[RU], hv[RU], sg[RU], tiv[RU], sr[RU], hd[RU], tprod = 1.0;
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
+                for (int u = 0; u < RU; u++) {
                     const int id = base + 64 * u; const bool v = id < ni;
                     tv[u] = v ? G[sc.T + id] : 1.0; nv[u] = v ? G[sc.NUm + id] : 1.0; hv[u] = v ? G[sc.HIN + id] : -1.0;
                     sg[u] = v ? G[sc.SG + id] : 0.0; tiv[u] = v ? G[sc.TI + id] : 0.0; sr[u] = v ? G[sc.SR + id] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
+                for (int u = 0; u < RU; u++) {
                     const int id = base + 64 * u; const int k = id / NI, i = id - k * NI;
                     hd[u] = id < ni ? ineq_dir(W.Dz + k * NZ, G + sc.REF + k * RREC, i) : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
+                for (int u = 0; u < RU; u++) {
                     const int id = base + 64 * u;
                     if (id < ni) {
                         const double t = tv[u], nu = nv[u], r = hv[u] + t, mti = mu * tiv[u], nuh = mti + sr[u];
@@ -1436,24 +1437,25 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                         G[sc.DT + id] = dt; G[sc.DNU + id] = dnu;
                         if (dt < 0) { const double a = -tau * t / dt; ap = a < ap ? a : ap; }
                         if (dnu < 0) { const double a = -tau * nu / dnu; adl = a < adl ? a : adl; }
-                        dbar += -mti * dt; nhd += nuh * hd[u]; th += BMPC_FABS(r); bar -= mu * BMPC_LOG(t);
+                        dbar += -mti * dt; nhd += nuh * hd[u]; th += BMPC_FABS(r); tprod *= t;
                     }
                 }
+                bar -= mu * BMPC_LOG(tprod);      // one log per batch of RU slacks: sum of logs = log of the product (t in [1e-12, 1e2])
             }
             double ghd = 0;
-            for (int base = lane; base < nw; base += 192) {
-                double gv[3];
+            for (int base = lane; base < nw; base += 64 * RU) {
+                double gv[RU];
 #pragma unroll
-                for (int u = 0; u < 3; u++) { const int id = base + 64 * u; gv[u] = id < nw ? G[sc.GH + id] : 0.0; }
+                for (int u = 0; u < RU; u++) { const int id = base + 64 * u; gv[u] = id < nw ? G[sc.GH + id] : 0.0; }
 #pragma unroll
-                for (int u = 0; u < 3; u++) { const int id = base + 64 * u; if (id < nw) ghd += gv[u] * W.Dz[id]; }
+                for (int u = 0; u < RU; u++) { const int id = base + 64 * u; if (id < nw) ghd += gv[u] * W.Dz[id]; }
             }
-            for (int base = lane; base < ne; base += 192) {
-                double gv[3];
+            for (int base = lane; base < ne; base += 64 * RU) {
+                double gv[RU];
 #pragma unroll
-                for (int u = 0; u < 3; u++) { const int id = base + 64 * u; gv[u] = id < ne ? G[sc.G + id] : 0.0; }
+                for (int u = 0; u < RU; u++) { const int id = base + 64 * u; gv[u] = id < ne ? G[sc.G + id] : 0.0; }
 #pragma unroll
-                for (int u = 0; u < 3; u++) th += BMPC_FABS(gv[u]);
+                for (int u = 0; u < RU; u++) th += BMPC_FABS(gv[u]);
             }
             L[L_RED + lane] = ap; L[L_RED + 64 + lane] = adl; L[L_RED + 128 + lane] = dbar; L[L_RED + 192 + lane] = ghd - nhd;
             L[L_RED + 256 + lane] = th; L[L_RED + 320 + lane] = bar;
@@ -1470,12 +1472,12 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         for (int ls = 0; ls < 14; ls++) {
             LANES_BEGIN
                 for (int id = lane; id < nw; id += 64) W.Zt[id] = W.Zc[id] + alpha * W.Dz[id];
-                for (int base = lane; base < ni; base += 192) {
-                    double tv[3], dv[3];
+                for (int base = lane; base < ni; base += 64 * RU) {
+                    double tv[RU], dv[RU];
 #pragma unroll
-                    for (int u = 0; u < 3; u++) { const int id = base + 64 * u; tv[u] = id < ni ? G[sc.T + id] : 0.0; dv[u] = id < ni ? G[sc.DT + id] : 0.0; }
+                    for (int u = 0; u < RU; u++) { const int id = base + 64 * u; tv[u] = id < ni ? G[sc.T + id] : 0.0; dv[u] = id < ni ? G[sc.DT + id] : 0.0; }
 #pragma unroll
-                    for (int u = 0; u < 3; u++) { const int id = base + 64 * u; if (id < ni) G[sc.TT + id] = tv[u] + alpha * dv[u]; }
+                    for (int u = 0; u < RU; u++) { const int id = base + 64 * u; if (id < ni) G[sc.TT + id] = tv[u] + alpha * dv[u]; }
                 }
             LANES_END
             BMPC_PROF(W, 9);
@@ -1483,19 +1485,21 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
             BMPC_PROF(W, 0);
             LANES_BEGIN
                 double th = 0, br = 0;
-                for (int base = lane; base < ne; base += 192) {
-                    double gv[3];
+                for (int base = lane; base < ne; base += 64 * RU) {
+                    double gv[RU];
 #pragma unroll
-                    for (int u = 0; u < 3; u++) { const int id = base + 64 * u; gv[u] = id < ne ? G[sc.GT + id] : 0.0; }
+                    for (int u = 0; u < RU; u++) { const int id = base + 64 * u; gv[u] = id < ne ? G[sc.GT + id] : 0.0; }
 #pragma unroll
-                    for (int u = 0; u < 3; u++) th += BMPC_FABS(gv[u]);
+                    for (int u = 0; u < RU; u++) th += BMPC_FABS(gv[u]);
                 }
-                for (int base = lane; base < ni; base += 192) {
-                    double tv[3], hv[3];
+                for (int base = lane; base < ni; base += 64 * RU) {
+                    double tv[RU], hv[RU];
 #pragma unroll
-                    for (int u = 0; u < 3; u++) { const int id = base + 64 * u; tv[u] = id < ni ? G[sc.TT + id] : 1.0; hv[u] = id < ni ? G[sc.HT + id] : -1.0; }
+                    for (int u = 0; u < RU; u++) { const int id = base + 64 * u; tv[u] = id < ni ? G[sc.TT + id] : 1.0; hv[u] = id < ni ? G[sc.HT + id] : -1.0; }
+                    double tprod = 1.0;
 #pragma unroll
-                    for (int u = 0; u < 3; u++) { const int id = base + 64 * u; if (id < ni) { th += BMPC_FABS(hv[u] + tv[u]); br -= mu * BMPC_LOG(tv[u]); } }
+                    for (int u = 0; u < RU; u++) { const int id = base + 64 * u; if (id < ni) { th += BMPC_FABS(hv[u] + tv[u]); tprod *= tv[u]; } }
+                    br -= mu * BMPC_LOG(tprod);
                 }
                 L[L_RED + lane] = th; L[L_RED + 64 + lane] = br;
             LANES_END
@@ -1532,15 +1536,15 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         fval = ft;
         LANES_BEGIN
             double ep = 0, cmax = -1e300, cmin = 1e300, sn = 0;
-            for (int base = lane; base < ni; base += 192) {
-                double tv[3], nv[3], dv[3], hv[3];
+            for (int base = lane; base < ni; base += 64 * RU) {
+                double tv[RU], nv[RU], dv[RU], hv[RU];
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
+                for (int u = 0; u < RU; u++) {
                     const int id = base + 64 * u; const bool v = id < ni;
                     tv[u] = v ? G[sc.T + id] : 1.0; nv[u] = v ? G[sc.NUm + id] : 0.0; dv[u] = v ? G[sc.DNU + id] : 0.0; hv[u] = v ? G[sc.HIN + id] : -1.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
+                for (int u = 0; u < RU; u++) {
                     const int id = base + 64 * u;
                     if (id < ni) {
                         const double t = tv[u], ti = 1.0 / t; double nu = nv[u] + ad * dv[u];
