@@ -110,24 +110,32 @@ extern "C" const char *bmpc_error_string(int c) {
 }
 extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bmpc_handle **out) {
     if (!out || N < 1 || N > 32 || S < 2 || S > bmpc::SMAX || !(dt > 0)) return BMPC_ERR_ARG;
+    if (opts && (!(opts->tol > 0) || opts->max_iter < 0 || !(opts->mu_init > 0) || !(opts->slack_push > 0))) return BMPC_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BMPC_ERR_NOGPU;
     bmpc_handle *h = new (std::nothrow) bmpc_handle();
     if (!h) return BMPC_ERR_ARG;
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->have_ev = 0; h->latency_us = nullptr;
+    h->scratch = nullptr; h->counter = nullptr; h->prof = nullptr;
     if (opts) h->o = *opts; else bmpc_default_options(&h->o);
-    int dev = 0; HIPCHK(hipGetDevice(&dev));
-    hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, dev));
-    int per_cu = 0;
-    if (N <= 11) { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel<true>, 64, 0)); }
-    else { HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel<false>, 64, 0)); }
-    if (per_cu < 1) per_cu = 1;
-    h->grid = per_cu * prop.multiProcessorCount;
-    h->scr_stride = bmpc::make_scr(N).size;
-    HIPCHK(hipMalloc(&h->scratch, sizeof(double) * (size_t)h->scr_stride * h->grid));
-    HIPCHK(hipMalloc(&h->counter, sizeof(int)));
-    HIPCHK(hipMalloc(&h->prof, 32 * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(h->prof, 0, 32 * sizeof(unsigned long long)));
+    int dev = 0, per_cu = 0; hipDeviceProp_t prop;
+    bool ok = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess;
+    if (ok) ok = (N <= 11 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel<true>, 64, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel<false>, 64, 0)) == hipSuccess;
+    if (ok) {
+        if (per_cu < 1) per_cu = 1;
+        h->grid = per_cu * prop.multiProcessorCount;
+        h->scr_stride = bmpc::make_scr(N).size;
+        ok = hipMalloc(&h->scratch, sizeof(double) * (size_t)h->scr_stride * h->grid) == hipSuccess
+          && hipMalloc(&h->counter, sizeof(int)) == hipSuccess
+          && hipMalloc(&h->prof, 32 * sizeof(unsigned long long)) == hipSuccess
+          && hipMemset(h->prof, 0, 32 * sizeof(unsigned long long)) == hipSuccess;
+    }
+    if (!ok) {   // nothing half-built survives a failed create
+        fprintf(stderr, "boundmpc_hip: bmpc_create failed: %s\n", hipGetErrorString(hipGetLastError()));
+        hipFree(h->scratch); hipFree(h->counter); hipFree(h->prof); delete h;
+        return BMPC_ERR_HIP;
+    }
     *out = h;
     return BMPC_OK;
 }

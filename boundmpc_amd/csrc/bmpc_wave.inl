@@ -74,7 +74,10 @@ enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV
        L_RD = L_QT + 36, L_DS = L_RD + 36, L_DSN = L_DS + 36, L_DU = L_DSN + 36, L_MV = L_DU + 8, L_AE = L_MV + 44, L_K0 = L_AE + 42,
        L_K1 = L_K0 + KREC, L_KV = L_K1 + KREC, L_XT = L_KV + KREC, L_NC = L_XT + 15 * 14, L_WY = L_NC + 160, L_WV = L_WY + 196, L_TOT = L_WV + 196,
        L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_ZL = L_ST + 432, L_SIZE = L_ZL + 484 };
-enum { L_KKP = L_WY };   // inequality part of the KKT error (4 x 64 slots), parked in the node-cost work area between sweeps (WY 196 + WV 196)   // L_ZL: iterate Z (N <= 11)
+enum { L_KKP = L_WY };
+// row descriptors of the 57 internal inequality rows (box rows: +-Z[src] - lim), built once per problem: [sgn 57 | lim 57 | src 57]
+enum { L_ROWT = L_XT + 8 };
+static_assert(8 + 3 * 57 <= 15 * 14, "row table must fit into the retired XT area");   // inequality part of the KKT error (4 x 64 slots), parked in the node-cost work area between sweeps (WY 196 + WV 196)   // L_ZL: iterate Z (N <= 11)
 // Block (chain-pair) Riccati storage, overlaid on the L_PM..L_RED region (column scheme retired):
 //   PB  [16 planes (f*4+g)][64 pairs (i*8+l)]  value-function Hessian blocks P[(f,i)][(g,l)]
 //   PCI [3][4][8]  P[(f,i)][iota_a] ;  PII [3][3] ;  GS [8][36] jerk rows of M (col 35 = m_j) ; R8 [8][8] ; KS [8][36] gains (col 35 = kff)
@@ -134,8 +137,9 @@ BMPC_D inline void cross3(const double *a, const double *b, double *c) {
     c[0] = x; c[1] = y; c[2] = z;
 }
 BMPC_D inline double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-BMPC_D inline double qlim(int i) { const double d[7] = {165, 115, 165, 115, 165, 115, 170}; return d[i] * 3.14159265358979323846 / 180.0; }
-BMPC_D inline double dqlim(int i) { const double d[7] = {85, 85, 100, 75, 130, 135, 135}; return d[i] * 3.14159265358979323846 / 180.0; }
+#define BMPC_DEG(x) ((x) * 3.14159265358979323846 / 180.0)
+BMPC_D inline double qlim(int i) { return (i == 0 || i == 2 || i == 4) ? BMPC_DEG(165.0) : (i == 6 ? BMPC_DEG(170.0) : BMPC_DEG(115.0)); }
+BMPC_D inline double dqlim(int i) { return i <= 1 ? BMPC_DEG(85.0) : (i == 2 ? BMPC_DEG(100.0) : (i == 3 ? BMPC_DEG(75.0) : (i == 4 ? BMPC_DEG(130.0) : BMPC_DEG(135.0)))); }
 constexpr double ULIM = 35.0;
 
 // node k (0..N) variable access: node 0 from the parameter vector, node k>=1 = Z[k-1]
@@ -367,6 +371,20 @@ BMPC_D inline void node_grad(const double *PAR, const POff &po, double h, const 
     gz[ZPHI] += gphi; gz[ZDPHI] += gdphi; gz[ZDDPHI] += gddphi;
 }
 
+// Box rows (i < ITUBE) are +-Z[src] - lim: descriptor without memory accesses, so that a batch of rows can issue all its
+// loads first.  Tube rows (i >= ITUBE) read the node's reference record instead.
+BMPC_D inline void ineq_box_row(const double *PAR, const POff &po, int i, int &src, double &sgn, double &lim) {
+    if (i < IJL) { src = ZJ + i; sgn = 1.0; lim = ULIM; }
+    else if (i < IQU) { src = ZJ + i - IJL; sgn = -1.0; lim = ULIM; }
+    else if (i < IQL) { src = ZQ + i - IQU; sgn = 1.0; lim = qlim(i - IQU); }
+    else if (i < IDQU) { src = ZQ + i - IQL; sgn = -1.0; lim = qlim(i - IQL); }
+    else if (i < IDQL) { src = ZDQ + i - IDQU; sgn = 1.0; lim = dqlim(i - IDQU); }
+    else if (i < IPHI0) { src = ZDQ + i - IDQL; sgn = -1.0; lim = dqlim(i - IDQL); }
+    else if (i == IPHI0) { src = ZPHI; sgn = -1.0; lim = 0.0; }
+    else if (i == IPHIMAX) { src = ZPHI; sgn = 1.0; lim = PAR[po.phimax]; }
+    else if (i == IDPHIMAX) { src = ZDPHI; sgn = 1.0; lim = PAR[po.dphimax]; }
+    else { src = 0; sgn = 0.0; lim = 0.0; }
+}
 // value of internal inequality row i (0..56) at node variables Zn with reference record rr
 BMPC_D inline double ineq_val(const double *PAR, const POff &po, const double *Zn, const double *rr, int i) {
     if (i < IJL) return Zn[ZJ + i] - ULIM;
@@ -407,6 +425,7 @@ BMPC_D inline double chain_cf(double h, int fr, int fc) {
 }
 BMPC_D inline int srow(int f, int i) { return i < 7 ? f * 7 + i : 28 + f; }   // reduced-state index of (field, chain)
 
+constexpr int RU = 9;   // rows of a lane-strided pass kept in flight per lane: one batch of global loads covers 576 rows (N = 10: 570)
 struct LaneRegs { double mc[16]; double pf[20]; };   // pf: software prefetch of the next stage's inputs (global -> registers -> LDS)   // a lane's 4x4 state block of M, kept in registers between the M and the Schur phases
 
 // ----------------------------------------------------------------------------------------
@@ -457,6 +476,7 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, const dou
             kin_point(q, dq, G + sc.KIN + lane * KREC);
         }
     LANES_END
+    BMPC_PROF(W, 25);
     LANES_BEGIN
         double fk = 0;
         if (lane < N) {
@@ -495,10 +515,28 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, const dou
         L[L_RED + lane] = fk;
     LANES_END
     const double f = red_sum(L + L_RED);
-    LANES_BEGIN   // inequality values, one lane per row
-        for (int id = lane; id < N * NI; id += 64) {
-            const int k = id / NI, i = id - k * NI;
-            G[oH + id] = ineq_val(PAR, po, Zs + k * NZ, G + sc.REF + k * RREC, i);
+    BMPC_PROF(W, 26);
+    LANES_BEGIN   // inequality values, lane-strided rows, RU rows in flight: all loads of a batch are issued before the first use
+        for (int base = lane; base < N * NI; base += 64 * RU) {
+            double zv[RU], rc[RU], rw[RU], sg[RU], lm[RU];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const int id = base + 64 * u; const bool v = id < N * NI;
+                const int k = v ? id / NI : 0, i = v ? id - k * NI : 0;
+                const bool tube = i >= ITUBE; const int m = tube ? (i - ITUBE) >> 1 : 0;
+                sg[u] = L[L_ROWT + i]; lm[u] = L[L_ROWT + NI + i];
+                zv[u] = Zs[k * NZ + (int)L[L_ROWT + 2 * NI + i]];
+                const double *rr = G + sc.REF + k * RREC;
+                rc[u] = tube ? rr[RC + m] : 0.0; rw[u] = tube ? rr[RWD + m] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const int id = base + 64 * u;
+                if (id < N * NI) {
+                    const int i = id % NI;
+                    G[oH + id] = i >= ITUBE ? (((i - ITUBE) & 1) ? (-rc[u] - rw[u]) : (rc[u] - rw[u])) : sg[u] * zv[u] - lm[u];
+                }
+            }
         }
     LANES_END
     return f;
@@ -543,6 +581,7 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
     LANES_BEGIN
         for (int id = lane; id < (N - 1) * 6; id += 64) { const int k = id / 6, c = id - k * 6; G[sc.GH + k * NZ + ZV + c] += G[sc.GVP + (k + 1) * 8 + c]; }
     LANES_END
+    BMPC_PROF(W, 27);
     if (use_hat) return;   // QP gradient only
     // sequential sweep; lam_{k+1} lives in LDS (ping-pong ST_LAM0/ST_LAM1), records of stage k+1 are staged in one burst
     for (int k = N - 1; k >= 0; k--) {
@@ -1302,7 +1341,6 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
 // ----------------------------------------------------------------------------------------
 // ZLDS: the iterate / trial iterate / direction live in LDS (horizons N <= 11); a compile-time switch so that the compiler
 // knows the address space of every access (a run-time select would degrade them to FLAT instructions).
-constexpr int RU = 9;   // rows of a lane-strided pass kept in flight per lane: one batch of global loads covers 576 rows (N = 10: 570)
 template <bool ZLDS>
 BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     const int N = W.N, S = W.S;
@@ -1322,6 +1360,12 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     LANES_BEGIN
         for (int id = lane; id < np; id += 64) L[L_PAR + id] = pr.p[id];
         for (int id = lane; id < nw; id += 64) W.Zc[id] = pr.x0[id];
+    LANES_END
+    LANES_BEGIN
+        if (lane < NI) {
+            int src; double sgn, lim; ineq_box_row(L + L_PAR, po, lane, src, sgn, lim);
+            L[L_ROWT + lane] = sgn; L[L_ROWT + NI + lane] = lim; L[L_ROWT + 2 * NI + lane] = (double)src;
+        }
     LANES_END
     const double *PAR = L + L_PAR;
     // warm start (oracle/bmpc_oracle.c solve_one): barrier restarts at clamp(stored mu, mu_warm, mu_init); the stored
@@ -1423,10 +1467,27 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                     tv[u] = v ? G[sc.T + id] : 1.0; nv[u] = v ? G[sc.NUm + id] : 1.0; hv[u] = v ? G[sc.HIN + id] : -1.0;
                     sg[u] = v ? G[sc.SG + id] : 0.0; tiv[u] = v ? G[sc.TI + id] : 0.0; sr[u] = v ? G[sc.SR + id] : 0.0;
                 }
+                {   // hd = grad h_i . dZ with the loads of the whole batch in front (see ineq_dir for the row formulas)
+                    double c0[RU], c1[RU], c2[RU], c3[RU], w1[RU], d0[RU], d1[RU], d2[RU], dph[RU];
 #pragma unroll
-                for (int u = 0; u < RU; u++) {
-                    const int id = base + 64 * u; const int k = id / NI, i = id - k * NI;
-                    hd[u] = id < ni ? ineq_dir(W.Dz + k * NZ, G + sc.REF + k * RREC, i) : 0.0;
+                    for (int u = 0; u < RU; u++) {
+                        const int id = base + 64 * u; const bool v = id < ni;
+                        const int k = v ? id / NI : 0, i = v ? id - k * NI : 0;
+                        const bool tube = i >= ITUBE; const int m = tube ? (i - ITUBE) >> 1 : 0;
+                        const double sgn = L[L_ROWT + i]; const int src = (int)L[L_ROWT + 2 * NI + i];
+                        const double *rr = G + sc.REF + k * RREC, *dz = W.Dz + k * NZ;
+                        const int vo = tube ? tube_voff(m) : src;
+                        c0[u] = tube ? rr[RGC + m * 4 + 0] : sgn; c1[u] = tube ? rr[RGC + m * 4 + 1] : 0.0; c2[u] = tube ? rr[RGC + m * 4 + 2] : 0.0;
+                        c3[u] = tube ? rr[RGC + m * 4 + 3] : 0.0; w1[u] = tube ? rr[RW1 + m] : 0.0;
+                        d0[u] = dz[vo]; d1[u] = tube ? dz[vo + 1] : 0.0; d2[u] = tube ? dz[vo + 2] : 0.0; dph[u] = dz[ZPHI];
+                    }
+#pragma unroll
+                    for (int u = 0; u < RU; u++) {
+                        const int id = base + 64 * u; const int i = id % NI;
+                        if (id >= ni) hd[u] = 0.0;
+                        else if (i >= ITUBE) { const double sv = c0[u] * d0[u] + c1[u] * d1[u] + c2[u] * d2[u] + c3[u] * dph[u]; hd[u] = (((i - ITUBE) & 1) ? -sv : sv) - w1[u] * dph[u]; }
+                        else hd[u] = c0[u] * d0[u];
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < RU; u++) {
