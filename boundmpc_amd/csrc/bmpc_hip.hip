@@ -31,6 +31,7 @@
 // outstanding prefetch / store).  A wavefront-scope fence keeps the COMPILER from moving memory operations across it.
 #define LANES_END } __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 #define LIDX 0
+#define BMPC_WAVE_RED 1
 #define BMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 #ifdef BMPC_MARKS

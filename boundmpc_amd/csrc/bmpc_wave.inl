@@ -432,6 +432,27 @@ struct LaneRegs { double mc[16]; double pf[20]; };   // pf: software prefetch of
 // wave-uniform deterministic reductions through LDS (RED has 6 x 64 slots)
 // ----------------------------------------------------------------------------------------
 // fixed-order pairwise trees over the 64 slots (order identical in the emulator -> bitwise reproducible)
+#ifdef BMPC_WAVE_RED
+// GPU: every lane reads its own slot and the wave reduces by a butterfly of cross-lane exchanges (xor 8,16,32,1,2,4): exactly
+// the tree written out below (fp addition is commutative, so every lane ends with the same bits), without 64 LDS reads per lane
+BMPC_D inline double red_sum(const double *r) {
+    double v = r[threadIdx.x];
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    return v;
+}
+BMPC_D inline double red_max(const double *r) {
+    double v = r[threadIdx.x];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = BMPC_FMAX(v, __shfl_xor(v, m));
+    return v;
+}
+BMPC_D inline double red_min(const double *r) {
+    double v = r[threadIdx.x];
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = BMPC_FMIN(v, __shfl_xor(v, m));
+    return v;
+}
+#else
 BMPC_D inline double red_sum(const double *r) {
     double a[8];
 #pragma unroll
@@ -444,6 +465,7 @@ BMPC_D inline double red_max(const double *r) { double s = r[0];
 BMPC_D inline double red_min(const double *r) { double s = r[0];
 #pragma unroll
     for (int i = 1; i < 64; i++) s = BMPC_FMIN(s, r[i]); return s; }
+#endif
 
 // ========================================================================================
 //                                   the wave program
@@ -1503,6 +1525,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                 }
                 bar -= mu * BMPC_LOG(tprod);      // one log per batch of RU slacks: sum of logs = log of the product (t in [1e-12, 1e2])
             }
+            BMPC_PROF(W, 28);
             double ghd = 0;
             for (int base = lane; base < nw; base += 64 * RU) {
                 double gv[RU];
@@ -1518,6 +1541,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
 #pragma unroll
                 for (int u = 0; u < RU; u++) th += BMPC_FABS(gv[u]);
             }
+            BMPC_PROF(W, 29);
             L[L_RED + lane] = ap; L[L_RED + 64 + lane] = adl; L[L_RED + 128 + lane] = dbar; L[L_RED + 192 + lane] = ghd - nhd;
             L[L_RED + 256 + lane] = th; L[L_RED + 320 + lane] = bar;
         LANES_END
