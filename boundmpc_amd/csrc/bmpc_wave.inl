@@ -123,6 +123,8 @@ struct Wave {
     double *L;             // LDS base (L_SIZE doubles)
     double *G;             // scratch base
     long long tprev;       // diagnostic build only (BMPC_PROFILE): last phase stamp
+    double ca, cb;         // wave-uniform constants 2 w_a / h^2 and 2 w_a / h (w_a = weights[5]), hoisted out of the phases: a run-time
+                           // fp64 division costs ~40 instructions
     double *Zc, *Zt, *Dz;  // iterate, trial iterate, Newton direction [N][44]: LDS-resident for N <= 11, else in the scratch slab
 #ifdef BMPC_EMU
     int order[64];
@@ -424,6 +426,18 @@ BMPC_D inline double chain_cf(double h, int fr, int fc) {
     return fc == 4 ? 1.0 : 0.0;
 }
 BMPC_D inline int srow(int f, int i) { return i < 7 ? f * 7 + i : 28 + f; }   // reduced-state index of (field, chain)
+
+// per-problem tables and constants that depend only on the parameter vector (already in LDS)
+BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
+    double *L = W.L;
+    LANES_BEGIN
+        if (lane < NI) {
+            int src; double sgn, lim; ineq_box_row(L + L_PAR, po, lane, src, sgn, lim);
+            L[L_ROWT + lane] = sgn; L[L_ROWT + NI + lane] = lim; L[L_ROWT + 2 * NI + lane] = (double)src;
+        }
+    LANES_END
+    W.ca = 2 * L[L_PAR + po.w + 5] / (W.h * W.h); W.cb = 2 * L[L_PAR + po.w + 5] / W.h;
+}
 
 constexpr int RU = 9;   // rows of a lane-strided pass kept in flight per lane: one batch of global loads covers 576 rows (N = 10: 570)
 struct LaneRegs { double mc[16]; double pf[20]; };   // pf: software prefetch of the next stage's inputs (global -> registers -> LDS)   // a lane's 4x4 state block of M, kept in registers between the M and the Schur phases
@@ -793,7 +807,7 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
             NC[NC_SC + 0] = hff;
             NC[NC_SC + 1] = 2 * w[2] * dpdp + 2 * w[7] + sgk[IDPHIMAX];
             NC[NC_SC + 2] = 2 * w[5] * dpdp + 2 * w[8];
-            NC[NC_SC + 3] = 2 * w[2] + 2 * w[5] / (h * h) * (has_next ? 2.0 : 1.0);
+            NC[NC_SC + 3] = 2 * w[2] + W.ca * (has_next ? 2.0 : 1.0);
         }
     LANES_END
     BMPC_PROF(W, 16);
@@ -842,12 +856,12 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
             else if (z == ZPHI) { for (int b = 0; b < 3; b++) g += NC[NC_HPF + b] * rl[b]; }
             else if (z >= ZV && z < ZV + 6) {
                 const int c = z - ZV; g += cv * rl[3 + c];
-                if (k >= 1) g += -2 * w[5] / (h * h) * ST[ST_RLVM + 3 + c];
-                if (has_next) g += -2 * w[5] / (h * h) * ST[ST_RLVP + 3 + c];
+                if (k >= 1) g += -W.ca * ST[ST_RLVM + 3 + c];
+                if (has_next) g += -W.ca * ST[ST_RLVP + 3 + c];
             } else if (z == ZDPHI) { for (int c = 0; c < 6; c++) g += -2 * w[2] * d[c] * rl[3 + c]; }
             else if (z == ZDDPHI) {
-                for (int c = 0; c < 6; c++) g += -2 * w[5] / h * d[c] * rl[3 + c];
-                if (k >= 1) for (int c = 0; c < 6; c++) g += 2 * w[5] / h * d[c] * ST[ST_RLVM + 3 + c];
+                for (int c = 0; c < 6; c++) g += -W.cb * d[c] * rl[3 + c];
+                if (k >= 1) for (int c = 0; c < 6; c++) g += W.cb * d[c] * ST[ST_RLVM + 3 + c];
             }
             NC[NC_GL + z] = g;
         }
@@ -906,7 +920,7 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
                 for (int c = 0; c < 3; c++) vf += 0.5 * h * (f == 0 ? K0[KD + (3 + c) * 7 + ci] : K0[KA + c * 7 + ci]) * NC[NC_HRF + c];
                 for (int c6 = 0; c6 < 6; c6++) {
                     const double ga = f == 0 ? K0[KD + c6 * 7 + ci] : (c6 < 3 ? K0[KW + c6 * 7 + ci] : K0[KA + (c6 - 3) * 7 + ci]);
-                    vd += -2 * w[2] * d[c6] * ga; vdd += -2 * w[5] / h * d[c6] * ga;
+                    vd += -2 * w[2] * d[c6] * ga; vdd += -W.cb * d[c6] * ga;
                 }
                 if (!tr) { L[L_PB + pbi(f, 0, i, l)] += vf; L[L_PB + pbi(f, 1, i, l)] += vd; L[L_PB + pbi(f, 2, i, l)] += vdd; }
                 else     { L[L_PB + pbi(0, f, i, l)] += vf; L[L_PB + pbi(1, f, i, l)] += vd; L[L_PB + pbi(2, f, i, l)] += vdd; }
@@ -1075,7 +1089,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 BMPC_ACC4_DECL(ta);
 #pragma unroll
                 for (int r = 0; r < 7; r++) { BMPC_ACC4(ta, r, K0[KD + c6 * 7 + r] * L[L_RD + r]); BMPC_ACC4(ta, r + 1, jrow[r] * L[L_RD + 7 + r]); }
-                L[L_XT + c6] = -2 * w[5] / (h * h) * BMPC_ACC4_SUM(ta) + 2 * w[5] / h * dpn[c6] * L[L_RD + SDDPHI];
+                L[L_XT + c6] = -W.ca * BMPC_ACC4_SUM(ta) + W.cb * dpn[c6] * L[L_RD + SDDPHI];
             }
         LANES_END
         BMPC_PROF(W, 21);
@@ -1144,7 +1158,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
             // on the fly from the rank-6 factors: X[r][c] = sum_c6 C[c6][r] Gv(K1)[c6][c], C = -2 w_a/h^2 Gv(K0) (rows < 14), 2 w_a/h dpn
             {
                 const double *K0 = L + L_K0, *K1 = L + L_K1, *dpn = L + L_ST + ST_REF + RDP;
-                const double fx = -2 * w[5] / (h * h) * mx * ml * mi, fphi = 2 * w[5] / h * mx * mi * (1.0 - ml);
+                const double fx = -W.ca * mx * ml * mi, fphi = W.cb * mx * mi * (1.0 - ml);
                 double xl0[2] = {0, 0}, xl1[2] = {0, 0}, xi0[2] = {0, 0}, xi1[2] = {0, 0}, xi2[2] = {0, 0};
 #pragma unroll
                 for (int c6 = 0; c6 < 6; c6++) {
@@ -1383,12 +1397,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         for (int id = lane; id < np; id += 64) L[L_PAR + id] = pr.p[id];
         for (int id = lane; id < nw; id += 64) W.Zc[id] = pr.x0[id];
     LANES_END
-    LANES_BEGIN
-        if (lane < NI) {
-            int src; double sgn, lim; ineq_box_row(L + L_PAR, po, lane, src, sgn, lim);
-            L[L_ROWT + lane] = sgn; L[L_ROWT + NI + lane] = lim; L[L_ROWT + 2 * NI + lane] = (double)src;
-        }
-    LANES_END
+    wave_init_tables(W, po);
     const double *PAR = L + L_PAR;
     // warm start (oracle/bmpc_oracle.c solve_one): barrier restarts at clamp(stored mu, mu_warm, mu_init); the stored
     // multiplier of a row bounds its initial slack from below by mu/nu, so active rows keep their multiplier
@@ -1480,7 +1489,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         // ---- row pass "B": slack / multiplier directions, fraction to the boundary, merit ingredients ----
         const double tau = BMPC_FMAX(0.99, 1.0 - mu);
         LANES_BEGIN
-            double ap = 1.0, adl = 1.0, dbar = 0, nhd = 0, th = 0, bar = 0;
+            double ap = 1.0, adl = 1.0, dbar = 0, nhd = 0, th = 0, bar = 0, pn_ = 1.0, pd_ = 0.0, dn_ = 1.0, dd_ = 0.0;
             for (int base = lane; base < ni; base += 64 * RU) {
                 double tv[RU], nv[RU], hv[RU], sg[RU], tiv[RU], sr[RU], hd[RU], tprod = 1.0;
 #pragma unroll
@@ -1518,13 +1527,17 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                         const double t = tv[u], nu = nv[u], r = hv[u] + t, mti = mu * tiv[u], nuh = mti + sr[u];
                         const double dt = -r - hd[u], dnu = mti - nu - sg[u] * dt;
                         G[sc.DT + id] = dt; G[sc.DNU + id] = dnu;
-                        if (dt < 0) { const double a = -tau * t / dt; ap = a < ap ? a : ap; }
-                        if (dnu < 0) { const double a = -tau * nu / dnu; adl = a < adl ? a : adl; }
+                        // fraction to the boundary: the smallest ratio t/|dt| (nu/|dnu|) is tracked by cross-multiplication, one
+                        // division per lane at the end instead of two per row
+                        if (dt < 0 && t * pd_ < pn_ * -dt) { pn_ = t; pd_ = -dt; }
+                        if (dnu < 0 && nu * dd_ < dn_ * -dnu) { dn_ = nu; dd_ = -dnu; }
                         dbar += -mti * dt; nhd += nuh * hd[u]; th += BMPC_FABS(r); tprod *= t;
                     }
                 }
                 bar -= mu * BMPC_LOG(tprod);      // one log per batch of RU slacks: sum of logs = log of the product (t in [1e-12, 1e2])
             }
+            if (pd_ > 0.0) { const double a = tau * pn_ / pd_; ap = a < ap ? a : ap; }
+            if (dd_ > 0.0) { const double a = tau * dn_ / dd_; adl = a < adl ? a : adl; }
             BMPC_PROF(W, 28);
             double ghd = 0;
             for (int base = lane; base < nw; base += 64 * RU) {

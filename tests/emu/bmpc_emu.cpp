@@ -85,6 +85,7 @@ extern "C" int bmpc_emu_newton(int N, int S, double h, const bmpc::Opts *opts, c
     Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = scr.data();
     for (int i = 0; i < 64; i++) W.order[i] = i;
     for (int i = 0; i < po.size; i++) W.L[L_PAR + i] = p[i];
+    wave_init_tables(W, po);
     const bool zl = N <= 11; W.Zc = zl ? W.L + L_ZL : W.G + sc.Z; W.Zt = zl ? W.L + L_PB : W.G + sc.ZT; W.Dz = zl ? W.L + L_PB + 512 : W.G + sc.DZ;
     for (int i = 0; i < N * NZ; i++) W.Zc[i] = x[i];
     for (int i = 0; i < N * NI; i++) { W.G[sc.T + i] = t[i]; W.G[sc.NUm + i] = nu[i]; }

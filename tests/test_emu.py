@@ -120,3 +120,35 @@ def test_emu_other_window_sizes_and_horizons(S, N):
     assert (ref["status"] == 0).all() and (out["status"] == 0).all()
     assert np.abs(out["iters"] - ref["iters"]).max() <= 1
     assert np.sqrt(np.mean((out["x"] - ref["x"]).reshape(-1, N, 44)[:, :, 8:15] ** 2)) < 1e-7
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 10])
+def test_emu_newton_direction_equals_oracle_dense_solve(N):
+    """One Newton direction at a random interior point: the wave program's block-Riccati (gains, feed-forward, dZ) against the
+    oracle's dense per-stage Riccati on the same QP -- isolates the linear algebra from the globalisation."""
+    import ctypes
+    from oracle import nlp
+    L, CO = emu.lib(), c_oracle.lib()
+    d = np.load(os.path.join(G, "g6_pack_exp1_tick0.npz"))
+    p, x0f = d["p_f64"], d["x0_f64"]
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    names = "Z ZT T TT NUm LAM G GT HIN HT DZ DT DNU GH GVP RJ KIN REF KT KF RDY AES RLV SG TI SR size".split()
+    rng = np.random.default_rng(3 + N)
+    S, h = 4, 0.1
+    offs = (ctypes.c_int * len(names))(); L.bmpc_emu_scr_offsets(N, offs); off = dict(zip(names, list(offs)))
+    x = x0f[:44 * N] + rng.normal(size=44 * N) * 0.02
+    x.reshape(N, 44)[:, 41] = np.linspace(0.3, 1.0, N)
+    hin = nlp.internal_ineq(x, p, N, S)
+    t = np.maximum(-hin, 1e-2); mu = 0.1; nu = mu / t * rng.uniform(0.5, 2, t.shape); delta = 10.0 if N < 10 else 1000.0
+    scr = np.zeros(off["size"]); lds = np.zeros(L.bmpc_emu_lds_doubles())
+    o = emu.default_opts()
+    rc = L.bmpc_emu_newton(N, S, ctypes.c_double(h), ctypes.byref(o), P(p), P(x), P(t), P(nu), ctypes.c_double(mu), ctypes.c_double(delta), P(scr), P(lds))
+    Qt = np.zeros((N, 35, 35)); qt = np.zeros((N, 35)); Xt = np.zeros((N, 35, 35)); A = np.zeros((N, 35, 43)); rd = np.zeros((N, 35))
+    T = np.zeros((N, 44, 35)); rl = np.zeros((N, 44)); Kg = np.zeros((N, 8, 35)); kff = np.zeros((N, 8)); dZ = np.zeros(N * 44)
+    rc2 = CO.bmpc_oracle_debug_qp(N, S, ctypes.c_double(h), P(p), P(x), P(t), P(nu), ctypes.c_double(mu), 1, ctypes.c_double(delta), P(Qt), P(qt),
+                                  P(Xt), P(A), P(rd), P(T), P(rl), P(Kg), P(kff), P(dZ))
+    assert rc == 0 and rc2 == 0
+    KT = scr[off["KT"]:off["KT"] + N * 35 * 8].reshape(N, 35, 8).transpose(0, 2, 1)
+    np.testing.assert_allclose(KT, Kg, atol=1e-12)
+    np.testing.assert_allclose(scr[off["KF"]:off["KF"] + 8 * N], kff.ravel(), atol=1e-12)
+    np.testing.assert_allclose(scr[off["DZ"]:off["DZ"] + 44 * N], dZ, atol=1e-12)
