@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libboundmpc_hip.so")
-SOURCES = [os.path.join(CSRC, "bmpc_hip.hip"), os.path.join(CSRC, "bmpc_wave.inl"),
+SOURCES = [os.path.join(CSRC, "bmpc_hip.hip"), os.path.join(CSRC, "bmpc_wave.inl"), os.path.join(CSRC, "bmpc_stream.inl"),
            os.path.join(HERE, "..", "include", "boundmpc_hip.h")]
 
 
@@ -20,8 +20,10 @@ def hipcc():
 def build(force=False, verbose=False):
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in SOURCES):
         return LIB
-    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-variable",
-           "-Wno-unused-value", "-Wno-duplicate-decl-specifier", "-o", LIB, SOURCES[0]]
+    # -amdgpu-sched-strategy=iterative-ilp: the solver runs at one wave per SIMD, so the scheduler should chase instruction-level
+    # parallelism (loads hoisted ahead of their uses), not occupancy; measured 12.7 -> 10.8 ms at B=1024 (profiles/)
+    cmd = [hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
+           "-Wno-unused-variable", "-Wno-unused-value", "-Wno-duplicate-decl-specifier", "-o", LIB, SOURCES[0]]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

@@ -439,7 +439,7 @@ BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
     W.ca = 2 * L[L_PAR + po.w + 5] / (W.h * W.h); W.cb = 2 * L[L_PAR + po.w + 5] / W.h;
 }
 
-constexpr int RU = 9;   // rows of a lane-strided pass kept in flight per lane: one batch of global loads covers 576 rows (N = 10: 570)
+constexpr int RU = 6;   // rows of a lane-strided pass kept in flight per lane (loads of a batch are issued before their first use)
 struct LaneRegs { double mc[16]; double pf[20]; };   // pf: software prefetch of the next stage's inputs (global -> registers -> LDS)   // a lane's 4x4 state block of M, kept in registers between the M and the Schur phases
 
 // ----------------------------------------------------------------------------------------

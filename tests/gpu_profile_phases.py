@@ -10,7 +10,7 @@ from boundmpc_amd import workload, _lib
 csrc = os.path.join(ROOT, "boundmpc_amd", "csrc")
 prof_lib = os.path.join(ROOT, "gpurun_out", "libboundmpc_hip_prof.so")
 os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DBMPC_PROFILE",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DBMPC_PROFILE", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
                        "-Wno-unused-variable", "-Wno-unused-value", "-Wno-duplicate-decl-specifier", "-o", prof_lib,
                        os.path.join(csrc, "bmpc_hip.hip")])
 lib = ctypes.CDLL(prof_lib)
