@@ -1059,7 +1059,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 #pragma unroll
                     for (int l = 0; l < 8; l++)
 #pragma unroll
-                        for (int g = 0; g < 4; g++) BMPC_ACC4(pa, g, L[L_PB + pbi(f, g, i, l)] * L[L_RD + srow(g, l)]);
+                        for (int g = 0; g < 3; g++) BMPC_ACC4(pa, g, L[L_PB + pbi(f, g, i, l)] * L[L_RD + srow(g, l)]);   // rdyn of the jerk states (g = 3) is zero
 #pragma unroll
                     for (int a = 0; a < 3; a++) BMPC_ACC4(pa, a, L[L_PCI + pci(a, f, i)] * L[L_RD + SIOTA + a]);
                 } else {
@@ -1067,7 +1067,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 #pragma unroll
                     for (int l = 0; l < 8; l++)
 #pragma unroll
-                        for (int g = 0; g < 4; g++) BMPC_ACC4(pa, g, L[L_PCI + pci(a, g, l)] * L[L_RD + srow(g, l)]);
+                        for (int g = 0; g < 3; g++) BMPC_ACC4(pa, g, L[L_PCI + pci(a, g, l)] * L[L_RD + srow(g, l)]);
 #pragma unroll
                     for (int b = 0; b < 3; b++) BMPC_ACC4(pa, b, L[L_PII + a * 3 + b] * L[L_RD + SIOTA + b]);
                 }
