@@ -255,3 +255,23 @@ def test_other_window_sizes_and_horizons(S, N):
     assert np.abs(o["iters"].cpu().numpy() - ref["iters"]).max() <= 1
     assert _rms_q(o["x"].cpu().numpy(), ref["x"], N) < TOL_Q_RMS
     s.close()
+
+
+def test_plain_c_caller_of_the_abi(tmp_path):
+    """The boundary is a C ABI: a gcc-built C program (tests/cabi/cabi_demo.c) links the in-tree library, solves experiment1
+    tick 0 from host buffers and must print the oracle's solution."""
+    import subprocess
+    from boundmpc_amd import LIB_PATH
+    from oracle import c_oracle
+    d = np.load(os.path.join(G, "g6_pack_exp1_tick0.npz"))
+    prob = tmp_path / "problem.bin"
+    np.concatenate([d["p_f64"], d["x0_f64"]]).astype(np.float64).tofile(prob)
+    exe = tmp_path / "cabi_demo"
+    libdir = os.path.dirname(os.path.realpath(LIB_PATH))
+    subprocess.check_call(["gcc", "-O1", "-o", str(exe), os.path.join(os.path.dirname(__file__), "cabi", "cabi_demo.c"),
+                           "-L" + libdir, "-lboundmpc_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe), str(prob)], check=True, capture_output=True, text=True, timeout=120).stdout.split()
+    ref = c_oracle.solve(d["p_f64"], d["x0_f64"], 10, 4, 0.1)
+    assert int(out[0]) == 0 and abs(int(out[1]) - int(ref["iters"][0])) <= 1
+    assert abs(float(out[2]) - ref["f"][0]) < 1e-8 * abs(ref["f"][0])
+    np.testing.assert_allclose([float(v) for v in out[3:10]], ref["x"][0][8:15], atol=1e-8)
