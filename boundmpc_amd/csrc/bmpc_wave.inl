@@ -76,7 +76,8 @@ enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV
        L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_ZL = L_ST + 432, L_SIZE = L_ZL + 484 };
 enum { L_KKP = L_WY };
 // row descriptors of the 57 internal inequality rows (box rows: +-Z[src] - lim), built once per problem: [sgn 57 | lim 57 | src 57]
-enum { L_ROWT = L_XT + 8 };
+enum { L_ROWT = L_XT + 8, L_RJP = L_XT + 8 + 3 * 57 + 1 /* 2 x 8: jerk residual partials of the adjoint sweep (ping-pong) */ };
+static_assert(8 + 3 * 57 + 1 + 16 <= 15 * 14, "adjoint partials must fit into the retired XT area");
 static_assert(8 + 3 * 57 <= 15 * 14, "row table must fit into the retired XT area");   // inequality part of the KKT error (4 x 64 slots), parked in the node-cost work area between sweeps (WY 196 + WV 196)   // L_ZL: iterate Z (N <= 11)
 // Block (chain-pair) Riccati storage, overlaid on the L_PM..L_RED region (column scheme retired):
 //   PB  [16 planes (f*4+g)][64 pairs (i*8+l)]  value-function Hessian blocks P[(f,i)][(g,l)]
@@ -598,7 +599,7 @@ BMPC_D inline void stage_mu(Wave &W, const double *lam, const double *kp, int la
 
 // Adjoint sweep with multipliers nu (scratch offset oNU; scale = 0 -> objective only is NOT supported here):
 // LAM[N][36], RJ[N][8]; GH receives d(f + nu.h)/dZ.
-BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU, bool use_hat, double mu) {
+BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU, bool use_hat, double mu, LaneRegs *LR) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
     double *L = W.L, *G = W.G;
     const double *PAR = L + L_PAR, *Zs = W.Zc;
@@ -619,13 +620,26 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
     LANES_END
     BMPC_PROF(W, 27);
     if (use_hat) return;   // QP gradient only
-    // sequential sweep; lam_{k+1} lives in LDS (ping-pong ST_LAM0/ST_LAM1), records of stage k+1 are staged in one burst
+    // sequential sweep; lam_{k+1} lives in LDS (ping-pong ST_LAM0/ST_LAM1).  The inputs of a stage (gradient row, the two kinematics
+    // records of node k+1) are prefetched into registers one stage ahead and dropped into LDS in one burst: a blocking global
+    // load per stage would cost a full memory round trip with nothing else in flight
+    LANES_BEGIN
+        double *pf = LR[LIDX].pf;
+        pf[0] = lane < NZ ? G[sc.GH + (N - 1) * NZ + lane] : 0.0;
+    LANES_END
     for (int k = N - 1; k >= 0; k--) {
         double *lam1 = L + L_ST + (((N - 1 - k) & 1) ? ST_LAM0 : ST_LAM1);     // lam_{k+1} (written one step earlier)
         double *lam0 = L + L_ST + (((N - 1 - k) & 1) ? ST_LAM1 : ST_LAM0);     // lam_k (written now)
         LANES_BEGIN
-            if (lane < NZ) L[L_ST + ST_GH + lane] = G[sc.GH + k * NZ + lane];
-            if (k < N - 1) for (int id = lane; id < KREC; id += 64) { L[L_K0 + id] = G[sc.KIN + (k + 1) * KREC + id]; L[L_KV + id] = G[sc.KIN + (N + k + 1) * KREC + id]; }
+            const double *pf = LR[LIDX].pf;
+            if (lane < NZ) L[L_ST + ST_GH + lane] = pf[0];
+            if (k < N - 1) { L[L_K0 + lane] = pf[1]; L[L_KV + lane] = pf[3]; if (lane < KREC - 64) { L[L_K0 + 64 + lane] = pf[2]; L[L_KV + 64 + lane] = pf[4]; } }
+        LANES_END
+        LANES_BEGIN   // loads for stage k-1 (records of node k); for k = 0 the record of node 0, used after the loop
+            double *pf = LR[LIDX].pf;
+            if (k >= 1) pf[0] = lane < NZ ? G[sc.GH + (k - 1) * NZ + lane] : 0.0;
+            pf[1] = G[sc.KIN + k * KREC + lane]; pf[2] = lane < KREC - 64 ? G[sc.KIN + k * KREC + 64 + lane] : 0.0;
+            if (k >= 1) { pf[3] = G[sc.KIN + (N + k) * KREC + lane]; pf[4] = lane < KREC - 64 ? G[sc.KIN + (N + k) * KREC + 64 + lane] : 0.0; }
         LANES_END
         if (k < N - 1) {
             LANES_BEGIN
@@ -652,8 +666,10 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
                         }
                     } else if (z >= ZIW && z < ZIW + 3) tot += lam1[GIW + z - ZIW];
                 }
-                if (z < 7) G[sc.RJ + k * NU + z] = tot;
-                else if (z == ZJPHI) G[sc.RJ + k * NU + 7] = tot;
+                // jerk rows: the residual of node k still lacks the term of the NEXT sweep step (stage k-1 -> k); it is parked in LDS
+                // and completed there -- a global read-modify-write would wait for this store to land and come back
+                if (z < 7) L[L_RJP + (k & 1) * 8 + z] = tot;
+                else if (z == ZJPHI) L[L_RJP + (k & 1) * 8 + 7] = tot;
                 else {
                     const int e = z < ZPOS ? z - ZQ : (z < ZPHI ? GPOS + (z - ZPOS) : GPHI + (z - ZPHI));
                     G[sc.LAM + k * NE + e] = tot; lam0[e] = tot;
@@ -661,13 +677,14 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
             } else if (lane < NZ + 8 && k < N - 1) {   // jerk of node k+2 enters stage k+1
                 const int i = lane - NZ;
                 const double mdd = i < 7 ? lam1[GDDQ + i] : lam1[GDDPHI];
-                G[sc.RJ + (k + 1) * NU + i] += h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd;
+                G[sc.RJ + (k + 1) * NU + i] = L[L_RJP + ((k + 1) & 1) * 8 + i] + (h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd);
             }
         LANES_END
     }
     const double *lamz = L + L_ST + (((N - 1) & 1) ? ST_LAM1 : ST_LAM0);   // lam_0
     LANES_BEGIN
-        for (int id = lane; id < KREC; id += 64) L[L_K0 + id] = G[sc.KIN + id];
+        const double *pf = LR[LIDX].pf;
+        L[L_K0 + lane] = pf[1]; if (lane < KREC - 64) L[L_K0 + 64 + lane] = pf[2];
     LANES_END
     LANES_BEGIN
         stage_mu(W, lamz, L + L_K0, lane);
@@ -676,7 +693,7 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
         if (lane < 8) {
             const int i = lane;
             const double mdd = i < 7 ? lamz[GDDQ + i] : lamz[GDDPHI];
-            G[sc.RJ + i] += h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd;
+            G[sc.RJ + i] = L[L_RJP + i] + (h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd);
         }
     LANES_END
 }
@@ -1439,7 +1456,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     int it = 0, status = 1; double E0 = 0;
     for (it = 0; it <= o.max_iter; it++) {
         BMPC_PROF(W, 10);
-        wave_adjoint(W, po, sc, sc.NUm, false, 0.0);
+        wave_adjoint(W, po, sc, sc.NUm, false, 0.0, LRs);
         BMPC_PROF(W, 1);
         // ---- KKT error (Ipopt-style scaling), deterministic reductions; the inequality part comes from row pass A ----
         LANES_BEGIN
@@ -1470,7 +1487,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         }
         // ---- Newton system: QP gradient, lifted residuals, Riccati ----
         BMPC_PROF(W, 2);
-        wave_adjoint(W, po, sc, sc.NUm, true, mu);
+        wave_adjoint(W, po, sc, sc.NUm, true, mu, LRs);
         BMPC_PROF(W, 3);
         wave_prepare_rlv(W, sc);
         BMPC_PROF(W, 4);
