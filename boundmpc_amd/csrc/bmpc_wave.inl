@@ -50,7 +50,10 @@ enum { IJU = 0, IJL = 8, IQU = 16, IQL = 23, IDQU = 30, IDQL = 37, IPHI0 = 44, I
 enum { KA = 0, KW = 21, KD = 42, KPOS = 84, KV = 87, KDQ = 93, KREC = 104 };
 // node-reference record (stride RREC)
 enum { RSEG = 0, RX = 1, RDP = 2, RDH = 8, REP = 11, RER = 14, RERPAR = 17, RL2 = 20, RRR = 23, RV2RR = 26, RSIG = 27, RSIG1 = 28,
-       RSIG2 = 29, RC = 30, RWD = 35, RW1 = 40, RW2 = 45, RC2 = 50, RGC = 55 /* [5][4]: 3 vector comps + phi */, RREC = 80 };
+       RSIG2 = 29, RC = 30, RWD = 35, RW1 = 40, RW2 = 45, RC2 = 50, RGC = 55 /* [5][4]: 3 vector comps + phi */,
+       // multiplier-independent part of the (pos, iw, phi) cost Hessian, evaluated once per iterate with the record (wide over the
+       // nodes) instead of once per Riccati stage: Hpp 3x3, Hrr 3x3, Hp,phi 3, Hr,phi 3, H phi,phi, |dp_d|^2
+       RHPPG = 80, RHRRG = 89, RHPFG = 98, RHRFG = 101, RHFFG = 104, RDPDP = 105, RREC = 108 };
 // parameter offsets (casadi_ocp_formulation.py:361-376) as functions of S
 struct POff {
     int q0, dq0, ddq0, phi0, p0, v0, iwref0, dtau, ipar, io1, io2, xphid, jerk, jerkphi, sw, jacr, jacl, pref, dpref, dpn, bp1, bp2,
@@ -73,7 +76,7 @@ BMPC_HD inline POff make_poff(int S) {
 enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV = L_RED + 6 * 64, L_PR = L_PV + 36, L_QT = L_PR + 36,
        L_RD = L_QT + 36, L_DS = L_RD + 36, L_DSN = L_DS + 36, L_DU = L_DSN + 36, L_MV = L_DU + 8, L_AE = L_MV + 44, L_K0 = L_AE + 42,
        L_K1 = L_K0 + KREC, L_KV = L_K1 + KREC, L_XT = L_KV + KREC, L_NC = L_XT + 15 * 14, L_WY = L_NC + 160, L_WV = L_WY + 196, L_TOT = L_WV + 196,
-       L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_ZL = L_ST + 432, L_SIZE = L_ZL + 484 };
+       L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_ZL = L_ST + 460, L_SIZE = L_ZL + 484 };
 enum { L_KKP = L_WY };
 // row descriptors of the 57 internal inequality rows (box rows: +-Z[src] - lim), built once per problem: [sgn 57 | lim 57 | src 57]
 enum { L_ROWT = L_XT + 8, L_RJP = L_XT + 8 + 3 * 57 + 1 /* 2 x 8: jerk residual partials of the adjoint sweep (ping-pong) */ };
@@ -87,7 +90,7 @@ enum { L_PB = L_PM, L_PCI = L_PB + 1024, L_PII = L_PCI + 96, L_GS = L_PII + 12, 
        L_PE = L_MCI + 120, L_BLK_END = L_PE + 42, L_KHP = L_WV /* 144 of the 196 */ };
 static_assert((int)L_BLK_END <= (int)L_PV, "block Riccati storage must fit into the retired PM/SR/RED region");
 // staging area inside L_ST: per-stage inputs of the sequential sweeps, loaded from the scratch slab in ONE burst per stage
-enum { ST_REF = 0, ST_Z = 80, ST_SG = 124, ST_NU = 184, ST_G = 244, ST_LAM0 = 280, ST_LAM1 = 316, ST_GH = 352, ST_RLVM = 396, ST_RLV0 = 408, ST_RLVP = 420,
+enum { ST_REF = 0, ST_Z = 108, ST_SG = 152, ST_NU = 212, ST_G = 272, ST_LAM0 = 308, ST_LAM1 = 344, ST_GH = 380, ST_RLVM = 424, ST_RLV0 = 436, ST_RLVP = 448,
        /* forward sweep view */ ST_KT = 0, ST_KF = 280, ST_RDY = 288, ST_AES = 324, ST_RLVF = 366 };
 // node-cost work area inside L_NC
 enum { NC_HPP = 0, NC_HRR = 9, NC_HPF = 18, NC_HRF = 21, NC_SC = 24 /* hff,hdd,hddd,cv */, NC_A1 = 28 /* Hpp*Jp 3x7 */, NC_A2 = 49 /* Hrr*Ehat 3x14 */,
@@ -245,7 +248,7 @@ BMPC_D inline double kin_hess_entry(const double *rec, const double *mu_p, const
 // node quantities depending on (pos, iw, phi): segment, tubes, errors -> record rr[RREC]
 // (bound_mpc_functions.py:13-20,34-40,43-149,152-202; mpc_utils_casadi.py:6-10,52,163)
 // ----------------------------------------------------------------------------------------
-BMPC_D inline void node_ref(const double *PAR, const POff &po, int S, const double *pos, const double *iw, double phi, double *rr) {
+BMPC_D inline void node_ref(const double *PAR, const POff &po, int S, const double *pos, const double *iw, double phi, double *rr, int ex) {
     const double *sw = PAR + po.sw;
     int seg = S - 1;
     for (int i = S - 2; i >= 0; i--) if (phi < sw[i + 1]) seg = i;
@@ -278,17 +281,17 @@ BMPC_D inline void node_ref(const double *PAR, const POff &po, int S, const doub
         for (int r = 0; r < 3; r++) { const double jl = jacl[c * 3 + r]; l1[c] += jl * v1[r]; l2[c] += jl * v2[r]; l3[c] += jl * v3[r]; }
         rr[RRR + c] = rrv[c]; rr[RL2 + c] = l2[c];
     }
-    double ep[3], dlt[3];
+    double ep[3], dlt[3], er[3], erpar[3];
     for (int c = 0; c < 3; c++) { ep[c] = pos[c] - (PAR[po.pref + c * S + seg] + d[c] * x); rr[REP + c] = ep[c]; }
     for (int r = 0; r < 3; r++) {
         double s = 0;
         for (int c = 0; c < 3; c++)
             s += jacl[c * 3 + r] * (iw[c] - PAR[po.p0 + 3 + c]) - jacr[c * 3 + r] * (PAR[po.pref + (3 + c) * S + seg] + rho[c] * x - PAR[po.iwref0 + c]);
-        dlt[r] = s; rr[RER + r] = PAR[po.dtau + r] + s;
+        dlt[r] = s; er[r] = PAR[po.dtau + r] + s; rr[RER + r] = er[r];
     }
     const double s1 = dot3(dlt, v1), s2 = dot3(dlt, v2), s3 = dot3(dlt, v3);
     const double *ipar = PAR + po.ipar + 3 * seg, *io1 = PAR + po.io1 + 3 * seg, *io2 = PAR + po.io2 + 3 * seg;
-    for (int c = 0; c < 3; c++) rr[RERPAR + c] = ipar[c] + s2 * dh[c];
+    for (int c = 0; c < 3; c++) { erpar[c] = ipar[c] + s2 * dh[c]; rr[RERPAR + c] = erpar[c]; }
     const double aa = 100.0 * (phi - (PAR[po.phimax] - 0.02));
     const double sig = 1.0 / (1.0 + BMPC_EXP(-aa));
     rr[RSIG] = sig; rr[RSIG1] = 100.0 * sig * (1.0 - sig); rr[RSIG2] = 100.0 * (100.0 * sig * (1.0 - sig)) * (1.0 - 2.0 * sig);
@@ -318,6 +321,45 @@ BMPC_D inline void node_ref(const double *PAR, const POff &po, int S, const doub
         for (int c = 0; c < 3; c++) rr[RGC + (3 + m) * 4 + c] = bb * l[c];
         rr[RGC + (3 + m) * 4 + 3] = -bb * vrr - off1; rr[RC2 + 3 + m] = -off2;
         rr[RWD + 3 + m] = sg * hw; rr[RW1 + 3 + m] = sg * 0.5 * (b1[4 + m] - b1[6 + m]); rr[RW2 + 3 + m] = sg * 0.5 * (b2[4 + m] - b2[6 + m]);
+    }
+    // ---- multiplier-independent Hessian blocks of the tracking cost over (pos, iw, phi) (objective_function with the blended
+    //      errors e_obj = sig e + (1 - sig) e_par; exact second-order terms when ex) ----
+    {
+        const double *w = PAR + po.w;
+        const double sig1 = 100.0 * sig * (1.0 - sig), sig2 = 100.0 * sig1 * (1.0 - 2.0 * sig);
+        const double dde = dot3(d, ep), dd = dot3(d, d);
+        double jp[3][3], jr[3][3], jpf[3], jrf[3], epo[3], ero[3], eperp[3], erd[3];
+        for (int r = 0; r < 3; r++) {
+            eperp[r] = ep[r] - dde * d[r]; erd[r] = er[r] - erpar[r];
+            epo[r] = sig * ep[r] + (1 - sig) * dde * d[r]; ero[r] = sig * er[r] + (1 - sig) * erpar[r];
+            jpf[r] = -(sig * d[r] + (1 - sig) * dd * d[r]) + sig1 * eperp[r];
+            jrf[r] = -sig * rrv[r] - (1 - sig) * dh[r] * v2rr + sig1 * erd[r];
+            for (int a = 0; a < 3; a++) { jp[r][a] = (r == a ? sig : 0.0) + (1 - sig) * d[r] * d[a]; jr[r][a] = sig * jacl[a * 3 + r] + (1 - sig) * dh[r] * l2[a]; }
+        }
+        const double depo = dot3(d, epo), dhero = dot3(dh, ero);
+        double spf = 0, srf = 0, spp = 0, srr = 0, dpdp = 0;
+        for (int a = 0; a < 3; a++) {
+            for (int b2_ = 0; b2_ < 3; b2_++) {
+                double sp = 0, sr = 0;
+                for (int r = 0; r < 3; r++) { sp += jp[r][a] * jp[r][b2_]; sr += jr[r][a] * jr[r][b2_]; }
+                rr[RHPPG + a * 3 + b2_] = 2 * w[0] * sp; rr[RHRRG + a * 3 + b2_] = 2 * w[1] * sr;
+            }
+            double sp = 0, sr = 0;
+            for (int r = 0; r < 3; r++) { sp += jp[r][a] * jpf[r]; sr += jr[r][a] * jrf[r]; }
+            double hp = 2 * w[0] * sp, hr = 2 * w[1] * sr;
+            if (ex) {
+                double jl = 0; for (int r = 0; r < 3; r++) jl += ero[r] * jacl[a * 3 + r];
+                hp += 2 * w[0] * sig1 * (epo[a] - depo * d[a]); hr += 2 * w[1] * sig1 * (jl - dhero * l2[a]);
+            }
+            rr[RHPFG + a] = hp; rr[RHRFG + a] = hr;
+            spf += jpf[a] * jpf[a]; srf += jrf[a] * jrf[a];
+            spp += epo[a] * (sig2 * eperp[a] - 2 * sig1 * (d[a] - dd * d[a]));
+            srr += ero[a] * (sig2 * erd[a] + 2 * sig1 * (-rrv[a] + dh[a] * v2rr));
+        }
+        for (int c = 0; c < 6; c++) dpdp += dp[c] * dp[c];
+        double hff = 2 * w[0] * spf + 2 * w[1] * srf;
+        if (ex) hff += 2 * w[0] * spp + 2 * w[1] * srr;
+        rr[RHFFG] = hff; rr[RDPDP] = dpdp;
     }
 }
 // tube row m uses pos (m = 1,2) or iw (m = 0,3,4) as its 3-vector variable
@@ -530,7 +572,7 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, const dou
             gk[GPHI] = ph + h * dph + h2 / 2 * ddph + h3 / 8 * jp0 + h3 / 24 * jp1 - Zn[ZPHI];
             gk[GDPHI] = dph + h * ddph + h2 / 3 * jp0 + h2 / 6 * jp1 - Zn[ZDPHI];
             gk[GDDPHI] = ddph + h / 2 * (jp0 + jp1) - Zn[ZDDPHI];
-            node_ref(PAR, po, W.S, Zn + ZPOS, Zn + ZIW, Zn[ZPHI], rr);
+            node_ref(PAR, po, W.S, Zn + ZPOS, Zn + ZIW, Zn[ZPHI], rr, W.o.exact_hessian);
             // objective of node k+1 (bound_mpc_functions.py:205-246; casadi_ocp_formulation.py:227-265)
             const double *w = PAR + po.w, *d = rr + RDP;
             const double sig = rr[RSIG], dde = dot3(d, rr + REP);
@@ -752,17 +794,9 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
     // phase 1: small Hessian blocks over (pos, iw, phi)
     LANES_BEGIN
         if (lane < 14) NC[NC_GY + lane] = lane < 7 ? gk[GQ + lane] : gk[GDQ + lane - 7];
-        if (lane >= 16 && lane < 16 + 9) {
+        if (lane >= 16 && lane < 16 + 9) {        // Hpp, Hrr: geometric part from the record + barrier terms of the tube rows
             const int a = (lane - 16) / 3, b = (lane - 16) % 3;
-            const double sig = rr[RSIG], *d = rr + RDP, *dh = rr + RDH, *l2 = rr + RL2, *jacl = PAR + po.jacl;
-            double sp = 0, sr = 0;
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const double jpa = (r == a ? sig : 0.0) + (1 - sig) * d[r] * d[a], jpb = (r == b ? sig : 0.0) + (1 - sig) * d[r] * d[b];
-                const double jra = sig * jacl[a * 3 + r] + (1 - sig) * dh[r] * l2[a], jrb = sig * jacl[b * 3 + r] + (1 - sig) * dh[r] * l2[b];
-                sp += jpa * jpb; sr += jra * jrb;
-            }
-            double hp = 2 * w[0] * sp, hr = 2 * w[1] * sr;
+            double hp = rr[RHPPG + a * 3 + b], hr = rr[RHRRG + a * 3 + b];
 #pragma unroll
             for (int m = 0; m < 5; m++) {
                 const double gg = (sgk[ITUBE + 2 * m] + sgk[ITUBE + 2 * m + 1]) * rr[RGC + m * 4 + a] * rr[RGC + m * 4 + b];
@@ -770,25 +804,9 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
             }
             NC[NC_HPP + a * 3 + b] = hp; NC[NC_HRR + a * 3 + b] = hr;
         }
-        if (lane >= 32 && lane < 35) {
+        if (lane >= 32 && lane < 35) {            // Hp,phi, Hr,phi
             const int a = lane - 32;
-            const double sig = rr[RSIG], sig1 = rr[RSIG1], *d = rr + RDP, *dh = rr + RDH, *l2 = rr + RL2, *jacl = PAR + po.jacl;
-            const double dde = dot3(d, rr + REP), dd = dot3(d, d);
-            double sp = 0, sr = 0, epo[3], ero[3];
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const double eperp = rr[REP + r] - dde * d[r], erd = rr[RER + r] - rr[RERPAR + r];
-                epo[r] = sig * rr[REP + r] + (1 - sig) * dde * d[r]; ero[r] = sig * rr[RER + r] + (1 - sig) * rr[RERPAR + r];
-                const double jpa = (r == a ? sig : 0.0) + (1 - sig) * d[r] * d[a], jpf = -(sig * d[r] + (1 - sig) * dd * d[r]) + sig1 * eperp;
-                const double jra = sig * jacl[a * 3 + r] + (1 - sig) * dh[r] * l2[a], jrf = -sig * rr[RRR + r] - (1 - sig) * dh[r] * rr[RV2RR] + sig1 * erd;
-                sp += jpa * jpf; sr += jra * jrf;
-            }
-            double hp = 2 * w[0] * sp, hr = 2 * w[1] * sr;
-            if (ex) {
-                const double depo = dot3(d, epo), dhero = dot3(dh, ero);
-                double jl = 0; for (int r = 0; r < 3; r++) jl += ero[r] * jacl[a * 3 + r];
-                hp += 2 * w[0] * sig1 * (epo[a] - depo * d[a]); hr += 2 * w[1] * sig1 * (jl - dhero * l2[a]);
-            }
+            double hp = rr[RHPFG + a], hr = rr[RHRFG + a];
 #pragma unroll
             for (int m = 0; m < 5; m++) {
                 const double su = sgk[ITUBE + 2 * m], sl = sgk[ITUBE + 2 * m + 1];
@@ -798,28 +816,15 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
             }
             NC[NC_HPF + a] = hp; NC[NC_HRF + a] = hr;
         }
-        if (lane == 40) {
-            const double sig = rr[RSIG], sig1 = rr[RSIG1], sig2 = rr[RSIG2], *d = rr + RDP, *dh = rr + RDH;
-            const double dde = dot3(d, rr + REP), dd = dot3(d, d);
-            double sp = 0, sr = 0, spp = 0, srr = 0, dpdp = 0;
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                const double eperp = rr[REP + r] - dde * d[r], erd = rr[RER + r] - rr[RERPAR + r];
-                const double epo = sig * rr[REP + r] + (1 - sig) * dde * d[r], ero = sig * rr[RER + r] + (1 - sig) * rr[RERPAR + r];
-                const double jpf = -(sig * d[r] + (1 - sig) * dd * d[r]) + sig1 * eperp, jrf = -sig * rr[RRR + r] - (1 - sig) * dh[r] * rr[RV2RR] + sig1 * erd;
-                sp += jpf * jpf; sr += jrf * jrf;
-                spp += epo * (sig2 * eperp - 2 * sig1 * (d[r] - dd * d[r]));
-                srr += ero * (sig2 * erd + 2 * sig1 * (-rr[RRR + r] + dh[r] * rr[RV2RR]));
-            }
-            for (int c = 0; c < 6; c++) dpdp += d[c] * d[c];
-            double hff = 2 * w[0] * sp + 2 * w[1] * sr + 2 * w[6] + sgk[IPHI0] + sgk[IPHIMAX];
-            if (ex) hff += 2 * w[0] * spp + 2 * w[1] * srr;
+        if (lane == 40) {                          // H phi,phi and the scalar curvatures
+            const double dpdp = rr[RDPDP], exm = ex ? 1.0 : 0.0;
+            double hff = rr[RHFFG] + 2 * w[6] + sgk[IPHI0] + sgk[IPHIMAX];
 #pragma unroll
             for (int m = 0; m < 5; m++) {
                 const double su = sgk[ITUBE + 2 * m], sl = sgk[ITUBE + 2 * m + 1];
                 const double gpu_ = rr[RGC + m * 4 + 3] - rr[RW1 + m], gpl_ = -rr[RGC + m * 4 + 3] - rr[RW1 + m];
                 hff += su * gpu_ * gpu_ + sl * gpl_ * gpl_;
-                if (ex) hff += nuk[ITUBE + 2 * m] * (rr[RC2 + m] - rr[RW2 + m]) + nuk[ITUBE + 2 * m + 1] * (-rr[RC2 + m] - rr[RW2 + m]);
+                hff += exm * (nuk[ITUBE + 2 * m] * (rr[RC2 + m] - rr[RW2 + m]) + nuk[ITUBE + 2 * m + 1] * (-rr[RC2 + m] - rr[RW2 + m]));
             }
             NC[NC_SC + 0] = hff;
             NC[NC_SC + 1] = 2 * w[2] * dpdp + 2 * w[7] + sgk[IDPHIMAX];
