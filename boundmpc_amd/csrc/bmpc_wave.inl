@@ -1344,23 +1344,25 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
             L[L_K0 + lane] = pf[9]; if (lane < KREC - 64) L[L_K0 + 64 + lane] = pf[10];
         LANES_END
         if (k + 1 < N) wave_forward_prefetch(W, sc, k + 1, LR);
-        LANES_BEGIN   // du = kff + K ds
-            if (lane < NU) {
-                BMPC_ACC4_DECL(da);
+        LANES_BEGIN   // du = kff + K ds: partial sums on all 64 lanes (control u = lane & 7, every 8th state b), reduced by the consumers
+            {
+                const int u = lane & 7, part = lane >> 3; double acc = 0.0;
 #pragma unroll
-                for (int b = 0; b < NS; b++) BMPC_ACC4(da, b, L[L_ST + ST_KT + b * NU + lane] * L[L_DS + b]);
-                L[L_DU + lane] = L[L_ST + ST_KF + lane] + BMPC_ACC4_SUM(da);
+                for (int j = 0; j < 5; j++) { const int b = part + 8 * j; if (b < NS) acc += L[L_ST + ST_KT + b * NU + u] * L[L_DS + b]; }
+                L[L_RED + part * 8 + u] = acc;
             }
         LANES_END
         LANES_BEGIN
             if (lane < NS) {
                 const int r = lane; double v = L[L_ST + ST_RDY + r];
-                const double *ds = L + L_DS, *du = L + L_DU;
+                const double *ds = L + L_DS;
                 if (r < 28 || (r >= SPHI && r <= SJPHI)) {
                     const int f = r < 28 ? r / 7 : r - 28, i = r < 28 ? r % 7 : 7;
+                    const double *dp_ = L + L_RED + i;   // fixed-order tree over the 8 partial sums
+                    const double du_i = L[L_ST + ST_KF + i] + (((dp_[0] + dp_[8]) + (dp_[16] + dp_[24])) + ((dp_[32] + dp_[40]) + (dp_[48] + dp_[56])));
 #pragma unroll
                     for (int fc = 0; fc < 4; fc++) v += chain_cf(h, f, fc) * ds[srow(fc, i)];
-                    v += chain_cf(h, f, 4) * du[i];
+                    v += chain_cf(h, f, 4) * du_i;
                 } else {
                     const int a = r - SIOTA; v += ds[r]; BMPC_ACC4_DECL(ia);
 #pragma unroll
