@@ -5,7 +5,8 @@
 // The same text is compiled
 //   * by hipcc for gfx950 inside bmpc_hip.hip (the product), where a "phase"
 //     (LANES_BEGIN ... LANES_END) is the body executed by the 64 lanes followed by a
-//     workgroup barrier (the workgroup IS one wave), and
+//     wavefront-scope fence (the workgroup IS one wave: its LDS and memory instructions execute
+//     in program order, so no s_barrier / waitcnt drain is needed between phases), and
 //   * by g++ inside tests/emu/bmpc_emu.cpp (TEST-ONLY lane emulator, never shipped or loaded
 //     by the product), where a phase is a loop over the 64 lanes in a configurable order --
 //     running forward and reverse lane orders exposes any intra-phase cross-lane dependence.
@@ -17,7 +18,7 @@
 // CasADi->Ipopt->MUMPS at BoundMPC.py:446-453.  Algorithm: primal-dual interior point with
 // the exact Lagrangian Hessian; the block-tridiagonal Newton system is factorised stage by
 // stage (Riccati recursion on a 35-dim reduced node state, lifted pos/v variables and the
-// trapezoidal omega coupling eliminated node-locally), l1-merit backtracking line search.
+// trapezoidal omega coupling eliminated node-locally), filter line search (Waechter-Biegler).
 //
 // Lane maps: evaluation = one lane per kinematic evaluation point (2N points); adjoint /
 // forward sweeps = one lane per state component; Riccati = one lane per PAIR of integrator chains
@@ -79,7 +80,8 @@ enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV
        L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_ZL = L_ST + 460, L_SIZE = L_ZL + 484 };
 enum { L_KKP = L_WY };
 // row descriptors of the 57 internal inequality rows (box rows: +-Z[src] - lim), built once per problem: [sgn 57 | lim 57 | src 57]
-enum { L_ROWT = L_XT + 8, L_RJP = L_XT + 8 + 3 * 57 + 1 /* 2 x 8: jerk residual partials of the adjoint sweep (ping-pong) */ };
+// the 15x14 area of the retired cross block XT now holds: t6 (6), the row table (3 x 57), the adjoint partials (2 x 8)
+enum { L_T6 = L_XT, L_ROWT = L_XT + 8, L_RJP = L_XT + 8 + 3 * 57 + 1 /* 2 x 8: jerk residual partials of the adjoint sweep (ping-pong) */ };
 static_assert(8 + 3 * 57 + 1 + 16 <= 15 * 14, "adjoint partials must fit into the retired XT area");
 static_assert(8 + 3 * 57 <= 15 * 14, "row table must fit into the retired XT area");   // inequality part of the KKT error (4 x 64 slots), parked in the node-cost work area between sweeps (WY 196 + WV 196)   // L_ZL: iterate Z (N <= 11)
 // Block (chain-pair) Riccati storage, overlaid on the L_PM..L_RED region (column scheme retired):
@@ -1111,7 +1113,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 BMPC_ACC4_DECL(ta);
 #pragma unroll
                 for (int r = 0; r < 7; r++) { BMPC_ACC4(ta, r, K0[KD + c6 * 7 + r] * L[L_RD + r]); BMPC_ACC4(ta, r + 1, jrow[r] * L[L_RD + 7 + r]); }
-                L[L_XT + c6] = -W.ca * BMPC_ACC4_SUM(ta) + W.cb * dpn[c6] * L[L_RD + SDDPHI];
+                L[L_T6 + c6] = -W.ca * BMPC_ACC4_SUM(ta) + W.cb * dpn[c6] * L[L_RD + SDDPHI];
             }
         LANES_END
         BMPC_PROF(W, 21);
@@ -1129,7 +1131,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                     if (k >= 1) {
                         const double *K1 = L + L_K1; double sx = 0;
 #pragma unroll
-                        for (int c6 = 0; c6 < 6; c6++) sx += (fp == 0 ? K1[KD + c6 * 7 + i] : (c6 < 3 ? K1[KW + c6 * 7 + i] : K1[KA + (c6 - 3) * 7 + i])) * L[L_XT + c6];
+                        for (int c6 = 0; c6 < 6; c6++) sx += (fp == 0 ? K1[KD + c6 * 7 + i] : (c6 < 3 ? K1[KW + c6 * 7 + i] : K1[KA + (c6 - 3) * 7 + i])) * L[L_T6 + c6];
                         v += sx;
                     }
                 }
