@@ -275,3 +275,17 @@ def test_plain_c_caller_of_the_abi(tmp_path):
     assert int(out[0]) == 0 and abs(int(out[1]) - int(ref["iters"][0])) <= 1
     assert abs(float(out[2]) - ref["f"][0]) < 1e-8 * abs(ref["f"][0])
     np.testing.assert_allclose([float(v) for v in out[3:10]], ref["x"][0][8:15], atol=1e-8)
+
+
+def test_gauss_newton_option_matches_oracle():
+    """options.exact_hessian = 0 (Gauss-Newton Hessian) takes the other branch of the node-cost phases."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver
+    from oracle import c_oracle
+    d = np.load(os.path.join(G, "g6_pack_exp1_tick0.npz"))
+    s = BatchedOCPSolver(10, 4, 0.1, exact_hessian=False)
+    out = s.solve_host(d["p_f64"], d["x0_f64"])
+    ref = c_oracle.solve(d["p_f64"], d["x0_f64"], 10, 4, 0.1, c_oracle.default_opts(exact_hessian=0))
+    assert out["status"][0] == 0 and abs(int(out["iters"][0]) - int(ref["iters"][0])) <= 1
+    assert _rms_q(out["x"], ref["x"]) < TOL_Q_RMS
+    s.close()
