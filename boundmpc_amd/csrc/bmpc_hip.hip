@@ -96,6 +96,7 @@ struct bmpc_handle {
     int grid; long long scr_stride; double *scratch; int *counter; unsigned long long *prof;
     int timing; hipEvent_t ev0, ev1; int have_ev;
     double *latency_us;
+    double *stage_d; int *stage_i; int stage_cap;   // device staging of the host-buffer path
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "boundmpc_hip: %s failed: %s\n", #x, hipGetErrorString(e_)); return BMPC_ERR_HIP; } } while (0)
@@ -117,7 +118,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     bmpc_handle *h = new (std::nothrow) bmpc_handle();
     if (!h) return BMPC_ERR_ARG;
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->have_ev = 0; h->latency_us = nullptr;
-    h->scratch = nullptr; h->counter = nullptr; h->prof = nullptr;
+    h->scratch = nullptr; h->counter = nullptr; h->prof = nullptr; h->stage_d = nullptr; h->stage_i = nullptr; h->stage_cap = 0;
     if (opts) h->o = *opts; else bmpc_default_options(&h->o);
     int dev = 0, per_cu = 0; hipDeviceProp_t prop;
     bool ok = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess;
@@ -143,7 +144,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
 extern "C" int bmpc_destroy(bmpc_handle *h) {
     if (!h) return BMPC_ERR_ARG;
     if (h->have_ev) { hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); }
-    hipFree(h->scratch); hipFree(h->counter); hipFree(h->prof);
+    hipFree(h->scratch); hipFree(h->counter); hipFree(h->prof); hipFree(h->stage_d); hipFree(h->stage_i);
     delete h;
     return BMPC_OK;
 }
@@ -250,30 +251,44 @@ extern "C" int bmpc_graph_destroy(bmpc_graph *gr) {
     return BMPC_OK;
 }
 
+// host-buffer path: device staging buffers are owned by the handle and grow on demand (no hipMalloc per call: the single-problem
+// solver(...) call of the drop-in shim runs every tick)
+static int host_stage_reserve(bmpc_handle *h, int B) {
+    if (B <= h->stage_cap) return BMPC_OK;
+    const size_t np = 141 + 91 * h->S, nw = (size_t)h->N * 44, ng = (size_t)h->N * 43;
+    const size_t nd = (size_t)B * (np + 3 * nw + 2 * ng + 2), ni = (size_t)B * 2;
+    if (h->stage_d) { hipFree(h->stage_d); h->stage_d = nullptr; }
+    if (h->stage_i) { hipFree(h->stage_i); h->stage_i = nullptr; }
+    h->stage_cap = 0;
+    if (hipMalloc(&h->stage_d, nd * sizeof(double)) != hipSuccess || hipMalloc(&h->stage_i, ni * sizeof(int)) != hipSuccess) {
+        hipFree(h->stage_d); hipFree(h->stage_i); h->stage_d = nullptr; h->stage_i = nullptr;
+        return BMPC_ERR_HIP;
+    }
+    h->stage_cap = B;
+    return BMPC_OK;
+}
 extern "C" int bmpc_solve_batch_host(bmpc_handle *h, int B, const double *p, const double *x0, double *x, double *g, double *lam_g, double *lam_x,
                                      double *f, int *iters, int *status, double *kkt) {
     if (!h || B < 0 || (B > 0 && (!p || !x0 || !x))) return BMPC_ERR_ARG;
     if (B == 0) return BMPC_OK;
-    const size_t np = 141 + 91 * h->S, nw = (size_t)h->N * 44, ng = (size_t)h->N * 43;
-    double *dp = nullptr, *dx0 = nullptr, *dx = nullptr, *dg = nullptr, *dlg = nullptr, *dlx = nullptr, *df = nullptr, *dk = nullptr; int *dit = nullptr, *dst = nullptr;
-    int rc = BMPC_OK;
+    int rc = host_stage_reserve(h, B);
+    if (rc != BMPC_OK) return rc;
+    const size_t np = 141 + 91 * h->S, nw = (size_t)h->N * 44, ng = (size_t)h->N * 43, b = (size_t)B;
+    double *dp = h->stage_d, *dx0 = dp + b * np, *dx = dx0 + b * nw, *dlx = dx + b * nw, *dg = dlx + b * nw, *dlg = dg + b * ng, *df = dlg + b * ng, *dk = df + b;
+    int *dit = h->stage_i, *dst = dit + b;
 #define TRY(x) do { if (rc == BMPC_OK && (x) != hipSuccess) rc = BMPC_ERR_HIP; } while (0)
-    TRY(hipMalloc(&dp, B * np * 8)); TRY(hipMalloc(&dx0, B * nw * 8)); TRY(hipMalloc(&dx, B * nw * 8)); TRY(hipMalloc(&dg, B * ng * 8));
-    TRY(hipMalloc(&dlg, B * ng * 8)); TRY(hipMalloc(&dlx, B * nw * 8)); TRY(hipMalloc(&df, B * 8)); TRY(hipMalloc(&dk, B * 8));
-    TRY(hipMalloc(&dit, B * 4)); TRY(hipMalloc(&dst, B * 4));
-    TRY(hipMemcpy(dp, p, B * np * 8, hipMemcpyHostToDevice)); TRY(hipMemcpy(dx0, x0, B * nw * 8, hipMemcpyHostToDevice));
+    TRY(hipMemcpy(dp, p, b * np * 8, hipMemcpyHostToDevice)); TRY(hipMemcpy(dx0, x0, b * nw * 8, hipMemcpyHostToDevice));
     if (rc == BMPC_OK) rc = bmpc_solve_batch(h, B, dp, dx0, dx, dg, dlg, dlx, df, dit, dst, dk, nullptr);
     TRY(hipDeviceSynchronize());
-    TRY(hipMemcpy(x, dx, B * nw * 8, hipMemcpyDeviceToHost));
-    if (g) TRY(hipMemcpy(g, dg, B * ng * 8, hipMemcpyDeviceToHost));
-    if (lam_g) TRY(hipMemcpy(lam_g, dlg, B * ng * 8, hipMemcpyDeviceToHost));
-    if (lam_x) TRY(hipMemcpy(lam_x, dlx, B * nw * 8, hipMemcpyDeviceToHost));
-    if (f) TRY(hipMemcpy(f, df, B * 8, hipMemcpyDeviceToHost));
-    if (kkt) TRY(hipMemcpy(kkt, dk, B * 8, hipMemcpyDeviceToHost));
-    if (iters) TRY(hipMemcpy(iters, dit, B * 4, hipMemcpyDeviceToHost));
-    if (status) TRY(hipMemcpy(status, dst, B * 4, hipMemcpyDeviceToHost));
+    TRY(hipMemcpy(x, dx, b * nw * 8, hipMemcpyDeviceToHost));
+    if (g) TRY(hipMemcpy(g, dg, b * ng * 8, hipMemcpyDeviceToHost));
+    if (lam_g) TRY(hipMemcpy(lam_g, dlg, b * ng * 8, hipMemcpyDeviceToHost));
+    if (lam_x) TRY(hipMemcpy(lam_x, dlx, b * nw * 8, hipMemcpyDeviceToHost));
+    if (f) TRY(hipMemcpy(f, df, b * 8, hipMemcpyDeviceToHost));
+    if (kkt) TRY(hipMemcpy(kkt, dk, b * 8, hipMemcpyDeviceToHost));
+    if (iters) TRY(hipMemcpy(iters, dit, b * 4, hipMemcpyDeviceToHost));
+    if (status) TRY(hipMemcpy(status, dst, b * 4, hipMemcpyDeviceToHost));
 #undef TRY
-    hipFree(dp); hipFree(dx0); hipFree(dx); hipFree(dg); hipFree(dlg); hipFree(dlx); hipFree(df); hipFree(dk); hipFree(dit); hipFree(dst);
     return rc;
 }
 
