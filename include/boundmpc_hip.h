@@ -86,7 +86,8 @@ int bmpc_solve_batch_warm(bmpc_handle *h, int B, const double *p, const double *
 
 /* The same step captured once into a hipGraph (work-queue reset + solver kernel) and replayed per tick with hipGraphLaunch: the
  * buffers are fixed at capture time, the caller refreshes their contents (p, x0, state) between launches.  state may be NULL
- * (cold starts).  One graph or solve in flight per handle. */
+ * (cold starts).  One graph or solve in flight per handle.  A graph keeps the handle's workspace and the latency buffer registered
+ * at capture time: destroy graphs before their handle, re-capture after bmpc_set_latency_buffer. */
 typedef struct bmpc_graph bmpc_graph;
 int bmpc_graph_create(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g,
                       double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, bmpc_graph **out);
