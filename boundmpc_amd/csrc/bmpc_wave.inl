@@ -80,6 +80,9 @@ enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV
        L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_ZL = L_ST + 460, L_SIZE = L_ZL + 484 };
 enum { L_KKP = L_WY };
 // row descriptors of the 57 internal inequality rows (box rows: +-Z[src] - lim), built once per problem: [sgn 57 | lim 57 | src 57]
+// integrator-chain coefficients CF[fr][fc] (4 x 5) as a table: chain_cf() with a lane-dependent argument compiles into a nest of
+// branches, a table look-up is one LDS read
+enum { L_CFT = L_QT };
 // the 15x14 area of the retired cross block XT now holds: t6 (6), the row table (3 x 57), the adjoint partials (2 x 8)
 enum { L_T6 = L_XT, L_ROWT = L_XT + 8, L_RJP = L_XT + 8 + 3 * 57 + 1 /* 2 x 8: jerk residual partials of the adjoint sweep (ping-pong) */ };
 static_assert(8 + 3 * 57 + 1 + 16 <= 15 * 14, "adjoint partials must fit into the retired XT area");
@@ -481,6 +484,9 @@ BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
             L[L_ROWT + lane] = sgn; L[L_ROWT + NI + lane] = lim; L[L_ROWT + 2 * NI + lane] = (double)src;
         }
     LANES_END
+    LANES_BEGIN
+        if (lane < 20) L[L_CFT + lane] = chain_cf(W.h, lane / 5, lane % 5);
+    LANES_END
     W.ca = 2 * L[L_PAR + po.w + 5] / (W.h * W.h); W.cb = 2 * L[L_PAR + po.w + 5] / W.h;
 }
 
@@ -702,7 +708,7 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
                     else if (z >= ZPHI) { f = z - ZPHI; i = 7; }
                     if (f >= 0) {
                         const double mdd = i < 7 ? lam1[GDDQ + i] : lam1[GDDPHI];
-                        tot += chain_cf(h, 0, f) * L[L_MU + i] + chain_cf(h, 1, f) * L[L_MU + 8 + i] + chain_cf(h, 2, f) * mdd;
+                        tot += L[L_CFT + f] * L[L_MU + i] + L[L_CFT + 5 + f] * L[L_MU + 8 + i] + L[L_CFT + 10 + f] * mdd;
                         if (i < 7 && f <= 1) {
                             double e = 0;
                             for (int c = 0; c < 3; c++) e += (f == 0 ? kv[KD + (3 + c) * 7 + i] : kv[KA + c * 7 + i]) * lam1[GIW + c];
@@ -1075,45 +1081,61 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         LANES_END
         BMPC_PROF(W, 11);
         // ---- S0: PR = P' rdyn + p ; C^T P_c,iota ; P_ii E ----
+        // The five roles of this phase are written as PREDICATED straight-line code (every lane runs every role on a clamped,
+        // always-valid index; only the final stores are conditional): one basic block, so the scheduler overlaps the LDS
+        // round trips of the roles instead of running them one after the other.
         LANES_BEGIN
-            if (lane < NS) {
-                const int r = lane; BMPC_ACC4_DECL(pa);
-                if (r < 32) {
-                    const int f = r < 28 ? r / 7 : r - 28, i = r < 28 ? r % 7 : 7;
+            {   // chain rows (f,i) of PR
+                const bool on = lane < 32; const int r = on ? lane : 0;
+                const int f = r < 28 ? r / 7 : r - 28, i = r < 28 ? r % 7 : 7;
+                BMPC_ACC4_DECL(pa);
 #pragma unroll
-                    for (int l = 0; l < 8; l++)
+                for (int l = 0; l < 8; l++)
 #pragma unroll
-                        for (int g = 0; g < 3; g++) BMPC_ACC4(pa, g, L[L_PB + pbi(f, g, i, l)] * L[L_RD + srow(g, l)]);   // rdyn of the jerk states (g = 3) is zero
+                    for (int g = 0; g < 3; g++) BMPC_ACC4(pa, g, L[L_PB + pbi(f, g, i, l)] * L[L_RD + srow(g, l)]);   // rdyn of the jerk states (g = 3) is zero
 #pragma unroll
-                    for (int a = 0; a < 3; a++) BMPC_ACC4(pa, a, L[L_PCI + pci(a, f, i)] * L[L_RD + SIOTA + a]);
-                } else {
-                    const int a = r - SIOTA;
-#pragma unroll
-                    for (int l = 0; l < 8; l++)
-#pragma unroll
-                        for (int g = 0; g < 3; g++) BMPC_ACC4(pa, g, L[L_PCI + pci(a, g, l)] * L[L_RD + srow(g, l)]);
-#pragma unroll
-                    for (int b = 0; b < 3; b++) BMPC_ACC4(pa, b, L[L_PII + a * 3 + b] * L[L_RD + SIOTA + b]);
-                }
-                L[L_PR + r] = L[L_PV + r] + BMPC_ACC4_SUM(pa);
+                for (int a = 0; a < 3; a++) BMPC_ACC4(pa, a, L[L_PCI + pci(a, f, i)] * L[L_RD + SIOTA + a]);
+                const double v = L[L_PV + r] + BMPC_ACC4_SUM(pa);
+                if (on) L[L_PR + r] = v;
             }
-            if (lane < 40) {   // U[(f',i)][a] = sum_f CF[f][f'] P[(f,i)][iota_a]
-                const int fp = lane >> 3, i = lane & 7;
+            {   // iota rows of PR
+                const bool on = lane >= 32 && lane < NS; const int a = on ? lane - SIOTA : 0;
+                BMPC_ACC4_DECL(pa);
+#pragma unroll
+                for (int l = 0; l < 8; l++)
+#pragma unroll
+                    for (int g = 0; g < 3; g++) BMPC_ACC4(pa, g, L[L_PCI + pci(a, g, l)] * L[L_RD + srow(g, l)]);
+#pragma unroll
+                for (int b2 = 0; b2 < 3; b2++) BMPC_ACC4(pa, b2, L[L_PII + a * 3 + b2] * L[L_RD + SIOTA + b2]);
+                const double v = L[L_PV + SIOTA + a] + BMPC_ACC4_SUM(pa);
+                if (on) L[L_PR + SIOTA + a] = v;
+            }
+            {   // U[(f',i)][a] = sum_f CF[f][f'] P[(f,i)][iota_a]
+                const bool on = lane < 40; const int ln = on ? lane : 0, fp = ln >> 3, i = ln & 7;
+                double u[3];
+#pragma unroll
                 for (int a = 0; a < 3; a++) {
-                    double u = 0;
+                    u[a] = 0;
 #pragma unroll
-                    for (int f = 0; f < 4; f++) u += chain_cf(h, f, fp) * L[L_PCI + pci(a, f, i)];
-                    L[L_MCI + mci(a, fp, i)] = u;
+                    for (int f = 0; f < 4; f++) u[a] += L[L_CFT + f * 5 + fp] * L[L_PCI + pci(a, f, i)];
                 }
+                if (on) { L[L_MCI + mci(0, fp, i)] = u[0]; L[L_MCI + mci(1, fp, i)] = u[1]; L[L_MCI + mci(2, fp, i)] = u[2]; }
             }
-            if (lane < 42) { const int a = lane / 14, y = lane % 14; double sacc = 0; for (int b = 0; b < 3; b++) sacc += L[L_PII + a * 3 + b] * L[L_AE + b * 14 + y]; L[L_PE + lane] = sacc; }
-            if (k >= 1 && lane >= 48 && lane < 54) {   // t6 = C rdyn: the rdyn side of X^T rdyn = Gv(K1)^T (C rdyn)
-                const int c6 = lane - 48; const double *K0 = L + L_K0, *dpn = L + L_ST + ST_REF + RDP;
+            {   // PE = P_ii E
+                const bool on = lane < 42; const int ln = on ? lane : 0, a = ln / 14, y = ln % 14; double sacc = 0;
+#pragma unroll
+                for (int b2 = 0; b2 < 3; b2++) sacc += L[L_PII + a * 3 + b2] * L[L_AE + b2 * 14 + y];
+                if (on) L[L_PE + ln] = sacc;
+            }
+            {   // t6 = C rdyn: the rdyn side of X^T rdyn = Gv(K1)^T (C rdyn)
+                const bool on = k >= 1 && lane >= 48 && lane < 54; const int c6 = on ? lane - 48 : 0;
+                const double *K0 = L + L_K0, *dpn = L + L_ST + ST_REF + RDP;
                 const double *jrow = c6 < 3 ? K0 + KW + c6 * 7 : K0 + KA + (c6 - 3) * 7;
                 BMPC_ACC4_DECL(ta);
 #pragma unroll
                 for (int r = 0; r < 7; r++) { BMPC_ACC4(ta, r, K0[KD + c6 * 7 + r] * L[L_RD + r]); BMPC_ACC4(ta, r + 1, jrow[r] * L[L_RD + 7 + r]); }
-                L[L_T6 + c6] = -W.ca * BMPC_ACC4_SUM(ta) + W.cb * dpn[c6] * L[L_RD + SDDPHI];
+                const double v = -W.ca * BMPC_ACC4_SUM(ta) + W.cb * dpn[c6] * L[L_RD + SDDPHI];
+                if (on) L[L_T6 + c6] = v;
             }
         LANES_END
         BMPC_PROF(W, 21);
@@ -1124,7 +1146,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 if (fp <= 1 && i < 7) for (int a = 0; a < 3; a++) { double sacc = 0; for (int b = 0; b < 3; b++) sacc += L[L_AE + b * 14 + fp * 7 + i] * L[L_PII + b * 3 + a]; L[L_MCI + mci(a, fp, i)] += sacc; }
                 double v = 0;
 #pragma unroll
-                for (int f = 0; f < 4; f++) v += chain_cf(h, f, fp) * L[L_PR + srow(f, i)];
+                for (int f = 0; f < 4; f++) v += L[L_CFT + f * 5 + fp] * L[L_PR + srow(f, i)];
                 if (fp <= 1 && i < 7) {
                     const int y = fp * 7 + i;
                     for (int a = 0; a < 3; a++) v += L[L_AE + a * 14 + y] * L[L_PR + SIOTA + a];
@@ -1363,8 +1385,8 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
                     const double *dp_ = L + L_RED + i;   // fixed-order tree over the 8 partial sums
                     const double du_i = L[L_ST + ST_KF + i] + (((dp_[0] + dp_[8]) + (dp_[16] + dp_[24])) + ((dp_[32] + dp_[40]) + (dp_[48] + dp_[56])));
 #pragma unroll
-                    for (int fc = 0; fc < 4; fc++) v += chain_cf(h, f, fc) * ds[srow(fc, i)];
-                    v += chain_cf(h, f, 4) * du_i;
+                    for (int fc = 0; fc < 4; fc++) v += L[L_CFT + f * 5 + fc] * ds[srow(fc, i)];
+                    v += L[L_CFT + f * 5 + 4] * du_i;
                 } else {
                     const int a = r - SIOTA; v += ds[r]; BMPC_ACC4_DECL(ia);
 #pragma unroll
