@@ -83,6 +83,8 @@ enum { L_KKP = L_WY };
 // integrator-chain coefficients CF[fr][fc] (4 x 5) as a table: chain_cf() with a lane-dependent argument compiles into a nest of
 // branches, a table look-up is one LDS read
 enum { L_CFT = L_QT };
+// Z index of every reduced-state row (35): q, dq, ddq, jerk (7 each), phi, dphi, ddphi, jerk_phi, iota -> iw
+enum { L_ZMAP = L_TOT };
 // the 15x14 area of the retired cross block XT now holds: t6 (6), the row table (3 x 57), the adjoint partials (2 x 8)
 enum { L_T6 = L_XT, L_ROWT = L_XT + 8, L_RJP = L_XT + 8 + 3 * 57 + 1 /* 2 x 8: jerk residual partials of the adjoint sweep (ping-pong) */ };
 static_assert(8 + 3 * 57 + 1 + 16 <= 15 * 14, "adjoint partials must fit into the retired XT area");
@@ -486,6 +488,12 @@ BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
     LANES_END
     LANES_BEGIN
         if (lane < 20) L[L_CFT + lane] = chain_cf(W.h, lane / 5, lane % 5);
+        if (lane < NS) {
+            const int r = lane;
+            const int z = r < 7 ? ZQ + r : (r < 14 ? ZDQ + r - 7 : (r < SJ ? ZDDQ + r - SDDQ : (r < SPHI ? ZJ + r - SJ : (r == SPHI ? ZPHI : (r == SDPHI ? ZDPHI :
+                          (r == SDDPHI ? ZDDPHI : (r == SJPHI ? ZJPHI : ZIW + r - SIOTA)))))));
+            L[L_ZMAP + r] = (double)z;
+        }
     LANES_END
     W.ca = 2 * L[L_PAR + po.w + 5] / (W.h * W.h); W.cb = 2 * L[L_PAR + po.w + 5] / W.h;
 }
@@ -877,23 +885,27 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
         }
     LANES_END
     BMPC_PROF(W, 17);
-    // phase 3: Z-space gradient gl = g^ + H r + cross terms
+    // phase 3: Z-space gradient gl = g^ + H r + cross terms (predicated straight-line code: the row kinds select coefficients,
+    // not code paths)
     LANES_BEGIN
-        if (lane < NZ) {
-            const int z = lane; double g = ST[ST_GH + z];
+        {
+            const bool on = lane < NZ; const int z = on ? lane : 0;
             const double *rl = NC + NC_RL, cv = NC[NC_SC + 3], *d = rr + RDP;
-            if (z >= ZPOS && z < ZPOS + 3) { for (int b = 0; b < 3; b++) g += NC[NC_HPP + (z - ZPOS) * 3 + b] * rl[b]; }
-            else if (z == ZPHI) { for (int b = 0; b < 3; b++) g += NC[NC_HPF + b] * rl[b]; }
-            else if (z >= ZV && z < ZV + 6) {
-                const int c = z - ZV; g += cv * rl[3 + c];
-                if (k >= 1) g += -W.ca * ST[ST_RLVM + 3 + c];
-                if (has_next) g += -W.ca * ST[ST_RLVP + 3 + c];
-            } else if (z == ZDPHI) { for (int c = 0; c < 6; c++) g += -2 * w[2] * d[c] * rl[3 + c]; }
-            else if (z == ZDDPHI) {
-                for (int c = 0; c < 6; c++) g += -W.cb * d[c] * rl[3 + c];
-                if (k >= 1) for (int c = 0; c < 6; c++) g += W.cb * d[c] * ST[ST_RLVM + 3 + c];
-            }
-            NC[NC_GL + z] = g;
+            const bool isPos = z >= ZPOS && z < ZPOS + 3, isPhi = z == ZPHI, isV = z >= ZV && z < ZV + 6, isD = z == ZDPHI, isDD = z == ZDDPHI;
+            const int pa = isPos ? NC_HPP + (z - ZPOS) * 3 : NC_HPF;            // 3-vector that multiplies r_pos
+            const int c = isV ? z - ZV : 0;
+            double g = ST[ST_GH + z];
+            double sA = 0, s1 = 0, s2 = 0;
+#pragma unroll
+            for (int b2 = 0; b2 < 3; b2++) sA += NC[pa + b2] * rl[b2];
+#pragma unroll
+            for (int c6 = 0; c6 < 6; c6++) { s1 += d[c6] * rl[3 + c6]; s2 += d[c6] * ST[ST_RLVM + 3 + c6]; }
+            const double vm = k >= 1 ? ST[ST_RLVM + 3 + c] : 0.0, vp = has_next ? ST[ST_RLVP + 3 + c] : 0.0;
+            if (isPos || isPhi) g += sA;
+            else if (isV) g += cv * rl[3 + c] - W.ca * vm - W.ca * vp;
+            else if (isD) g += -2 * w[2] * s1;
+            else if (isDD) g += -W.cb * s1 + (k >= 1 ? W.cb * s2 : 0.0);
+            if (on) NC[NC_GL + z] = g;
         }
     LANES_END
     BMPC_PROF(W, 18);
@@ -967,22 +979,26 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
     LANES_END
     BMPC_PROF(W, 19);
     // phase 5: gradient q~
-    LANES_BEGIN
+    LANES_BEGIN   // predicated straight-line code: every lane evaluates the (q, dq)-row formula on a clamped row, rows >= 14 only copy
         const double *gl = NC + NC_GL;
-        if (lane < NS) {
-            const int r = lane; double v;
-            if (r < 14) {
-                const int a = r; v = gl[a < 7 ? ZQ + a : ZDQ + a - 7];
-                if (a < 7) for (int c = 0; c < 3; c++) v += K0[KW + c * 7 + a] * gl[ZPOS + c];
-                for (int c = 0; c < 3; c++) v += 0.5 * h * (a < 7 ? K0[KD + (3 + c) * 7 + a] : K0[KA + c * 7 + a - 7]) * gl[ZIW + c];
-                for (int c6 = 0; c6 < 6; c6++) v += (a < 7 ? K0[KD + c6 * 7 + a] : (c6 < 3 ? K0[KW + c6 * 7 + a - 7] : K0[KA + (c6 - 3) * 7 + a - 7])) * gl[ZV + c6];
-                if (ex) { double sW = 0; for (int b = 0; b < 14; b++) sW += WY[a * 14 + b] * NC[NC_GY + b]; v -= sW; }
-            } else if (r < SJ) v = gl[ZDDQ + r - SDDQ];
-            else if (r < SPHI) v = gl[ZJ + r - SJ];
-            else if (r == SPHI) v = gl[ZPHI]; else if (r == SDPHI) v = gl[ZDPHI]; else if (r == SDDPHI) v = gl[ZDDPHI];
-            else if (r == SJPHI) v = gl[ZJPHI];
-            else v = gl[ZIW + r - SIOTA];
-            L[L_PV + r] += v;
+        {
+            const bool on = lane < NS; const int r = on ? lane : 0;
+            const bool heavy = r < 14; const int a = heavy ? r : 0; const bool isq = a < 7; const int ai = isq ? a : a - 7;
+            const double base = gl[(int)L[L_ZMAP + r]];
+            double t1 = 0, t2 = 0, t3 = 0, sW = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                t1 += K0[KW + c * 7 + ai] * gl[ZPOS + c];
+                t2 += K0[(isq ? KD + (3 + c) * 7 : KA + c * 7) + ai] * gl[ZIW + c];
+            }
+#pragma unroll
+            for (int c6 = 0; c6 < 6; c6++) t3 += K0[(isq ? KD + c6 * 7 : (c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7)) + ai] * gl[ZV + c6];
+            if (ex) {
+#pragma unroll
+                for (int b2 = 0; b2 < 14; b2++) sW += WY[a * 14 + b2] * NC[NC_GY + b2];
+            }
+            const double v = base + (heavy ? (isq ? t1 : 0.0) + 0.5 * h * t2 + t3 - sW : 0.0);
+            if (on) L[L_PV + r] += v;
         }
     LANES_END
     BMPC_PROF(W, 20);
