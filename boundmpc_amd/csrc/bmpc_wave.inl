@@ -808,80 +808,89 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
     double *NC = L + L_NC, *K0 = L + L_K0, *KV1 = L + L_KV1, *WY = L + L_WY, *KHP = L + L_KHP;
     const bool has_next = k < N - 1;
     // phase 1: small Hessian blocks over (pos, iw, phi)
-    LANES_BEGIN
-        if (lane < 14) NC[NC_GY + lane] = lane < 7 ? gk[GQ + lane] : gk[GDQ + lane - 7];
-        if (lane >= 16 && lane < 16 + 9) {        // Hpp, Hrr: geometric part from the record + barrier terms of the tube rows
-            const int a = (lane - 16) / 3, b = (lane - 16) % 3;
+    LANES_BEGIN   // predicated straight-line code
+        {
+            const bool on = lane < 14; const int ln = on ? lane : 0; const double v = gk[ln < 7 ? GQ + ln : GDQ + ln - 7];
+            if (on) NC[NC_GY + ln] = v;
+        }
+        // tube rows: barrier weights su, sl and the gradient pieces, shared by the three roles below
+        double su[5], sl[5], g3[5], w1[5];
+#pragma unroll
+        for (int m = 0; m < 5; m++) { su[m] = sgk[ITUBE + 2 * m]; sl[m] = sgk[ITUBE + 2 * m + 1]; g3[m] = rr[RGC + m * 4 + 3]; w1[m] = rr[RW1 + m]; }
+        {   // Hpp, Hrr: geometric part from the record + barrier terms of the tube rows
+            const bool on = lane >= 16 && lane < 16 + 9; const int ln = on ? lane - 16 : 0, a = ln / 3, b = ln % 3;
             double hp = rr[RHPPG + a * 3 + b], hr = rr[RHRRG + a * 3 + b];
 #pragma unroll
             for (int m = 0; m < 5; m++) {
-                const double gg = (sgk[ITUBE + 2 * m] + sgk[ITUBE + 2 * m + 1]) * rr[RGC + m * 4 + a] * rr[RGC + m * 4 + b];
+                const double gg = (su[m] + sl[m]) * rr[RGC + m * 4 + a] * rr[RGC + m * 4 + b];
                 if (m == 1 || m == 2) hp += gg; else hr += gg;
             }
-            NC[NC_HPP + a * 3 + b] = hp; NC[NC_HRR + a * 3 + b] = hr;
+            if (on) { NC[NC_HPP + a * 3 + b] = hp; NC[NC_HRR + a * 3 + b] = hr; }
         }
-        if (lane >= 32 && lane < 35) {            // Hp,phi, Hr,phi
-            const int a = lane - 32;
+        {   // Hp,phi, Hr,phi
+            const bool on = lane >= 32 && lane < 35; const int a = on ? lane - 32 : 0;
             double hp = rr[RHPFG + a], hr = rr[RHRFG + a];
 #pragma unroll
             for (int m = 0; m < 5; m++) {
-                const double su = sgk[ITUBE + 2 * m], sl = sgk[ITUBE + 2 * m + 1];
-                const double gpu_ = rr[RGC + m * 4 + 3] - rr[RW1 + m], gpl_ = -rr[RGC + m * 4 + 3] - rr[RW1 + m];
-                const double gg = su * rr[RGC + m * 4 + a] * gpu_ - sl * rr[RGC + m * 4 + a] * gpl_;
+                const double gpu_ = g3[m] - w1[m], gpl_ = -g3[m] - w1[m];
+                const double gg = su[m] * rr[RGC + m * 4 + a] * gpu_ - sl[m] * rr[RGC + m * 4 + a] * gpl_;
                 if (m == 1 || m == 2) hp += gg; else hr += gg;
             }
-            NC[NC_HPF + a] = hp; NC[NC_HRF + a] = hr;
+            if (on) { NC[NC_HPF + a] = hp; NC[NC_HRF + a] = hr; }
         }
-        if (lane == 40) {                          // H phi,phi and the scalar curvatures
+        {   // H phi,phi and the scalar curvatures (every lane computes them, lane 40 stores)
             const double dpdp = rr[RDPDP], exm = ex ? 1.0 : 0.0;
             double hff = rr[RHFFG] + 2 * w[6] + sgk[IPHI0] + sgk[IPHIMAX];
 #pragma unroll
             for (int m = 0; m < 5; m++) {
-                const double su = sgk[ITUBE + 2 * m], sl = sgk[ITUBE + 2 * m + 1];
-                const double gpu_ = rr[RGC + m * 4 + 3] - rr[RW1 + m], gpl_ = -rr[RGC + m * 4 + 3] - rr[RW1 + m];
-                hff += su * gpu_ * gpu_ + sl * gpl_ * gpl_;
+                const double gpu_ = g3[m] - w1[m], gpl_ = -g3[m] - w1[m];
+                hff += su[m] * gpu_ * gpu_ + sl[m] * gpl_ * gpl_;
                 hff += exm * (nuk[ITUBE + 2 * m] * (rr[RC2 + m] - rr[RW2 + m]) + nuk[ITUBE + 2 * m + 1] * (-rr[RC2 + m] - rr[RW2 + m]));
             }
-            NC[NC_SC + 0] = hff;
-            NC[NC_SC + 1] = 2 * w[2] * dpdp + 2 * w[7] + sgk[IDPHIMAX];
-            NC[NC_SC + 2] = 2 * w[5] * dpdp + 2 * w[8];
-            NC[NC_SC + 3] = 2 * w[2] + W.ca * (has_next ? 2.0 : 1.0);
+            if (lane == 40) {
+                NC[NC_SC + 0] = hff;
+                NC[NC_SC + 1] = 2 * w[2] * dpdp + 2 * w[7] + sgk[IDPHIMAX];
+                NC[NC_SC + 2] = 2 * w[5] * dpdp + 2 * w[8];
+                NC[NC_SC + 3] = 2 * w[2] + W.ca * (has_next ? 2.0 : 1.0);
+            }
         }
     LANES_END
     BMPC_PROF(W, 16);
     // phase 2: A1 = Hpp Jp, A2 = (h/2) Hrr Ehat, curvature multipliers, prefix vectors of the curvature records
-    LANES_BEGIN
-        if (ex) {   // hp = [Wlt 8x3 | Vge 7x3 | Wgt 7x3] per record: one lane per (record, joint, component), three short sums each
-            const int rec = lane >> 5, jj = (lane >> 2) & 7, c = lane & 3;
-            if (c < 3) {
-                const double *R_ = rec ? KV1 : K0; double *hp = KHP + rec * 72;
-                double wlt = 0, vge = 0, wgt = 0;
+    LANES_BEGIN   // predicated straight-line code (see S0): all roles in one basic block, conditional stores only
+        {   // hp = [Wlt 8x3 | Vge 7x3 | Wgt 7x3] per record: one lane per (record, joint, component), three short sums each
+            const int rec = lane >> 5, jj = (lane >> 2) & 7, c4 = lane & 3; const bool on = ex && c4 < 3; const int c = c4 < 3 ? c4 : 0;
+            const double *R_ = rec ? KV1 : K0; double *hp = KHP + rec * 72;
+            double wlt = 0, vge = 0, wgt = 0;
 #pragma unroll
-                for (int m = 0; m < 7; m++) {
-                    const double dqm = R_[KDQ + m], am = R_[KA + c * 7 + m], wm = R_[KW + c * 7 + m];
-                    wlt += (m < jj ? dqm : 0.0) * am; vge += (m >= jj ? dqm : 0.0) * wm; wgt += (m > jj ? dqm : 0.0) * am;
-                }
-                hp[3 * jj + c] = wlt;
-                if (jj < 7) { hp[24 + 3 * jj + c] = vge; hp[45 + 3 * jj + c] = wgt; }
+            for (int m = 0; m < 7; m++) {
+                const double dqm = R_[KDQ + m], am = R_[KA + c * 7 + m], wm = R_[KW + c * 7 + m];
+                wlt += (m < jj ? dqm : 0.0) * am; vge += (m >= jj ? dqm : 0.0) * wm; wgt += (m > jj ? dqm : 0.0) * am;
             }
+            if (on) { hp[3 * jj + c] = wlt; if (jj < 7) { hp[24 + 3 * jj + c] = vge; hp[45 + 3 * jj + c] = wgt; } }
         }
-        if (lane < 9) NC[NC_RL + lane] = ST[ST_RLV0 + lane];
-        else if (lane >= 16 && lane < 16 + 21) {
-            const int c = (lane - 16) / 7, i = (lane - 16) % 7; double s = 0;
-            for (int b = 0; b < 3; b++) s += NC[NC_HPP + c * 3 + b] * K0[KW + b * 7 + i];
-            NC[NC_A1 + c * 7 + i] = s;
+        {   // r_pos, r_v of this node next to the work blocks
+            const bool on = lane < 9; const double v = ST[ST_RLV0 + (on ? lane : 0)];
+            if (on) NC[NC_RL + lane] = v;
         }
-        if (lane < 42) {
-            const int c = lane / 14, y = lane % 14; double s = 0;
-            for (int b = 0; b < 3; b++) s += NC[NC_HRR + c * 3 + b] * (y < 7 ? K0[KD + (3 + b) * 7 + y] : K0[KA + b * 7 + y - 7]);
-            NC[NC_A2 + c * 14 + y] = 0.5 * h * s;
+        {   // A1 = Hpp Jp (3 x 7)
+            const bool on = lane >= 16 && lane < 16 + 21; const int ln = on ? lane - 16 : 0, c = ln / 7, i = ln % 7; double sacc = 0;
+#pragma unroll
+            for (int b2 = 0; b2 < 3; b2++) sacc += NC[NC_HPP + c * 3 + b2] * K0[KW + b2 * 7 + i];
+            if (on) NC[NC_A1 + c * 7 + i] = sacc;
         }
-        if (lane >= 48 && lane < 60) {
-            const int c = (lane - 48) % 3, g = (lane - 48) / 3; const double *lam = ST + ST_LAM0;
-            double v = 0;
-            if (g == 0) v = lam[GPOS + c]; else if (g == 1) v = lam[GV + c]; else if (g == 2) v = lam[GW + c] + 0.5 * h * lam[GIW + c];
-            else v = has_next ? 0.5 * h * ST[ST_LAM1 + GIW + c] : 0.0;
-            L[L_MU + 4 + (lane - 48)] = v;
+        {   // A2 = (h/2) Hrr Ehat (3 x 14)
+            const bool on = lane < 42; const int ln = on ? lane : 0, c = ln / 14, y = ln % 14; double sacc = 0;
+            const int eb = y < 7 ? KD + 21 + y : KA + y - 7;                 // Ehat column y: rows at stride 7
+#pragma unroll
+            for (int b2 = 0; b2 < 3; b2++) sacc += NC[NC_HRR + c * 3 + b2] * K0[eb + b2 * 7];
+            if (on) NC[NC_A2 + c * 14 + y] = 0.5 * h * sacc;
+        }
+        {   // curvature multipliers mu_p, mu_v, mu_w (this node) and mu_w of the next node's velocity point
+            const bool on = lane >= 48 && lane < 60; const int ln = on ? lane - 48 : 0, c = ln % 3, g = ln / 3; const double *lam = ST + ST_LAM0;
+            const double lp = lam[GPOS + c], lv = lam[GV + c], lw = lam[GW + c], li = lam[GIW + c], ln1 = ST[ST_LAM1 + GIW + c];
+            const double v = g == 0 ? lp : (g == 1 ? lv : (g == 2 ? lw + 0.5 * h * li : (has_next ? 0.5 * h * ln1 : 0.0)));
+            if (on) L[L_MU + 4 + ln] = v;
         }
     LANES_END
     BMPC_PROF(W, 17);
@@ -1077,22 +1086,25 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         BMPC_PROF(W, 5);
         // ---- stage data: rdyn, iota coupling AE (3x14).  The acceleration cross block XT = C^T Gv(K1) (15x14, rank 6) is never
         //      formed: its consumers contract the two rank-6 factors on the fly (t6 below, chain-pair entries in S1) ----
-        LANES_BEGIN
+        LANES_BEGIN   // predicated straight-line code
             const double *K0 = L + L_K0, *K1 = L + L_K1, *KVk = L + L_KV, *gk = L + L_ST + ST_G;
-            if (lane < NS) {
-                const int r = lane; double v = 0;
-                if (r < SJ) v = gk[r];
-                else if (r >= SPHI && r <= SDDPHI) v = gk[GPHI + r - SPHI];
-                else if (r >= SIOTA) {
-                    const int c = r - SIOTA; v = gk[GIW + c];
-                    for (int i = 0; i < 7; i++) v -= 0.5 * h * (K0[KD + (3 + c) * 7 + i] * gk[GQ + i] + K0[KA + c * 7 + i] * gk[GDQ + i]);
-                }
-                L[L_RD + r] = v; G[sc.RDY + k * 36 + r] = v;
+            {
+                const bool on = lane < NS; const int r = on ? lane : 0;
+                const bool io = r >= SIOTA; const int c = io ? r - SIOTA : 0;
+                const int gsrc = r < SJ ? r : ((r >= SPHI && r <= SDDPHI) ? GPHI + r - SPHI : (io ? GIW + c : 0));
+                const double gval = gk[gsrc];
+                BMPC_ACC4_DECL(ia);
+#pragma unroll
+                for (int i = 0; i < 7; i++) { BMPC_ACC4(ia, i, K0[KD + (3 + c) * 7 + i] * gk[GQ + i]); BMPC_ACC4(ia, i + 1, K0[KA + c * 7 + i] * gk[GDQ + i]); }
+                const bool zero = (r >= SJ && r < SPHI) || r == SJPHI;          // jerk states carry no defect
+                const double v = zero ? 0.0 : (io ? gval - 0.5 * h * BMPC_ACC4_SUM(ia) : gval);
+                if (on) { L[L_RD + r] = v; G[sc.RDY + k * 36 + r] = v; }
             }
-            if (lane < 42) {
-                const int a = lane / 14, y = lane % 14; double v = 0;
-                if (k >= 1) v = 0.5 * h * (y < 7 ? K1[KD + (3 + a) * 7 + y] + KVk[KD + (3 + a) * 7 + y] : K1[KA + a * 7 + y - 7] + KVk[KA + a * 7 + y - 7]);
-                L[L_AE + lane] = v; G[sc.AES + k * 42 + lane] = v;
+            {
+                const bool on = lane < 42; const int ln = on ? lane : 0, a = ln / 14, y = ln % 14;
+                const int eb = y < 7 ? KD + (3 + a) * 7 + y : KA + a * 7 + y - 7;
+                const double v = k >= 1 ? 0.5 * h * (K1[eb] + KVk[eb]) : 0.0;
+                if (on) { L[L_AE + ln] = v; G[sc.AES + k * 42 + ln] = v; }
             }
         LANES_END
         BMPC_PROF(W, 11);
@@ -1156,25 +1168,39 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         LANES_END
         BMPC_PROF(W, 21);
         // ---- S0b: M_c,iota = U + E^T P_ii ; gradient column m = F^T PR + S^T X^T rdyn ----
-        LANES_BEGIN
-            if (lane < 40) {
-                const int fp = lane >> 3, i = lane & 7;
-                if (fp <= 1 && i < 7) for (int a = 0; a < 3; a++) { double sacc = 0; for (int b = 0; b < 3; b++) sacc += L[L_AE + b * 14 + fp * 7 + i] * L[L_PII + b * 3 + a]; L[L_MCI + mci(a, fp, i)] += sacc; }
-                double v = 0;
+        LANES_BEGIN   // predicated straight-line code
+            {
+                const bool on = lane < 40; const int ln = on ? lane : 0, fp = ln >> 3, i = ln & 7;
+                const bool yq = fp <= 1 && i < 7;                   // (q, dq) rows couple with iota through E and with the next node through X
+                const int y = yq ? fp * 7 + i : 0, ic = i < 7 ? i : 0;
+                double mc3[3];
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    double sacc = 0;
+#pragma unroll
+                    for (int b2 = 0; b2 < 3; b2++) sacc += L[L_AE + b2 * 14 + y] * L[L_PII + b2 * 3 + a];
+                    mc3[a] = L[L_MCI + mci(a, fp, i)] + sacc;
+                }
+                double v = 0, ve = 0, sx = 0;
 #pragma unroll
                 for (int f = 0; f < 4; f++) v += L[L_CFT + f * 5 + fp] * L[L_PR + srow(f, i)];
-                if (fp <= 1 && i < 7) {
-                    const int y = fp * 7 + i;
-                    for (int a = 0; a < 3; a++) v += L[L_AE + a * 14 + y] * L[L_PR + SIOTA + a];
-                    if (k >= 1) {
-                        const double *K1 = L + L_K1; double sx = 0;
 #pragma unroll
-                        for (int c6 = 0; c6 < 6; c6++) sx += (fp == 0 ? K1[KD + c6 * 7 + i] : (c6 < 3 ? K1[KW + c6 * 7 + i] : K1[KA + (c6 - 3) * 7 + i])) * L[L_T6 + c6];
-                        v += sx;
-                    }
+                for (int a = 0; a < 3; a++) ve += L[L_AE + a * 14 + y] * L[L_PR + SIOTA + a];
+                {
+                    const double *K1 = L + L_K1;
+#pragma unroll
+                    for (int c6 = 0; c6 < 6; c6++) sx += K1[(fp == 0 ? KD + c6 * 7 : (c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7)) + ic] * L[L_T6 + c6];
                 }
-                if (fp < 4) L[L_MV + srow(fp, i)] = v; else L[L_GS + i * 36 + 35] = v;
-            } else if (lane < 43) L[L_MV + SIOTA + lane - 40] = L[L_PR + SIOTA + lane - 40];
+                if (yq) { v += ve; if (k >= 1) v += sx; }
+                if (on) {
+                    if (yq) { L[L_MCI + mci(0, fp, i)] = mc3[0]; L[L_MCI + mci(1, fp, i)] = mc3[1]; L[L_MCI + mci(2, fp, i)] = mc3[2]; }
+                    if (fp < 4) L[L_MV + srow(fp, i)] = v; else L[L_GS + i * 36 + 35] = v;
+                }
+            }
+            {
+                const bool on = lane >= 40 && lane < 43; const int a = on ? lane - 40 : 0; const double v = L[L_PR + SIOTA + a];
+                if (on) L[L_MV + SIOTA + a] = v;
+            }
         LANES_END
         LANES_BEGIN   // jerk rows of the iota columns: M[u_i][iota_a] = M_c,iota[(4,i)][a]
             if (lane < 24) { const int i = lane & 7, a = lane >> 3; L[L_GS + i * 36 + SIOTA + a] = L[L_MCI + mci(a, 4, i)]; }
