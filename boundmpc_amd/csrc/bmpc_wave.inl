@@ -918,68 +918,82 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
         }
     LANES_END
     BMPC_PROF(W, 18);
-    // phase 4: one lane per chain pair adds its block of Q~ (and writes the predicted-point curvature to WY for q~)
+    // phase 4: one lane per chain pair adds its block of Q~ (and writes the predicted-point curvature to WY for q~).
+    // Predicated: every lane evaluates the joint-pair block AND the joint/phi coupling on clamped chain indices (all loads up
+    // front, one basic block), the pair kind only selects what is stored.
     LANES_BEGIN
         const int i = lane >> 3, l = lane & 7, ci = i < l ? i : l, cl = i < l ? l : i; const bool tr = i > l;
+        const bool both = cl < 7, mix = !both && ci < 7;
+        const int cic = ci < 7 ? ci : 0, clc = cl < 7 ? cl : 0;
         const double *A1 = NC + NC_A1, *A2 = NC + NC_A2, cv = NC[NC_SC + 3], *d = rr + RDP;
-        if (cl < 7) {
-            double e[2][2];
+        double e[2][2], wpv[2][2], vf[2], vd[2], vdd[2];
+        // Gv columns of the two chains: [D | J] columns (q part f = 0, dq part f = 1)
+        double gi[2][6], gl_[2][6];
 #pragma unroll
-            for (int f = 0; f < 2; f++) {
+        for (int c6 = 0; c6 < 6; c6++) {
+            const int jo = c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7;
+            gi[0][c6] = K0[KD + c6 * 7 + cic]; gi[1][c6] = K0[jo + cic];
+            gl_[0][c6] = K0[KD + c6 * 7 + clc]; gl_[1][c6] = K0[jo + clc];
+        }
 #pragma unroll
-                for (int g = 0; g < 2; g++) {
-                    const int a = f * 7 + ci, b = g * 7 + cl;
-                    double v = 0;
-                    if (f == 0 && g == 0) for (int c = 0; c < 3; c++) v += K0[KW + c * 7 + ci] * A1[c * 7 + cl];
-                    for (int c = 0; c < 3; c++) v += 0.5 * h * (f == 0 ? K0[KD + (3 + c) * 7 + ci] : K0[KA + c * 7 + ci]) * A2[c * 14 + b];
-                    double gv = 0;
-                    for (int c6 = 0; c6 < 6; c6++) {
-                        const double ga = f == 0 ? K0[KD + c6 * 7 + ci] : (c6 < 3 ? K0[KW + c6 * 7 + ci] : K0[KA + (c6 - 3) * 7 + ci]);
-                        const double gb = g == 0 ? K0[KD + c6 * 7 + cl] : (c6 < 3 ? K0[KW + c6 * 7 + cl] : K0[KA + (c6 - 3) * 7 + cl]);
-                        gv += ga * gb;
-                    }
-                    v += cv * gv;
-                    double wp = 0, wn = 0;
-                    if (ex && !(f == 1 && g == 1)) {
-                        const double z3[3] = {0, 0, 0};
-                        if (f == 0 && g == 0) { wp = kh_qq(K0, KHP, L + L_MU + 4, L + L_MU + 7, L + L_MU + 10, ci, cl);
-                                                if (has_next) wn = kh_qq(KV1, KHP + 72, z3, z3, L + L_MU + 13, ci, cl); }
-                        else { const int qi = f == 0 ? ci : cl, dj = f == 0 ? cl : ci;
-                               wp = kh_qdq(K0, L + L_MU + 7, L + L_MU + 10, qi, dj);
-                               if (has_next) wn = kh_qdq(KV1, z3, L + L_MU + 13, qi, dj); }
-                    }
-                    WY[a * 14 + b] = wp; WY[b * 14 + a] = wp;
-                    e[f][g] = v + wp + wn;
+        for (int f = 0; f < 2; f++) {
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const int b = g * 7 + clc;
+                double v = 0;
+                if (f == 0 && g == 0) for (int c = 0; c < 3; c++) v += K0[KW + c * 7 + cic] * A1[c * 7 + clc];
+#pragma unroll
+                for (int c = 0; c < 3; c++) v += 0.5 * h * gi[f][3 + c] * A2[c * 14 + b];      // Ehat columns are the rotational rows 3..5 of Gv
+                double gv = 0;
+#pragma unroll
+                for (int c6 = 0; c6 < 6; c6++) gv += gi[f][c6] * gl_[g][c6];
+                v += cv * gv;
+                double wp = 0, wn = 0;
+                if (ex && !(f == 1 && g == 1)) {
+                    const double z3[3] = {0, 0, 0};
+                    if (f == 0 && g == 0) { wp = kh_qq(K0, KHP, L + L_MU + 4, L + L_MU + 7, L + L_MU + 10, cic, clc);
+                                            if (has_next) wn = kh_qq(KV1, KHP + 72, z3, z3, L + L_MU + 13, cic, clc); }
+                    else { const int qi = f == 0 ? cic : clc, dj = f == 0 ? clc : cic;
+                           wp = kh_qdq(K0, L + L_MU + 7, L + L_MU + 10, qi, dj);
+                           if (has_next) wn = kh_qdq(KV1, z3, L + L_MU + 13, qi, dj); }
                 }
+                wpv[f][g] = wp;
+                e[f][g] = v + wp + wn;
             }
+            // coupling of (q, dq) of chain ci with (phi, dphi, ddphi)
+            double f1 = 0, f2 = 0, dsum = 0;
+            if (f == 0) for (int c = 0; c < 3; c++) f1 += K0[KW + c * 7 + cic] * NC[NC_HPF + c];
+#pragma unroll
+            for (int c = 0; c < 3; c++) f2 += gi[f][3 + c] * NC[NC_HRF + c];
+#pragma unroll
+            for (int c6 = 0; c6 < 6; c6++) dsum += d[c6] * gi[f][c6];
+            vf[f] = f1 + 0.5 * h * f2; vd[f] = -2 * w[2] * dsum; vdd[f] = -W.cb * dsum;
+        }
+        const double dq0 = 2 * w[10] + sgk[IQU + cic] + sgk[IQL + cic] + delta, dq1 = 2 * w[11] + sgk[IDQU + cic] + sgk[IDQL + cic] + delta,
+                     dq2 = 2 * w[12] + delta, dq3 = 2 * w[13] + sgk[IJU + cic] + sgk[IJL + cic] + delta;
+        const double p0 = NC[NC_SC + 0] + delta, p1 = NC[NC_SC + 1] + delta, p2 = NC[NC_SC + 2] + delta, p3 = 2 * w[9] + sgk[IJU + 7] + sgk[IJL + 7] + delta;
+        // ---- stores ----
+        if (both) {
+#pragma unroll
+            for (int f = 0; f < 2; f++)
+#pragma unroll
+                for (int g = 0; g < 2; g++) { const int a = f * 7 + ci, b = g * 7 + cl; WY[a * 14 + b] = wpv[f][g]; WY[b * 14 + a] = wpv[f][g]; }
             if (ci == cl) {
-                e[1][0] = e[0][1];
-                e[0][0] += 2 * w[10] + sgk[IQU + ci] + sgk[IQL + ci] + delta;
-                e[1][1] += 2 * w[11] + sgk[IDQU + ci] + sgk[IDQL + ci] + delta;
-                L[L_PB + pbi(2, 2, i, l)] += 2 * w[12] + delta;
-                L[L_PB + pbi(3, 3, i, l)] += 2 * w[13] + sgk[IJU + ci] + sgk[IJL + ci] + delta;
+                e[1][0] = e[0][1]; e[0][0] += dq0; e[1][1] += dq1;
+                L[L_PB + pbi(2, 2, i, l)] += dq2; L[L_PB + pbi(3, 3, i, l)] += dq3;
             }
 #pragma unroll
             for (int f = 0; f < 2; f++)
 #pragma unroll
                 for (int g = 0; g < 2; g++) L[L_PB + pbi(f, g, i, l)] += tr ? e[g][f] : e[f][g];
-        } else if (ci < 7) {          // coupling of (q, dq) of chain ci with (phi, dphi, ddphi)
+        } else if (mix) {
 #pragma unroll
             for (int f = 0; f < 2; f++) {
-                double vf = 0, vd = 0, vdd = 0;
-                if (f == 0) for (int c = 0; c < 3; c++) vf += K0[KW + c * 7 + ci] * NC[NC_HPF + c];
-                for (int c = 0; c < 3; c++) vf += 0.5 * h * (f == 0 ? K0[KD + (3 + c) * 7 + ci] : K0[KA + c * 7 + ci]) * NC[NC_HRF + c];
-                for (int c6 = 0; c6 < 6; c6++) {
-                    const double ga = f == 0 ? K0[KD + c6 * 7 + ci] : (c6 < 3 ? K0[KW + c6 * 7 + ci] : K0[KA + (c6 - 3) * 7 + ci]);
-                    vd += -2 * w[2] * d[c6] * ga; vdd += -W.cb * d[c6] * ga;
-                }
-                if (!tr) { L[L_PB + pbi(f, 0, i, l)] += vf; L[L_PB + pbi(f, 1, i, l)] += vd; L[L_PB + pbi(f, 2, i, l)] += vdd; }
-                else     { L[L_PB + pbi(0, f, i, l)] += vf; L[L_PB + pbi(1, f, i, l)] += vd; L[L_PB + pbi(2, f, i, l)] += vdd; }
+                if (!tr) { L[L_PB + pbi(f, 0, i, l)] += vf[f]; L[L_PB + pbi(f, 1, i, l)] += vd[f]; L[L_PB + pbi(f, 2, i, l)] += vdd[f]; }
+                else     { L[L_PB + pbi(0, f, i, l)] += vf[f]; L[L_PB + pbi(1, f, i, l)] += vd[f]; L[L_PB + pbi(2, f, i, l)] += vdd[f]; }
             }
         } else {                      // path-parameter chain with itself
-            L[L_PB + pbi(0, 0, 7, 7)] += NC[NC_SC + 0] + delta; L[L_PB + pbi(1, 1, 7, 7)] += NC[NC_SC + 1] + delta;
-            L[L_PB + pbi(2, 2, 7, 7)] += NC[NC_SC + 2] + delta;
-            L[L_PB + pbi(3, 3, 7, 7)] += 2 * w[9] + sgk[IJU + 7] + sgk[IJL + 7] + delta;
+            L[L_PB + pbi(0, 0, 7, 7)] += p0; L[L_PB + pbi(1, 1, 7, 7)] += p1; L[L_PB + pbi(2, 2, 7, 7)] += p2; L[L_PB + pbi(3, 3, 7, 7)] += p3;
         }
         // iota couplings
         if (lane < 14) { const int f = lane / 7, ii = lane % 7; for (int a = 0; a < 3; a++) L[L_PCI + pci(a, f, ii)] += A2[a * 14 + lane]; }
