@@ -704,38 +704,39 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
                 stage_mu(W, lam1, L + L_K0, lane);
             LANES_END
         }
-        LANES_BEGIN
-            if (lane < NZ) {
-                const int z = lane;
+        LANES_BEGIN   // predicated: the component kind selects coefficients (integer selects), not code paths
+            {
+                const bool on = lane < NZ; const int z = on ? lane : 0;
+                const double *kv = L + L_KV;
+                // field f (0 q, 1 dq, 2 ddq, 3 jerk) and chain i of this component; f = -1: lifted variable (pos, iw, v)
+                const int f = z < 7 ? 3 : (z == ZJPHI ? 3 : (z < ZDQ ? 0 : (z < ZDDQ ? 1 : (z < ZPOS ? 2 : (z >= ZPHI ? z - ZPHI : -1)))));
+                const int i = z < 7 ? z : (z == ZJPHI ? 7 : (z < ZDQ ? z - ZQ : (z < ZDDQ ? z - ZDQ : (z < ZPOS ? z - ZDDQ : (z >= ZPHI ? 7 : 0)))));
+                const bool has = f >= 0, nxt = k < N - 1; const int fc = has ? f : 0, i7 = i < 7 ? i : 0;
+                const bool isIw = z >= ZIW && z < ZIW + 3; const int cw = isIw ? z - ZIW : 0;
+                const double mdd = lam1[i < 7 ? GDDQ + i : GDDPHI];
+                const double chainv = L[L_CFT + fc] * L[L_MU + i] + L[L_CFT + 5 + fc] * L[L_MU + 8 + i] + L[L_CFT + 10 + fc] * mdd;
+                const int eb = fc == 0 ? KD + 21 + i7 : KA + i7;                    // Ehat column of (q_i) or (dq_i): rows at stride 7
+                double e = 0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) e += kv[eb + c * 7] * lam1[GIW + c];
                 double tot = L[L_ST + ST_GH + z];
-                if (k < N - 1) {
-                    const double *kv = L + L_KV;
-                    int f = -1, i = 0;   // field / chain of this component
-                    if (z < 7) { f = 3; i = z; } else if (z == ZJPHI) { f = 3; i = 7; }
-                    else if (z < ZDQ) { f = 0; i = z - ZQ; } else if (z < ZDDQ) { f = 1; i = z - ZDQ; } else if (z < ZPOS) { f = 2; i = z - ZDDQ; }
-                    else if (z >= ZPHI) { f = z - ZPHI; i = 7; }
-                    if (f >= 0) {
-                        const double mdd = i < 7 ? lam1[GDDQ + i] : lam1[GDDPHI];
-                        tot += L[L_CFT + f] * L[L_MU + i] + L[L_CFT + 5 + f] * L[L_MU + 8 + i] + L[L_CFT + 10 + f] * mdd;
-                        if (i < 7 && f <= 1) {
-                            double e = 0;
-                            for (int c = 0; c < 3; c++) e += (f == 0 ? kv[KD + (3 + c) * 7 + i] : kv[KA + c * 7 + i]) * lam1[GIW + c];
-                            tot += 0.5 * h * e;
-                        }
-                    } else if (z >= ZIW && z < ZIW + 3) tot += lam1[GIW + z - ZIW];
+                if (nxt) tot += has ? chainv + ((i < 7 && fc <= 1) ? 0.5 * h * e : 0.0) : (isIw ? lam1[GIW + cw] : 0.0);
+                if (on) {
+                    // jerk rows: the residual of node k still lacks the term of the NEXT sweep step (stage k-1 -> k); it is parked in LDS
+                    // and completed there -- a global read-modify-write would wait for this store to land and come back
+                    if (z < 7) L[L_RJP + (k & 1) * 8 + z] = tot;
+                    else if (z == ZJPHI) L[L_RJP + (k & 1) * 8 + 7] = tot;
+                    else {
+                        const int ee = z < ZPOS ? z - ZQ : (z < ZPHI ? GPOS + (z - ZPOS) : GPHI + (z - ZPHI));
+                        G[sc.LAM + k * NE + ee] = tot; lam0[ee] = tot;
+                    }
                 }
-                // jerk rows: the residual of node k still lacks the term of the NEXT sweep step (stage k-1 -> k); it is parked in LDS
-                // and completed there -- a global read-modify-write would wait for this store to land and come back
-                if (z < 7) L[L_RJP + (k & 1) * 8 + z] = tot;
-                else if (z == ZJPHI) L[L_RJP + (k & 1) * 8 + 7] = tot;
-                else {
-                    const int e = z < ZPOS ? z - ZQ : (z < ZPHI ? GPOS + (z - ZPOS) : GPHI + (z - ZPHI));
-                    G[sc.LAM + k * NE + e] = tot; lam0[e] = tot;
-                }
-            } else if (lane < NZ + 8 && k < N - 1) {   // jerk of node k+2 enters stage k+1
-                const int i = lane - NZ;
-                const double mdd = i < 7 ? lam1[GDDQ + i] : lam1[GDDPHI];
-                G[sc.RJ + (k + 1) * NU + i] = L[L_RJP + ((k + 1) & 1) * 8 + i] + (h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd);
+            }
+            {   // jerk of node k+2 enters stage k+1
+                const bool on = lane >= NZ && lane < NZ + 8 && k < N - 1; const int i = on ? lane - NZ : 0;
+                const double mdd = lam1[i < 7 ? GDDQ + i : GDDPHI];
+                const double v = L[L_RJP + ((k + 1) & 1) * 8 + i] + (h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd);
+                if (on) G[sc.RJ + (k + 1) * NU + i] = v;
             }
         LANES_END
     }
@@ -1432,44 +1433,43 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
                 L[L_RED + part * 8 + u] = acc;
             }
         LANES_END
-        LANES_BEGIN
-            if (lane < NS) {
-                const int r = lane; double v = L[L_ST + ST_RDY + r];
-                const double *ds = L + L_DS;
-                if (r < 28 || (r >= SPHI && r <= SJPHI)) {
-                    const int f = r < 28 ? r / 7 : r - 28, i = r < 28 ? r % 7 : 7;
-                    const double *dp_ = L + L_RED + i;   // fixed-order tree over the 8 partial sums
-                    const double du_i = L[L_ST + ST_KF + i] + (((dp_[0] + dp_[8]) + (dp_[16] + dp_[24])) + ((dp_[32] + dp_[40]) + (dp_[48] + dp_[56])));
+        LANES_BEGIN   // next reduced state, predicated: chain rows and iota rows evaluated by every lane on clamped indices
+            {
+                const bool on = lane < NS; const int r = on ? lane : 0;
+                const bool chain = r < 28 || (r >= SPHI && r <= SJPHI);
+                const int f = r < 28 ? r / 7 : (chain ? r - 28 : 0), i = r < 28 ? r % 7 : 7, a = chain ? 0 : r - SIOTA;
+                const double *ds = L + L_DS, *dp_ = L + L_RED + i;   // fixed-order tree over the 8 partial sums of du
+                const double du_i = L[L_ST + ST_KF + i] + (((dp_[0] + dp_[8]) + (dp_[16] + dp_[24])) + ((dp_[32] + dp_[40]) + (dp_[48] + dp_[56])));
+                double vc = 0;
 #pragma unroll
-                    for (int fc = 0; fc < 4; fc++) v += L[L_CFT + f * 5 + fc] * ds[srow(fc, i)];
-                    v += L[L_CFT + f * 5 + 4] * du_i;
-                } else {
-                    const int a = r - SIOTA; v += ds[r]; BMPC_ACC4_DECL(ia);
+                for (int fc = 0; fc < 4; fc++) vc += L[L_CFT + f * 5 + fc] * ds[srow(fc, i)];
+                vc += L[L_CFT + f * 5 + 4] * du_i;
+                BMPC_ACC4_DECL(ia);
 #pragma unroll
-                    for (int y = 0; y < 14; y++) BMPC_ACC4(ia, y, L[L_ST + ST_AES + a * 14 + y] * ds[y]);
-                    v += BMPC_ACC4_SUM(ia);
-                }
-                L[L_DSN + r] = v;
+                for (int y = 0; y < 14; y++) BMPC_ACC4(ia, y, L[L_ST + ST_AES + a * 14 + y] * ds[y]);
+                const double v = L[L_ST + ST_RDY + r] + (chain ? vc : ds[r] + BMPC_ACC4_SUM(ia));
+                if (on) L[L_DSN + r] = v;
             }
         LANES_END
-        LANES_BEGIN
-            if (lane < NZ) {
-                const int z = lane; const double *dn = L + L_DSN, *K0 = L + L_K0, *rlv = L + L_ST + ST_RLVF; double v;
-                if (z < 7) v = dn[SJ + z]; else if (z == ZJPHI) v = dn[SJPHI];
-                else if (z < ZPOS) v = dn[z - ZQ];
-                else if (z < ZIW) { const int c = z - ZPOS; v = rlv[c];
+        LANES_BEGIN   // dZ of the stage, predicated: v = add + scale (P1 . dq_part + m2 P2 . ddq_part); copy rows have scale 0
+            {
+                const bool on = lane < NZ; const int z = on ? lane : 0;
+                const double *dn = L + L_DSN, *K0 = L + L_K0, *rlv = L + L_ST + ST_RLVF;
+                const bool isPos = z >= ZPOS && z < ZIW, isIw = z >= ZIW && z < ZV, isV = z >= ZV && z < ZPHI;
+                const int c = isPos ? z - ZPOS : (isIw ? z - ZIW : (isV ? z - ZV : 0));            // c6 for the v rows
+                const int src = z < 7 ? SJ + z : (z == ZJPHI ? SJPHI : (z < ZPOS ? z - ZQ : (z >= ZPHI ? SPHI + z - ZPHI : (isIw ? SIOTA + c : 0))));
+                const int p1 = isPos ? KW + c * 7 : (isIw ? KD + (3 + c) * 7 : KD + c * 7);
+                const int p2 = isIw ? KA + c * 7 : (c < 3 ? KW + c * 7 : KA + (c - 3) * 7);
+                BMPC_ACC4_DECL(za);
 #pragma unroll
-                    for (int i = 0; i < 7; i++) v += K0[KW + c * 7 + i] * dn[SQ + i]; }
-                else if (z < ZV) { const int c = z - ZIW; BMPC_ACC4_DECL(za);
+                for (int i = 0; i < 7; i++) { BMPC_ACC4(za, i, K0[p1 + i] * dn[SQ + i]); }
+                BMPC_ACC4_DECL(zb);
 #pragma unroll
-                    for (int i = 0; i < 7; i++) { BMPC_ACC4(za, i, K0[KD + (3 + c) * 7 + i] * dn[SQ + i]); BMPC_ACC4(za, i + 2, K0[KA + c * 7 + i] * dn[SDQ + i]); }
-                    v = dn[SIOTA + c] + 0.5 * h * BMPC_ACC4_SUM(za); }
-                else if (z < ZPHI) { const int c6 = z - ZV; BMPC_ACC4_DECL(va);
-#pragma unroll
-                    for (int y = 0; y < 14; y++) BMPC_ACC4(va, y, gv_at(K0, c6, y) * dn[y]);
-                    v = rlv[3 + c6] + BMPC_ACC4_SUM(va); }
-                else v = dn[SPHI + z - ZPHI];
-                W.Dz[k * NZ + z] = v;
+                for (int i = 0; i < 7; i++) { BMPC_ACC4(zb, i, K0[p2 + i] * dn[SDQ + i]); }
+                const double s1 = BMPC_ACC4_SUM(za), s2 = BMPC_ACC4_SUM(zb);
+                const double addv = (isPos || isV) ? rlv[isPos ? c : 3 + c] : dn[src];
+                const double v = isPos ? addv + s1 : (isIw ? addv + 0.5 * h * (s1 + s2) : (isV ? addv + (s1 + s2) : addv));
+                if (on) W.Dz[k * NZ + z] = v;
             }
             if (lane < 36) L[L_DS + lane] = lane < NS ? L[L_DSN + lane] : 0.0;
         LANES_END
