@@ -1369,21 +1369,34 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 #pragma unroll
                         for (int g = 0; g < f; g++) C[f][g] = C[g][f];
                 }
+                // the small roles (chain x iota, iota x iota, gradient) are predicated and evaluated BEFORE any store of this phase,
+                // so that all LDS reads of the phase can be in flight together
+                const int lf = (lane & 31) >> 3, lii = lane & 7;
+                double ci3[3];
+#pragma unroll
+                for (int b2 = 0; b2 < 3; b2++) {
+                    double sacc = L[L_MCI + mci(b2, lf, lii)];
+#pragma unroll
+                    for (int a = 0; a < NU; a++) sacc += L[L_GS + a * 36 + srow(lf, lii)] * L[L_KS + a * 36 + SIOTA + b2];
+                    ci3[b2] = sacc;
+                }
+                const bool onII = lane >= 32 && lane < 32 + 6; const int t = onII ? lane - 32 : 0;
+                const int ib = t < 3 ? 0 : (t < 5 ? 1 : 2), ic = t < 3 ? t : (t < 5 ? t - 2 : 2);
+                double pii = L[L_PII + ib * 3 + ic];
+#pragma unroll
+                for (int a = 0; a < NU; a++) pii += L[L_GS + a * 36 + SIOTA + ib] * L[L_KS + a * 36 + SIOTA + ic];
+                const bool onPV = lane < NS; const int pr_ = onPV ? lane : 0;
+                double pvv = L[L_MV + pr_];
+#pragma unroll
+                for (int a = 0; a < NU; a++) pvv += L[L_GS + a * 36 + pr_] * L[L_KS + a * 36 + 35];
+                // ---- stores ----
 #pragma unroll
                 for (int f = 0; f < 4; f++)
 #pragma unroll
                     for (int g = 0; g < 4; g++) L[L_PB + pbi(f, g, i, l)] = tr ? C[g][f] : C[f][g];
-                if (lane < 32) {   // chain x iota
-                    const int f = lane >> 3, ii = lane & 7;
-                    for (int b = 0; b < 3; b++) { double sacc = L[L_MCI + mci(b, f, ii)]; for (int a = 0; a < NU; a++) sacc += L[L_GS + a * 36 + srow(f, ii)] * L[L_KS + a * 36 + SIOTA + b]; L[L_PCI + pci(b, f, ii)] = sacc; }
-                } else if (lane < 32 + 6) {   // iota x iota, upper triangle mirrored
-                    const int t = lane - 32; const int b = t < 3 ? 0 : (t < 5 ? 1 : 2), c = t < 3 ? t : (t < 5 ? t - 2 : 2);
-                    double sacc = L[L_PII + b * 3 + c]; for (int a = 0; a < NU; a++) sacc += L[L_GS + a * 36 + SIOTA + b] * L[L_KS + a * 36 + SIOTA + c];
-                    L[L_PII + b * 3 + c] = sacc; L[L_PII + c * 3 + b] = sacc;
-                }
-            LANES_END
-            LANES_BEGIN
-                if (lane < NS) { double sacc = L[L_MV + lane]; for (int a = 0; a < NU; a++) sacc += L[L_GS + a * 36 + lane] * L[L_KS + a * 36 + 35]; L[L_PV + lane] = sacc; }
+                if (lane < 32) { L[L_PCI + pci(0, lf, lii)] = ci3[0]; L[L_PCI + pci(1, lf, lii)] = ci3[1]; L[L_PCI + pci(2, lf, lii)] = ci3[2]; }
+                if (onII) { L[L_PII + ib * 3 + ic] = pii; L[L_PII + ic * 3 + ib] = pii; }
+                if (onPV) L[L_PV + pr_] = pvv;
             LANES_END
         }
         BMPC_PROF(W, 13);
