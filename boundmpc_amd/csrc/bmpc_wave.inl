@@ -95,6 +95,7 @@ static_assert(8 + 3 * 57 <= 15 * 14, "row table must fit into the retired XT are
 //   MCI [3][5][8]  C^T P_c,iota, then M_c,iota in place ;  PE [3][14] = P_ii E ;  KHP [2][72] prefix vectors of the kinematic curvature
 enum { L_PB = L_PM, L_PCI = L_PB + 1024, L_PII = L_PCI + 96, L_GS = L_PII + 12, L_R8 = L_GS + 288, L_KS = L_R8 + 64, L_MCI = L_KS + 288,
        L_PE = L_MCI + 120, L_BLK_END = L_PE + 42, L_KHP = L_WV /* 144 of the 196 */ };
+static_assert(32 * 57 <= (int)L_PV - (int)L_PB, "multiplier staging of the adjoint must fit into the block area");
 static_assert((int)L_BLK_END <= (int)L_PV, "block Riccati storage must fit into the retired PM/SR/RED region");
 // staging area inside L_ST: per-stage inputs of the sequential sweeps, loaded from the scratch slab in ONE burst per stage
 enum { ST_REF = 0, ST_Z = 108, ST_SG = 152, ST_NU = 212, ST_G = 272, ST_LAM0 = 308, ST_LAM1 = 344, ST_GH = 380, ST_RLVM = 424, ST_RLV0 = 436, ST_RLVP = 448,
@@ -661,11 +662,25 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
     double *L = W.L, *G = W.G;
     const double *PAR = L + L_PAR, *Zs = W.Zc;
+    // the multipliers of all rows are staged through LDS with coalesced loads (the value-function block area is free outside the
+    // Riccati sweep): one lane per NODE would otherwise issue 57-114 scattered global loads of its own
+    LANES_BEGIN
+        for (int base = lane; base < N * NI; base += 64 * RU) {
+            double a_[RU], b_[RU];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const int id = base + 64 * u; const bool v = id < N * NI;
+                a_[u] = v ? (use_hat ? G[sc.TI + id] : G[oNU + id]) : 0.0; b_[u] = (v && use_hat) ? G[sc.SR + id] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < RU; u++) { const int id = base + 64 * u; if (id < N * NI) L[L_PB + id] = use_hat ? mu * a_[u] + b_[u] : a_[u]; }
+        }
+    LANES_END
     LANES_BEGIN
         if (lane < N) {
             const int k = lane;
             double nuv[NI], vprev[6];
-            for (int i = 0; i < NI; i++) nuv[i] = use_hat ? mu * G[sc.TI + k * NI + i] + G[sc.SR + k * NI + i] : G[oNU + k * NI + i];
+            for (int i = 0; i < NI; i++) nuv[i] = L[L_PB + k * NI + i];
             for (int c = 0; c < 6; c++) vprev[c] = ndv(PAR, po, Zs, k, ZV + c, po.v0 + c);
             double gz[NZ], gvp[6];
             node_grad(PAR, po, h, Zs + k * NZ, vprev, G + sc.REF + k * RREC, nuv, gz, gvp);
