@@ -1069,20 +1069,23 @@ BMPC_D inline double gv_at(const double *rec, int c6, int y) {
 // issue the global loads of stage k's inputs into per-lane registers (consumed one stage later by the commit phase)
 BMPC_D inline void wave_backward_prefetch(Wave &W, const Scr &sc, int k, LaneRegs *LR) {
     const int N = W.N; double *G = W.G;
+    // Branch-free: every lane loads from a clamped, always-valid index (lanes beyond the end of an array repeat its last element;
+    // a neighbour node that does not exist is replaced by the nearest one -- its data is masked by the consumers), and the commit
+    // phase stores to the same clamped slots (identical values), so neither phase has a single exec-mask branch.
     LANES_BEGIN
         double *pf = LR[LIDX].pf;
-        const bool hn = k < N - 1, hp = k >= 1, lo = lane < KREC - 64;
-        pf[0] = G[sc.KIN + k * KREC + lane]; pf[1] = lo ? G[sc.KIN + k * KREC + 64 + lane] : 0.0;
-        pf[2] = hn ? G[sc.KIN + (N + k + 1) * KREC + lane] : 0.0; pf[3] = (hn && lo) ? G[sc.KIN + (N + k + 1) * KREC + 64 + lane] : 0.0;
-        pf[4] = hp ? G[sc.KIN + (k - 1) * KREC + lane] : 0.0; pf[5] = (hp && lo) ? G[sc.KIN + (k - 1) * KREC + 64 + lane] : 0.0;
-        pf[6] = hp ? G[sc.KIN + (N + k) * KREC + lane] : 0.0; pf[7] = (hp && lo) ? G[sc.KIN + (N + k) * KREC + 64 + lane] : 0.0;
-        pf[8] = G[sc.REF + k * RREC + lane]; pf[9] = lane < RREC - 64 ? G[sc.REF + k * RREC + 64 + lane] : 0.0;
-        pf[10] = 0.0; pf[11] = lane < NZ ? G[sc.GH + k * NZ + lane] : 0.0;
-        pf[12] = lane < NI ? G[sc.SG + k * NI + lane] : 0.0; pf[13] = lane < NI ? G[sc.NUm + k * NI + lane] : 0.0;
-        pf[14] = lane < NE ? G[sc.G + k * NE + lane] : 0.0; pf[15] = lane < NE ? G[sc.LAM + k * NE + lane] : 0.0;
-        pf[16] = (lane < NE && hn) ? G[sc.LAM + (k + 1) * NE + lane] : 0.0;
-        pf[17] = lane < 12 ? G[sc.RLV + k * 12 + lane] : 0.0; pf[18] = (lane < 12 && hp) ? G[sc.RLV + (k - 1) * 12 + lane] : 0.0;
-        pf[19] = (lane < 12 && hn) ? G[sc.RLV + (k + 1) * 12 + lane] : 0.0;
+        const int kn = k < N - 1 ? k + 1 : k, kp = k >= 1 ? k - 1 : 0;
+        const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, r2 = lane < RREC - 64 ? 64 + lane : RREC - 1;
+        const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l12 = lane < 12 ? lane : 11;
+        pf[0] = G[sc.KIN + k * KREC + lane]; pf[1] = G[sc.KIN + k * KREC + l2];
+        pf[2] = G[sc.KIN + (N + kn) * KREC + lane]; pf[3] = G[sc.KIN + (N + kn) * KREC + l2];
+        pf[4] = G[sc.KIN + kp * KREC + lane]; pf[5] = G[sc.KIN + kp * KREC + l2];
+        pf[6] = G[sc.KIN + (N + k) * KREC + lane]; pf[7] = G[sc.KIN + (N + k) * KREC + l2];
+        pf[8] = G[sc.REF + k * RREC + lane]; pf[9] = G[sc.REF + k * RREC + r2];
+        pf[10] = 0.0; pf[11] = G[sc.GH + k * NZ + lz];
+        pf[12] = G[sc.SG + k * NI + li]; pf[13] = G[sc.NUm + k * NI + li];
+        pf[14] = G[sc.G + k * NE + le]; pf[15] = G[sc.LAM + k * NE + le]; pf[16] = G[sc.LAM + kn * NE + le];
+        pf[17] = G[sc.RLV + k * 12 + l12]; pf[18] = G[sc.RLV + kp * 12 + l12]; pf[19] = G[sc.RLV + kn * 12 + l12];
     LANES_END
 }
 
@@ -1102,13 +1105,15 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         BMPC_PROF(W, 6);
         LANES_BEGIN   // ---- commit the prefetched inputs of this stage (registers -> LDS) ----
             const double *pf = LR[LIDX].pf;
+            const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, r2 = lane < RREC - 64 ? 64 + lane : RREC - 1;
+            const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l12 = lane < 12 ? lane : 11;
             L[L_K0 + lane] = pf[0]; L[L_KV1 + lane] = pf[2]; L[L_K1 + lane] = pf[4]; L[L_KV + lane] = pf[6];
-            if (lane < KREC - 64) { L[L_K0 + 64 + lane] = pf[1]; L[L_KV1 + 64 + lane] = pf[3]; L[L_K1 + 64 + lane] = pf[5]; L[L_KV + 64 + lane] = pf[7]; }
-            L[L_ST + ST_REF + lane] = pf[8]; if (lane < RREC - 64) L[L_ST + ST_REF + 64 + lane] = pf[9];
-            if (lane < NZ) L[L_ST + ST_GH + lane] = pf[11];
-            if (lane < NI) { L[L_ST + ST_SG + lane] = pf[12]; L[L_ST + ST_NU + lane] = pf[13]; }
-            if (lane < NE) { L[L_ST + ST_G + lane] = pf[14]; L[L_ST + ST_LAM0 + lane] = pf[15]; L[L_ST + ST_LAM1 + lane] = pf[16]; }
-            if (lane < 12) { L[L_ST + ST_RLV0 + lane] = pf[17]; L[L_ST + ST_RLVM + lane] = pf[18]; L[L_ST + ST_RLVP + lane] = pf[19]; }
+            L[L_K0 + l2] = pf[1]; L[L_KV1 + l2] = pf[3]; L[L_K1 + l2] = pf[5]; L[L_KV + l2] = pf[7];
+            L[L_ST + ST_REF + lane] = pf[8]; L[L_ST + ST_REF + r2] = pf[9];
+            L[L_ST + ST_GH + lz] = pf[11];
+            L[L_ST + ST_SG + li] = pf[12]; L[L_ST + ST_NU + li] = pf[13];
+            L[L_ST + ST_G + le] = pf[14]; L[L_ST + ST_LAM0 + le] = pf[15]; L[L_ST + ST_LAM1 + le] = pf[16];
+            L[L_ST + ST_RLV0 + l12] = pf[17]; L[L_ST + ST_RLVM + l12] = pf[18]; L[L_ST + ST_RLVP + l12] = pf[19];
         LANES_END
         if (k >= 1) wave_backward_prefetch(W, sc, k - 1, LR);   // loads for the NEXT stage fly while this stage computes
         BMPC_PROF(W, 24);
