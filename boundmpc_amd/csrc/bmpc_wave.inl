@@ -698,21 +698,23 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
     // load per stage would cost a full memory round trip with nothing else in flight
     LANES_BEGIN
         double *pf = LR[LIDX].pf;
-        pf[0] = lane < NZ ? G[sc.GH + (N - 1) * NZ + lane] : 0.0;
+        pf[0] = G[sc.GH + (N - 1) * NZ + (lane < NZ ? lane : NZ - 1)];
     LANES_END
     for (int k = N - 1; k >= 0; k--) {
         double *lam1 = L + L_ST + (((N - 1 - k) & 1) ? ST_LAM0 : ST_LAM1);     // lam_{k+1} (written one step earlier)
         double *lam0 = L + L_ST + (((N - 1 - k) & 1) ? ST_LAM1 : ST_LAM0);     // lam_k (written now)
         LANES_BEGIN
             const double *pf = LR[LIDX].pf;
-            if (lane < NZ) L[L_ST + ST_GH + lane] = pf[0];
-            if (k < N - 1) { L[L_K0 + lane] = pf[1]; L[L_KV + lane] = pf[3]; if (lane < KREC - 64) { L[L_K0 + 64 + lane] = pf[2]; L[L_KV + 64 + lane] = pf[4]; } }
+            const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1;
+            L[L_ST + ST_GH + (lane < NZ ? lane : NZ - 1)] = pf[0];
+            if (k < N - 1) { L[L_K0 + lane] = pf[1]; L[L_KV + lane] = pf[3]; L[L_K0 + l2] = pf[2]; L[L_KV + l2] = pf[4]; }
         LANES_END
-        LANES_BEGIN   // loads for stage k-1 (records of node k); for k = 0 the record of node 0, used after the loop
+        LANES_BEGIN   // loads for stage k-1 (records of node k); for k = 0 the record of node 0, used after the loop; branch-free
             double *pf = LR[LIDX].pf;
-            if (k >= 1) pf[0] = lane < NZ ? G[sc.GH + (k - 1) * NZ + lane] : 0.0;
-            pf[1] = G[sc.KIN + k * KREC + lane]; pf[2] = lane < KREC - 64 ? G[sc.KIN + k * KREC + 64 + lane] : 0.0;
-            if (k >= 1) { pf[3] = G[sc.KIN + (N + k) * KREC + lane]; pf[4] = lane < KREC - 64 ? G[sc.KIN + (N + k) * KREC + 64 + lane] : 0.0; }
+            const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, kp = k >= 1 ? k - 1 : 0;
+            pf[0] = G[sc.GH + kp * NZ + (lane < NZ ? lane : NZ - 1)];
+            pf[1] = G[sc.KIN + k * KREC + lane]; pf[2] = G[sc.KIN + k * KREC + l2];
+            pf[3] = G[sc.KIN + (N + k) * KREC + lane]; pf[4] = G[sc.KIN + (N + k) * KREC + l2];
         LANES_END
         if (k < N - 1) {
             LANES_BEGIN
@@ -758,7 +760,7 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
     const double *lamz = L + L_ST + (((N - 1) & 1) ? ST_LAM1 : ST_LAM0);   // lam_0
     LANES_BEGIN
         const double *pf = LR[LIDX].pf;
-        L[L_K0 + lane] = pf[1]; if (lane < KREC - 64) L[L_K0 + 64 + lane] = pf[2];
+        L[L_K0 + lane] = pf[1]; L[L_K0 + (lane < KREC - 64 ? 64 + lane : KREC - 1)] = pf[2];
     LANES_END
     LANES_BEGIN
         stage_mu(W, lamz, L + L_K0, lane);
@@ -1428,15 +1430,15 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 // while stage k computes.
 BMPC_D inline void wave_forward_prefetch(Wave &W, const Scr &sc, int k, LaneRegs *LR) {
     double *G = W.G;
-    LANES_BEGIN
+    LANES_BEGIN   // branch-free: clamped indices (see wave_backward_prefetch)
         double *pf = LR[LIDX].pf;
 #pragma unroll
-        for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; pf[u] = id < NS * NU ? G[sc.KT + k * NS * NU + id] : 0.0; }
-        pf[5] = lane < NU ? G[sc.KF + k * NU + lane] : 0.0;
-        pf[6] = lane < 36 ? G[sc.RDY + k * 36 + lane] : 0.0;
-        pf[7] = lane < 42 ? G[sc.AES + k * 42 + lane] : 0.0;
-        pf[8] = lane < 12 ? G[sc.RLV + k * 12 + lane] : 0.0;
-        pf[9] = G[sc.KIN + k * KREC + lane]; pf[10] = lane < KREC - 64 ? G[sc.KIN + k * KREC + 64 + lane] : 0.0;
+        for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; pf[u] = G[sc.KT + k * NS * NU + (id < NS * NU ? id : NS * NU - 1)]; }
+        pf[5] = G[sc.KF + k * NU + (lane < NU ? lane : NU - 1)];
+        pf[6] = G[sc.RDY + k * 36 + (lane < 36 ? lane : 35)];
+        pf[7] = G[sc.AES + k * 42 + (lane < 42 ? lane : 41)];
+        pf[8] = G[sc.RLV + k * 12 + (lane < 12 ? lane : 11)];
+        pf[9] = G[sc.KIN + k * KREC + lane]; pf[10] = G[sc.KIN + k * KREC + (lane < KREC - 64 ? 64 + lane : KREC - 1)];
     LANES_END
 }
 BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
@@ -1450,12 +1452,12 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
         LANES_BEGIN   // commit the prefetched stage inputs
             const double *pf = LR[LIDX].pf;
 #pragma unroll
-            for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; if (id < NS * NU) L[L_ST + ST_KT + id] = pf[u]; }
-            if (lane < NU) L[L_ST + ST_KF + lane] = pf[5];
-            if (lane < 36) L[L_ST + ST_RDY + lane] = pf[6];
-            if (lane < 42) L[L_ST + ST_AES + lane] = pf[7];
-            if (lane < 12) L[L_ST + ST_RLVF + lane] = pf[8];
-            L[L_K0 + lane] = pf[9]; if (lane < KREC - 64) L[L_K0 + 64 + lane] = pf[10];
+            for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; L[L_ST + ST_KT + (id < NS * NU ? id : NS * NU - 1)] = pf[u]; }
+            L[L_ST + ST_KF + (lane < NU ? lane : NU - 1)] = pf[5];
+            L[L_ST + ST_RDY + (lane < 36 ? lane : 35)] = pf[6];
+            L[L_ST + ST_AES + (lane < 42 ? lane : 41)] = pf[7];
+            L[L_ST + ST_RLVF + (lane < 12 ? lane : 11)] = pf[8];
+            L[L_K0 + lane] = pf[9]; L[L_K0 + (lane < KREC - 64 ? 64 + lane : KREC - 1)] = pf[10];
         LANES_END
         if (k + 1 < N) wave_forward_prefetch(W, sc, k + 1, LR);
         LANES_BEGIN   // du = kff + K ds: partial sums on all 64 lanes (control u = lane & 7, every 8th state b), reduced by the consumers
