@@ -616,22 +616,22 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, const dou
         for (int base = lane; base < N * NI; base += 64 * RU) {
             double zv[RU], rc[RU], rw[RU], sg[RU], lm[RU];
 #pragma unroll
+            // rows past the end are clamped to the last row: they load, compute and store exactly what its owner does (no exec-mask
+            // branch anywhere in the pass)
             for (int u = 0; u < RU; u++) {
-                const int id = base + 64 * u; const bool v = id < N * NI;
-                const int k = v ? id / NI : 0, i = v ? id - k * NI : 0;
-                const bool tube = i >= ITUBE; const int m = tube ? (i - ITUBE) >> 1 : 0;
+                const int id0 = base + 64 * u, id = id0 < N * NI ? id0 : N * NI - 1;
+                const int k = id / NI, i = id - k * NI;
+                const int m = i >= ITUBE ? (i - ITUBE) >> 1 : 0;
                 sg[u] = L[L_ROWT + i]; lm[u] = L[L_ROWT + NI + i];
                 zv[u] = Zs[k * NZ + (int)L[L_ROWT + 2 * NI + i]];
                 const double *rr = G + sc.REF + k * RREC;
-                rc[u] = tube ? rr[RC + m] : 0.0; rw[u] = tube ? rr[RWD + m] : 0.0;
+                rc[u] = rr[RC + m]; rw[u] = rr[RWD + m];
             }
 #pragma unroll
             for (int u = 0; u < RU; u++) {
-                const int id = base + 64 * u;
-                if (id < N * NI) {
-                    const int i = id % NI;
-                    G[oH + id] = i >= ITUBE ? (((i - ITUBE) & 1) ? (-rc[u] - rw[u]) : (rc[u] - rw[u])) : sg[u] * zv[u] - lm[u];
-                }
+                const int id0 = base + 64 * u, id = id0 < N * NI ? id0 : N * NI - 1;
+                const int i = id % NI;
+                G[oH + id] = i >= ITUBE ? (((i - ITUBE) & 1) ? (-rc[u] - rw[u]) : (rc[u] - rw[u])) : sg[u] * zv[u] - lm[u];
             }
         }
     LANES_END
@@ -669,11 +669,11 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
             double a_[RU], b_[RU];
 #pragma unroll
             for (int u = 0; u < RU; u++) {
-                const int id = base + 64 * u; const bool v = id < N * NI;
-                a_[u] = v ? (use_hat ? G[sc.TI + id] : G[oNU + id]) : 0.0; b_[u] = (v && use_hat) ? G[sc.SR + id] : 0.0;
+                const int id0 = base + 64 * u, id = id0 < N * NI ? id0 : N * NI - 1;
+                a_[u] = G[(use_hat ? sc.TI : oNU) + id]; b_[u] = G[sc.SR + id];
             }
 #pragma unroll
-            for (int u = 0; u < RU; u++) { const int id = base + 64 * u; if (id < N * NI) L[L_PB + id] = use_hat ? mu * a_[u] + b_[u] : a_[u]; }
+            for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < N * NI ? id0 : N * NI - 1; L[L_PB + id] = use_hat ? mu * a_[u] + b_[u] : a_[u]; }
         }
     LANES_END
     LANES_BEGIN
@@ -1587,9 +1587,9 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
             for (int base = lane; base < ne; base += 64 * RU) {
                 double gv[RU], lv[RU];
 #pragma unroll
-                for (int u = 0; u < RU; u++) { const int id = base + 64 * u; gv[u] = id < ne ? G[sc.G + id] : 0.0; lv[u] = id < ne ? G[sc.LAM + id] : 0.0; }
+                for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < ne ? id0 : ne - 1; gv[u] = G[sc.G + id]; lv[u] = G[sc.LAM + id]; }
 #pragma unroll
-                for (int u = 0; u < RU; u++) { const double v = BMPC_FABS(gv[u]); ep = v > ep ? v : ep; sl += BMPC_FABS(lv[u]); }
+                for (int u = 0; u < RU; u++) { const bool ok_ = base + 64 * u < ne; const double v = ok_ ? BMPC_FABS(gv[u]) : 0.0; ep = v > ep ? v : ep; sl += ok_ ? BMPC_FABS(lv[u]) : 0.0; }
             }
             L[L_RED + lane] = ed; L[L_RED + 64 + lane] = ep; L[L_RED + 128 + lane] = sl;
         LANES_END
@@ -1632,17 +1632,17 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
             for (int base = lane; base < ni; base += 64 * RU) {
                 double tv[RU], nv[RU], hv[RU], sg[RU], tiv[RU], sr[RU], hd[RU], tprod = 1.0;
 #pragma unroll
-                for (int u = 0; u < RU; u++) {
-                    const int id = base + 64 * u; const bool v = id < ni;
-                    tv[u] = v ? G[sc.T + id] : 1.0; nv[u] = v ? G[sc.NUm + id] : 1.0; hv[u] = v ? G[sc.HIN + id] : -1.0;
-                    sg[u] = v ? G[sc.SG + id] : 0.0; tiv[u] = v ? G[sc.TI + id] : 0.0; sr[u] = v ? G[sc.SR + id] : 0.0;
+                for (int u = 0; u < RU; u++) {   // rows past the end are clamped to the last row (branch-free); their contributions are masked below
+                    const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1;
+                    tv[u] = G[sc.T + id]; nv[u] = G[sc.NUm + id]; hv[u] = G[sc.HIN + id];
+                    sg[u] = G[sc.SG + id]; tiv[u] = G[sc.TI + id]; sr[u] = G[sc.SR + id];
                 }
                 {   // hd = grad h_i . dZ with the loads of the whole batch in front (see ineq_dir for the row formulas)
                     double c0[RU], c1[RU], c2[RU], c3[RU], w1[RU], d0[RU], d1[RU], d2[RU], dph[RU];
 #pragma unroll
                     for (int u = 0; u < RU; u++) {
-                        const int id = base + 64 * u; const bool v = id < ni;
-                        const int k = v ? id / NI : 0, i = v ? id - k * NI : 0;
+                        const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1;
+                        const int k = id / NI, i = id - k * NI;
                         const bool tube = i >= ITUBE; const int m = tube ? (i - ITUBE) >> 1 : 0;
                         const double sgn = L[L_ROWT + i]; const int src = (int)L[L_ROWT + 2 * NI + i];
                         const double *rr = G + sc.REF + k * RREC, *dz = W.Dz + k * NZ;
@@ -1653,25 +1653,22 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                     }
 #pragma unroll
                     for (int u = 0; u < RU; u++) {
-                        const int id = base + 64 * u; const int i = id % NI;
-                        if (id >= ni) hd[u] = 0.0;
-                        else if (i >= ITUBE) { const double sv = c0[u] * d0[u] + c1[u] * d1[u] + c2[u] * d2[u] + c3[u] * dph[u]; hd[u] = (((i - ITUBE) & 1) ? -sv : sv) - w1[u] * dph[u]; }
+                        const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1; const int i = id % NI;
+                        if (i >= ITUBE) { const double sv = c0[u] * d0[u] + c1[u] * d1[u] + c2[u] * d2[u] + c3[u] * dph[u]; hd[u] = (((i - ITUBE) & 1) ? -sv : sv) - w1[u] * dph[u]; }
                         else hd[u] = c0[u] * d0[u];
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < RU; u++) {
-                    const int id = base + 64 * u;
-                    if (id < ni) {
-                        const double t = tv[u], nu = nv[u], r = hv[u] + t, mti = mu * tiv[u], nuh = mti + sr[u];
-                        const double dt = -r - hd[u], dnu = mti - nu - sg[u] * dt;
-                        G[sc.DT + id] = dt; G[sc.DNU + id] = dnu;
-                        // fraction to the boundary: the smallest ratio t/|dt| (nu/|dnu|) is tracked by cross-multiplication, one
-                        // division per lane at the end instead of two per row
-                        if (dt < 0 && t * pd_ < pn_ * -dt) { pn_ = t; pd_ = -dt; }
-                        if (dnu < 0 && nu * dd_ < dn_ * -dnu) { dn_ = nu; dd_ = -dnu; }
-                        dbar += -mti * dt; nhd += nuh * hd[u]; th += BMPC_FABS(r); tprod *= t;
-                    }
+                    const int id0 = base + 64 * u; const bool ok_ = id0 < ni; const int id = ok_ ? id0 : ni - 1;
+                    const double t = tv[u], nu = nv[u], r = hv[u] + t, mti = mu * tiv[u], nuh = mti + sr[u];
+                    const double dt = -r - hd[u], dnu = mti - nu - sg[u] * dt;
+                    G[sc.DT + id] = dt; G[sc.DNU + id] = dnu;          // a clamped row rewrites the last row with the same values
+                    // fraction to the boundary: the smallest ratio t/|dt| (nu/|dnu|) is tracked by cross-multiplication, one
+                    // division per lane at the end instead of two per row
+                    const bool c1 = ok_ && dt < 0 && t * pd_ < pn_ * -dt, c2 = ok_ && dnu < 0 && nu * dd_ < dn_ * -dnu;
+                    pn_ = c1 ? t : pn_; pd_ = c1 ? -dt : pd_; dn_ = c2 ? nu : dn_; dd_ = c2 ? -dnu : dd_;
+                    dbar += ok_ ? -mti * dt : 0.0; nhd += ok_ ? nuh * hd[u] : 0.0; th += ok_ ? BMPC_FABS(r) : 0.0; tprod *= ok_ ? t : 1.0;
                 }
                 bar -= mu * BMPC_LOG(tprod);      // one log per batch of RU slacks: sum of logs = log of the product (t in [1e-12, 1e2])
             }
@@ -1682,16 +1679,16 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
             for (int base = lane; base < nw; base += 64 * RU) {
                 double gv[RU];
 #pragma unroll
-                for (int u = 0; u < RU; u++) { const int id = base + 64 * u; gv[u] = id < nw ? G[sc.GH + id] : 0.0; }
+                for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < nw ? id0 : nw - 1; gv[u] = G[sc.GH + id] * W.Dz[id]; }
 #pragma unroll
-                for (int u = 0; u < RU; u++) { const int id = base + 64 * u; if (id < nw) ghd += gv[u] * W.Dz[id]; }
+                for (int u = 0; u < RU; u++) ghd += base + 64 * u < nw ? gv[u] : 0.0;
             }
             for (int base = lane; base < ne; base += 64 * RU) {
                 double gv[RU];
 #pragma unroll
-                for (int u = 0; u < RU; u++) { const int id = base + 64 * u; gv[u] = id < ne ? G[sc.G + id] : 0.0; }
+                for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u; gv[u] = G[sc.G + (id0 < ne ? id0 : ne - 1)]; }
 #pragma unroll
-                for (int u = 0; u < RU; u++) th += BMPC_FABS(gv[u]);
+                for (int u = 0; u < RU; u++) th += base + 64 * u < ne ? BMPC_FABS(gv[u]) : 0.0;
             }
             BMPC_PROF(W, 29);
             L[L_RED + lane] = ap; L[L_RED + 64 + lane] = adl; L[L_RED + 128 + lane] = dbar; L[L_RED + 192 + lane] = ghd - nhd;
@@ -1712,9 +1709,9 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                 for (int base = lane; base < ni; base += 64 * RU) {
                     double tv[RU], dv[RU];
 #pragma unroll
-                    for (int u = 0; u < RU; u++) { const int id = base + 64 * u; tv[u] = id < ni ? G[sc.T + id] : 0.0; dv[u] = id < ni ? G[sc.DT + id] : 0.0; }
+                    for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1; tv[u] = G[sc.T + id]; dv[u] = G[sc.DT + id]; }
 #pragma unroll
-                    for (int u = 0; u < RU; u++) { const int id = base + 64 * u; if (id < ni) G[sc.TT + id] = tv[u] + alpha * dv[u]; }
+                    for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1; G[sc.TT + id] = tv[u] + alpha * dv[u]; }
                 }
             LANES_END
             BMPC_PROF(W, 9);
@@ -1725,17 +1722,17 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                 for (int base = lane; base < ne; base += 64 * RU) {
                     double gv[RU];
 #pragma unroll
-                    for (int u = 0; u < RU; u++) { const int id = base + 64 * u; gv[u] = id < ne ? G[sc.GT + id] : 0.0; }
+                    for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u; gv[u] = G[sc.GT + (id0 < ne ? id0 : ne - 1)]; }
 #pragma unroll
-                    for (int u = 0; u < RU; u++) th += BMPC_FABS(gv[u]);
+                    for (int u = 0; u < RU; u++) th += base + 64 * u < ne ? BMPC_FABS(gv[u]) : 0.0;
                 }
                 for (int base = lane; base < ni; base += 64 * RU) {
                     double tv[RU], hv[RU];
 #pragma unroll
-                    for (int u = 0; u < RU; u++) { const int id = base + 64 * u; tv[u] = id < ni ? G[sc.TT + id] : 1.0; hv[u] = id < ni ? G[sc.HT + id] : -1.0; }
+                    for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1; tv[u] = G[sc.TT + id]; hv[u] = G[sc.HT + id]; }
                     double tprod = 1.0;
 #pragma unroll
-                    for (int u = 0; u < RU; u++) { const int id = base + 64 * u; if (id < ni) { th += BMPC_FABS(hv[u] + tv[u]); tprod *= tv[u]; } }
+                    for (int u = 0; u < RU; u++) { const bool ok_ = base + 64 * u < ni; th += ok_ ? BMPC_FABS(hv[u] + tv[u]) : 0.0; tprod *= ok_ ? tv[u] : 1.0; }
                     br -= mu * BMPC_LOG(tprod);
                 }
                 L[L_RED + lane] = th; L[L_RED + 64 + lane] = br;
@@ -1776,22 +1773,21 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
             for (int base = lane; base < ni; base += 64 * RU) {
                 double tv[RU], nv[RU], dv[RU], hv[RU];
 #pragma unroll
-                for (int u = 0; u < RU; u++) {
-                    const int id = base + 64 * u; const bool v = id < ni;
-                    tv[u] = v ? G[sc.T + id] : 1.0; nv[u] = v ? G[sc.NUm + id] : 0.0; dv[u] = v ? G[sc.DNU + id] : 0.0; hv[u] = v ? G[sc.HIN + id] : -1.0;
+                for (int u = 0; u < RU; u++) {   // loads on clamped rows (branch-free)
+                    const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1;
+                    tv[u] = G[sc.T + id]; nv[u] = G[sc.NUm + id]; dv[u] = G[sc.DNU + id]; hv[u] = G[sc.HIN + id];
                 }
 #pragma unroll
                 for (int u = 0; u < RU; u++) {
-                    const int id = base + 64 * u;
-                    if (id < ni) {
-                        const double t = tv[u], ti = 1.0 / t; double nu = nv[u] + ad * dv[u];
-                        const double lo = mu * ti * 1e-10, hi = 1e10 * mu * ti;
-                        nu = nu < lo ? lo : (nu > hi ? hi : nu);
-                        const double r = hv[u] + t, sgm = nu * ti;
-                        G[sc.NUm + id] = nu; G[sc.SG + id] = sgm; G[sc.TI + id] = ti; G[sc.SR + id] = sgm * r;
-                        const double v = BMPC_FABS(r), c = nu * t;
-                        ep = v > ep ? v : ep; cmax = c > cmax ? c : cmax; cmin = c < cmin ? c : cmin; sn += nu;
-                    }
+                    const int id = base + 64 * u; const bool ok_ = id < ni;
+                    const double t = tv[u], ti = 1.0 / t; double nu = nv[u] + ad * dv[u];
+                    const double lo = mu * ti * 1e-10, hi = 1e10 * mu * ti;
+                    nu = nu < lo ? lo : (nu > hi ? hi : nu);
+                    const double r = hv[u] + t, sgm = nu * ti;
+                    // nu is updated in place (read-modify-write): only the owner of a row stores
+                    if (ok_) { G[sc.NUm + id] = nu; G[sc.SG + id] = sgm; G[sc.TI + id] = ti; G[sc.SR + id] = sgm * r; }
+                    const double v = ok_ ? BMPC_FABS(r) : 0.0, c = nu * t;
+                    ep = v > ep ? v : ep; cmax = (ok_ && c > cmax) ? c : cmax; cmin = (ok_ && c < cmin) ? c : cmin; sn += ok_ ? nu : 0.0;
                 }
             }
             L[L_KKP + lane] = ep; L[L_KKP + 64 + lane] = cmax; L[L_KKP + 128 + lane] = cmin; L[L_KKP + 192 + lane] = sn;
