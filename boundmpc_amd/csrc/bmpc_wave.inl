@@ -110,7 +110,7 @@ struct Opts {
 
 // global scratch layout (doubles) for horizon N
 struct Scr {
-    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, size;
+    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, NU2, size;
 };
 BMPC_HD inline Scr make_scr(int N) {
     Scr s; int c = 0;
@@ -118,7 +118,7 @@ BMPC_HD inline Scr make_scr(int N) {
     s.LAM = c; c += N * NE; s.G = c; c += N * NE; s.GT = c; c += N * NE; s.HIN = c; c += N * NI; s.HT = c; c += N * NI;
     s.DZ = c; c += N * NZ; s.DT = c; c += N * NI; s.DNU = c; c += N * NI; s.GH = c; c += N * NZ; s.GVP = c; c += N * 8;
     s.RJ = c; c += N * NU; s.KIN = c; c += 2 * N * KREC; s.REF = c; c += N * RREC; s.KT = c; c += N * NS * NU; s.KF = c; c += N * NU;
-    s.RDY = c; c += N * 36; s.AES = c; c += N * 42; s.RLV = c; c += N * 12; s.SG = c; c += N * NI; s.TI = c; c += N * NI; s.SR = c; c += N * NI;
+    s.RDY = c; c += N * 36; s.AES = c; c += N * 42; s.RLV = c; c += N * 12; s.SG = c; c += N * NI; s.TI = c; c += N * NI; s.SR = c; c += N * NI; s.NU2 = c; c += N * NI;   // NU2: second multiplier buffer (the update ping-pongs)
     s.size = (c + 15) & ~15;
     return s;
 }
@@ -1784,14 +1784,15 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                     const double lo = mu * ti * 1e-10, hi = 1e10 * mu * ti;
                     nu = nu < lo ? lo : (nu > hi ? hi : nu);
                     const double r = hv[u] + t, sgm = nu * ti;
-                    // nu is updated in place (read-modify-write): only the owner of a row stores
-                    if (ok_) { G[sc.NUm + id] = nu; G[sc.SG + id] = sgm; G[sc.TI + id] = ti; G[sc.SR + id] = sgm * r; }
+                    // the new multipliers go to the OTHER buffer (ping-pong), so a clamped duplicate of the last row may store too
+                    { const int ic = ok_ ? id : ni - 1; G[sc.NU2 + ic] = nu; G[sc.SG + ic] = sgm; G[sc.TI + ic] = ti; G[sc.SR + ic] = sgm * r; }
                     const double v = ok_ ? BMPC_FABS(r) : 0.0, c = nu * t;
                     ep = v > ep ? v : ep; cmax = (ok_ && c > cmax) ? c : cmax; cmin = (ok_ && c < cmin) ? c : cmin; sn += ok_ ? nu : 0.0;
                 }
             }
             L[L_KKP + lane] = ep; L[L_KKP + 64 + lane] = cmax; L[L_KKP + 128 + lane] = cmin; L[L_KKP + 192 + lane] = sn;
         LANES_END
+        { const int t_ = sc.NUm; sc.NUm = sc.NU2; sc.NU2 = t_; }
     }
     // ---- outputs in the reference's conventions (casadi nlpsol: x, g, lam_g, lam_x, f) ----
     LANES_BEGIN
