@@ -829,7 +829,7 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
     LANES_BEGIN   // predicated straight-line code
         {
             const bool on = lane < 14; const int ln = on ? lane : 0; const double v = gk[ln < 7 ? GQ + ln : GDQ + ln - 7];
-            if (on) NC[NC_GY + ln] = v;
+            NC[NC_GY + ln] = v;
         }
         // tube rows: barrier weights su, sl and the gradient pieces, shared by the three roles below
         double su[5], sl[5], g3[5], w1[5];
@@ -843,7 +843,7 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
                 const double gg = (su[m] + sl[m]) * rr[RGC + m * 4 + a] * rr[RGC + m * 4 + b];
                 if (m == 1 || m == 2) hp += gg; else hr += gg;
             }
-            if (on) { NC[NC_HPP + a * 3 + b] = hp; NC[NC_HRR + a * 3 + b] = hr; }
+            NC[NC_HPP + a * 3 + b] = hp; NC[NC_HRR + a * 3 + b] = hr;
         }
         {   // Hp,phi, Hr,phi
             const bool on = lane >= 32 && lane < 35; const int a = on ? lane - 32 : 0;
@@ -854,7 +854,7 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
                 const double gg = su[m] * rr[RGC + m * 4 + a] * gpu_ - sl[m] * rr[RGC + m * 4 + a] * gpl_;
                 if (m == 1 || m == 2) hp += gg; else hr += gg;
             }
-            if (on) { NC[NC_HPF + a] = hp; NC[NC_HRF + a] = hr; }
+            NC[NC_HPF + a] = hp; NC[NC_HRF + a] = hr;
         }
         {   // H phi,phi and the scalar curvatures (every lane computes them, lane 40 stores)
             const double dpdp = rr[RDPDP], exm = ex ? 1.0 : 0.0;
@@ -889,26 +889,26 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
         }
         {   // r_pos, r_v of this node next to the work blocks
             const bool on = lane < 9; const double v = ST[ST_RLV0 + (on ? lane : 0)];
-            if (on) NC[NC_RL + lane] = v;
+            NC[NC_RL + (on ? lane : 0)] = v;
         }
         {   // A1 = Hpp Jp (3 x 7)
             const bool on = lane >= 16 && lane < 16 + 21; const int ln = on ? lane - 16 : 0, c = ln / 7, i = ln % 7; double sacc = 0;
 #pragma unroll
             for (int b2 = 0; b2 < 3; b2++) sacc += NC[NC_HPP + c * 3 + b2] * K0[KW + b2 * 7 + i];
-            if (on) NC[NC_A1 + c * 7 + i] = sacc;
+            NC[NC_A1 + c * 7 + i] = sacc;
         }
         {   // A2 = (h/2) Hrr Ehat (3 x 14)
             const bool on = lane < 42; const int ln = on ? lane : 0, c = ln / 14, y = ln % 14; double sacc = 0;
             const int eb = y < 7 ? KD + 21 + y : KA + y - 7;                 // Ehat column y: rows at stride 7
 #pragma unroll
             for (int b2 = 0; b2 < 3; b2++) sacc += NC[NC_HRR + c * 3 + b2] * K0[eb + b2 * 7];
-            if (on) NC[NC_A2 + c * 14 + y] = 0.5 * h * sacc;
+            NC[NC_A2 + c * 14 + y] = 0.5 * h * sacc;
         }
         {   // curvature multipliers mu_p, mu_v, mu_w (this node) and mu_w of the next node's velocity point
             const bool on = lane >= 48 && lane < 60; const int ln = on ? lane - 48 : 0, c = ln % 3, g = ln / 3; const double *lam = ST + ST_LAM0;
             const double lp = lam[GPOS + c], lv = lam[GV + c], lw = lam[GW + c], li = lam[GIW + c], ln1 = ST[ST_LAM1 + GIW + c];
             const double v = g == 0 ? lp : (g == 1 ? lv : (g == 2 ? lw + 0.5 * h * li : (has_next ? 0.5 * h * ln1 : 0.0)));
-            if (on) L[L_MU + 4 + ln] = v;
+            L[L_MU + 4 + ln] = v;
         }
     LANES_END
     BMPC_PROF(W, 17);
@@ -932,7 +932,7 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
             else if (isV) g += cv * rl[3 + c] - W.ca * vm - W.ca * vp;
             else if (isD) g += -2 * w[2] * s1;
             else if (isDD) g += -W.cb * s1 + (k >= 1 ? W.cb * s2 : 0.0);
-            if (on) NC[NC_GL + z] = g;
+            NC[NC_GL + z] = g;
         }
     LANES_END
     BMPC_PROF(W, 18);
@@ -1135,13 +1135,13 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 for (int i = 0; i < 7; i++) { BMPC_ACC4(ia, i, K0[KD + (3 + c) * 7 + i] * gk[GQ + i]); BMPC_ACC4(ia, i + 1, K0[KA + c * 7 + i] * gk[GDQ + i]); }
                 const bool zero = (r >= SJ && r < SPHI) || r == SJPHI;          // jerk states carry no defect
                 const double v = zero ? 0.0 : (io ? gval - 0.5 * h * BMPC_ACC4_SUM(ia) : gval);
-                if (on) { L[L_RD + r] = v; G[sc.RDY + k * 36 + r] = v; }
+                L[L_RD + r] = v; G[sc.RDY + k * 36 + r] = v;
             }
             {
                 const bool on = lane < 42; const int ln = on ? lane : 0, a = ln / 14, y = ln % 14;
                 const int eb = y < 7 ? KD + (3 + a) * 7 + y : KA + a * 7 + y - 7;
                 const double v = k >= 1 ? 0.5 * h * (K1[eb] + KVk[eb]) : 0.0;
-                if (on) { L[L_AE + ln] = v; G[sc.AES + k * 42 + ln] = v; }
+                L[L_AE + ln] = v; G[sc.AES + k * 42 + ln] = v;
             }
         LANES_END
         BMPC_PROF(W, 11);
@@ -1160,8 +1160,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                     for (int g = 0; g < 3; g++) BMPC_ACC4(pa, g, L[L_PB + pbi(f, g, i, l)] * L[L_RD + srow(g, l)]);   // rdyn of the jerk states (g = 3) is zero
 #pragma unroll
                 for (int a = 0; a < 3; a++) BMPC_ACC4(pa, a, L[L_PCI + pci(a, f, i)] * L[L_RD + SIOTA + a]);
-                const double v = L[L_PV + r] + BMPC_ACC4_SUM(pa);
-                if (on) L[L_PR + r] = v;
+                L[L_PR + r] = L[L_PV + r] + BMPC_ACC4_SUM(pa);      // off-lanes repeat row 0 (same value): no conditional store
             }
             {   // iota rows of PR
                 const bool on = lane >= 32 && lane < NS; const int a = on ? lane - SIOTA : 0;
@@ -1172,8 +1171,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                     for (int g = 0; g < 3; g++) BMPC_ACC4(pa, g, L[L_PCI + pci(a, g, l)] * L[L_RD + srow(g, l)]);
 #pragma unroll
                 for (int b2 = 0; b2 < 3; b2++) BMPC_ACC4(pa, b2, L[L_PII + a * 3 + b2] * L[L_RD + SIOTA + b2]);
-                const double v = L[L_PV + SIOTA + a] + BMPC_ACC4_SUM(pa);
-                if (on) L[L_PR + SIOTA + a] = v;
+                L[L_PR + SIOTA + a] = L[L_PV + SIOTA + a] + BMPC_ACC4_SUM(pa);
             }
             {   // U[(f',i)][a] = sum_f CF[f][f'] P[(f,i)][iota_a]
                 const bool on = lane < 40; const int ln = on ? lane : 0, fp = ln >> 3, i = ln & 7;
@@ -1184,13 +1182,13 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 #pragma unroll
                     for (int f = 0; f < 4; f++) u[a] += L[L_CFT + f * 5 + fp] * L[L_PCI + pci(a, f, i)];
                 }
-                if (on) { L[L_MCI + mci(0, fp, i)] = u[0]; L[L_MCI + mci(1, fp, i)] = u[1]; L[L_MCI + mci(2, fp, i)] = u[2]; }
+                L[L_MCI + mci(0, fp, i)] = u[0]; L[L_MCI + mci(1, fp, i)] = u[1]; L[L_MCI + mci(2, fp, i)] = u[2];
             }
             {   // PE = P_ii E
                 const bool on = lane < 42; const int ln = on ? lane : 0, a = ln / 14, y = ln % 14; double sacc = 0;
 #pragma unroll
                 for (int b2 = 0; b2 < 3; b2++) sacc += L[L_PII + a * 3 + b2] * L[L_AE + b2 * 14 + y];
-                if (on) L[L_PE + ln] = sacc;
+                L[L_PE + ln] = sacc;
             }
             {   // t6 = C rdyn: the rdyn side of X^T rdyn = Gv(K1)^T (C rdyn)
                 const bool on = k >= 1 && lane >= 48 && lane < 54; const int c6 = on ? lane - 48 : 0;
@@ -1236,7 +1234,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
             }
             {
                 const bool on = lane >= 40 && lane < 43; const int a = on ? lane - 40 : 0; const double v = L[L_PR + SIOTA + a];
-                if (on) L[L_MV + SIOTA + a] = v;
+                L[L_MV + SIOTA + a] = v;
             }
         LANES_END
         LANES_BEGIN   // jerk rows of the iota columns: M[u_i][iota_a] = M_c,iota[(4,i)][a]
@@ -1418,7 +1416,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                     for (int g = 0; g < 4; g++) L[L_PB + pbi(f, g, i, l)] = tr ? C[g][f] : C[f][g];
                 if (lane < 32) { L[L_PCI + pci(0, lf, lii)] = ci3[0]; L[L_PCI + pci(1, lf, lii)] = ci3[1]; L[L_PCI + pci(2, lf, lii)] = ci3[2]; }
                 if (onII) { L[L_PII + ib * 3 + ic] = pii; L[L_PII + ic * 3 + ib] = pii; }
-                if (onPV) L[L_PV + pr_] = pvv;
+                L[L_PV + pr_] = pvv;
             LANES_END
         }
         BMPC_PROF(W, 13);
@@ -1483,7 +1481,7 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
 #pragma unroll
                 for (int y = 0; y < 14; y++) BMPC_ACC4(ia, y, L[L_ST + ST_AES + a * 14 + y] * ds[y]);
                 const double v = L[L_ST + ST_RDY + r] + (chain ? vc : ds[r] + BMPC_ACC4_SUM(ia));
-                if (on) L[L_DSN + r] = v;
+                L[L_DSN + r] = v;
             }
         LANES_END
         LANES_BEGIN   // dZ of the stage, predicated: v = add + scale (P1 . dq_part + m2 P2 . ddq_part); copy rows have scale 0
@@ -1504,7 +1502,7 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
                 const double s1 = BMPC_ACC4_SUM(za), s2 = BMPC_ACC4_SUM(zb);
                 const double addv = (isPos || isV) ? rlv[isPos ? c : 3 + c] : dn[src];
                 const double v = isPos ? addv + s1 : (isIw ? addv + 0.5 * h * (s1 + s2) : (isV ? addv + (s1 + s2) : addv));
-                if (on) W.Dz[k * NZ + z] = v;
+                W.Dz[k * NZ + z] = v;
             }
             if (lane < 36) L[L_DS + lane] = lane < NS ? L[L_DSN + lane] : 0.0;
         LANES_END
