@@ -805,6 +805,22 @@ BMPC_D inline double kh_qdq(const double *rec, const double *mu_v, const double 
     if (i < j) { double aj[3]; ldA(rec, j, aj); cross3(alo, aj, t); val += dot3(mu_w, t); }
     return val;
 }
+// the same entries with only an angular-velocity multiplier (mu_p = mu_v = 0): what the velocity point of the NEXT node
+// contributes (its position and linear-velocity rows belong to that node's own cost).  Written out because 0 * x cannot be
+// folded away under IEEE rules: the general forms would do all the work and multiply it by zero.
+BMPC_D inline double kh_qq_w(const double *rec, const double *hp, const double *mu_w, int i, int l) {
+    double ai[3], al[3], t2[3], u[3];
+    ldA(rec, i, ai); ldA(rec, l, al);
+    const double *Gl = hp + 45 + 3 * l;
+    cross3(al, Gl, t2); cross3(ai, t2, u);
+    return dot3(mu_w, u);
+}
+BMPC_D inline double kh_qdq_w(const double *rec, const double *mu_w, int i, int j) {
+    const int lo = i <= j ? i : j;
+    double alo[3], aj[3], t[3]; ldA(rec, lo, alo); ldA(rec, j, aj);
+    cross3(alo, aj, t);
+    return i < j ? dot3(mu_w, t) : 0.0;
+}
 BMPC_D inline void kh_prefix(const double *rec, double *hp) {   // sequential over the 7 joints (one lane)
     double wl[3] = {0, 0, 0};
     for (int j = 0; j < 7; j++) { for (int c = 0; c < 3; c++) { hp[3 * j + c] = wl[c]; wl[c] += rec[KDQ + j] * rec[KA + c * 7 + j]; } }
@@ -968,12 +984,11 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
                 v += cv * gv;
                 double wp = 0, wn = 0;
                 if (ex && !(f == 1 && g == 1)) {
-                    const double z3[3] = {0, 0, 0};
                     if (f == 0 && g == 0) { wp = kh_qq(K0, KHP, L + L_MU + 4, L + L_MU + 7, L + L_MU + 10, cic, clc);
-                                            if (has_next) wn = kh_qq(KV1, KHP + 72, z3, z3, L + L_MU + 13, cic, clc); }
+                                            if (has_next) wn = kh_qq_w(KV1, KHP + 72, L + L_MU + 13, cic, clc); }
                     else { const int qi = f == 0 ? cic : clc, dj = f == 0 ? clc : cic;
                            wp = kh_qdq(K0, L + L_MU + 7, L + L_MU + 10, qi, dj);
-                           if (has_next) wn = kh_qdq(KV1, z3, L + L_MU + 13, qi, dj); }
+                           if (has_next) wn = kh_qdq_w(KV1, L + L_MU + 13, qi, dj); }
                 }
                 wpv[f][g] = wp;
                 e[f][g] = v + wp + wn;
