@@ -944,10 +944,8 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
 #pragma unroll
             for (int c6 = 0; c6 < 6; c6++) { s1 += d[c6] * rl[3 + c6]; s2 += d[c6] * ST[ST_RLVM + 3 + c6]; }
             const double vm = k >= 1 ? ST[ST_RLVM + 3 + c] : 0.0, vp = has_next ? ST[ST_RLVP + 3 + c] : 0.0;
-            if (isPos || isPhi) g += sA;
-            else if (isV) g += cv * rl[3 + c] - W.ca * vm - W.ca * vp;
-            else if (isD) g += -2 * w[2] * s1;
-            else if (isDD) g += -W.cb * s1 + (k >= 1 ? W.cb * s2 : 0.0);
+            const double tV = cv * rl[3 + c] - W.ca * vm - W.ca * vp, tD = -2 * w[2] * s1, tDD = -W.cb * s1 + (k >= 1 ? W.cb * s2 : 0.0);
+            g += (isPos || isPhi) ? sA : (isV ? tV : (isD ? tD : (isDD ? tDD : 0.0)));
             NC[NC_GL + z] = g;
         }
     LANES_END
@@ -1477,7 +1475,7 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
             {
                 const int u = lane & 7, part = lane >> 3; double acc = 0.0;
 #pragma unroll
-                for (int j = 0; j < 5; j++) { const int b = part + 8 * j; if (b < NS) acc += L[L_ST + ST_KT + b * NU + u] * L[L_DS + b]; }
+                for (int j = 0; j < 5; j++) { const int b0 = part + 8 * j, b = b0 < NS ? b0 : NS - 1; const double pr_ = L[L_ST + ST_KT + b * NU + u] * L[L_DS + b]; acc += b0 < NS ? pr_ : 0.0; }
                 L[L_RED + part * 8 + u] = acc;
             }
         LANES_END
