@@ -1003,28 +1003,40 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
         const double dq0 = 2 * w[10] + sgk[IQU + cic] + sgk[IQL + cic] + delta, dq1 = 2 * w[11] + sgk[IDQU + cic] + sgk[IDQL + cic] + delta,
                      dq2 = 2 * w[12] + delta, dq3 = 2 * w[13] + sgk[IJU + cic] + sgk[IJL + cic] + delta;
         const double p0 = NC[NC_SC + 0] + delta, p1 = NC[NC_SC + 1] + delta, p2 = NC[NC_SC + 2] + delta, p3 = 2 * w[9] + sgk[IJU + 7] + sgk[IJL + 7] + delta;
-        // ---- stores ----
+        // ---- stores: six read-modify-write adds per lane into its own pair's planes; the pair kind selects planes and values
+        //      (a lane with fewer than six contributions adds 0.0 to its (0,0) entry), so there is no branch on the kind ----
         if (both) {
 #pragma unroll
             for (int f = 0; f < 2; f++)
 #pragma unroll
                 for (int g = 0; g < 2; g++) { const int a = f * 7 + ci, b = g * 7 + cl; WY[a * 14 + b] = wpv[f][g]; WY[b * 14 + a] = wpv[f][g]; }
-            if (ci == cl) {
-                e[1][0] = e[0][1]; e[0][0] += dq0; e[1][1] += dq1;
-                L[L_PB + pbi(2, 2, i, l)] += dq2; L[L_PB + pbi(3, 3, i, l)] += dq3;
+        }
+        {
+            const bool dg = both && ci == cl;
+            const double e00 = e[0][0] + (dg ? dq0 : 0.0), e11 = e[1][1] + (dg ? dq1 : 0.0), e01 = e[0][1], e10 = dg ? e[0][1] : e[1][0];
+            // plane ids (f*4+g) and values of the six adds
+            const int pl[6] = { both ? 0 : (mix ? 0 : 0),
+                                both ? 1 : (mix ? (tr ? 4 : 1) : 5),
+                                both ? 4 : (mix ? (tr ? 8 : 2) : 10),
+                                both ? 5 : (mix ? (tr ? 1 : 4) : 15),
+                                both ? 10 : (mix ? 5 : 0),
+                                both ? 15 : (mix ? (tr ? 9 : 6) : 0) };
+            const double vl[6] = { both ? e00 : (mix ? vf[0] : p0),
+                                   both ? (tr ? e10 : e01) : (mix ? vd[0] : p1),
+                                   both ? (tr ? e01 : e10) : (mix ? vdd[0] : p2),
+                                   both ? e11 : (mix ? vf[1] : p3),
+                                   both ? (dg ? dq2 : 0.0) : (mix ? vd[1] : 0.0),
+                                   both ? (dg ? dq3 : 0.0) : (mix ? vdd[1] : 0.0) };
+            double cur[6];
+#pragma unroll
+            for (int t = 0; t < 6; t++) cur[t] = L[L_PB + pl[t] * 64 + lane];
+            // entries 4 and 5 of a (7,7) lane alias entry 0: accumulate in order on the same slot
+            if (!both && !mix) { cur[0] += vl[0]; L[L_PB + pl[0] * 64 + lane] = cur[0]; L[L_PB + pl[1] * 64 + lane] = cur[1] + vl[1];
+                                 L[L_PB + pl[2] * 64 + lane] = cur[2] + vl[2]; L[L_PB + pl[3] * 64 + lane] = cur[3] + vl[3]; }
+            else {
+#pragma unroll
+                for (int t = 0; t < 6; t++) L[L_PB + pl[t] * 64 + lane] = cur[t] + vl[t];
             }
-#pragma unroll
-            for (int f = 0; f < 2; f++)
-#pragma unroll
-                for (int g = 0; g < 2; g++) L[L_PB + pbi(f, g, i, l)] += tr ? e[g][f] : e[f][g];
-        } else if (mix) {
-#pragma unroll
-            for (int f = 0; f < 2; f++) {
-                if (!tr) { L[L_PB + pbi(f, 0, i, l)] += vf[f]; L[L_PB + pbi(f, 1, i, l)] += vd[f]; L[L_PB + pbi(f, 2, i, l)] += vdd[f]; }
-                else     { L[L_PB + pbi(0, f, i, l)] += vf[f]; L[L_PB + pbi(1, f, i, l)] += vd[f]; L[L_PB + pbi(2, f, i, l)] += vdd[f]; }
-            }
-        } else {                      // path-parameter chain with itself
-            L[L_PB + pbi(0, 0, 7, 7)] += p0; L[L_PB + pbi(1, 1, 7, 7)] += p1; L[L_PB + pbi(2, 2, 7, 7)] += p2; L[L_PB + pbi(3, 3, 7, 7)] += p3;
         }
         // iota couplings
         if (lane < 14) { const int f = lane / 7, ii = lane % 7; for (int a = 0; a < 3; a++) L[L_PCI + pci(a, f, ii)] += A2[a * 14 + lane]; }
