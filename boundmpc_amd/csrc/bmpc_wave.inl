@@ -738,22 +738,23 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
                 for (int c = 0; c < 3; c++) e += kv[eb + c * 7] * lam1[GIW + c];
                 double tot = L[L_ST + ST_GH + z];
                 if (nxt) tot += has ? chainv + ((i < 7 && fc <= 1) ? 0.5 * h * e : 0.0) : (isIw ? lam1[GIW + cw] : 0.0);
-                if (on) {
-                    // jerk rows: the residual of node k still lacks the term of the NEXT sweep step (stage k-1 -> k); it is parked in LDS
-                    // and completed there -- a global read-modify-write would wait for this store to land and come back
-                    if (z < 7) L[L_RJP + (k & 1) * 8 + z] = tot;
-                    else if (z == ZJPHI) L[L_RJP + (k & 1) * 8 + 7] = tot;
-                    else {
-                        const int ee = z < ZPOS ? z - ZQ : (z < ZPHI ? GPOS + (z - ZPOS) : GPHI + (z - ZPHI));
-                        G[sc.LAM + k * NE + ee] = tot; lam0[ee] = tot;
-                    }
+                // Stores without branches: one LDS store and one global store per lane, the row kind selects the ADDRESS.
+                // jerk rows: the residual of node k still lacks the term of the NEXT sweep step (stage k-1 -> k); it is parked in LDS
+                // and completed there (a global read-modify-write would wait for this store to land and come back); their global
+                // store goes to a spare slot of the node's GVP row.  Off-lanes repeat row 0 (a jerk row) with identical values.
+                {
+                    const bool isJ = z < 7 || z == ZJPHI;
+                    const int ee = z < ZPOS ? z - ZQ : (z < ZPHI ? GPOS + (z - ZPOS) : GPHI + (z - ZPHI));
+                    double *ldst = isJ ? L + L_RJP + (k & 1) * 8 + (z < 7 ? z : 7) : lam0 + ee;
+                    const int gdst = isJ ? sc.GVP + k * 8 + 6 : sc.LAM + k * NE + ee;
+                    *ldst = tot; G[gdst] = tot;
                 }
             }
-            {   // jerk of node k+2 enters stage k+1
+            {   // jerk of node k+2 enters stage k+1 (lanes 44..51; everyone else, and the last stage, write to the spare GVP slot)
                 const bool on = lane >= NZ && lane < NZ + 8 && k < N - 1; const int i = on ? lane - NZ : 0;
                 const double mdd = lam1[i < 7 ? GDDQ + i : GDDPHI];
                 const double v = L[L_RJP + ((k + 1) & 1) * 8 + i] + (h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd);
-                if (on) G[sc.RJ + (k + 1) * NU + i] = v;
+                G[on ? sc.RJ + (k + 1) * NU + i : sc.GVP + k * 8 + 7] = v;
             }
         LANES_END
     }
