@@ -642,18 +642,17 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, const dou
 // (lanes 0..7; chain 7 = path parameter)
 BMPC_D inline void stage_mu(Wave &W, const double *lam, const double *kp, int lane) {
     double *L = W.L; const double h = W.h;
-    if (lane < 8) {
-        if (lane < 7) {
-            const int i = lane;
-            double s = lam[GQ + i], s2 = lam[GDQ + i];
-            for (int c = 0; c < 3; c++) {
-                const double mv = lam[GV + c], mw = lam[GW + c] + 0.5 * h * lam[GIW + c];
-                s += kp[KW + c * 7 + i] * lam[GPOS + c] + kp[KD + c * 7 + i] * mv + kp[KD + (3 + c) * 7 + i] * mw;
-                s2 += kp[KW + c * 7 + i] * mv + kp[KA + c * 7 + i] * mw;
-            }
-            L[L_MU + i] = s; L[L_MU + 8 + i] = s2;
-        } else { L[L_MU + 7] = lam[GPHI]; L[L_MU + 15] = lam[GDPHI]; }
+    // branch-free: lanes >= 8 repeat chain 0 (identical values, duplicate stores); chain 7 (path parameter) selects its own pair
+    const int ch = lane < 8 ? lane : 0, i = ch < 7 ? ch : 0;
+    double s = lam[GQ + i], s2 = lam[GDQ + i];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double mv = lam[GV + c], mw = lam[GW + c] + 0.5 * h * lam[GIW + c];
+        s += kp[KW + c * 7 + i] * lam[GPOS + c] + kp[KD + c * 7 + i] * mv + kp[KD + (3 + c) * 7 + i] * mw;
+        s2 += kp[KW + c * 7 + i] * mv + kp[KA + c * 7 + i] * mw;
     }
+    const double lp = lam[GPHI], ld = lam[GDPHI];
+    L[L_MU + ch] = ch < 7 ? s : lp; L[L_MU + 8 + ch] = ch < 7 ? s2 : ld;
 }
 
 // Adjoint sweep with multipliers nu (scratch offset oNU; scale = 0 -> objective only is NOT supported here):
