@@ -1370,9 +1370,10 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                     else Lc[a][b] = sacc * dinv[b];
                 }
             }
-            if (lane == 0) L[L_FLAG] = pd ? 1.0 : 0.0;
-            if (pd && lane < 36) {
-                const int c = lane; double kc[NU];
+            L[L_FLAG] = pd ? 1.0 : 0.0;            // identical in every lane
+            {   // gains: one column per lane (lanes >= 36 repeat column 0: identical values, duplicate stores; when the block is not
+                // positive definite the values are discarded with the whole sweep)
+                const int c = lane < 36 ? lane : 0; double kc[NU];
 #pragma unroll
                 for (int a = 0; a < NU; a++) kc[a] = -L[L_GS + a * 36 + c];
 #pragma unroll
@@ -1387,8 +1388,9 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                     kc[a] = sacc * dinv[a]; }
 #pragma unroll
                 for (int a = 0; a < NU; a++) L[L_KS + a * 36 + c] = kc[a];
-                if (c < NS) { for (int a = 0; a < NU; a++) G[sc.KT + (k * NS + c) * NU + a] = kc[a]; }
-                else { for (int a = 0; a < NU; a++) G[sc.KF + k * NU + a] = kc[a]; }
+                const int gb = c < NS ? sc.KT + (k * NS + c) * NU : sc.KF + k * NU;
+#pragma unroll
+                for (int a = 0; a < NU; a++) G[gb + a] = kc[a];
             }
         LANES_END
         BMPC_PROF(W, 23);
