@@ -1,0 +1,24 @@
+"""Diagnostic (GPU box): soak comparison of the HIP solver with the CPU oracle on several random batches (N=10 and N=30 tight)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from boundmpc_amd import BatchedOCPSolver, workload
+from oracle import c_oracle
+worst = 0.0
+for (N, tight, B, seeds) in ((10, False, 1024, (1, 2, 3, 4)), (30, True, 128, (5,)), (5, False, 256, (6,))):
+    s = BatchedOCPSolver(N, 4, 0.1)
+    for seed in seeds:
+        P, X, _ = workload.make_batch(B, seed=seed, N=N, tight=tight)
+        o = s.solve_batch(torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda"))
+        ref = c_oracle.solve(P, X, N, 4, 0.1, nthreads=16)
+        st, it, x = o["status"].cpu().numpy(), o["iters"].cpu().numpy(), o["x"].cpu().numpy()
+        ok = (st == 0) & (ref["status"] == 0)
+        d = (x[ok] - ref["x"][ok]).reshape(-1, N, 44)[:, :, 8:15]
+        per = np.sqrt((d ** 2).mean(axis=(1, 2)))
+        print(f"N={N} tight={tight} seed={seed}: status equal {int((st == ref['status']).sum())}/{B}, |iters diff| max {int(np.abs(it - ref['iters']).max())}, "
+              f"joint RMS {np.sqrt((d ** 2).mean()):.2e}, worst problem {per.max():.2e}, problems > 1e-6: {int((per > 1e-6).sum())}", flush=True)
+        worst = max(worst, float(np.sqrt((d ** 2).mean())))
+    s.close()
+print("worst batch RMS", worst)
