@@ -493,7 +493,12 @@ BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
             const int r = lane;
             const int z = r < 7 ? ZQ + r : (r < 14 ? ZDQ + r - 7 : (r < SJ ? ZDDQ + r - SDDQ : (r < SPHI ? ZJ + r - SJ : (r == SPHI ? ZPHI : (r == SDPHI ? ZDPHI :
                           (r == SDDPHI ? ZDDPHI : (r == SJPHI ? ZJPHI : ZIW + r - SIOTA)))))));
-            L[L_ZMAP + r] = (double)z;
+            // packed with the row's defect source in g (bits 8..15) and the "carries no defect" flag (bit 16): functions of a
+            // lane-dependent integer compile into divergent branches, a table look-up does not
+            const bool io = r >= SIOTA;
+            const int gsrc = r < SJ ? r : ((r >= SPHI && r <= SDDPHI) ? GPHI + r - SPHI : (io ? GIW + r - SIOTA : 0));
+            const int zero = ((r >= SJ && r < SPHI) || r == SJPHI) ? 1 : 0;          // jerk states carry no defect
+            L[L_ZMAP + r] = (double)(z + (gsrc << 8) + (zero << 16));
         }
     LANES_END
     W.ca = 2 * L[L_PAR + po.w + 5] / (W.h * W.h); W.cb = 2 * L[L_PAR + po.w + 5] / W.h;
@@ -832,6 +837,53 @@ BMPC_D inline void kh_prefix(const double *rec, double *hp) {   // sequential ov
     }
 }
 
+// q~ row r (reduced-state row, r < NS) of the node cost: gl mapped through the lifting Jacobians; rows >= 14 only copy.
+// Predicated straight-line code: every lane evaluates the (q, dq)-row formula on a clamped row.
+BMPC_D inline double node_q_row(const double *L, int r, double h, int ex) {
+    const double *gl = L + L_NC + NC_GL, *K0 = L + L_K0, *WY = L + L_WY, *gy = L + L_ST + ST_G;   // g_y = (g_q, g_dq): rows 0..13 of g
+    const bool heavy = r < 14; const int a = heavy ? r : 0; const bool isq = a < 7; const int ai = isq ? a : a - 7;
+    const double base = gl[(int)L[L_ZMAP + r] & 255];
+    double t1 = 0, t2 = 0, t3 = 0, sW = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        t1 += K0[KW + c * 7 + ai] * gl[ZPOS + c];
+        t2 += K0[(isq ? KD + (3 + c) * 7 : KA + c * 7) + ai] * gl[ZIW + c];
+    }
+#pragma unroll
+    for (int c6 = 0; c6 < 6; c6++) t3 += K0[(isq ? KD + c6 * 7 : (c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7)) + ai] * gl[ZV + c6];
+    if (ex) {
+#pragma unroll
+        for (int b2 = 0; b2 < 14; b2++) sW += WY[a * 14 + b2] * gy[b2];
+    }
+    return base + (heavy ? (isq ? t1 : 0.0) + 0.5 * h * t2 + t3 - sW : 0.0);
+}
+
+// Stage data of Riccati stage k: defect vector rdyn (35) and the iota coupling AE (3x14), for one lane (predicated straight-line
+// code; runs inside phase 1 of the node cost, with which it shares no data).  The acceleration cross block XT = C^T Gv(K1)
+// (15x14, rank 6) is never formed: its consumers contract the two rank-6 factors on the fly (t6 in S0, chain-pair entries in S1).
+BMPC_D inline void stage_data_lane(Wave &W, const Scr &sc, int k, int lane) {
+    double *L = W.L, *G = W.G; const double h = W.h;
+    const double *K0 = L + L_K0, *K1 = L + L_K1, *KVk = L + L_KV, *gk = L + L_ST + ST_G;
+    {
+        const bool on = lane < NS; const int r = on ? lane : 0;
+        const bool io = r >= SIOTA; const int c = io ? r - SIOTA : 0;
+        const int code = (int)L[L_ZMAP + r], gsrc = (code >> 8) & 255;
+        const double gval = gk[gsrc];
+        BMPC_ACC4_DECL(ia);
+#pragma unroll
+        for (int i = 0; i < 7; i++) { BMPC_ACC4(ia, i, K0[KD + (3 + c) * 7 + i] * gk[GQ + i]); BMPC_ACC4(ia, i + 1, K0[KA + c * 7 + i] * gk[GDQ + i]); }
+        const bool zero = (code >> 16) != 0;                            // jerk states carry no defect
+        const double v = zero ? 0.0 : (io ? gval - 0.5 * h * BMPC_ACC4_SUM(ia) : gval);
+        L[L_RD + r] = v; G[sc.RDY + k * 36 + r] = v;
+    }
+    {
+        const bool on = lane < 42; const int ln = on ? lane : 0, a = ln / 14, y = ln % 14;
+        const int eb = y < 7 ? KD + (3 + a) * 7 + y : KA + a * 7 + y - 7;
+        const double v = k >= 1 ? 0.5 * h * (K1[eb] + KVk[eb]) : 0.0;
+        L[L_AE + ln] = v; G[sc.AES + k * 42 + ln] = v;
+    }
+}
+
 // Node cost in block form: Q~ of node k+1 (index k) added into PB / PCI / PII, q~ into PV.
 BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, int k, double mu, double delta) {
     const int N = W.N; const double h = W.h; const int ex = W.o.exact_hessian;
@@ -843,10 +895,7 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
     const bool has_next = k < N - 1;
     // phase 1: small Hessian blocks over (pos, iw, phi)
     LANES_BEGIN   // predicated straight-line code
-        {
-            const bool on = lane < 14; const int ln = on ? lane : 0; const double v = gk[ln < 7 ? GQ + ln : GDQ + ln - 7];
-            NC[NC_GY + ln] = v;
-        }
+        stage_data_lane(W, sc, k, lane);
         // tube rows: barrier weights su, sl and the gradient pieces, shared by the three roles below
         double su[5], sl[5], g3[5], w1[5];
 #pragma unroll
@@ -903,10 +952,6 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
             }
             if (on) { hp[3 * jj + c] = wlt; if (jj < 7) { hp[24 + 3 * jj + c] = vge; hp[45 + 3 * jj + c] = wgt; } }
         }
-        {   // r_pos, r_v of this node next to the work blocks
-            const bool on = lane < 9; const double v = ST[ST_RLV0 + (on ? lane : 0)];
-            NC[NC_RL + (on ? lane : 0)] = v;
-        }
         {   // A1 = Hpp Jp (3 x 7)
             const bool on = lane >= 16 && lane < 16 + 21; const int ln = on ? lane - 16 : 0, c = ln / 7, i = ln % 7; double sacc = 0;
 #pragma unroll
@@ -926,14 +971,11 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
             const double v = g == 0 ? lp : (g == 1 ? lv : (g == 2 ? lw + 0.5 * h * li : (has_next ? 0.5 * h * ln1 : 0.0)));
             L[L_MU + 4 + ln] = v;
         }
-    LANES_END
-    BMPC_PROF(W, 17);
-    // phase 3: Z-space gradient gl = g^ + H r + cross terms (predicated straight-line code: the row kinds select coefficients,
-    // not code paths)
-    LANES_BEGIN
+        // (same phase) Z-space gradient gl = g^ + H r + cross terms: reads only phase-1 results and the staging area (the row kinds
+        // select coefficients, not code paths)
         {
             const bool on = lane < NZ; const int z = on ? lane : 0;
-            const double *rl = NC + NC_RL, cv = NC[NC_SC + 3], *d = rr + RDP;
+            const double *rl = ST + ST_RLV0, cv = NC[NC_SC + 3], *d = rr + RDP;
             const bool isPos = z >= ZPOS && z < ZPOS + 3, isPhi = z == ZPHI, isV = z >= ZV && z < ZV + 6, isD = z == ZDPHI, isDD = z == ZDDPHI;
             const int pa = isPos ? NC_HPP + (z - ZPOS) * 3 : NC_HPF;            // 3-vector that multiplies r_pos
             const int c = isV ? z - ZV : 0;
@@ -1044,29 +1086,7 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
         else if (lane >= 24 && lane < 33) { const int a = (lane - 24) / 3, b = (lane - 24) % 3; L[L_PII + a * 3 + b] += NC[NC_HRR + a * 3 + b] + (a == b ? delta : 0.0); }
     LANES_END
     BMPC_PROF(W, 19);
-    // phase 5: gradient q~
-    LANES_BEGIN   // predicated straight-line code: every lane evaluates the (q, dq)-row formula on a clamped row, rows >= 14 only copy
-        const double *gl = NC + NC_GL;
-        {
-            const bool on = lane < NS; const int r = on ? lane : 0;
-            const bool heavy = r < 14; const int a = heavy ? r : 0; const bool isq = a < 7; const int ai = isq ? a : a - 7;
-            const double base = gl[(int)L[L_ZMAP + r]];
-            double t1 = 0, t2 = 0, t3 = 0, sW = 0;
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                t1 += K0[KW + c * 7 + ai] * gl[ZPOS + c];
-                t2 += K0[(isq ? KD + (3 + c) * 7 : KA + c * 7) + ai] * gl[ZIW + c];
-            }
-#pragma unroll
-            for (int c6 = 0; c6 < 6; c6++) t3 += K0[(isq ? KD + c6 * 7 : (c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7)) + ai] * gl[ZV + c6];
-            if (ex) {
-#pragma unroll
-                for (int b2 = 0; b2 < 14; b2++) sW += WY[a * 14 + b2] * NC[NC_GY + b2];
-            }
-            const double v = base + (heavy ? (isq ? t1 : 0.0) + 0.5 * h * t2 + t3 - sW : 0.0);
-            if (on) L[L_PV + r] += v;
-        }
-    LANES_END
+    // (the gradient q~ of this node is added where it is consumed: node_q_row() in S0 of the Riccati stage)
     BMPC_PROF(W, 20);
 }
 
@@ -1146,29 +1166,6 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         BMPC_PROF(W, 24);
         wave_node_cost_blk(W, po, sc, k, mu, delta);     // PB/PCI/PII/PV now hold the value function of node k+1
         BMPC_PROF(W, 5);
-        // ---- stage data: rdyn, iota coupling AE (3x14).  The acceleration cross block XT = C^T Gv(K1) (15x14, rank 6) is never
-        //      formed: its consumers contract the two rank-6 factors on the fly (t6 below, chain-pair entries in S1) ----
-        LANES_BEGIN   // predicated straight-line code
-            const double *K0 = L + L_K0, *K1 = L + L_K1, *KVk = L + L_KV, *gk = L + L_ST + ST_G;
-            {
-                const bool on = lane < NS; const int r = on ? lane : 0;
-                const bool io = r >= SIOTA; const int c = io ? r - SIOTA : 0;
-                const int gsrc = r < SJ ? r : ((r >= SPHI && r <= SDDPHI) ? GPHI + r - SPHI : (io ? GIW + c : 0));
-                const double gval = gk[gsrc];
-                BMPC_ACC4_DECL(ia);
-#pragma unroll
-                for (int i = 0; i < 7; i++) { BMPC_ACC4(ia, i, K0[KD + (3 + c) * 7 + i] * gk[GQ + i]); BMPC_ACC4(ia, i + 1, K0[KA + c * 7 + i] * gk[GDQ + i]); }
-                const bool zero = (r >= SJ && r < SPHI) || r == SJPHI;          // jerk states carry no defect
-                const double v = zero ? 0.0 : (io ? gval - 0.5 * h * BMPC_ACC4_SUM(ia) : gval);
-                L[L_RD + r] = v; G[sc.RDY + k * 36 + r] = v;
-            }
-            {
-                const bool on = lane < 42; const int ln = on ? lane : 0, a = ln / 14, y = ln % 14;
-                const int eb = y < 7 ? KD + (3 + a) * 7 + y : KA + a * 7 + y - 7;
-                const double v = k >= 1 ? 0.5 * h * (K1[eb] + KVk[eb]) : 0.0;
-                L[L_AE + ln] = v; G[sc.AES + k * 42 + ln] = v;
-            }
-        LANES_END
         BMPC_PROF(W, 11);
         // ---- S0: PR = P' rdyn + p ; C^T P_c,iota ; P_ii E ----
         // The five roles of this phase are written as PREDICATED straight-line code (every lane runs every role on a clamped,
@@ -1185,7 +1182,8 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                     for (int g = 0; g < 3; g++) BMPC_ACC4(pa, g, L[L_PB + pbi(f, g, i, l)] * L[L_RD + srow(g, l)]);   // rdyn of the jerk states (g = 3) is zero
 #pragma unroll
                 for (int a = 0; a < 3; a++) BMPC_ACC4(pa, a, L[L_PCI + pci(a, f, i)] * L[L_RD + SIOTA + a]);
-                L[L_PR + r] = L[L_PV + r] + BMPC_ACC4_SUM(pa);      // off-lanes repeat row 0 (same value): no conditional store
+                const double qr = node_q_row(L, r, h, W.o.exact_hessian);          // q~ of node k+1 joins the value-function gradient here
+                L[L_PR + r] = (L[L_PV + r] + qr) + BMPC_ACC4_SUM(pa);      // off-lanes repeat row 0 (same value): no conditional store
             }
             {   // iota rows of PR
                 const bool on = lane >= 32 && lane < NS; const int a = on ? lane - SIOTA : 0;
@@ -1196,7 +1194,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                     for (int g = 0; g < 3; g++) BMPC_ACC4(pa, g, L[L_PCI + pci(a, g, l)] * L[L_RD + srow(g, l)]);
 #pragma unroll
                 for (int b2 = 0; b2 < 3; b2++) BMPC_ACC4(pa, b2, L[L_PII + a * 3 + b2] * L[L_RD + SIOTA + b2]);
-                L[L_PR + SIOTA + a] = L[L_PV + SIOTA + a] + BMPC_ACC4_SUM(pa);
+                L[L_PR + SIOTA + a] = (L[L_PV + SIOTA + a] + L[L_NC + NC_GL + ZIW + a]) + BMPC_ACC4_SUM(pa);   // iota rows of q~: gl[iw]
             }
             {   // U[(f',i)][a] = sum_f CF[f][f'] P[(f,i)][iota_a]
                 const bool on = lane < 40; const int ln = on ? lane : 0, fp = ln >> 3, i = ln & 7;
@@ -1261,9 +1259,11 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 const bool on = lane >= 40 && lane < 43; const int a = on ? lane - 40 : 0; const double v = L[L_PR + SIOTA + a];
                 L[L_MV + SIOTA + a] = v;
             }
-        LANES_END
-        LANES_BEGIN   // jerk rows of the iota columns: M[u_i][iota_a] = M_c,iota[(4,i)][a]
-            if (lane < 24) { const int i = lane & 7, a = lane >> 3; L[L_GS + i * 36 + SIOTA + a] = L[L_MCI + mci(a, 4, i)]; }
+            {   // jerk rows of the iota columns: M[u_i][iota_a] = M_c,iota[(4,i)][a] (rows f' = 4 of U are final after S0; lanes >= 24
+                // repeat a = 0: identical values)
+                const int i = lane & 7, a = lane < 24 ? lane >> 3 : 0; const double v = L[L_MCI + mci(a, 4, i)];
+                L[L_GS + i * 36 + SIOTA + a] = v;
+            }
         LANES_END
         BMPC_PROF(W, 22);
         // ---- S1: one lane per chain pair: 5x5 block of M = F^T P' F (+ iota and acceleration cross terms) ----

@@ -31,7 +31,7 @@ for rep in range(2):
     assert lib.bmpc_solve_batch(h, B, vp(p.data_ptr()), vp(x0.data_ptr()), vp(x.data_ptr()), None, None, None, None, vp(it.data_ptr()), None, None, None) == 0
     torch.cuda.synchronize(); dt = time.time() - t
     lib.bmpc_get_profile(h, vp(prof.ctypes.data))
-names = ["eval", "adjoint", "kkt+mu", "qp-gradient", "prepare-rlv", "bwd:node(after p5..)", "bwd:stage-in", "forward", "step-dirs", "ls-trial", "nu-update", "bwd:stage-data", "st:S1 M-blocks", "st:S3 schur", "(unused)", "load", "nc:p1 small blocks", "nc:p2 A1/A2/mu", "nc:p3 gl", "nc:p4 block add", "nc:p5 q~", "st:S0 PR/U/PE", "st:S0b Mci/m", "st:S2 chol+gains", "bwd:staging burst", "eval:kinematics (2N lanes)", "eval:node refs+objective (N lanes)", "adjoint:node gradients (N lanes)", "step-dirs: row loop", "step-dirs: grad.dz + theta loops"] + [""] * 2
+names = ["eval", "adjoint", "kkt+mu", "qp-gradient", "prepare-rlv", "bwd:node(after p5..)", "bwd:stage-in", "forward", "step-dirs", "ls-trial", "nu-update", "(merged into nc:p1)", "st:S1 M-blocks", "st:S3 schur", "(unused)", "load", "nc:p1 small blocks + stage data", "(merged)", "nc:p2+p3 A1/A2/mu/gl", "nc:p4 block add", "(merged into S0)", "st:S0 q~/PR/U/PE", "st:S0b Mci/m", "st:S2 chol+gains", "bwd:staging burst", "eval:kinematics (2N lanes)", "eval:node refs+objective (N lanes)", "adjoint:node gradients (N lanes)", "step-dirs: row loop", "step-dirs: grad.dz + theta loops"] + [""] * 2
 tot = float(prof.sum()); its = float(it.sum().item())
 print(f"B={B} N={N} wall {dt*1e3:.1f} ms, total iterations {its:.0f}, cycles/iteration (lane-0 stamps, profile build) {tot/its:.0f}")
 for n, c in zip(names, prof):
