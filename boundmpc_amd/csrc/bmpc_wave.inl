@@ -137,6 +137,8 @@ struct Wave {
     long long tprev;       // diagnostic build only (BMPC_PROFILE): last phase stamp
     double ca, cb;         // wave-uniform constants 2 w_a / h^2 and 2 w_a / h (w_a = weights[5]), hoisted out of the phases: a run-time
                            // fp64 division costs ~40 instructions
+    int oK0, oK1, oKV, oKV1;   // LDS offsets of the four kinematics records of the current Riccati stage (the buffers rotate, see
+                           // wave_backward_blk: two of the four records of stage k are records of stage k+1)
     double *Zc, *Zt, *Dz;  // iterate, trial iterate, Newton direction [N][44]: LDS-resident for N <= 11, else in the scratch slab
 #ifdef BMPC_EMU
     int order[64];
@@ -839,8 +841,8 @@ BMPC_D inline void kh_prefix(const double *rec, double *hp) {   // sequential ov
 
 // q~ row r (reduced-state row, r < NS) of the node cost: gl mapped through the lifting Jacobians; rows >= 14 only copy.
 // Predicated straight-line code: every lane evaluates the (q, dq)-row formula on a clamped row.
-BMPC_D inline double node_q_row(const double *L, int r, double h, int ex) {
-    const double *gl = L + L_NC + NC_GL, *K0 = L + L_K0, *WY = L + L_WY, *gy = L + L_ST + ST_G;   // g_y = (g_q, g_dq): rows 0..13 of g
+BMPC_D inline double node_q_row(const double *L, const double *K0, int r, double h, int ex) {
+    const double *gl = L + L_NC + NC_GL, *WY = L + L_WY, *gy = L + L_ST + ST_G;   // g_y = (g_q, g_dq): rows 0..13 of g
     const bool heavy = r < 14; const int a = heavy ? r : 0; const bool isq = a < 7; const int ai = isq ? a : a - 7;
     const double base = gl[(int)L[L_ZMAP + r] & 255];
     double t1 = 0, t2 = 0, t3 = 0, sW = 0;
@@ -863,7 +865,7 @@ BMPC_D inline double node_q_row(const double *L, int r, double h, int ex) {
 // (15x14, rank 6) is never formed: its consumers contract the two rank-6 factors on the fly (t6 in S0, chain-pair entries in S1).
 BMPC_D inline void stage_data_lane(Wave &W, const Scr &sc, int k, int lane) {
     double *L = W.L, *G = W.G; const double h = W.h;
-    const double *K0 = L + L_K0, *K1 = L + L_K1, *KVk = L + L_KV, *gk = L + L_ST + ST_G;
+    const double *K0 = L + W.oK0, *K1 = L + W.oK1, *KVk = L + W.oKV, *gk = L + L_ST + ST_G;
     {
         const bool on = lane < NS; const int r = on ? lane : 0;
         const bool io = r >= SIOTA; const int c = io ? r - SIOTA : 0;
@@ -891,7 +893,8 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
     const double *PAR = L + L_PAR, *w = PAR + po.w;
     const double *ST = L + L_ST;
     const double *rr = ST + ST_REF, *gk = ST + ST_G, *sgk = ST + ST_SG, *nuk = ST + ST_NU;
-    double *NC = L + L_NC, *K0 = L + L_K0, *KV1 = L + L_KV1, *WY = L + L_WY, *KHP = L + L_KHP;
+    double *NC = L + L_NC, *WY = L + L_WY, *KHP = L + L_KHP;
+    const double *K0 = L + W.oK0, *KV1 = L + W.oKV1;
     const bool has_next = k < N - 1;
     // phase 1: small Hessian blocks over (pos, iw, phi)
     LANES_BEGIN   // predicated straight-line code
@@ -1114,7 +1117,7 @@ BMPC_D inline double gv_at(const double *rec, int c6, int y) {
 }
 
 // issue the global loads of stage k's inputs into per-lane registers (consumed one stage later by the commit phase)
-BMPC_D inline void wave_backward_prefetch(Wave &W, const Scr &sc, int k, LaneRegs *LR) {
+BMPC_D inline void wave_backward_prefetch(Wave &W, const Scr &sc, int k, LaneRegs *LR, bool full) {
     const int N = W.N; double *G = W.G;
     // Branch-free: every lane loads from a clamped, always-valid index (lanes beyond the end of an array repeat its last element;
     // a neighbour node that does not exist is replaced by the nearest one -- its data is masked by the consumers), and the commit
@@ -1124,8 +1127,12 @@ BMPC_D inline void wave_backward_prefetch(Wave &W, const Scr &sc, int k, LaneReg
         const int kn = k < N - 1 ? k + 1 : k, kp = k >= 1 ? k - 1 : 0;
         const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, r2 = lane < RREC - 64 ? 64 + lane : RREC - 1;
         const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l12 = lane < 12 ? lane : 11;
-        pf[0] = G[sc.KIN + k * KREC + lane]; pf[1] = G[sc.KIN + k * KREC + l2];
-        pf[2] = G[sc.KIN + (N + kn) * KREC + lane]; pf[3] = G[sc.KIN + (N + kn) * KREC + l2];
+        // of the four kinematics records of a stage (node k, velocity point of node k+1, node k-1, velocity point of node k) the
+        // first two are the last two of the previous stage (k+1): they stay in LDS, only the first stage of a sweep loads all four
+        if (full) {
+            pf[0] = G[sc.KIN + k * KREC + lane]; pf[1] = G[sc.KIN + k * KREC + l2];
+            pf[2] = G[sc.KIN + (N + kn) * KREC + lane]; pf[3] = G[sc.KIN + (N + kn) * KREC + l2];
+        }
         pf[4] = G[sc.KIN + kp * KREC + lane]; pf[5] = G[sc.KIN + kp * KREC + l2];
         pf[6] = G[sc.KIN + (N + k) * KREC + lane]; pf[7] = G[sc.KIN + (N + k) * KREC + l2];
         pf[8] = G[sc.REF + k * RREC + lane]; pf[9] = G[sc.REF + k * RREC + r2];
@@ -1147,22 +1154,27 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         for (int id = lane; id < 1024 + 96 + 12; id += 64) L[L_PB + id] = 0.0;
         if (lane < 36) L[L_PV + lane] = 0.0;
     LANES_END
-    wave_backward_prefetch(W, sc, N - 1, LR);
+    wave_backward_prefetch(W, sc, N - 1, LR, true);
     for (int k = N - 1; k >= 0; k--) {
         BMPC_PROF(W, 6);
+        {   // record buffers of this stage: (K0, K1) and (KV1, KV) swap roles from stage to stage
+            const bool odd = ((N - 1 - k) & 1) != 0;
+            W.oK0 = odd ? L_K1 : L_K0; W.oK1 = odd ? L_K0 : L_K1; W.oKV1 = odd ? L_KV : L_KV1; W.oKV = odd ? L_KV1 : L_KV;
+        }
         LANES_BEGIN   // ---- commit the prefetched inputs of this stage (registers -> LDS) ----
             const double *pf = LR[LIDX].pf;
             const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, r2 = lane < RREC - 64 ? 64 + lane : RREC - 1;
             const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l12 = lane < 12 ? lane : 11;
-            L[L_K0 + lane] = pf[0]; L[L_KV1 + lane] = pf[2]; L[L_K1 + lane] = pf[4]; L[L_KV + lane] = pf[6];
-            L[L_K0 + l2] = pf[1]; L[L_KV1 + l2] = pf[3]; L[L_K1 + l2] = pf[5]; L[L_KV + l2] = pf[7];
+            if (k == N - 1) { L[W.oK0 + lane] = pf[0]; L[W.oKV1 + lane] = pf[2]; L[W.oK0 + l2] = pf[1]; L[W.oKV1 + l2] = pf[3]; }
+            L[W.oK1 + lane] = pf[4]; L[W.oKV + lane] = pf[6];
+            L[W.oK1 + l2] = pf[5]; L[W.oKV + l2] = pf[7];
             L[L_ST + ST_REF + lane] = pf[8]; L[L_ST + ST_REF + r2] = pf[9];
             L[L_ST + ST_GH + lz] = pf[11];
             L[L_ST + ST_SG + li] = pf[12]; L[L_ST + ST_NU + li] = pf[13];
             L[L_ST + ST_G + le] = pf[14]; L[L_ST + ST_LAM0 + le] = pf[15]; L[L_ST + ST_LAM1 + le] = pf[16];
             L[L_ST + ST_RLV0 + l12] = pf[17]; L[L_ST + ST_RLVM + l12] = pf[18]; L[L_ST + ST_RLVP + l12] = pf[19];
         LANES_END
-        if (k >= 1) wave_backward_prefetch(W, sc, k - 1, LR);   // loads for the NEXT stage fly while this stage computes
+        if (k >= 1) wave_backward_prefetch(W, sc, k - 1, LR, false);   // loads for the NEXT stage fly while this stage computes
         BMPC_PROF(W, 24);
         wave_node_cost_blk(W, po, sc, k, mu, delta);     // PB/PCI/PII/PV now hold the value function of node k+1
         BMPC_PROF(W, 5);
@@ -1182,7 +1194,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                     for (int g = 0; g < 3; g++) BMPC_ACC4(pa, g, L[L_PB + pbi(f, g, i, l)] * L[L_RD + srow(g, l)]);   // rdyn of the jerk states (g = 3) is zero
 #pragma unroll
                 for (int a = 0; a < 3; a++) BMPC_ACC4(pa, a, L[L_PCI + pci(a, f, i)] * L[L_RD + SIOTA + a]);
-                const double qr = node_q_row(L, r, h, W.o.exact_hessian);          // q~ of node k+1 joins the value-function gradient here
+                const double qr = node_q_row(L, L + W.oK0, r, h, W.o.exact_hessian);          // q~ of node k+1 joins the value-function gradient here
                 L[L_PR + r] = (L[L_PV + r] + qr) + BMPC_ACC4_SUM(pa);      // off-lanes repeat row 0 (same value): no conditional store
             }
             {   // iota rows of PR
@@ -1215,7 +1227,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
             }
             {   // t6 = C rdyn: the rdyn side of X^T rdyn = Gv(K1)^T (C rdyn)
                 const bool on = k >= 1 && lane >= 48 && lane < 54; const int c6 = on ? lane - 48 : 0;
-                const double *K0 = L + L_K0, *dpn = L + L_ST + ST_REF + RDP;
+                const double *K0 = L + W.oK0, *dpn = L + L_ST + ST_REF + RDP;
                 const double *jrow = c6 < 3 ? K0 + KW + c6 * 7 : K0 + KA + (c6 - 3) * 7;
                 BMPC_ACC4_DECL(ta);
 #pragma unroll
@@ -1245,7 +1257,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 #pragma unroll
                 for (int a = 0; a < 3; a++) ve += L[L_AE + a * 14 + y] * L[L_PR + SIOTA + a];
                 {
-                    const double *K1 = L + L_K1;
+                    const double *K1 = L + W.oK1;
 #pragma unroll
                     for (int c6 = 0; c6 < 6; c6++) sx += K1[(fp == 0 ? KD + c6 * 7 : (c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7)) + ic] * L[L_T6 + c6];
                 }
@@ -1305,7 +1317,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
             // acceleration cross block entries for chain ci / cl: X[q+_c], X[dq+_c] (chains < 7) or X[ddphi+] (chain 7), contracted
             // on the fly from the rank-6 factors: X[r][c] = sum_c6 C[c6][r] Gv(K1)[c6][c], C = -2 w_a/h^2 Gv(K0) (rows < 14), 2 w_a/h dpn
             {
-                const double *K0 = L + L_K0, *K1 = L + L_K1, *dpn = L + L_ST + ST_REF + RDP;
+                const double *K0 = L + W.oK0, *K1 = L + W.oK1, *dpn = L + L_ST + ST_REF + RDP;
                 const double fx = -W.ca * mx * ml * mi, fphi = W.cb * mx * mi * (1.0 - ml);
                 double xl0[2] = {0, 0}, xl1[2] = {0, 0}, xi0[2] = {0, 0}, xi1[2] = {0, 0}, xi2[2] = {0, 0};
 #pragma unroll
