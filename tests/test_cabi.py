@@ -56,3 +56,38 @@ def test_product_does_not_reference_oracle_or_emulator():
                 src = open(os.path.join(dp, f)).read()
                 for pat in (r"^\s*(from|import)\s+oracle", r"^\s*(from|import)\s+tests", r"libbmpc_oracle", r"libbmpc_emu"):
                     assert not re.search(pat, src, flags=re.M), f"{f} refers to test infrastructure ({pat})"
+
+
+def test_isa_lint_flags_copies_ahead_of_exec_restore(tmp_path):
+    """build.lint_isa: the signature of the register-allocator defect described in DESIGN.md 4 (copies ahead of the exec
+    restore of a join block) is flagged, ordinary join blocks are not; the ISA of the shipped library is clean."""
+    from boundmpc_amd import build as b
+    bad = """_Z6kernelv:
+; %bb.0:
+	s_and_saveexec_b64 s[12:13], s[0:1]
+; %bb.1:
+	v_add_f64 v[0:1], v[2:3], v[4:5]
+; %bb.2:
+	s_waitcnt vmcnt(4)
+	v_accvgpr_write_b32 a149, v9
+	v_accvgpr_write_b32 a148, v8
+	s_mov_b32 s25, s63
+	s_or_b64 exec, exec, s[12:13]
+	v_mov_b64_e32 v[26:27], 0
+.LBB0_3:
+	v_readlane_b32 s4, v255, 34
+	s_or_b64 exec, exec, s[4:5]
+	v_accvgpr_write_b32 a1, v2
+.LBB0_4:
+	v_cmp_lt_f64_e64 vcc, v[0:1], v[2:3]
+	v_accvgpr_read_b32 v52, a92
+	s_or_b64 exec, exec, s[6:7]
+	s_endpgm
+"""
+    f = tmp_path / "k.s"
+    f.write_text(bad)
+    hits = b.lint_isa(str(f))
+    assert len(hits) == 1 and hits[0][1] == "bb.2" and len(hits[0][3]) == 2
+    asm = os.path.join(ROOT, "build", "isa", "bmpc_hip_gfx950.s")
+    if os.path.exists(asm):
+        assert b.lint_isa(asm) == []
