@@ -702,35 +702,40 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
     // sequential sweep; lam_{k+1} lives in LDS (ping-pong ST_LAM0/ST_LAM1).  The inputs of a stage (gradient row, the two kinematics
     // records of node k+1) are prefetched into registers one stage ahead and dropped into LDS in one burst: a blocking global
     // load per stage would cost a full memory round trip with nothing else in flight
+    // Stage inputs are double-buffered in LDS by stage parity (records: L_K0/L_KV and L_K1/L_KV1, gradient row: ST_GH and ST_Z), so
+    // the burst that commits the inputs of stage k-1 and the loads for stage k-2 ride at the end of stage k's main phase instead of
+    // being phases of their own: two phases per stage (multipliers of the chain states; everything else).
+    // inputs of stage j: gradient row j, kinematics records of node j+1 (predicted point and velocity point); j = -1: record of node 0
+    #define BMPC_ADJ_LOADS(j_) { double *pf = LR[LIDX].pf; const int j = (j_), jc = j >= 0 ? j : 0, l2 = lane < KREC - 64 ? 64 + lane : KREC - 1; \
+        pf[0] = G[sc.GH + jc * NZ + (lane < NZ ? lane : NZ - 1)]; \
+        pf[1] = G[sc.KIN + (j + 1) * KREC + lane]; pf[2] = G[sc.KIN + (j + 1) * KREC + l2]; \
+        pf[3] = G[sc.KIN + (N + j + 1) * KREC + lane]; pf[4] = G[sc.KIN + (N + j + 1) * KREC + l2]; }
+    #define BMPC_ADJ_COMMIT(j_) { const double *pf = LR[LIDX].pf; const int odd = (N - 1 - (j_)) & 1, l2 = lane < KREC - 64 ? 64 + lane : KREC - 1; \
+        const int kb = odd ? L_K1 : L_K0, vb = odd ? L_KV1 : L_KV; \
+        L[L_ST + (odd ? ST_Z : ST_GH) + (lane < NZ ? lane : NZ - 1)] = pf[0]; \
+        L[kb + lane] = pf[1]; L[vb + lane] = pf[3]; L[kb + l2] = pf[2]; L[vb + l2] = pf[4]; }
     LANES_BEGIN
-        double *pf = LR[LIDX].pf;
-        pf[0] = G[sc.GH + (N - 1) * NZ + (lane < NZ ? lane : NZ - 1)];
+        BMPC_ADJ_LOADS(N - 2 >= -1 ? N - 2 : -1)      // the last stage has no next node: its record slots load those of stage N-2 (unused)
+        { double *pf = LR[LIDX].pf; pf[0] = G[sc.GH + (N - 1) * NZ + (lane < NZ ? lane : NZ - 1)]; }
+    LANES_END
+    LANES_BEGIN
+        BMPC_ADJ_COMMIT(N - 1)
+        BMPC_ADJ_LOADS(N - 2 >= -1 ? N - 2 : -1)
     LANES_END
     for (int k = N - 1; k >= 0; k--) {
-        double *lam1 = L + L_ST + (((N - 1 - k) & 1) ? ST_LAM0 : ST_LAM1);     // lam_{k+1} (written one step earlier)
-        double *lam0 = L + L_ST + (((N - 1 - k) & 1) ? ST_LAM1 : ST_LAM0);     // lam_k (written now)
-        LANES_BEGIN
-            const double *pf = LR[LIDX].pf;
-            const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1;
-            L[L_ST + ST_GH + (lane < NZ ? lane : NZ - 1)] = pf[0];
-            if (k < N - 1) { L[L_K0 + lane] = pf[1]; L[L_KV + lane] = pf[3]; L[L_K0 + l2] = pf[2]; L[L_KV + l2] = pf[4]; }
-        LANES_END
-        LANES_BEGIN   // loads for stage k-1 (records of node k); for k = 0 the record of node 0, used after the loop; branch-free
-            double *pf = LR[LIDX].pf;
-            const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, kp = k >= 1 ? k - 1 : 0;
-            pf[0] = G[sc.GH + kp * NZ + (lane < NZ ? lane : NZ - 1)];
-            pf[1] = G[sc.KIN + k * KREC + lane]; pf[2] = G[sc.KIN + k * KREC + l2];
-            pf[3] = G[sc.KIN + (N + k) * KREC + lane]; pf[4] = G[sc.KIN + (N + k) * KREC + l2];
-        LANES_END
+        const int odd = (N - 1 - k) & 1;
+        double *lam1 = L + L_ST + (odd ? ST_LAM0 : ST_LAM1);     // lam_{k+1} (written one step earlier)
+        double *lam0 = L + L_ST + (odd ? ST_LAM1 : ST_LAM0);     // lam_k (written now)
+        const double *k0 = L + (odd ? L_K1 : L_K0), *kvb = L + (odd ? L_KV1 : L_KV), *ghb = L + L_ST + (odd ? ST_Z : ST_GH);
         if (k < N - 1) {
             LANES_BEGIN
-                stage_mu(W, lam1, L + L_K0, lane);
+                stage_mu(W, lam1, k0, lane);
             LANES_END
         }
         LANES_BEGIN   // predicated: the component kind selects coefficients (integer selects), not code paths
             {
                 const bool on = lane < NZ; const int z = on ? lane : 0;
-                const double *kv = L + L_KV;
+                const double *kv = kvb;
                 // field f (0 q, 1 dq, 2 ddq, 3 jerk) and chain i of this component; f = -1: lifted variable (pos, iw, v)
                 const int f = z < 7 ? 3 : (z == ZJPHI ? 3 : (z < ZDQ ? 0 : (z < ZDDQ ? 1 : (z < ZPOS ? 2 : (z >= ZPHI ? z - ZPHI : -1)))));
                 const int i = z < 7 ? z : (z == ZJPHI ? 7 : (z < ZDQ ? z - ZQ : (z < ZDDQ ? z - ZDQ : (z < ZPOS ? z - ZDDQ : (z >= ZPHI ? 7 : 0)))));
@@ -742,7 +747,7 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
                 double e = 0;
 #pragma unroll
                 for (int c = 0; c < 3; c++) e += kv[eb + c * 7] * lam1[GIW + c];
-                double tot = L[L_ST + ST_GH + z];
+                double tot = ghb[z];
                 if (nxt) tot += has ? chainv + ((i < 7 && fc <= 1) ? 0.5 * h * e : 0.0) : (isIw ? lam1[GIW + cw] : 0.0);
                 // Stores without branches: one LDS store and one global store per lane, the row kind selects the ADDRESS.
                 // jerk rows: the residual of node k still lacks the term of the NEXT sweep step (stage k-1 -> k); it is parked in LDS
@@ -762,15 +767,16 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
                 const double v = L[L_RJP + ((k + 1) & 1) * 8 + i] + (h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd);
                 G[on ? sc.RJ + (k + 1) * NU + i : sc.GVP + k * 8 + 7] = v;
             }
+            // inputs of the next stage into the other buffer set (loaded one stage ago), then the loads of the stage after it
+            BMPC_ADJ_COMMIT(k - 1)
+            BMPC_ADJ_LOADS(k - 2 >= -1 ? k - 2 : -1)
         LANES_END
     }
+    #undef BMPC_ADJ_LOADS
+    #undef BMPC_ADJ_COMMIT
     const double *lamz = L + L_ST + (((N - 1) & 1) ? ST_LAM1 : ST_LAM0);   // lam_0
     LANES_BEGIN
-        const double *pf = LR[LIDX].pf;
-        L[L_K0 + lane] = pf[1]; L[L_K0 + (lane < KREC - 64 ? 64 + lane : KREC - 1)] = pf[2];
-    LANES_END
-    LANES_BEGIN
-        stage_mu(W, lamz, L + L_K0, lane);
+        stage_mu(W, lamz, L + ((N & 1) ? L_K1 : L_K0), lane);      // record of node 0: committed as "stage -1"
     LANES_END
     LANES_BEGIN
         if (lane < 8) {
