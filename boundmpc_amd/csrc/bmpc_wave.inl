@@ -507,7 +507,7 @@ BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
 }
 
 constexpr int RU = 6;   // rows of a lane-strided pass kept in flight per lane (loads of a batch are issued before their first use)
-struct LaneRegs { double mc[16]; double pf[20]; };   // pf: software prefetch of the next stage's inputs (global -> registers -> LDS)   // a lane's 4x4 state block of M, kept in registers between the M and the Schur phases
+struct LaneRegs { double mc[16]; double pf[24]; };   // pf: software prefetch of the next stage's inputs (global -> registers -> LDS)   // a lane's 4x4 state block of M, kept in registers between the M and the Schur phases
 
 // ----------------------------------------------------------------------------------------
 // wave-uniform deterministic reductions through LDS (RED has 6 x 64 slots)
@@ -662,6 +662,73 @@ BMPC_D inline void stage_mu(Wave &W, const double *lam, const double *kp, int la
     L[L_MU + ch] = ch < 7 ? s : lp; L[L_MU + 8 + ch] = ch < 7 ? s2 : ld;
 }
 
+// inputs of adjoint stage j: gradient row j, kinematics records of node j+1 (predicted point and velocity point); j = -1: record
+// of node 0.  Register set PO (0 or 5) of the lane's prefetch array; LDS buffer set by stage parity.
+#define BMPC_ADJ_LOADS(j_, PO_) { double *pf = LR[LIDX].pf + (PO_); const int j0 = (j_), j = j0 >= -1 ? j0 : -1, jc = j >= 0 ? j : 0, jr = j + 1 < N ? j + 1 : N - 1; \
+    const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1; \
+    pf[0] = G[sc.GH + jc * NZ + (lane < NZ ? lane : NZ - 1)]; \
+    pf[1] = G[sc.KIN + jr * KREC + lane]; pf[2] = G[sc.KIN + jr * KREC + l2]; \
+    pf[3] = G[sc.KIN + (N + jr) * KREC + lane]; pf[4] = G[sc.KIN + (N + jr) * KREC + l2]; }
+#define BMPC_ADJ_COMMIT(j_, PO_) { const double *pf = LR[LIDX].pf + (PO_); const int odd_ = (N - 1 - (j_)) & 1, l2 = lane < KREC - 64 ? 64 + lane : KREC - 1; \
+    const int kb = odd_ ? L_K1 : L_K0, vb = odd_ ? L_KV1 : L_KV; \
+    L[L_ST + (odd_ ? ST_Z : ST_GH) + (lane < NZ ? lane : NZ - 1)] = pf[0]; \
+    L[kb + lane] = pf[1]; L[vb + lane] = pf[3]; L[kb + l2] = pf[2]; L[vb + l2] = pf[4]; }
+// one stage of the sequential adjoint sweep (two phases); PO = register set that holds the inputs of stage k-1
+template <int PO>
+BMPC_D inline void adjoint_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
+    const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
+    double *L = W.L, *G = W.G;
+    const int odd = (N - 1 - k) & 1;
+    double *lam1 = L + L_ST + (odd ? ST_LAM0 : ST_LAM1);     // lam_{k+1} (written one step earlier)
+    double *lam0 = L + L_ST + (odd ? ST_LAM1 : ST_LAM0);     // lam_k (written now)
+    const double *k0 = L + (odd ? L_K1 : L_K0), *kvb = L + (odd ? L_KV1 : L_KV), *ghb = L + L_ST + (odd ? ST_Z : ST_GH);
+    if (k < N - 1) {
+        LANES_BEGIN
+            stage_mu(W, lam1, k0, lane);
+        LANES_END
+    }
+    LANES_BEGIN   // predicated: the component kind selects coefficients (integer selects), not code paths
+        {
+            const bool on = lane < NZ; const int z = on ? lane : 0;
+            const double *kv = kvb;
+            // field f (0 q, 1 dq, 2 ddq, 3 jerk) and chain i of this component; f = -1: lifted variable (pos, iw, v)
+            const int f = z < 7 ? 3 : (z == ZJPHI ? 3 : (z < ZDQ ? 0 : (z < ZDDQ ? 1 : (z < ZPOS ? 2 : (z >= ZPHI ? z - ZPHI : -1)))));
+            const int i = z < 7 ? z : (z == ZJPHI ? 7 : (z < ZDQ ? z - ZQ : (z < ZDDQ ? z - ZDQ : (z < ZPOS ? z - ZDDQ : (z >= ZPHI ? 7 : 0)))));
+            const bool has = f >= 0, nxt = k < N - 1; const int fc = has ? f : 0, i7 = i < 7 ? i : 0;
+            const bool isIw = z >= ZIW && z < ZIW + 3; const int cw = isIw ? z - ZIW : 0;
+            const double mdd = lam1[i < 7 ? GDDQ + i : GDDPHI];
+            const double chainv = L[L_CFT + fc] * L[L_MU + i] + L[L_CFT + 5 + fc] * L[L_MU + 8 + i] + L[L_CFT + 10 + fc] * mdd;
+            const int eb = fc == 0 ? KD + 21 + i7 : KA + i7;                    // Ehat column of (q_i) or (dq_i): rows at stride 7
+            double e = 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) e += kv[eb + c * 7] * lam1[GIW + c];
+            double tot = ghb[z];
+            if (nxt) tot += has ? chainv + ((i < 7 && fc <= 1) ? 0.5 * h * e : 0.0) : (isIw ? lam1[GIW + cw] : 0.0);
+            // Stores without branches: one LDS store and one global store per lane, the row kind selects the ADDRESS.
+            // jerk rows: the residual of node k still lacks the term of the NEXT sweep step (stage k-1 -> k); it is parked in LDS
+            // and completed there (a global read-modify-write would wait for this store to land and come back); their global
+            // store goes to a spare slot of the node's GVP row.  Off-lanes repeat row 0 (a jerk row) with identical values.
+            {
+                const bool isJ = z < 7 || z == ZJPHI;
+                const int ee = z < ZPOS ? z - ZQ : (z < ZPHI ? GPOS + (z - ZPOS) : GPHI + (z - ZPHI));
+                double *ldst = isJ ? L + L_RJP + (k & 1) * 8 + (z < 7 ? z : 7) : lam0 + ee;
+                const int gdst = isJ ? sc.GVP + k * 8 + 6 : sc.LAM + k * NE + ee;
+                *ldst = tot; G[gdst] = tot;
+            }
+        }
+        {   // jerk of node k+2 enters stage k+1 (lanes 44..51; everyone else, and the last stage, write to the spare GVP slot)
+            const bool on = lane >= NZ && lane < NZ + 8 && k < N - 1; const int i = on ? lane - NZ : 0;
+            const double mdd = lam1[i < 7 ? GDDQ + i : GDDPHI];
+            const double v = L[L_RJP + ((k + 1) & 1) * 8 + i] + (h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd);
+            G[on ? sc.RJ + (k + 1) * NU + i : sc.GVP + k * 8 + 7] = v;
+        }
+        // inputs of the next stage into the other LDS buffer set (loaded two stages ago), then the loads for three stages ahead
+        // into the registers this just freed
+        BMPC_ADJ_COMMIT(k - 1, PO)
+        BMPC_ADJ_LOADS(k - 3, PO)
+    LANES_END
+}
+
 // Adjoint sweep with multipliers nu (scratch offset oNU; scale = 0 -> objective only is NOT supported here):
 // LAM[N][36], RJ[N][8]; GH receives d(f + nu.h)/dZ.
 BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU, bool use_hat, double mu, LaneRegs *LR) {
@@ -699,81 +766,24 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
     LANES_END
     BMPC_PROF(W, 27);
     if (use_hat) return;   // QP gradient only
-    // sequential sweep; lam_{k+1} lives in LDS (ping-pong ST_LAM0/ST_LAM1).  The inputs of a stage (gradient row, the two kinematics
-    // records of node k+1) are prefetched into registers one stage ahead and dropped into LDS in one burst: a blocking global
-    // load per stage would cost a full memory round trip with nothing else in flight
-    // Stage inputs are double-buffered in LDS by stage parity (records: L_K0/L_KV and L_K1/L_KV1, gradient row: ST_GH and ST_Z), so
-    // the burst that commits the inputs of stage k-1 and the loads for stage k-2 ride at the end of stage k's main phase instead of
-    // being phases of their own: two phases per stage (multipliers of the chain states; everything else).
-    // inputs of stage j: gradient row j, kinematics records of node j+1 (predicted point and velocity point); j = -1: record of node 0
-    #define BMPC_ADJ_LOADS(j_) { double *pf = LR[LIDX].pf; const int j = (j_), jc = j >= 0 ? j : 0, l2 = lane < KREC - 64 ? 64 + lane : KREC - 1; \
-        pf[0] = G[sc.GH + jc * NZ + (lane < NZ ? lane : NZ - 1)]; \
-        pf[1] = G[sc.KIN + (j + 1) * KREC + lane]; pf[2] = G[sc.KIN + (j + 1) * KREC + l2]; \
-        pf[3] = G[sc.KIN + (N + j + 1) * KREC + lane]; pf[4] = G[sc.KIN + (N + j + 1) * KREC + l2]; }
-    #define BMPC_ADJ_COMMIT(j_) { const double *pf = LR[LIDX].pf; const int odd = (N - 1 - (j_)) & 1, l2 = lane < KREC - 64 ? 64 + lane : KREC - 1; \
-        const int kb = odd ? L_K1 : L_K0, vb = odd ? L_KV1 : L_KV; \
-        L[L_ST + (odd ? ST_Z : ST_GH) + (lane < NZ ? lane : NZ - 1)] = pf[0]; \
-        L[kb + lane] = pf[1]; L[vb + lane] = pf[3]; L[kb + l2] = pf[2]; L[vb + l2] = pf[4]; }
+    // sequential sweep; lam_{k+1} lives in LDS (ping-pong ST_LAM0/ST_LAM1).  A blocking global load per stage would cost a full
+    // memory round trip with nothing else in flight, and the stages are short (the round trip is longer than a stage), so the
+    // inputs of a stage are loaded into registers THREE stages ahead (two register sets, the stage loop is unrolled by two) and
+    // committed to LDS one stage ahead, double-buffered by stage parity (records: L_K0/L_KV and L_K1/L_KV1, gradient row: ST_GH
+    // and ST_Z); the commit burst and the next loads ride at the end of a stage's main phase: two phases per stage.
     LANES_BEGIN
-        BMPC_ADJ_LOADS(N - 2 >= -1 ? N - 2 : -1)      // the last stage has no next node: its record slots load those of stage N-2 (unused)
-        { double *pf = LR[LIDX].pf; pf[0] = G[sc.GH + (N - 1) * NZ + (lane < NZ ? lane : NZ - 1)]; }
+        BMPC_ADJ_LOADS(N - 1, 0)
+        BMPC_ADJ_LOADS(N - 2, 5)
     LANES_END
     LANES_BEGIN
-        BMPC_ADJ_COMMIT(N - 1)
-        BMPC_ADJ_LOADS(N - 2 >= -1 ? N - 2 : -1)
+        BMPC_ADJ_COMMIT(N - 1, 0)
+        BMPC_ADJ_LOADS(N - 3, 0)
     LANES_END
-    for (int k = N - 1; k >= 0; k--) {
-        const int odd = (N - 1 - k) & 1;
-        double *lam1 = L + L_ST + (odd ? ST_LAM0 : ST_LAM1);     // lam_{k+1} (written one step earlier)
-        double *lam0 = L + L_ST + (odd ? ST_LAM1 : ST_LAM0);     // lam_k (written now)
-        const double *k0 = L + (odd ? L_K1 : L_K0), *kvb = L + (odd ? L_KV1 : L_KV), *ghb = L + L_ST + (odd ? ST_Z : ST_GH);
-        if (k < N - 1) {
-            LANES_BEGIN
-                stage_mu(W, lam1, k0, lane);
-            LANES_END
-        }
-        LANES_BEGIN   // predicated: the component kind selects coefficients (integer selects), not code paths
-            {
-                const bool on = lane < NZ; const int z = on ? lane : 0;
-                const double *kv = kvb;
-                // field f (0 q, 1 dq, 2 ddq, 3 jerk) and chain i of this component; f = -1: lifted variable (pos, iw, v)
-                const int f = z < 7 ? 3 : (z == ZJPHI ? 3 : (z < ZDQ ? 0 : (z < ZDDQ ? 1 : (z < ZPOS ? 2 : (z >= ZPHI ? z - ZPHI : -1)))));
-                const int i = z < 7 ? z : (z == ZJPHI ? 7 : (z < ZDQ ? z - ZQ : (z < ZDDQ ? z - ZDQ : (z < ZPOS ? z - ZDDQ : (z >= ZPHI ? 7 : 0)))));
-                const bool has = f >= 0, nxt = k < N - 1; const int fc = has ? f : 0, i7 = i < 7 ? i : 0;
-                const bool isIw = z >= ZIW && z < ZIW + 3; const int cw = isIw ? z - ZIW : 0;
-                const double mdd = lam1[i < 7 ? GDDQ + i : GDDPHI];
-                const double chainv = L[L_CFT + fc] * L[L_MU + i] + L[L_CFT + 5 + fc] * L[L_MU + 8 + i] + L[L_CFT + 10 + fc] * mdd;
-                const int eb = fc == 0 ? KD + 21 + i7 : KA + i7;                    // Ehat column of (q_i) or (dq_i): rows at stride 7
-                double e = 0;
-#pragma unroll
-                for (int c = 0; c < 3; c++) e += kv[eb + c * 7] * lam1[GIW + c];
-                double tot = ghb[z];
-                if (nxt) tot += has ? chainv + ((i < 7 && fc <= 1) ? 0.5 * h * e : 0.0) : (isIw ? lam1[GIW + cw] : 0.0);
-                // Stores without branches: one LDS store and one global store per lane, the row kind selects the ADDRESS.
-                // jerk rows: the residual of node k still lacks the term of the NEXT sweep step (stage k-1 -> k); it is parked in LDS
-                // and completed there (a global read-modify-write would wait for this store to land and come back); their global
-                // store goes to a spare slot of the node's GVP row.  Off-lanes repeat row 0 (a jerk row) with identical values.
-                {
-                    const bool isJ = z < 7 || z == ZJPHI;
-                    const int ee = z < ZPOS ? z - ZQ : (z < ZPHI ? GPOS + (z - ZPOS) : GPHI + (z - ZPHI));
-                    double *ldst = isJ ? L + L_RJP + (k & 1) * 8 + (z < 7 ? z : 7) : lam0 + ee;
-                    const int gdst = isJ ? sc.GVP + k * 8 + 6 : sc.LAM + k * NE + ee;
-                    *ldst = tot; G[gdst] = tot;
-                }
-            }
-            {   // jerk of node k+2 enters stage k+1 (lanes 44..51; everyone else, and the last stage, write to the spare GVP slot)
-                const bool on = lane >= NZ && lane < NZ + 8 && k < N - 1; const int i = on ? lane - NZ : 0;
-                const double mdd = lam1[i < 7 ? GDDQ + i : GDDPHI];
-                const double v = L[L_RJP + ((k + 1) & 1) * 8 + i] + (h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd);
-                G[on ? sc.RJ + (k + 1) * NU + i : sc.GVP + k * 8 + 7] = v;
-            }
-            // inputs of the next stage into the other buffer set (loaded one stage ago), then the loads of the stage after it
-            BMPC_ADJ_COMMIT(k - 1)
-            BMPC_ADJ_LOADS(k - 2 >= -1 ? k - 2 : -1)
-        LANES_END
+    {
+        int k = N - 1;
+        for (; k >= 1; k -= 2) { adjoint_stage<5>(W, sc, LR, k); adjoint_stage<0>(W, sc, LR, k - 1); }
+        if (k == 0) adjoint_stage<5>(W, sc, LR, 0);
     }
-    #undef BMPC_ADJ_LOADS
-    #undef BMPC_ADJ_COMMIT
     const double *lamz = L + L_ST + (((N - 1) & 1) ? ST_LAM1 : ST_LAM0);   // lam_0
     LANES_BEGIN
         stage_mu(W, lamz, L + ((N & 1) ? L_K1 : L_K0), lane);      // record of node 0: committed as "stage -1"
@@ -1469,89 +1479,101 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
     return true;
 }
 
-// forward sweep: dZ[N][44].  The inputs of stage k+1 (gains, defects, kinematics record) are prefetched into registers
-// while stage k computes.
-BMPC_D inline void wave_forward_prefetch(Wave &W, const Scr &sc, int k, LaneRegs *LR) {
-    double *G = W.G;
-    LANES_BEGIN   // branch-free: clamped indices (see wave_backward_prefetch)
-        double *pf = LR[LIDX].pf;
+// forward sweep: dZ[N][44].  The stages are short (shorter than a memory round trip), so the inputs of a stage (gains, defects,
+// kinematics record) are loaded into registers three stages ahead (two register sets, the stage loop is unrolled by two) and
+// committed to LDS one stage ahead, double-buffered by stage parity (staging area: L_ST / the idle gain area L_GS; record:
+// L_K0 / L_K1); the commit burst and the next loads ride at the end of a stage's last phase: three phases per stage.
+#define BMPC_FWD_LOADS(j_, PO_) { double *pf = LR[LIDX].pf + (PO_); const int j = (j_) < N ? (j_) : N - 1; \
+    _Pragma("unroll") for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; pf[u] = G[sc.KT + j * NS * NU + (id < NS * NU ? id : NS * NU - 1)]; } \
+    pf[5] = G[sc.KF + j * NU + (lane < NU ? lane : NU - 1)]; \
+    pf[6] = G[sc.RDY + j * 36 + (lane < 36 ? lane : 35)]; \
+    pf[7] = G[sc.AES + j * 42 + (lane < 42 ? lane : 41)]; \
+    pf[8] = G[sc.RLV + j * 12 + (lane < 12 ? lane : 11)]; \
+    pf[9] = G[sc.KIN + j * KREC + lane]; pf[10] = G[sc.KIN + j * KREC + (lane < KREC - 64 ? 64 + lane : KREC - 1)]; }
+#define BMPC_FWD_COMMIT(j_, PO_) { const double *pf = LR[LIDX].pf + (PO_); const int odd_ = (j_) & 1; double *sb_ = L + (odd_ ? L_GS : L_ST), *kb_ = L + (odd_ ? L_K1 : L_K0); \
+    _Pragma("unroll") for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; sb_[ST_KT + (id < NS * NU ? id : NS * NU - 1)] = pf[u]; } \
+    sb_[ST_KF + (lane < NU ? lane : NU - 1)] = pf[5]; \
+    sb_[ST_RDY + (lane < 36 ? lane : 35)] = pf[6]; \
+    sb_[ST_AES + (lane < 42 ? lane : 41)] = pf[7]; \
+    sb_[ST_RLVF + (lane < 12 ? lane : 11)] = pf[8]; \
+    kb_[lane] = pf[9]; kb_[lane < KREC - 64 ? 64 + lane : KREC - 1] = pf[10]; }
+// one stage of the forward sweep (three phases); PO = register set that holds the inputs of stage k+1
+template <int PO>
+BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
+    const int N = W.N; const double h = W.h;
+    double *L = W.L, *G = W.G;
+    const double *sb = L + ((k & 1) ? L_GS : L_ST), *K0 = L + ((k & 1) ? L_K1 : L_K0);
+    LANES_BEGIN   // du = kff + K ds: partial sums on all 64 lanes (control u = lane & 7, every 8th state b), reduced by the consumers
+        {
+            const int u = lane & 7, part = lane >> 3; double acc = 0.0;
 #pragma unroll
-        for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; pf[u] = G[sc.KT + k * NS * NU + (id < NS * NU ? id : NS * NU - 1)]; }
-        pf[5] = G[sc.KF + k * NU + (lane < NU ? lane : NU - 1)];
-        pf[6] = G[sc.RDY + k * 36 + (lane < 36 ? lane : 35)];
-        pf[7] = G[sc.AES + k * 42 + (lane < 42 ? lane : 41)];
-        pf[8] = G[sc.RLV + k * 12 + (lane < 12 ? lane : 11)];
-        pf[9] = G[sc.KIN + k * KREC + lane]; pf[10] = G[sc.KIN + k * KREC + (lane < KREC - 64 ? 64 + lane : KREC - 1)];
+            for (int j = 0; j < 5; j++) { const int b0 = part + 8 * j, b = b0 < NS ? b0 : NS - 1; const double pr_ = sb[ST_KT + b * NU + u] * L[L_DS + b]; acc += b0 < NS ? pr_ : 0.0; }
+            L[L_RED + part * 8 + u] = acc;
+        }
+    LANES_END
+    LANES_BEGIN   // next reduced state, predicated: chain rows and iota rows evaluated by every lane on clamped indices
+        {
+            const bool on = lane < NS; const int r = on ? lane : 0;
+            const bool chain = r < 28 || (r >= SPHI && r <= SJPHI);
+            const int f = r < 28 ? r / 7 : (chain ? r - 28 : 0), i = r < 28 ? r % 7 : 7, a = chain ? 0 : r - SIOTA;
+            const double *ds = L + L_DS, *dp_ = L + L_RED + i;   // fixed-order tree over the 8 partial sums of du
+            const double du_i = sb[ST_KF + i] + (((dp_[0] + dp_[8]) + (dp_[16] + dp_[24])) + ((dp_[32] + dp_[40]) + (dp_[48] + dp_[56])));
+            double vc = 0;
+#pragma unroll
+            for (int fc = 0; fc < 4; fc++) vc += L[L_CFT + f * 5 + fc] * ds[srow(fc, i)];
+            vc += L[L_CFT + f * 5 + 4] * du_i;
+            BMPC_ACC4_DECL(ia);
+#pragma unroll
+            for (int y = 0; y < 14; y++) BMPC_ACC4(ia, y, sb[ST_AES + a * 14 + y] * ds[y]);
+            const double v = sb[ST_RDY + r] + (chain ? vc : ds[r] + BMPC_ACC4_SUM(ia));
+            L[L_DSN + r] = v;
+        }
+    LANES_END
+    LANES_BEGIN   // dZ of the stage: lanes 0..34 scatter the reduced state through the row map (iota rows add their lifting term),
+                  // lanes 35..43 evaluate the lifted rows (pos 3, v 6); contiguous lane ranges = shallow selects, no branch nest
+        {
+            const bool on = lane < NZ; const int t = on ? lane : 0;
+            const double *dn = L + L_DSN, *rlv = sb + ST_RLVF;
+            const bool isIw = t >= SIOTA && t < NS, isPos = t >= NS && t < NS + 3, isV = t >= NS + 3;
+            const int c = isIw ? t - SIOTA : (isPos ? t - NS : (isV ? t - NS - 3 : 0));              // c6 for the v rows
+            const int r = t < NS ? t : 0;
+            const int z = t < NS ? ((int)L[L_ZMAP + r] & 255) : (isPos ? ZPOS + c : ZV + c);
+            const int p1 = isPos ? KW + c * 7 : (isIw ? KD + (3 + c) * 7 : KD + c * 7);
+            const int p2 = isIw ? KA + c * 7 : (c < 3 ? KW + c * 7 : KA + (c - 3) * 7);
+            BMPC_ACC4_DECL(za);
+#pragma unroll
+            for (int i = 0; i < 7; i++) { BMPC_ACC4(za, i, K0[p1 + i] * dn[SQ + i]); }
+            BMPC_ACC4_DECL(zb);
+#pragma unroll
+            for (int i = 0; i < 7; i++) { BMPC_ACC4(zb, i, K0[p2 + i] * dn[SDQ + i]); }
+            const double s1 = BMPC_ACC4_SUM(za), s2 = BMPC_ACC4_SUM(zb);
+            const double addv = (isPos || isV) ? rlv[isPos ? c : 3 + c] : dn[r];
+            const double v = isPos ? addv + s1 : (isIw ? addv + 0.5 * h * (s1 + s2) : (isV ? addv + (s1 + s2) : addv));
+            W.Dz[k * NZ + z] = v;
+        }
+        { const int r = lane < 36 ? lane : 35; const double v = L[L_DSN + (r < NS ? r : 0)]; L[L_DS + r] = r < NS ? v : 0.0; }
+        // inputs of stage k+1 into the other LDS buffer set (loaded two stages ago), then the loads of stage k+3 (clamped to the
+        // last stage) into the registers this just freed
+        BMPC_FWD_COMMIT(k + 1, PO)
+        BMPC_FWD_LOADS(k + 3, PO)
     LANES_END
 }
 BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
-    const int N = W.N; const double h = W.h;
-    double *L = W.L;
+    const int N = W.N;
+    double *L = W.L, *G = W.G;
+    static_assert(ST_RLVF + 12 <= 288 + 64 + 288, "second forward staging buffer must fit into the idle GS/R8/KS area");
     LANES_BEGIN
         if (lane < 36) L[L_DS + lane] = 0.0;
+        BMPC_FWD_LOADS(0, 0)
+        BMPC_FWD_LOADS(1, 11)
     LANES_END
-    wave_forward_prefetch(W, sc, 0, LR);
-    for (int k = 0; k < N; k++) {
-        LANES_BEGIN   // commit the prefetched stage inputs
-            const double *pf = LR[LIDX].pf;
-#pragma unroll
-            for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; L[L_ST + ST_KT + (id < NS * NU ? id : NS * NU - 1)] = pf[u]; }
-            L[L_ST + ST_KF + (lane < NU ? lane : NU - 1)] = pf[5];
-            L[L_ST + ST_RDY + (lane < 36 ? lane : 35)] = pf[6];
-            L[L_ST + ST_AES + (lane < 42 ? lane : 41)] = pf[7];
-            L[L_ST + ST_RLVF + (lane < 12 ? lane : 11)] = pf[8];
-            L[L_K0 + lane] = pf[9]; L[L_K0 + (lane < KREC - 64 ? 64 + lane : KREC - 1)] = pf[10];
-        LANES_END
-        if (k + 1 < N) wave_forward_prefetch(W, sc, k + 1, LR);
-        LANES_BEGIN   // du = kff + K ds: partial sums on all 64 lanes (control u = lane & 7, every 8th state b), reduced by the consumers
-            {
-                const int u = lane & 7, part = lane >> 3; double acc = 0.0;
-#pragma unroll
-                for (int j = 0; j < 5; j++) { const int b0 = part + 8 * j, b = b0 < NS ? b0 : NS - 1; const double pr_ = L[L_ST + ST_KT + b * NU + u] * L[L_DS + b]; acc += b0 < NS ? pr_ : 0.0; }
-                L[L_RED + part * 8 + u] = acc;
-            }
-        LANES_END
-        LANES_BEGIN   // next reduced state, predicated: chain rows and iota rows evaluated by every lane on clamped indices
-            {
-                const bool on = lane < NS; const int r = on ? lane : 0;
-                const bool chain = r < 28 || (r >= SPHI && r <= SJPHI);
-                const int f = r < 28 ? r / 7 : (chain ? r - 28 : 0), i = r < 28 ? r % 7 : 7, a = chain ? 0 : r - SIOTA;
-                const double *ds = L + L_DS, *dp_ = L + L_RED + i;   // fixed-order tree over the 8 partial sums of du
-                const double du_i = L[L_ST + ST_KF + i] + (((dp_[0] + dp_[8]) + (dp_[16] + dp_[24])) + ((dp_[32] + dp_[40]) + (dp_[48] + dp_[56])));
-                double vc = 0;
-#pragma unroll
-                for (int fc = 0; fc < 4; fc++) vc += L[L_CFT + f * 5 + fc] * ds[srow(fc, i)];
-                vc += L[L_CFT + f * 5 + 4] * du_i;
-                BMPC_ACC4_DECL(ia);
-#pragma unroll
-                for (int y = 0; y < 14; y++) BMPC_ACC4(ia, y, L[L_ST + ST_AES + a * 14 + y] * ds[y]);
-                const double v = L[L_ST + ST_RDY + r] + (chain ? vc : ds[r] + BMPC_ACC4_SUM(ia));
-                L[L_DSN + r] = v;
-            }
-        LANES_END
-        LANES_BEGIN   // dZ of the stage, predicated: v = add + scale (P1 . dq_part + m2 P2 . ddq_part); copy rows have scale 0
-            {
-                const bool on = lane < NZ; const int z = on ? lane : 0;
-                const double *dn = L + L_DSN, *K0 = L + L_K0, *rlv = L + L_ST + ST_RLVF;
-                const bool isPos = z >= ZPOS && z < ZIW, isIw = z >= ZIW && z < ZV, isV = z >= ZV && z < ZPHI;
-                const int c = isPos ? z - ZPOS : (isIw ? z - ZIW : (isV ? z - ZV : 0));            // c6 for the v rows
-                const int src = z < 7 ? SJ + z : (z == ZJPHI ? SJPHI : (z < ZPOS ? z - ZQ : (z >= ZPHI ? SPHI + z - ZPHI : (isIw ? SIOTA + c : 0))));
-                const int p1 = isPos ? KW + c * 7 : (isIw ? KD + (3 + c) * 7 : KD + c * 7);
-                const int p2 = isIw ? KA + c * 7 : (c < 3 ? KW + c * 7 : KA + (c - 3) * 7);
-                BMPC_ACC4_DECL(za);
-#pragma unroll
-                for (int i = 0; i < 7; i++) { BMPC_ACC4(za, i, K0[p1 + i] * dn[SQ + i]); }
-                BMPC_ACC4_DECL(zb);
-#pragma unroll
-                for (int i = 0; i < 7; i++) { BMPC_ACC4(zb, i, K0[p2 + i] * dn[SDQ + i]); }
-                const double s1 = BMPC_ACC4_SUM(za), s2 = BMPC_ACC4_SUM(zb);
-                const double addv = (isPos || isV) ? rlv[isPos ? c : 3 + c] : dn[src];
-                const double v = isPos ? addv + s1 : (isIw ? addv + 0.5 * h * (s1 + s2) : (isV ? addv + (s1 + s2) : addv));
-                W.Dz[k * NZ + z] = v;
-            }
-            if (lane < 36) L[L_DS + lane] = lane < NS ? L[L_DSN + lane] : 0.0;
-        LANES_END
-    }
+    LANES_BEGIN
+        BMPC_FWD_COMMIT(0, 0)
+        BMPC_FWD_LOADS(2, 0)
+    LANES_END
+    int k = 0;
+    for (; k + 1 < N; k += 2) { forward_stage<11>(W, sc, LR, k); forward_stage<0>(W, sc, LR, k + 1); }
+    if (k < N) forward_stage<11>(W, sc, LR, k);
 }
 
 // ----------------------------------------------------------------------------------------
