@@ -1132,31 +1132,49 @@ BMPC_D inline double gv_at(const double *rec, int c6, int y) {
     return y < 7 ? rec[KD + c6 * 7 + y] : (c6 < 3 ? rec[KW + c6 * 7 + y - 7] : rec[KA + (c6 - 3) * 7 + y - 7]);
 }
 
-// issue the global loads of stage k's inputs into per-lane registers (consumed one stage later by the commit phase)
-BMPC_D inline void wave_backward_prefetch(Wave &W, const Scr &sc, int k, LaneRegs *LR, bool full) {
-    const int N = W.N; double *G = W.G;
-    // Branch-free: every lane loads from a clamped, always-valid index (lanes beyond the end of an array repeat its last element;
-    // a neighbour node that does not exist is replaced by the nearest one -- its data is masked by the consumers), and the commit
-    // phase stores to the same clamped slots (identical values), so neither phase has a single exec-mask branch.
-    LANES_BEGIN
-        double *pf = LR[LIDX].pf;
-        const int kn = k < N - 1 ? k + 1 : k, kp = k >= 1 ? k - 1 : 0;
-        const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, r2 = lane < RREC - 64 ? 64 + lane : RREC - 1;
-        const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l12 = lane < 12 ? lane : 11;
-        // of the four kinematics records of a stage (node k, velocity point of node k+1, node k-1, velocity point of node k) the
-        // first two are the last two of the previous stage (k+1): they stay in LDS, only the first stage of a sweep loads all four
-        if (full) {
-            pf[0] = G[sc.KIN + k * KREC + lane]; pf[1] = G[sc.KIN + k * KREC + l2];
-            pf[2] = G[sc.KIN + (N + kn) * KREC + lane]; pf[3] = G[sc.KIN + (N + kn) * KREC + l2];
-        }
-        pf[4] = G[sc.KIN + kp * KREC + lane]; pf[5] = G[sc.KIN + kp * KREC + l2];
-        pf[6] = G[sc.KIN + (N + k) * KREC + lane]; pf[7] = G[sc.KIN + (N + k) * KREC + l2];
-        pf[8] = G[sc.REF + k * RREC + lane]; pf[9] = G[sc.REF + k * RREC + r2];
-        pf[10] = 0.0; pf[11] = G[sc.GH + k * NZ + lz];
-        pf[12] = G[sc.SG + k * NI + li]; pf[13] = G[sc.NUm + k * NI + li];
-        pf[14] = G[sc.G + k * NE + le]; pf[15] = G[sc.LAM + k * NE + le]; pf[16] = G[sc.LAM + kn * NE + le];
-        pf[17] = G[sc.RLV + k * 12 + l12]; pf[18] = G[sc.RLV + kp * 12 + l12]; pf[19] = G[sc.RLV + kn * 12 + l12];
-    LANES_END
+// Stage inputs of the Riccati sweep: global -> registers (loads, issued a full stage ahead) -> LDS (commit).  Both are
+// lane-level pieces that ride at the end of the previous stage's last phase (the staging area and the record buffers a stage
+// reads are dead after its S1 phase), so they cost no phase of their own.
+// Branch-free: every lane loads from a clamped, always-valid index (lanes beyond the end of an array repeat its last element;
+// a neighbour node that does not exist is replaced by the nearest one -- its data is masked by the consumers), and the commit
+// stores to the same clamped slots (identical values), so neither has a single exec-mask branch.
+BMPC_D inline void backward_loads_lane(Wave &W, const Scr &sc, int k, double *pf, int lane, bool full) {
+    const int N = W.N; const double *G = W.G;
+    const int kn = k < N - 1 ? k + 1 : k, kp = k >= 1 ? k - 1 : 0;
+    const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, r2 = lane < RREC - 64 ? 64 + lane : RREC - 1;
+    const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l12 = lane < 12 ? lane : 11;
+    // of the four kinematics records of a stage (node k, velocity point of node k+1, node k-1, velocity point of node k) the
+    // first two are the last two of the previous stage (k+1): they stay in LDS, only the first stage of a sweep loads all four
+    if (full) {
+        pf[0] = G[sc.KIN + k * KREC + lane]; pf[1] = G[sc.KIN + k * KREC + l2];
+        pf[2] = G[sc.KIN + (N + kn) * KREC + lane]; pf[3] = G[sc.KIN + (N + kn) * KREC + l2];
+    }
+    pf[4] = G[sc.KIN + kp * KREC + lane]; pf[5] = G[sc.KIN + kp * KREC + l2];
+    pf[6] = G[sc.KIN + (N + k) * KREC + lane]; pf[7] = G[sc.KIN + (N + k) * KREC + l2];
+    pf[8] = G[sc.REF + k * RREC + lane]; pf[9] = G[sc.REF + k * RREC + r2];
+    pf[10] = 0.0; pf[11] = G[sc.GH + k * NZ + lz];
+    pf[12] = G[sc.SG + k * NI + li]; pf[13] = G[sc.NUm + k * NI + li];
+    pf[14] = G[sc.G + k * NE + le]; pf[15] = G[sc.LAM + k * NE + le]; pf[16] = G[sc.LAM + kn * NE + le];
+    pf[17] = G[sc.RLV + k * 12 + l12]; pf[18] = G[sc.RLV + kp * 12 + l12]; pf[19] = G[sc.RLV + kn * 12 + l12];
+}
+// record buffers of stage k: (K0, K1) and (KV1, KV) swap roles from stage to stage
+BMPC_D inline void backward_buffers(int N, int k, int &oK0, int &oK1, int &oKV, int &oKV1) {
+    const bool odd = ((N - 1 - k) & 1) != 0;
+    oK0 = odd ? L_K1 : L_K0; oK1 = odd ? L_K0 : L_K1; oKV1 = odd ? L_KV : L_KV1; oKV = odd ? L_KV1 : L_KV;
+}
+BMPC_D inline void backward_commit_lane(Wave &W, int k, const double *pf, int lane, bool first) {
+    double *L = W.L;
+    int oK0, oK1, oKV, oKV1; backward_buffers(W.N, k, oK0, oK1, oKV, oKV1);
+    const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, r2 = lane < RREC - 64 ? 64 + lane : RREC - 1;
+    const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l12 = lane < 12 ? lane : 11;
+    if (first) { L[oK0 + lane] = pf[0]; L[oKV1 + lane] = pf[2]; L[oK0 + l2] = pf[1]; L[oKV1 + l2] = pf[3]; }
+    L[oK1 + lane] = pf[4]; L[oKV + lane] = pf[6];
+    L[oK1 + l2] = pf[5]; L[oKV + l2] = pf[7];
+    L[L_ST + ST_REF + lane] = pf[8]; L[L_ST + ST_REF + r2] = pf[9];
+    L[L_ST + ST_GH + lz] = pf[11];
+    L[L_ST + ST_SG + li] = pf[12]; L[L_ST + ST_NU + li] = pf[13];
+    L[L_ST + ST_G + le] = pf[14]; L[L_ST + ST_LAM0 + le] = pf[15]; L[L_ST + ST_LAM1 + le] = pf[16];
+    L[L_ST + ST_RLV0 + l12] = pf[17]; L[L_ST + ST_RLVM + l12] = pf[18]; L[L_ST + ST_RLVP + l12] = pf[19];
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1170,27 +1188,16 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         for (int id = lane; id < 1024 + 96 + 12; id += 64) L[L_PB + id] = 0.0;
         if (lane < 36) L[L_PV + lane] = 0.0;
     LANES_END
-    wave_backward_prefetch(W, sc, N - 1, LR, true);
+    LANES_BEGIN
+        backward_loads_lane(W, sc, N - 1, LR[LIDX].pf, lane, true);
+    LANES_END
+    LANES_BEGIN
+        backward_commit_lane(W, N - 1, LR[LIDX].pf, lane, true);
+        backward_loads_lane(W, sc, N >= 2 ? N - 2 : 0, LR[LIDX].pf, lane, false);
+    LANES_END
     for (int k = N - 1; k >= 0; k--) {
         BMPC_PROF(W, 6);
-        {   // record buffers of this stage: (K0, K1) and (KV1, KV) swap roles from stage to stage
-            const bool odd = ((N - 1 - k) & 1) != 0;
-            W.oK0 = odd ? L_K1 : L_K0; W.oK1 = odd ? L_K0 : L_K1; W.oKV1 = odd ? L_KV : L_KV1; W.oKV = odd ? L_KV1 : L_KV;
-        }
-        LANES_BEGIN   // ---- commit the prefetched inputs of this stage (registers -> LDS) ----
-            const double *pf = LR[LIDX].pf;
-            const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, r2 = lane < RREC - 64 ? 64 + lane : RREC - 1;
-            const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l12 = lane < 12 ? lane : 11;
-            if (k == N - 1) { L[W.oK0 + lane] = pf[0]; L[W.oKV1 + lane] = pf[2]; L[W.oK0 + l2] = pf[1]; L[W.oKV1 + l2] = pf[3]; }
-            L[W.oK1 + lane] = pf[4]; L[W.oKV + lane] = pf[6];
-            L[W.oK1 + l2] = pf[5]; L[W.oKV + l2] = pf[7];
-            L[L_ST + ST_REF + lane] = pf[8]; L[L_ST + ST_REF + r2] = pf[9];
-            L[L_ST + ST_GH + lz] = pf[11];
-            L[L_ST + ST_SG + li] = pf[12]; L[L_ST + ST_NU + li] = pf[13];
-            L[L_ST + ST_G + le] = pf[14]; L[L_ST + ST_LAM0 + le] = pf[15]; L[L_ST + ST_LAM1 + le] = pf[16];
-            L[L_ST + ST_RLV0 + l12] = pf[17]; L[L_ST + ST_RLVM + l12] = pf[18]; L[L_ST + ST_RLVP + l12] = pf[19];
-        LANES_END
-        if (k >= 1) wave_backward_prefetch(W, sc, k - 1, LR, false);   // loads for the NEXT stage fly while this stage computes
+        backward_buffers(N, k, W.oK0, W.oK1, W.oKV, W.oKV1);
         BMPC_PROF(W, 24);
         wave_node_cost_blk(W, po, sc, k, mu, delta);     // PB/PCI/PII/PV now hold the value function of node k+1
         BMPC_PROF(W, 5);
@@ -1472,6 +1479,10 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 if (lane < 32) { L[L_PCI + pci(0, lf, lii)] = ci3[0]; L[L_PCI + pci(1, lf, lii)] = ci3[1]; L[L_PCI + pci(2, lf, lii)] = ci3[2]; }
                 if (onII) { L[L_PII + ib * 3 + ic] = pii; L[L_PII + ic * 3 + ib] = pii; }
                 L[L_PV + pr_] = pvv;
+                // inputs of stage k-1 (loaded a stage ago) into the staging area and the record buffers, all dead since S1;
+                // then the loads for stage k-2 into the registers this frees
+                backward_commit_lane(W, k - 1, LR[LIDX].pf, lane, false);
+                backward_loads_lane(W, sc, k >= 2 ? k - 2 : 0, LR[LIDX].pf, lane, false);
             LANES_END
         }
         BMPC_PROF(W, 13);
