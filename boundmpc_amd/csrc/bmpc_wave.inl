@@ -1436,6 +1436,38 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 const int i = lane >> 3, l = lane & 7, ci = i < l ? i : l, cl = i < l ? l : i; const bool tr = i > l;
                 const double *mc = LR[LIDX].mc;
                 double C[4][4];
+#ifdef BMPC_MFMA
+                // GPU build: the rank-8 update D = GS^T KS of the 32 x 32 chain block is the one dense contraction of the stage and
+                // runs on the matrix cores: v_mfma_f64_16x16x4_f64, 2 x 2 tiles x 2 k-steps.  Operand maps (one f64 per lane):
+                // A[row = lane & 15][k = lane >> 4], B[k = lane >> 4][col = lane & 15]; result register v of a lane holds
+                // D[row = (lane >> 4) + 4 v][col = lane & 15].  D is dropped in natural 32 x 32 layout into the PB area (the old
+                // value function is dead since S1) and every pair lane picks its 16 entries from there: 8 + 16 LDS reads per lane
+                // instead of 128, 8 MFMAs instead of 128 FMAs.  (The emulator and the oracle run the plain loops below; LDS
+                // operations of the one wave execute in program order, so the reads of D precede the block stores that overwrite it.)
+                {
+                    typedef double bmpc_d4 __attribute__((ext_vector_type(4)));
+                    const int lr = lane & 15, lk = lane >> 4;
+                    double a_[2][2], b_[2][2];
+#pragma unroll
+                    for (int t = 0; t < 2; t++)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ks++) { a_[t][ks] = L[L_GS + (4 * ks + lk) * 36 + 16 * t + lr]; b_[t][ks] = L[L_KS + (4 * ks + lk) * 36 + 16 * t + lr]; }
+#pragma unroll
+                    for (int tr_ = 0; tr_ < 2; tr_++)
+#pragma unroll
+                        for (int tc = 0; tc < 2; tc++) {
+                            bmpc_d4 acc = {0.0, 0.0, 0.0, 0.0};
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_[tr_][0], b_[tc][0], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a_[tr_][1], b_[tc][1], acc, 0, 0, 0);
+#pragma unroll
+                            for (int v = 0; v < 4; v++) L[L_PB + (16 * tr_ + lk + 4 * v) * 32 + 16 * tc + lr] = acc[v];
+                        }
+#pragma unroll
+                    for (int f = 0; f < 4; f++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++) C[f][g] = mc[f * 4 + g] + L[L_PB + srow(f, ci) * 32 + srow(g, cl)];
+                }
+#else
 #pragma unroll
                 for (int f = 0; f < 4; f++)
 #pragma unroll
@@ -1445,6 +1477,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                         for (int a = 0; a < NU; a++) sacc += L[L_GS + a * 36 + srow(f, ci)] * L[L_KS + a * 36 + srow(g, cl)];
                         C[f][g] = sacc;
                     }
+#endif
                 if (ci == cl) {
 #pragma unroll
                     for (int f = 0; f < 4; f++)
