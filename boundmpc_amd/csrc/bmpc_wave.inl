@@ -79,6 +79,7 @@ enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV
        L_K1 = L_K0 + KREC, L_KV = L_K1 + KREC, L_XT = L_KV + KREC, L_NC = L_XT + 15 * 14, L_WY = L_NC + 160, L_WV = L_WY + 196, L_TOT = L_WV + 196,
        L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_ZL = L_ST + 460, L_SIZE = L_ZL + 484 };
 enum { L_KKP = L_WY };
+enum { L_DUMMY = L_FLAG + 1 };   // write-only slot: target of the stores of lanes that have nothing to store (keeps phases branch-free)
 // row descriptors of the 57 internal inequality rows (box rows: +-Z[src] - lim), built once per problem: [sgn 57 | lim 57 | src 57]
 // integrator-chain coefficients CF[fr][fc] (4 x 5) as a table: chain_cf() with a lane-dependent argument compiles into a nest of
 // branches, a table look-up is one LDS read
@@ -500,7 +501,8 @@ BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
             const bool io = r >= SIOTA;
             const int gsrc = r < SJ ? r : ((r >= SPHI && r <= SDDPHI) ? GPHI + r - SPHI : (io ? GIW + r - SIOTA : 0));
             const int zero = ((r >= SJ && r < SPHI) || r == SJPHI) ? 1 : 0;          // jerk states carry no defect
-            L[L_ZMAP + r] = (double)(z + (gsrc << 8) + (zero << 16));
+            const int fr = r < 28 ? r / 7 : (r < SIOTA ? r - 28 : 0), ir = r < 28 ? r % 7 : (r < SIOTA ? 7 : 0);   // (field, chain) of a chain row: bits 17..19, 20..22
+            L[L_ZMAP + r] = (double)(z + (gsrc << 8) + (zero << 16) + (fr << 17) + (ir << 20));
         }
     LANES_END
     W.ca = 2 * L[L_PAR + po.w + 5] / (W.h * W.h); W.cb = 2 * L[L_PAR + po.w + 5] / W.h;
@@ -825,7 +827,9 @@ BMPC_D inline double kh_qdq(const double *rec, const double *mu_v, const double 
     const int lo = i <= j ? i : j, hi = i <= j ? j : i;
     double alo[3], whi[3], t[3]; ldA(rec, lo, alo); ldW(rec, hi, whi);
     cross3(alo, whi, t); double val = dot3(mu_v, t);
-    if (i < j) { double aj[3]; ldA(rec, j, aj); cross3(alo, aj, t); val += dot3(mu_w, t); }
+    // the i < j term is evaluated by every lane and masked by a 0/1 factor: a conditional with loads inside becomes an exec-mask
+    // branch, and `c ? x : 0.0` lets the compiler skip the work under a branch as well
+    { double aj[3]; ldA(rec, j, aj); cross3(alo, aj, t); val += (i < j ? 1.0 : 0.0) * dot3(mu_w, t); }
     return val;
 }
 // the same entries with only an angular-velocity multiplier (mu_p = mu_v = 0): what the velocity point of the NEXT node
@@ -842,7 +846,7 @@ BMPC_D inline double kh_qdq_w(const double *rec, const double *mu_w, int i, int 
     const int lo = i <= j ? i : j;
     double alo[3], aj[3], t[3]; ldA(rec, lo, alo); ldA(rec, j, aj);
     cross3(alo, aj, t);
-    return i < j ? dot3(mu_w, t) : 0.0;
+    return (i < j ? 1.0 : 0.0) * dot3(mu_w, t);
 }
 BMPC_D inline void kh_prefix(const double *rec, double *hp) {   // sequential over the 7 joints (one lane)
     double wl[3] = {0, 0, 0};
@@ -890,7 +894,7 @@ BMPC_D inline void stage_data_lane(Wave &W, const Scr &sc, int k, int lane) {
         BMPC_ACC4_DECL(ia);
 #pragma unroll
         for (int i = 0; i < 7; i++) { BMPC_ACC4(ia, i, K0[KD + (3 + c) * 7 + i] * gk[GQ + i]); BMPC_ACC4(ia, i + 1, K0[KA + c * 7 + i] * gk[GDQ + i]); }
-        const bool zero = (code >> 16) != 0;                            // jerk states carry no defect
+        const bool zero = ((code >> 16) & 1) != 0;                            // jerk states carry no defect
         const double v = zero ? 0.0 : (io ? gval - 0.5 * h * BMPC_ACC4_SUM(ia) : gval);
         L[L_RD + r] = v; G[sc.RDY + k * 36 + r] = v;
     }
@@ -899,6 +903,62 @@ BMPC_D inline void stage_data_lane(Wave &W, const Scr &sc, int k, int lane) {
         const int eb = y < 7 ? KD + (3 + a) * 7 + y : KA + a * 7 + y - 7;
         const double v = k >= 1 ? 0.5 * h * (K1[eb] + KVk[eb]) : 0.0;
         L[L_AE + ln] = v; G[sc.AES + k * 42 + ln] = v;
+    }
+}
+
+// Phase 1 of the node cost of stage k for one lane (predicated straight-line code): the stage data and the small Hessian blocks
+// over (pos, iw, phi).  It reads only the staging area and the record buffers of its stage and writes work areas nothing else
+// touches between S1 of the previous stage and phase 2, so it rides in the Schur phase of stage k+1 (after that stage's inputs
+// were replaced by this one's), where it fills the latency gaps of the matrix-core update.
+BMPC_D inline void node_cost_p1_lane(Wave &W, const POff &po, const Scr &sc, int k, int lane) {
+    const int N = W.N; const int ex = W.o.exact_hessian;
+    double *L = W.L;
+    const double *PAR = L + L_PAR, *w = PAR + po.w;
+    const double *ST = L + L_ST;
+    const double *rr = ST + ST_REF, *sgk = ST + ST_SG, *nuk = ST + ST_NU;
+    double *NC = L + L_NC;
+    const bool has_next = k < N - 1;
+    stage_data_lane(W, sc, k, lane);
+    // tube rows: barrier weights su, sl and the gradient pieces, shared by the three roles below
+    double su[5], sl[5], g3[5], w1[5];
+#pragma unroll
+    for (int m = 0; m < 5; m++) { su[m] = sgk[ITUBE + 2 * m]; sl[m] = sgk[ITUBE + 2 * m + 1]; g3[m] = rr[RGC + m * 4 + 3]; w1[m] = rr[RW1 + m]; }
+    {   // Hpp, Hrr: geometric part from the record + barrier terms of the tube rows
+        const bool on = lane >= 16 && lane < 16 + 9; const int ln = on ? lane - 16 : 0, a = ln / 3, b = ln % 3;
+        double hp = rr[RHPPG + a * 3 + b], hr = rr[RHRRG + a * 3 + b];
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            const double gg = (su[m] + sl[m]) * rr[RGC + m * 4 + a] * rr[RGC + m * 4 + b];
+            if (m == 1 || m == 2) hp += gg; else hr += gg;
+        }
+        NC[NC_HPP + a * 3 + b] = hp; NC[NC_HRR + a * 3 + b] = hr;
+    }
+    {   // Hp,phi, Hr,phi
+        const bool on = lane >= 32 && lane < 35; const int a = on ? lane - 32 : 0;
+        double hp = rr[RHPFG + a], hr = rr[RHRFG + a];
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            const double gpu_ = g3[m] - w1[m], gpl_ = -g3[m] - w1[m];
+            const double gg = su[m] * rr[RGC + m * 4 + a] * gpu_ - sl[m] * rr[RGC + m * 4 + a] * gpl_;
+            if (m == 1 || m == 2) hp += gg; else hr += gg;
+        }
+        NC[NC_HPF + a] = hp; NC[NC_HRF + a] = hr;
+    }
+    {   // H phi,phi and the scalar curvatures (every lane computes them, lane 40 stores)
+        const double dpdp = rr[RDPDP], exm = ex ? 1.0 : 0.0;
+        double hff = rr[RHFFG] + 2 * w[6] + sgk[IPHI0] + sgk[IPHIMAX];
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            const double gpu_ = g3[m] - w1[m], gpl_ = -g3[m] - w1[m];
+            hff += su[m] * gpu_ * gpu_ + sl[m] * gpl_ * gpl_;
+            hff += exm * (nuk[ITUBE + 2 * m] * (rr[RC2 + m] - rr[RW2 + m]) + nuk[ITUBE + 2 * m + 1] * (-rr[RC2 + m] - rr[RW2 + m]));
+        }
+        {   // identical in every lane: unconditional stores
+            NC[NC_SC + 0] = hff;
+            NC[NC_SC + 1] = 2 * w[2] * dpdp + 2 * w[7] + sgk[IDPHIMAX];
+            NC[NC_SC + 2] = 2 * w[5] * dpdp + 2 * w[8];
+            NC[NC_SC + 3] = 2 * w[2] + W.ca * (has_next ? 2.0 : 1.0);
+        }
     }
 }
 
@@ -912,51 +972,8 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
     double *NC = L + L_NC, *WY = L + L_WY, *KHP = L + L_KHP;
     const double *K0 = L + W.oK0, *KV1 = L + W.oKV1;
     const bool has_next = k < N - 1;
-    // phase 1: small Hessian blocks over (pos, iw, phi)
-    LANES_BEGIN   // predicated straight-line code
-        stage_data_lane(W, sc, k, lane);
-        // tube rows: barrier weights su, sl and the gradient pieces, shared by the three roles below
-        double su[5], sl[5], g3[5], w1[5];
-#pragma unroll
-        for (int m = 0; m < 5; m++) { su[m] = sgk[ITUBE + 2 * m]; sl[m] = sgk[ITUBE + 2 * m + 1]; g3[m] = rr[RGC + m * 4 + 3]; w1[m] = rr[RW1 + m]; }
-        {   // Hpp, Hrr: geometric part from the record + barrier terms of the tube rows
-            const bool on = lane >= 16 && lane < 16 + 9; const int ln = on ? lane - 16 : 0, a = ln / 3, b = ln % 3;
-            double hp = rr[RHPPG + a * 3 + b], hr = rr[RHRRG + a * 3 + b];
-#pragma unroll
-            for (int m = 0; m < 5; m++) {
-                const double gg = (su[m] + sl[m]) * rr[RGC + m * 4 + a] * rr[RGC + m * 4 + b];
-                if (m == 1 || m == 2) hp += gg; else hr += gg;
-            }
-            NC[NC_HPP + a * 3 + b] = hp; NC[NC_HRR + a * 3 + b] = hr;
-        }
-        {   // Hp,phi, Hr,phi
-            const bool on = lane >= 32 && lane < 35; const int a = on ? lane - 32 : 0;
-            double hp = rr[RHPFG + a], hr = rr[RHRFG + a];
-#pragma unroll
-            for (int m = 0; m < 5; m++) {
-                const double gpu_ = g3[m] - w1[m], gpl_ = -g3[m] - w1[m];
-                const double gg = su[m] * rr[RGC + m * 4 + a] * gpu_ - sl[m] * rr[RGC + m * 4 + a] * gpl_;
-                if (m == 1 || m == 2) hp += gg; else hr += gg;
-            }
-            NC[NC_HPF + a] = hp; NC[NC_HRF + a] = hr;
-        }
-        {   // H phi,phi and the scalar curvatures (every lane computes them, lane 40 stores)
-            const double dpdp = rr[RDPDP], exm = ex ? 1.0 : 0.0;
-            double hff = rr[RHFFG] + 2 * w[6] + sgk[IPHI0] + sgk[IPHIMAX];
-#pragma unroll
-            for (int m = 0; m < 5; m++) {
-                const double gpu_ = g3[m] - w1[m], gpl_ = -g3[m] - w1[m];
-                hff += su[m] * gpu_ * gpu_ + sl[m] * gpl_ * gpl_;
-                hff += exm * (nuk[ITUBE + 2 * m] * (rr[RC2 + m] - rr[RW2 + m]) + nuk[ITUBE + 2 * m + 1] * (-rr[RC2 + m] - rr[RW2 + m]));
-            }
-            if (lane == 40) {
-                NC[NC_SC + 0] = hff;
-                NC[NC_SC + 1] = 2 * w[2] * dpdp + 2 * w[7] + sgk[IDPHIMAX];
-                NC[NC_SC + 2] = 2 * w[5] * dpdp + 2 * w[8];
-                NC[NC_SC + 3] = 2 * w[2] + W.ca * (has_next ? 2.0 : 1.0);
-            }
-        }
-    LANES_END
+    // (phase 1 -- stage data and the small Hessian blocks -- has already run: node_cost_p1_lane(), in the prologue of the sweep for
+    // the first stage and inside the Schur phase of the previous stage for all others)
     BMPC_PROF(W, 16);
     // phase 2: A1 = Hpp Jp, A2 = (h/2) Hrr Ehat, curvature multipliers, prefix vectors of the curvature records
     LANES_BEGIN   // predicated straight-line code (see S0): all roles in one basic block, conditional stores only
@@ -969,7 +986,10 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
                 const double dqm = R_[KDQ + m], am = R_[KA + c * 7 + m], wm = R_[KW + c * 7 + m];
                 wlt += (m < jj ? dqm : 0.0) * am; vge += (m >= jj ? dqm : 0.0) * wm; wgt += (m > jj ? dqm : 0.0) * am;
             }
-            if (on) { hp[3 * jj + c] = wlt; if (jj < 7) { hp[24 + 3 * jj + c] = vge; hp[45 + 3 * jj + c] = wgt; } }
+            {   // unconditional stores: lanes without a slot write to the dummy word
+                const int hb = L_KHP + rec * 72, j7 = jj < 7 ? jj : 0; const bool on7 = on && jj < 7;
+                L[on ? hb + 3 * jj + c : L_DUMMY] = wlt; L[on7 ? hb + 24 + 3 * j7 + c : L_DUMMY] = vge; L[on7 ? hb + 45 + 3 * j7 + c : L_DUMMY] = wgt;
+            }
         }
         {   // A1 = Hpp Jp (3 x 7)
             const bool on = lane >= 16 && lane < 16 + 21; const int ln = on ? lane - 16 : 0, c = ln / 7, i = ln % 7; double sacc = 0;
@@ -987,7 +1007,9 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
         {   // curvature multipliers mu_p, mu_v, mu_w (this node) and mu_w of the next node's velocity point
             const bool on = lane >= 48 && lane < 60; const int ln = on ? lane - 48 : 0, c = ln % 3, g = ln / 3; const double *lam = ST + ST_LAM0;
             const double lp = lam[GPOS + c], lv = lam[GV + c], lw = lam[GW + c], li = lam[GIW + c], ln1 = ST[ST_LAM1 + GIW + c];
-            const double v = g == 0 ? lp : (g == 1 ? lv : (g == 2 ? lw + 0.5 * h * li : (has_next ? 0.5 * h * ln1 : 0.0)));
+            // 0/1 factors instead of selects: a select between loaded values compiles into a branch nest with the loads inside
+            const double m0 = g == 0 ? 1.0 : 0.0, m1 = g == 1 ? 1.0 : 0.0, m2 = g == 2 ? 1.0 : 0.0, m3 = (g == 3 && has_next) ? 1.0 : 0.0;
+            const double v = m0 * lp + m1 * lv + m2 * (lw + 0.5 * h * li) + m3 * (0.5 * h * ln1);
             L[L_MU + 4 + ln] = v;
         }
         // (same phase) Z-space gradient gl = g^ + H r + cross terms: reads only phase-1 results and the staging area (the row kinds
@@ -1006,7 +1028,9 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
             for (int c6 = 0; c6 < 6; c6++) { s1 += d[c6] * rl[3 + c6]; s2 += d[c6] * ST[ST_RLVM + 3 + c6]; }
             const double vm = k >= 1 ? ST[ST_RLVM + 3 + c] : 0.0, vp = has_next ? ST[ST_RLVP + 3 + c] : 0.0;
             const double tV = cv * rl[3 + c] - W.ca * vm - W.ca * vp, tD = -2 * w[2] * s1, tDD = -W.cb * s1 + (k >= 1 ? W.cb * s2 : 0.0);
-            g += (isPos || isPhi) ? sA : (isV ? tV : (isD ? tD : (isDD ? tDD : 0.0)));
+            double addv = 0.0;
+            addv = isDD ? tDD : addv; addv = isD ? tD : addv; addv = isV ? tV : addv; addv = (isPos || isPhi) ? sA : addv;
+            g += addv;
             NC[NC_GL + z] = g;
         }
     LANES_END
@@ -1066,43 +1090,53 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
         const double p0 = NC[NC_SC + 0] + delta, p1 = NC[NC_SC + 1] + delta, p2 = NC[NC_SC + 2] + delta, p3 = 2 * w[9] + sgk[IJU + 7] + sgk[IJL + 7] + delta;
         // ---- stores: six read-modify-write adds per lane into its own pair's planes; the pair kind selects planes and values
         //      (a lane with fewer than six contributions adds 0.0 to its (0,0) entry), so there is no branch on the kind ----
-        if (both) {
+        // ---- all stores of this phase are unconditional: a lane that has nothing to store for a role stores to / accumulates on
+        //      a dummy LDS slot (L_DUMMY) instead, so the phase has no exec-mask branch around its memory operations ----
+        {
 #pragma unroll
             for (int f = 0; f < 2; f++)
 #pragma unroll
-                for (int g = 0; g < 2; g++) { const int a = f * 7 + ci, b = g * 7 + cl; WY[a * 14 + b] = wpv[f][g]; WY[b * 14 + a] = wpv[f][g]; }
+                for (int g = 0; g < 2; g++) {
+                    const int a = f * 7 + cic, b = g * 7 + clc;
+                    const int o1 = both ? L_WY + a * 14 + b : L_DUMMY, o2 = both ? L_WY + b * 14 + a : L_DUMMY;
+                    L[o1] = wpv[f][g]; L[o2] = wpv[f][g];
+                }
         }
         {
-            const bool dg = both && ci == cl;
+            const bool dg = both && ci == cl, c77 = !both && !mix;
             const double e00 = e[0][0] + (dg ? dq0 : 0.0), e11 = e[1][1] + (dg ? dq1 : 0.0), e01 = e[0][1], e10 = dg ? e[0][1] : e[1][0];
-            // plane ids (f*4+g) and values of the six adds
-            const int pl[6] = { both ? 0 : (mix ? 0 : 0),
+            // plane ids (f*4+g) and values of the six adds; the (7,7) lane has four
+            const int pl[6] = { 0,
                                 both ? 1 : (mix ? (tr ? 4 : 1) : 5),
                                 both ? 4 : (mix ? (tr ? 8 : 2) : 10),
                                 both ? 5 : (mix ? (tr ? 1 : 4) : 15),
-                                both ? 10 : (mix ? 5 : 0),
-                                both ? 15 : (mix ? (tr ? 9 : 6) : 0) };
+                                both ? 10 : 5,
+                                both ? 15 : (tr ? 9 : 6) };
             const double vl[6] = { both ? e00 : (mix ? vf[0] : p0),
                                    both ? (tr ? e10 : e01) : (mix ? vd[0] : p1),
                                    both ? (tr ? e01 : e10) : (mix ? vdd[0] : p2),
                                    both ? e11 : (mix ? vf[1] : p3),
                                    both ? (dg ? dq2 : 0.0) : (mix ? vd[1] : 0.0),
                                    both ? (dg ? dq3 : 0.0) : (mix ? vdd[1] : 0.0) };
-            double cur[6];
+            int ad[6]; double cur[6];
 #pragma unroll
-            for (int t = 0; t < 6; t++) cur[t] = L[L_PB + pl[t] * 64 + lane];
-            // entries 4 and 5 of a (7,7) lane alias entry 0: accumulate in order on the same slot
-            if (!both && !mix) { cur[0] += vl[0]; L[L_PB + pl[0] * 64 + lane] = cur[0]; L[L_PB + pl[1] * 64 + lane] = cur[1] + vl[1];
-                                 L[L_PB + pl[2] * 64 + lane] = cur[2] + vl[2]; L[L_PB + pl[3] * 64 + lane] = cur[3] + vl[3]; }
-            else {
+            for (int t = 0; t < 6; t++) { ad[t] = (c77 && t >= 4) ? L_DUMMY : L_PB + pl[t] * 64 + lane; cur[t] = L[ad[t]]; }
 #pragma unroll
-                for (int t = 0; t < 6; t++) L[L_PB + pl[t] * 64 + lane] = cur[t] + vl[t];
-            }
+            for (int t = 0; t < 6; t++) L[ad[t]] = cur[t] + vl[t];
         }
-        // iota couplings
-        if (lane < 14) { const int f = lane / 7, ii = lane % 7; for (int a = 0; a < 3; a++) L[L_PCI + pci(a, f, ii)] += A2[a * 14 + lane]; }
-        else if (lane >= 16 && lane < 19) L[L_PCI + pci(lane - 16, 0, 7)] += NC[NC_HRF + lane - 16];
-        else if (lane >= 24 && lane < 33) { const int a = (lane - 24) / 3, b = (lane - 24) % 3; L[L_PII + a * 3 + b] += NC[NC_HRR + a * 3 + b] + (a == b ? delta : 0.0); }
+        {   // iota couplings: 42 + 3 + 9 read-modify-write items, one per lane
+            const int t = lane;
+            const bool m1 = t < 42, m2 = t >= 42 && t < 45, m3 = t >= 45 && t < 54;
+            const int t1 = m1 ? t : 0, a1 = t1 / 14, y = t1 % 14, f1 = y / 7, ii = y % 7;
+            const int t2 = m2 ? t - 42 : 0, t3 = m3 ? t - 45 : 0, a3 = t3 / 3, b3 = t3 % 3;
+            int dst = L_DUMMY, src = NC_HRR + t3;           // flat chains of selects (a nested one compiles into a branch nest)
+            dst = m3 ? L_PII + t3 : dst;
+            dst = m2 ? L_PCI + pci(t2, 0, 7) : dst; src = m2 ? NC_HRF + t2 : src;
+            dst = m1 ? L_PCI + pci(a1, f1, ii) : dst; src = m1 ? NC_A2 + t1 : src;
+            const double add = NC[src] + ((m3 && a3 == b3) ? delta : 0.0);
+            const double cur = L[dst];
+            L[dst] = cur + ((m1 || m2 || m3) ? add : 0.0);
+        }
     LANES_END
     BMPC_PROF(W, 19);
     // (the gradient q~ of this node is added where it is consumed: node_q_row() in S0 of the Riccati stage)
@@ -1195,6 +1229,10 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         backward_commit_lane(W, N - 1, LR[LIDX].pf, lane, true);
         backward_loads_lane(W, sc, N >= 2 ? N - 2 : 0, LR[LIDX].pf, lane, false);
     LANES_END
+    backward_buffers(N, N - 1, W.oK0, W.oK1, W.oKV, W.oKV1);
+    LANES_BEGIN
+        node_cost_p1_lane(W, po, sc, N - 1, lane);
+    LANES_END
     for (int k = N - 1; k >= 0; k--) {
         BMPC_PROF(W, 6);
         backward_buffers(N, k, W.oK0, W.oK1, W.oKV, W.oKV1);
@@ -1209,7 +1247,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         LANES_BEGIN
             {   // chain rows (f,i) of PR
                 const bool on = lane < 32; const int r = on ? lane : 0;
-                const int f = r < 28 ? r / 7 : r - 28, i = r < 28 ? r % 7 : 7;
+                const int code = (int)L[L_ZMAP + r], f = (code >> 17) & 7, i = (code >> 20) & 7;     // (field, chain) of the row, from the row table
                 BMPC_ACC4_DECL(pa);
 #pragma unroll
                 for (int l = 0; l < 8; l++)
@@ -1251,12 +1289,12 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
             {   // t6 = C rdyn: the rdyn side of X^T rdyn = Gv(K1)^T (C rdyn)
                 const bool on = k >= 1 && lane >= 48 && lane < 54; const int c6 = on ? lane - 48 : 0;
                 const double *K0 = L + W.oK0, *dpn = L + L_ST + ST_REF + RDP;
-                const double *jrow = c6 < 3 ? K0 + KW + c6 * 7 : K0 + KA + (c6 - 3) * 7;
+                const int jo = c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7;
                 BMPC_ACC4_DECL(ta);
 #pragma unroll
-                for (int r = 0; r < 7; r++) { BMPC_ACC4(ta, r, K0[KD + c6 * 7 + r] * L[L_RD + r]); BMPC_ACC4(ta, r + 1, jrow[r] * L[L_RD + 7 + r]); }
+                for (int r = 0; r < 7; r++) { BMPC_ACC4(ta, r, K0[KD + c6 * 7 + r] * L[L_RD + r]); BMPC_ACC4(ta, r + 1, K0[jo + r] * L[L_RD + 7 + r]); }
                 const double v = -W.ca * BMPC_ACC4_SUM(ta) + W.cb * dpn[c6] * L[L_RD + SDDPHI];
-                if (on) L[L_T6 + c6] = v;
+                L[on ? L_T6 + c6 : L_DUMMY] = v;
             }
         LANES_END
         BMPC_PROF(W, 21);
@@ -1284,10 +1322,12 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 #pragma unroll
                     for (int c6 = 0; c6 < 6; c6++) sx += K1[(fp == 0 ? KD + c6 * 7 : (c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7)) + ic] * L[L_T6 + c6];
                 }
-                if (yq) { v += ve; if (k >= 1) v += sx; }
-                if (on) {
-                    if (yq) { L[L_MCI + mci(0, fp, i)] = mc3[0]; L[L_MCI + mci(1, fp, i)] = mc3[1]; L[L_MCI + mci(2, fp, i)] = mc3[2]; }
-                    if (fp < 4) L[L_MV + srow(fp, i)] = v; else L[L_GS + i * 36 + 35] = v;
+                v += (yq ? 1.0 : 0.0) * ve + ((yq && k >= 1) ? 1.0 : 0.0) * sx;
+                {   // unconditional stores, the row kind selects the address (lanes without a row write to the dummy word)
+                    const bool sm = on && yq;
+                    L[sm ? L_MCI + mci(0, fp, i) : L_DUMMY] = mc3[0]; L[sm ? L_MCI + mci(1, fp, i) : L_DUMMY] = mc3[1]; L[sm ? L_MCI + mci(2, fp, i) : L_DUMMY] = mc3[2];
+                    int vd = L_DUMMY; vd = (on && fp == 4) ? L_GS + i * 36 + 35 : vd; vd = (on && fp < 4) ? L_MV + srow(fp, i) : vd;
+                    L[vd] = v;
                 }
             }
             {
@@ -1393,6 +1433,11 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         BMPC_PROF(W, 12);
         // ---- S2: 8x8 Cholesky (identical data in every lane), gains ----
         LANES_BEGIN
+            if (k >= 1) {   // inputs of stage k-1 (loaded a stage ago) replace this stage's in the staging area and the record buffers,
+                            // all dead since S1; then the loads for stage k-2 into the registers this frees
+                backward_commit_lane(W, k - 1, LR[LIDX].pf, lane, false);
+                backward_loads_lane(W, sc, k >= 2 ? k - 2 : 0, LR[LIDX].pf, lane, false);
+            }
             double Lc[NU][NU], dinv[NU]; bool pd = true;
 #pragma unroll
             for (int a = 0; a < NU; a++) {
@@ -1430,6 +1475,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         LANES_END
         BMPC_PROF(W, 23);
         if (L[L_FLAG] == 0.0) return false;
+        if (k >= 1) backward_buffers(N, k - 1, W.oK0, W.oK1, W.oKV, W.oKV1);     // for phase 1 of the next stage's node cost, fused below
         // ---- S3: Schur complement, block lanes write the value function of node k ----
         if (k >= 1) {
             LANES_BEGIN
@@ -1509,13 +1555,10 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 for (int f = 0; f < 4; f++)
 #pragma unroll
                     for (int g = 0; g < 4; g++) L[L_PB + pbi(f, g, i, l)] = tr ? C[g][f] : C[f][g];
-                if (lane < 32) { L[L_PCI + pci(0, lf, lii)] = ci3[0]; L[L_PCI + pci(1, lf, lii)] = ci3[1]; L[L_PCI + pci(2, lf, lii)] = ci3[2]; }
-                if (onII) { L[L_PII + ib * 3 + ic] = pii; L[L_PII + ic * 3 + ib] = pii; }
+                L[L_PCI + pci(0, lf, lii)] = ci3[0]; L[L_PCI + pci(1, lf, lii)] = ci3[1]; L[L_PCI + pci(2, lf, lii)] = ci3[2];   // lanes >= 32 repeat lanes 0..31
+                L[onII ? L_PII + ib * 3 + ic : L_DUMMY] = pii; L[onII ? L_PII + ic * 3 + ib : L_DUMMY] = pii;
                 L[L_PV + pr_] = pvv;
-                // inputs of stage k-1 (loaded a stage ago) into the staging area and the record buffers, all dead since S1;
-                // then the loads for stage k-2 into the registers this frees
-                backward_commit_lane(W, k - 1, LR[LIDX].pf, lane, false);
-                backward_loads_lane(W, sc, k >= 2 ? k - 2 : 0, LR[LIDX].pf, lane, false);
+                node_cost_p1_lane(W, po, sc, k - 1, lane);      // phase 1 of the next stage's node cost
             LANES_END
         }
         BMPC_PROF(W, 13);
@@ -1558,8 +1601,8 @@ BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
     LANES_BEGIN   // next reduced state, predicated: chain rows and iota rows evaluated by every lane on clamped indices
         {
             const bool on = lane < NS; const int r = on ? lane : 0;
-            const bool chain = r < 28 || (r >= SPHI && r <= SJPHI);
-            const int f = r < 28 ? r / 7 : (chain ? r - 28 : 0), i = r < 28 ? r % 7 : 7, a = chain ? 0 : r - SIOTA;
+            const bool chain = r < SIOTA;
+            const int code = (int)L[L_ZMAP + r], f = (code >> 17) & 7, i = chain ? (code >> 20) & 7 : 7, a = chain ? 0 : r - SIOTA;
             const double *ds = L + L_DS, *dp_ = L + L_RED + i;   // fixed-order tree over the 8 partial sums of du
             const double du_i = sb[ST_KF + i] + (((dp_[0] + dp_[8]) + (dp_[16] + dp_[24])) + ((dp_[32] + dp_[40]) + (dp_[48] + dp_[56])));
             double vc = 0;
