@@ -675,6 +675,21 @@ BMPC_D inline void stage_mu(Wave &W, const double *lam, const double *kp, int la
     const int kb = odd_ ? L_K1 : L_K0, vb = odd_ ? L_KV1 : L_KV; \
     L[L_ST + (odd_ ? ST_Z : ST_GH) + (lane < NZ ? lane : NZ - 1)] = pf[0]; \
     L[kb + lane] = pf[1]; L[vb + lane] = pf[3]; L[kb + l2] = pf[2]; L[vb + l2] = pf[4]; }
+// Component table of the adjoint sweep, one packed integer per component z of Z (built per sweep into the part of the staging
+// area that is idle during the adjoint, under the latency of the sweep's first loads): bits 0-1 field fc (0 q, 1 dq, 2 ddq,
+// 3 jerk), 2-4 chain i, 5 "is a chain state", 6 "couples with iota through Ehat" (i < 7, fc <= 1), 7 "is an iw component",
+// 8-9 its coordinate, 10 "is a jerk", 11-16 row in lam (or jerk slot), 17-22 index of the ddq multiplier, 23-29 Ehat column base.
+BMPC_D inline int adjoint_zcode(int z) {
+    const int f = z < 7 ? 3 : (z == ZJPHI ? 3 : (z < ZDQ ? 0 : (z < ZDDQ ? 1 : (z < ZPOS ? 2 : (z >= ZPHI ? z - ZPHI : -1)))));
+    const int i = z < 7 ? z : (z == ZJPHI ? 7 : (z < ZDQ ? z - ZQ : (z < ZDDQ ? z - ZDQ : (z < ZPOS ? z - ZDDQ : (z >= ZPHI ? 7 : 0)))));
+    const bool has = f >= 0; const int fc = has ? f : 0, i7 = i < 7 ? i : 0;
+    const bool isIw = z >= ZIW && z < ZIW + 3; const int cw = isIw ? z - ZIW : 0;
+    const bool isJ = z < 7 || z == ZJPHI;
+    const int ee = isJ ? (z < 7 ? z : 7) : (z < ZPOS ? z - ZQ : (z < ZPHI ? GPOS + (z - ZPOS) : GPHI + (z - ZPHI)));
+    const int mdd = i < 7 ? GDDQ + i : GDDPHI, eb = fc == 0 ? KD + 21 + i7 : KA + i7;
+    return fc | (i << 2) | ((has ? 1 : 0) << 5) | (((i < 7 && fc <= 1) ? 1 : 0) << 6) | ((isIw ? 1 : 0) << 7) | (cw << 8) | ((isJ ? 1 : 0) << 10)
+         | (ee << 11) | (mdd << 17) | (eb << 23);
+}
 // one stage of the sequential adjoint sweep (two phases); PO = register set that holds the inputs of stage k-1
 template <int PO>
 BMPC_D inline void adjoint_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
@@ -689,33 +704,32 @@ BMPC_D inline void adjoint_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
             stage_mu(W, lam1, k0, lane);
         LANES_END
     }
-    LANES_BEGIN   // predicated: the component kind selects coefficients (integer selects), not code paths
+    LANES_BEGIN   // one lane per component of Z; its kind comes from the component table (adjoint_ztab), decoded with shifts: integer
+                  // indices and 0/1 factors, no exec-mask branch
         {
             const bool on = lane < NZ; const int z = on ? lane : 0;
             const double *kv = kvb;
-            // field f (0 q, 1 dq, 2 ddq, 3 jerk) and chain i of this component; f = -1: lifted variable (pos, iw, v)
-            const int f = z < 7 ? 3 : (z == ZJPHI ? 3 : (z < ZDQ ? 0 : (z < ZDDQ ? 1 : (z < ZPOS ? 2 : (z >= ZPHI ? z - ZPHI : -1)))));
-            const int i = z < 7 ? z : (z == ZJPHI ? 7 : (z < ZDQ ? z - ZQ : (z < ZDDQ ? z - ZDQ : (z < ZPOS ? z - ZDDQ : (z >= ZPHI ? 7 : 0)))));
-            const bool has = f >= 0, nxt = k < N - 1; const int fc = has ? f : 0, i7 = i < 7 ? i : 0;
-            const bool isIw = z >= ZIW && z < ZIW + 3; const int cw = isIw ? z - ZIW : 0;
-            const double mdd = lam1[i < 7 ? GDDQ + i : GDDPHI];
+            const int code = (int)L[L_ST + ST_REF + z];
+            const int fc = code & 3, i = (code >> 2) & 7, cw = (code >> 8) & 3, ee = (code >> 11) & 63;
+            const double mh = ((code >> 5) & 1) ? 1.0 : 0.0, me = ((code >> 6) & 1) ? 1.0 : 0.0, mi = ((code >> 7) & 1) ? 1.0 : 0.0;
+            const bool isJ = ((code >> 10) & 1) != 0, nxt = k < N - 1;
+            const double mdd = lam1[(code >> 17) & 63];
             const double chainv = L[L_CFT + fc] * L[L_MU + i] + L[L_CFT + 5 + fc] * L[L_MU + 8 + i] + L[L_CFT + 10 + fc] * mdd;
-            const int eb = fc == 0 ? KD + 21 + i7 : KA + i7;                    // Ehat column of (q_i) or (dq_i): rows at stride 7
+            const int eb = (code >> 23) & 127;                                  // Ehat column of (q_i) or (dq_i): rows at stride 7
             double e = 0;
 #pragma unroll
             for (int c = 0; c < 3; c++) e += kv[eb + c * 7] * lam1[GIW + c];
             double tot = ghb[z];
-            if (nxt) tot += has ? chainv + ((i < 7 && fc <= 1) ? 0.5 * h * e : 0.0) : (isIw ? lam1[GIW + cw] : 0.0);
+            const double addv = mh * (chainv + me * (0.5 * h * e)) + mi * lam1[GIW + cw];
+            if (nxt) tot += addv;               // wave-uniform condition (lam_{k+1} does not exist at the last stage)
             // Stores without branches: one LDS store and one global store per lane, the row kind selects the ADDRESS.
             // jerk rows: the residual of node k still lacks the term of the NEXT sweep step (stage k-1 -> k); it is parked in LDS
             // and completed there (a global read-modify-write would wait for this store to land and come back); their global
             // store goes to a spare slot of the node's GVP row.  Off-lanes repeat row 0 (a jerk row) with identical values.
             {
-                const bool isJ = z < 7 || z == ZJPHI;
-                const int ee = z < ZPOS ? z - ZQ : (z < ZPHI ? GPOS + (z - ZPOS) : GPHI + (z - ZPHI));
-                double *ldst = isJ ? L + L_RJP + (k & 1) * 8 + (z < 7 ? z : 7) : lam0 + ee;
+                const int lo_ = isJ ? L_RJP + (k & 1) * 8 + ee : (int)(lam0 - L) + ee;
                 const int gdst = isJ ? sc.GVP + k * 8 + 6 : sc.LAM + k * NE + ee;
-                *ldst = tot; G[gdst] = tot;
+                L[lo_] = tot; G[gdst] = tot;
             }
         }
         {   // jerk of node k+2 enters stage k+1 (lanes 44..51; everyone else, and the last stage, write to the spare GVP slot)
@@ -776,6 +790,7 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
     LANES_BEGIN
         BMPC_ADJ_LOADS(N - 1, 0)
         BMPC_ADJ_LOADS(N - 2, 5)
+        L[L_ST + ST_REF + (lane < NZ ? lane : NZ - 1)] = (double)adjoint_zcode(lane < NZ ? lane : NZ - 1);
     LANES_END
     LANES_BEGIN
         BMPC_ADJ_COMMIT(N - 1, 0)
@@ -1612,7 +1627,8 @@ BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
             BMPC_ACC4_DECL(ia);
 #pragma unroll
             for (int y = 0; y < 14; y++) BMPC_ACC4(ia, y, sb[ST_AES + a * 14 + y] * ds[y]);
-            const double v = sb[ST_RDY + r] + (chain ? vc : ds[r] + BMPC_ACC4_SUM(ia));
+            const double mc_ = chain ? 1.0 : 0.0;            // 0/1 factors, not a select between loaded values (that would be a branch)
+            const double v = sb[ST_RDY + r] + (mc_ * vc + (1.0 - mc_) * (ds[r] + BMPC_ACC4_SUM(ia)));
             L[L_DSN + r] = v;
         }
     LANES_END
@@ -1624,9 +1640,10 @@ BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
             const bool isIw = t >= SIOTA && t < NS, isPos = t >= NS && t < NS + 3, isV = t >= NS + 3;
             const int c = isIw ? t - SIOTA : (isPos ? t - NS : (isV ? t - NS - 3 : 0));              // c6 for the v rows
             const int r = t < NS ? t : 0;
-            const int z = t < NS ? ((int)L[L_ZMAP + r] & 255) : (isPos ? ZPOS + c : ZV + c);
-            const int p1 = isPos ? KW + c * 7 : (isIw ? KD + (3 + c) * 7 : KD + c * 7);
-            const int p2 = isIw ? KA + c * 7 : (c < 3 ? KW + c * 7 : KA + (c - 3) * 7);
+            // flat chains of selects on integers and 0/1 factors on values: no exec-mask branch in the phase
+            int z = (int)L[L_ZMAP + r] & 255; z = isPos ? ZPOS + c : z; z = isV ? ZV + c : z;
+            int p1 = KD + c * 7; p1 = isIw ? KD + (3 + c) * 7 : p1; p1 = isPos ? KW + c * 7 : p1;
+            int p2 = c < 3 ? KW + c * 7 : KA + (c - 3) * 7; p2 = isIw ? KA + c * 7 : p2;
             BMPC_ACC4_DECL(za);
 #pragma unroll
             for (int i = 0; i < 7; i++) { BMPC_ACC4(za, i, K0[p1 + i] * dn[SQ + i]); }
@@ -1634,8 +1651,9 @@ BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
 #pragma unroll
             for (int i = 0; i < 7; i++) { BMPC_ACC4(zb, i, K0[p2 + i] * dn[SDQ + i]); }
             const double s1 = BMPC_ACC4_SUM(za), s2 = BMPC_ACC4_SUM(zb);
-            const double addv = (isPos || isV) ? rlv[isPos ? c : 3 + c] : dn[r];
-            const double v = isPos ? addv + s1 : (isIw ? addv + 0.5 * h * (s1 + s2) : (isV ? addv + (s1 + s2) : addv));
+            const double ml = (isPos || isV) ? 1.0 : 0.0, addv = ml * rlv[isPos ? c : 3 + c] + (1.0 - ml) * dn[r];
+            double fa = 0.0; fa = isV ? 1.0 : fa; fa = isIw ? 0.5 * h : fa; fa = isPos ? 1.0 : fa;
+            const double v = addv + fa * (s1 + ((isIw || isV) ? 1.0 : 0.0) * s2);
             W.Dz[k * NZ + z] = v;
         }
         { const int r = lane < 36 ? lane : 35; const double v = L[L_DSN + (r < NS ? r : 0)]; L[L_DS + r] = r < NS ? v : 0.0; }
