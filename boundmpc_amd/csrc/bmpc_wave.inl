@@ -640,7 +640,9 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, const dou
             for (int u = 0; u < RU; u++) {
                 const int id0 = base + 64 * u, id = id0 < N * NI ? id0 : N * NI - 1;
                 const int i = id % NI;
-                G[oH + id] = i >= ITUBE ? (((i - ITUBE) & 1) ? (-rc[u] - rw[u]) : (rc[u] - rw[u])) : sg[u] * zv[u] - lm[u];
+                // 0/1 factors instead of a select between the two row formulas (their operands are loads: a select becomes a branch nest)
+                const double mt = i >= ITUBE ? 1.0 : 0.0, s2 = (i >= ITUBE && ((i - ITUBE) & 1)) ? -1.0 : 1.0;
+                G[oH + id] = mt * (s2 * rc[u] - rw[u]) + (1.0 - mt) * (sg[u] * zv[u] - lm[u]);
             }
         }
     LANES_END
@@ -1813,19 +1815,21 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                     for (int u = 0; u < RU; u++) {
                         const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1;
                         const int k = id / NI, i = id - k * NI;
-                        const bool tube = i >= ITUBE; const int m = tube ? (i - ITUBE) >> 1 : 0;
+                        // box rows and tube rows run the same instructions: clamped indices, unconditional loads, 0/1 factors (a select
+                        // between loaded values would put the loads under an exec-mask branch)
+                        const bool tube = i >= ITUBE; const int m = tube ? (i - ITUBE) >> 1 : 0, ti = tube ? 1 : 0; const double mt = tube ? 1.0 : 0.0;
                         const double sgn = L[L_ROWT + i]; const int src = (int)L[L_ROWT + 2 * NI + i];
                         const double *rr = G + sc.REF + k * RREC, *dz = W.Dz + k * NZ;
-                        const int vo = tube ? tube_voff(m) : src;
-                        c0[u] = tube ? rr[RGC + m * 4 + 0] : sgn; c1[u] = tube ? rr[RGC + m * 4 + 1] : 0.0; c2[u] = tube ? rr[RGC + m * 4 + 2] : 0.0;
-                        c3[u] = tube ? rr[RGC + m * 4 + 3] : 0.0; w1[u] = tube ? rr[RW1 + m] : 0.0;
-                        d0[u] = dz[vo]; d1[u] = tube ? dz[vo + 1] : 0.0; d2[u] = tube ? dz[vo + 2] : 0.0; dph[u] = dz[ZPHI];
+                        const int vo = src + ti * (tube_voff(m) - src);
+                        c0[u] = mt * rr[RGC + m * 4 + 0] + (1.0 - mt) * sgn; c1[u] = mt * rr[RGC + m * 4 + 1]; c2[u] = mt * rr[RGC + m * 4 + 2];
+                        c3[u] = mt * rr[RGC + m * 4 + 3]; w1[u] = mt * rr[RW1 + m];
+                        d0[u] = dz[vo]; d1[u] = dz[vo + ti]; d2[u] = dz[vo + 2 * ti]; dph[u] = dz[ZPHI];
                     }
 #pragma unroll
                     for (int u = 0; u < RU; u++) {
                         const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1; const int i = id % NI;
-                        if (i >= ITUBE) { const double sv = c0[u] * d0[u] + c1[u] * d1[u] + c2[u] * d2[u] + c3[u] * dph[u]; hd[u] = (((i - ITUBE) & 1) ? -sv : sv) - w1[u] * dph[u]; }
-                        else hd[u] = c0[u] * d0[u];
+                        const double sv = c0[u] * d0[u] + c1[u] * d1[u] + c2[u] * d2[u] + c3[u] * dph[u];
+                        hd[u] = ((i >= ITUBE && ((i - ITUBE) & 1)) ? -1.0 : 1.0) * sv - w1[u] * dph[u];
                     }
                 }
 #pragma unroll
