@@ -289,3 +289,22 @@ def test_gauss_newton_option_matches_oracle():
     assert out["status"][0] == 0 and abs(int(out["iters"][0]) - int(ref["iters"][0])) <= 1
     assert _rms_q(out["x"], ref["x"]) < TOL_Q_RMS
     s.close()
+
+
+@pytest.mark.gpu
+def test_second_seed_against_oracle():
+    """A second synthetic batch (seed 1, 512 problems): same statuses, iteration counts within one, joint trajectories within 1e-6 rad
+    per problem of the CPU oracle (tests/gpu_soak.py runs the long version of this check)."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    from oracle import c_oracle
+    P, X, _ = workload.make_batch(512, seed=1)
+    s = BatchedOCPSolver(10, 4, 0.1)
+    out = s.solve_batch(torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda"))
+    ref = c_oracle.solve(P, X, 10, 4, 0.1)
+    st, it, x = out["status"].cpu().numpy(), out["iters"].cpu().numpy(), out["x"].cpu().numpy()
+    s.close()
+    assert (st == ref["status"]).all() and (st == 0).all()
+    assert np.abs(it - ref["iters"]).max() <= 1
+    d = (x - ref["x"]).reshape(512, 10, 44)[:, :, 8:15]
+    assert np.sqrt((d ** 2).mean(axis=(1, 2))).max() < 1e-6
