@@ -6,14 +6,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from boundmpc_amd import BatchedOCPSolver, NlpSolverShim
 from oracle import c_oracle
-d = np.load(os.path.join(ROOT, "tests", "golden", "g7_closedloop_exp1.npz"))
+d = dict(np.load(os.path.join(ROOT, "tests", "golden", "g7_closedloop_exp1.npz")))   # materialise: an NpzFile re-reads the archive on every access
 s = BatchedOCPSolver(10, 4, 0.1); shim = NlpSolverShim(s)
+s.set_timing(True)
 for warm in range(3):
     shim(x0=d["x0"][0], p=d["p"][0])
-tg, tc, it = [], [], []
-for t in range(0, 155, 3):
-    t0 = time.perf_counter(); sol = shim(x0=d["x0"][t], p=d["p"][t]); tg.append(time.perf_counter() - t0); it.append(shim.stats()["iter_count"])
+tg, tc, it, tk, tgi = [], [], [], [], []
+ticks = list(range(0, 155, 3))
+for t in ticks:      # back-to-back calls
+    t0 = time.perf_counter(); sol = shim(x0=d["x0"][t], p=d["p"][t]); tg.append(time.perf_counter() - t0); it.append(shim.stats()["iter_count"]); tk.append(s.last_kernel_ms())
+for t in ticks:      # the same calls with the device idle in between (the CPU oracle solves the tick on one thread: ~10 ms)
     t0 = time.perf_counter(); c_oracle.solve(d["p"][t], d["x0"][t], 10, 4, 0.1, nthreads=1); tc.append(time.perf_counter() - t0)
-tg, tc = np.array(tg) * 1e3, np.array(tc) * 1e3
-print(f"single-problem call over {len(tg)} recorded ticks (mean {np.mean(it):.1f} iterations): GPU shim p50 {np.percentile(tg,50):.2f} ms p99 {np.percentile(tg,99):.2f} ms; "
-      f"CPU oracle (1 thread) p50 {np.percentile(tc,50):.2f} ms p99 {np.percentile(tc,99):.2f} ms")
+    t0 = time.perf_counter(); sol = shim(x0=d["x0"][t], p=d["p"][t]); tgi.append(time.perf_counter() - t0)
+tg, tc, tgi = np.array(tg) * 1e3, np.array(tc) * 1e3, np.array(tgi) * 1e3
+print(f"kernel time of the one-problem launch (HIP events): p50 {np.percentile(tk,50):.2f} ms p99 {np.percentile(tk,99):.2f} ms")
+print(f"single-problem call over {len(tg)} recorded ticks (mean {np.mean(it):.1f} iterations): GPU shim back-to-back p50 {np.percentile(tg,50):.2f} ms p99 {np.percentile(tg,99):.2f} ms; "
+      f"after ~10 ms of device idle p50 {np.percentile(tgi,50):.2f} ms p99 {np.percentile(tgi,99):.2f} ms; CPU oracle (1 thread) p50 {np.percentile(tc,50):.2f} ms p99 {np.percentile(tc,99):.2f} ms")
