@@ -308,3 +308,29 @@ def test_second_seed_against_oracle():
     assert np.abs(it - ref["iters"]).max() <= 1
     d = (x - ref["x"]).reshape(512, 10, 44)[:, :, 8:15]
     assert np.sqrt((d ** 2).mean(axis=(1, 2))).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_prints_one_json_line_with_the_contract_keys():
+    """bench.py (driver contract): ONE JSON line with the metric keys, the roofline object and, at N=1, the cpu_baseline object."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "128", "--cpu-seconds", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f64"
+    assert d["value"] > 0 and "workload" in d["config"] and d["config"]["solved_fraction"] == 1.0
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["gpu_vs_cpu_sample_joint_rms_rad"] < 1e-6
