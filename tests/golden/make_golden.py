@@ -39,43 +39,10 @@ OUT = os.path.dirname(os.path.abspath(__file__))
 
 
 def _install_standins():
-    d = tempfile.mkdtemp(prefix="bmpc_standin_")
-    with open(os.path.join(d, "casadi.py"), "w") as f:
-        f.write(textwrap.dedent('''
-            import numpy as np
-            class SX:  # placeholders for isinstance() checks only
-                pass
-            class MX:
-                pass
-            class DM:
-                pass
-            sin, cos, acos, sqrt, exp = np.sin, np.cos, np.arccos, np.sqrt, np.exp
-            def dot(a, b):
-                return float(np.dot(np.asarray(a).ravel(), np.asarray(b).ravel()))
-            def sumsqr(a):
-                return float(np.sum(np.asarray(a) ** 2))
-            def norm_2(a):
-                return float(np.linalg.norm(a))
-            def vertcat(*a):
-                return np.concatenate([np.atleast_1d(np.asarray(x, dtype=float)).ravel() for x in a])
-            def if_else(c, a, b):
-                return a if c else b
-        '''))
-    for pkg, sub, names in (("sensor_msgs", "msg", ["JointState"]),
-                            ("bound_mpc_msg", "msg", ["Vector", "MPCData"])):
-        os.makedirs(os.path.join(d, pkg, sub))
-        open(os.path.join(d, pkg, "__init__.py"), "w").close()
-        with open(os.path.join(d, pkg, sub, "__init__.py"), "w") as f:
-            for n in names:
-                f.write(f"class {n}:\n    pass\n")
-    os.makedirs(os.path.join(d, "bound_mpc_msg", "srv"))
-    with open(os.path.join(d, "bound_mpc_msg", "srv", "__init__.py"), "w") as f:
-        f.write("class Trajectory:\n    pass\nclass MPCParams:\n    pass\n")
-    with open(os.path.join(d, "bound_mpc_msg", "srv", "_trajectory.py"), "w") as f:
-        f.write("class Trajectory_Request:\n    pass\n")
-    sys.dont_write_bytecode = True
-    sys.path.insert(0, REF)
-    sys.path.insert(0, d)
+    """Temp-dir stand-ins for the absent casadi / ROS message modules: see ref_nlp.install_standins and numeric_sx.py."""
+    sys.path.insert(0, OUT)
+    import ref_nlp
+    return ref_nlp.install_standins()
 
 
 class _Params:

@@ -206,3 +206,116 @@ def test_scipy_independent_solution(which):
     rms_q = np.sqrt(np.mean((z[:, 8:15] - zs[:, 8:15]) ** 2))
     assert rms_q < 1e-6, rms_q                # measured 2.5e-8 / 5.4e-9 rad; the north-star tolerance is 1e-4 rad RMS
     assert abs(out["f"][0] - float(d["f"])) < 1e-9 * abs(float(d["f"]))
+
+
+# ---------------------------------------------------------------------------------------------
+# G9: the NLP itself -- f(x,p), g(x,p), bounds, parameter order and exact derivatives produced by the reference's own,
+# unmodified setup_optimization_problem (casadi_ocp_formulation.py:9-391) run with numbers in place of symbols
+# (tests/golden/make_g9.py, ref_nlp.py, numeric_sx.py).  Pins the composites reference_function / error_function /
+# objective_function / decomp_function / integration_function and the constraint assembly, not only the leaves.
+# ---------------------------------------------------------------------------------------------
+G9 = np.load(os.path.join(G, "g9_nlp.npz"))
+G9_SETS = (("n10", 10, 4, 0.1), ("n30", 30, 4, 0.1), ("n3s2", 3, 2, 0.05), ("n5s3", 5, 3, 0.05), ("n4s5", 4, 5, 0.05))
+
+
+def _close(a, b, tol):
+    a, b = np.asarray(a), np.asarray(b)
+    assert np.all(np.abs(a - b) <= tol * np.maximum(1.0, np.abs(b))), float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+@pytest.mark.parametrize("key,N,S,h", G9_SETS)
+def test_g9_numpy_restatement_equals_reference_nlp(key, N, S, h):
+    X, P, F, Gg = G9[key + "_x"], G9[key + "_p"], G9[key + "_f"], G9[key + "_g"]
+    assert len(X) >= 4
+    for i in range(len(X)):
+        f, g = nlp.nlp_eval(X[i], P[i], N, S, h)
+        _close(f, F[i], 1e-13)
+        _close(g, Gg[i], 1e-12)
+    lbx, ubx, lbg, ubg = nlp.bounds(N)
+    for mine, name in ((lbx, "lbx"), (ubx, "ubx"), (lbg, "lbg"), (ubg, "ubg")):
+        np.testing.assert_array_equal(mine, G9[f"{key}_{name}"])
+
+
+def test_g9_cases_cover_every_segment_and_the_past_the_end_row():
+    X, P = G9["n10_x"], G9["n10_p"]
+    seen = set()
+    for x, p in zip(X, P):
+        sw = p[89:94]
+        for ph in x.reshape(10, 44)[:, 41]:
+            seen.add(int(np.searchsorted(sw[1:], ph, side="right")))
+    assert seen == {0, 1, 2, 3, 4}                 # 4 = phi >= phi_switch[S]: row S of a4..a0 is read
+    tags = [str(t) for t in G9["n10_tag"]]
+    assert sum(t.startswith("exp1") for t in tags) >= 30 and sum(t.startswith("exp2") for t in tags) >= 30
+    # sigmoid of the objective (casadi_ocp_formulation.py:237) in its transition zone on some stage of some case
+    mid = 0
+    for x, p in zip(X, P):
+        s = 1 / (1 + np.exp(-np.clip(100 * (x.reshape(10, 44)[:, 41] - (p[460] - 0.02)), -700, 700)))
+        mid += int(np.any((s > 0.05) & (s < 0.95)))
+    assert mid >= 5
+
+
+@pytest.mark.parametrize("key,S", [("n10", 4), ("n3s2", 2), ("n5s3", 3), ("n4s5", 5)])
+def test_g9_parameter_order_is_the_references(key, S):
+    """The symbol behind every entry of p, as learned from the reference's own `params = ca.vertcat(...)`
+    (casadi_ocp_formulation.py:361-376), against the offsets of nlp.p_layout."""
+    names = [str(n) for n in G9[key + "_p_names"]]
+    assert len(names) == nlp.n_p(S)
+    lay = nlp.p_layout(S)
+    # reference symbol name -> (layout name, CasADi shape)
+    table = [("q_0", "q0", (7, 1)), ("dq_0", "dq0", (7, 1)), ("ddq_0", "ddq0", (7, 1)), ("phi_0", "phi0", (1, 1)),
+             ("dphi_0", "dphi0", (1, 1)), ("ddphi_0", "ddphi0", (1, 1)), ("p_0", "p0", (6, 1)), ("v_0", "v0", (6, 1)),
+             ("i_omega_ref_0", "iw_ref0", (3, 1)), ("initial lie space error", "dtau_init", (3, 1)),
+             ("initial lie space error par", "dtau_init_par", (3, S)), ("initial lie space error orth1", "dtau_init_orth1", (3, S)),
+             ("initial lie space error orth2", "dtau_init_orth2", (3, S)), ("x phi_desired", "x_phi_d", (3, 1)),
+             ("jerk_current", "jerk_cur", (1, 7)), ("jerk_phi_current", "jerk_phi_cur", (1, 1)),
+             ("path parameter switch", "phi_switch", (S + 1, 1)), ("right jacobian at initial error", "jac_dtau_r_T", (3, 3)),
+             ("left jacobian at initial error", "jac_dtau_l_T", (3, 3)), ("linear ref position", "p_ref", (S, 6)),
+             ("linear ref velocity", "dp_ref", (S, 6)), ("norm of orientation reference", "dp_normed_ref", (S, 3)),
+             ("orthogonal error basis 1", "bp1", (S, 3)), ("orthogonal error basis 2", "bp2", (S, 3)),
+             ("orthogonal error basis 1r", "br1", (S, 3)), ("orthogonal error basis 2r", "br2", (S, 3)),
+             ("parameter 4 error function", "a4", (S + 1, 9)), ("parameter 3 error function", "a3", (S + 1, 9)),
+             ("parameter 2 error function", "a2", (S + 1, 9)), ("parameter 1 error function", "a1", (S + 1, 9)),
+             ("parameter 0 error function", "a0", (S + 1, 9)), ("cost weights", "weights", (15, 1)),
+             ("max path parameter", "phi_max", (1, 1)), ("max path parameter", "dphi_max", (1, 1)),
+             ("v1", "v1", (S, 3)), ("v2", "v2", (S, 3)), ("v3", "v3", (S, 3)), ("q desired", "qd", (7, 1))]
+    k = 0
+    for ref_name, mine, (n, m) in table:
+        assert lay[mine][0] == k, (mine, lay[mine][0], k)
+        # column-major flattening of the (n, m) symbol (the jerk row is transposed first, a 1 x 7 either way)
+        for c in range(m):
+            for r in range(n):
+                assert names[k] == "%s[%d,%d]" % (ref_name, r, c), (k, names[k], ref_name, r, c)
+                k += 1
+        assert int(np.prod(lay[mine][1])) == n * m
+    assert k == nlp.n_p(S)
+    if key == "n10":
+        xn = [str(n) for n in G9["n10_x_names"]]
+        stage = (["u_%d[%d,0]" % (0, i) for i in range(8)] + ["q_1[%d,0]" % i for i in range(7)] + ["dq_1[%d,0]" % i for i in range(7)]
+                 + ["ddq_1[%d,0]" % i for i in range(7)] + ["i_omega_1[%d,0]" % i for i in range(6)] + ["v_1[%d,0]" % i for i in range(6)]
+                 + ["phi_1[0,0]", "dphi_1[0,0]", "ddphi_1[0,0]"])
+        assert xn[:44] == stage and xn[44] == "u_1[0,0]" and xn[44 + 8] == "q_2[0,0]" and len(xn) == 440
+
+
+def test_g9_exact_derivatives_of_the_reference():
+    """Gradient of f and Jacobian of g by a complex step THROUGH THE REFERENCE'S CODE, against the same of the numpy
+    restatement (which in turn certifies the C oracle's analytic derivatives in the tests above)."""
+    for j, i in enumerate(G9["n10_deriv_case"]):
+        x, p = G9["n10_x"][i], G9["n10_p"][i]
+        gf, Jg = nlp.jac_g_complex_step(x, p, 10, 4, 0.1)
+        _close(gf, G9["n10_grad_f"][j], 1e-11)
+        _close(Jg, G9["n10_jac_g"][j], 1e-11)
+        # structure the solver relies on (SURVEY A.6): stage k's constraints touch stages k-1 and k only
+        J = G9["n10_jac_g"][j].reshape(10, 43, 10, 44)
+        for k in range(10):
+            for l in range(10):
+                if l > k or l < k - 1:
+                    assert not J[k, :, l, :].any()
+
+
+@pytest.mark.parametrize("key,N,S,h", [s for s in G9_SETS if s[2] <= 4])
+def test_g9_c_oracle_equals_reference_nlp(key, N, S, h):
+    X, P, F, Gg = G9[key + "_x"], G9[key + "_p"], G9[key + "_f"], G9[key + "_g"]
+    for i in range(len(X)):
+        f, g = c_oracle.eval_fg(P[i], X[i], N, S, h)
+        _close(f, F[i], 1e-12)
+        _close(g, Gg[i], 1e-11)
