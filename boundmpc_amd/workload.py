@@ -86,9 +86,13 @@ def _chunk(args):
     return P, X
 
 
-def make_batch(B, seed=0, N=10, S=4, dt=0.1, tight=False, workers=None):
-    """SURVEY 8(d) config 2/3/4 generator -> (p [B][n_p], x0 [B][44N], q0 [B][7])."""
+def make_batch(B, seed=0, N=10, S=4, dt=0.1, tight=False, workers=None, rows=None):
+    """SURVEY 8(d) config 2/3/4 generator -> (p [B][n_p], x0 [B][44N], q0 [B][7]).
+    rows=(lo, hi): only that slice of the B-problem batch (a rank's shard of a sharded batch, boundmpc_amd.distributed.shard_range)."""
     q0 = random_q0(B, seed)
+    if rows is not None:
+        q0 = q0[rows[0]:rows[1]]
+        B = len(q0)
     workers = workers if workers is not None else max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 2)))
     if workers <= 1 or B < 64:
         P, X = _chunk((q0, N, S, dt, tight))

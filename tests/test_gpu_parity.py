@@ -358,3 +358,59 @@ def test_g9_kernel_f_and_g_equal_the_reference_nlp(key, N, S, h):
     assert rel(out["g"], Gg) <= 1e-11, rel(out["g"], Gg)
     for mine, name in ((lbx, "lbx"), (ubx, "ubx"), (lbg, "lbg"), (ubg, "ubg")):
         np.testing.assert_array_equal(mine, d[f"{key}_{name}"])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE.json configs[2]: batch = 65536 over 8 GPUs.  One GPU here: rank 3's shard (8192 problems) of the seed-1 batch.
+# ---------------------------------------------------------------------------------------------------------------
+def test_configs2_shard_8192_properties_and_oracle_sample(solver):
+    import torch
+    from boundmpc_amd import workload
+    from boundmpc_amd.distributed import shard_range
+    from oracle import c_oracle
+    lo, hi = shard_range(65536, 3, 8)
+    assert hi - lo == 8192
+    P, X, _ = workload.make_batch(65536, seed=1, rows=(lo, hi))
+    p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
+    o = solver.solve_batch(p, x0)
+    torch.cuda.synchronize()
+    x, st, it, kkt = o["x"].cpu().numpy(), o["status"].cpu().numpy(), o["iters"].cpu().numpy(), o["kkt"].cpu().numpy()
+    ok = st == 0
+    assert ok.mean() >= 0.999, (ok.mean(), np.bincount(st))
+    # size-independent properties at full size: KKT error, feasibility of the reference-form constraints and of the bounds
+    assert (kkt[ok] <= 1e-8).all()
+    g = o["g"].cpu().numpy()[ok].reshape(-1, 10, 43)
+    assert np.abs(g[:, :, :36]).max() < 1e-6 and g[:, :, 36:].max() < 1e-6
+    lbx, ubx, _, _ = solver.bounds()
+    assert (x[ok] >= lbx - 1e-8).all() and (x[ok] <= ubx + 1e-8).all()
+    # every problem started on its own path: first-stage joints stay near q0 (cheap sanity of the per-row independence)
+    assert np.abs(x[ok].reshape(-1, 10, 44)[:, 0, 8:15] - X[ok].reshape(-1, 10, 44)[:, 0, 8:15]).max() < 0.2
+    # determinism at this size
+    o2 = solver.solve_batch(p, x0, out={})
+    torch.cuda.synchronize()
+    assert torch.equal(o2["x"], o["x"]) and torch.equal(o2["iters"], o["iters"])
+    # oracle on a 256-problem sample spread over the shard
+    idx = np.arange(0, 8192, 32)
+    ref = c_oracle.solve(P[idx], X[idx], 10, 4, 0.1)
+    assert (ref["status"] == st[idx]).all()
+    k = ref["status"] == 0
+    assert np.abs(it[idx][k] - ref["iters"][k]).max() <= 2
+    assert _rms_q(x[idx][k], ref["x"][k]) < TOL_Q_RMS
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` from a plain interpreter (no torch.distributed.run): the script starts its two ranks itself.
+    One-GPU box: --rehearse-one-gpu puts both ranks on cuda:0 and gathers over gloo (a rehearsal of the plumbing, not a number)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-one-gpu", "--steps", "2", "--warmup", "1",
+                        "--batch", "128", "--workers", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 256 and rec["value"] > 0
+    assert rec["config"]["solved_fraction"] == 1.0

@@ -319,3 +319,21 @@ def test_g9_c_oracle_equals_reference_nlp(key, N, S, h):
         f, g = c_oracle.eval_fg(P[i], X[i], N, S, h)
         _close(f, F[i], 1e-12)
         _close(g, Gg[i], 1e-11)
+
+
+def test_g9_kkt_certificate_with_the_references_own_derivatives():
+    """The solution of experiment1 tick 0 is a KKT point of the REFERENCE's NLP: stationarity evaluated with the gradient and
+    Jacobian that came out of the reference's code (complex step through setup_optimization_problem, fixture G9) and the
+    multipliers of the solver in CasADi's sign convention; feasibility with the reference's g."""
+    tags = [str(t) for t in G9["n10_tag"]]
+    i = tags.index("exp1_tick0_sol")
+    j = list(G9["n10_deriv_case"]).index(i)
+    d = np.load(os.path.join(G, "g6_pack_exp1_tick0.npz"))
+    out = c_oracle.solve(d["p_f64"], d["x0_f64"], 10, 4, 0.1, c_oracle.default_opts(tol=1e-8))
+    x, lam_g, lam_x = out["x"][0], out["lam_g"][0], out["lam_x"][0]
+    assert np.abs(x - G9["n10_x"][i]).max() < 1e-6                     # same point as the fixture (solver is deterministic up to libm)
+    r = G9["n10_grad_f"][j] + G9["n10_jac_g"][j].T @ lam_g + lam_x
+    assert np.abs(r).max() < 1e-5, np.abs(r).max()
+    g = G9["n10_g"][i].reshape(10, 43)
+    assert np.abs(g[:, :36]).max() < 1e-8 and g[:, 36:].max() < 1e-8
+    assert (lam_g.reshape(10, 43)[:, 36:] >= 0).all()
