@@ -43,6 +43,7 @@ namespace bmpc {
 // dimensions and index maps
 // ----------------------------------------------------------------------------------------
 constexpr int NZ = 44, NG = 43, NE = 36, NS = 35, NU = 8, NW = 43, NI = 57, SMAX = 4, NPMAX = 141 + 91 * SMAX;
+#define KAPPA_EPS 100.0   // barrier problem "solved" at KKT error <= KAPPA_EPS * mu (oracle/bmpc_oracle.c; Ipopt barrier_tol_factor)
 enum { ZJ = 0, ZJPHI = 7, ZQ = 8, ZDQ = 15, ZDDQ = 22, ZPOS = 29, ZIW = 32, ZV = 35, ZW = 38, ZPHI = 41, ZDPHI = 42, ZDDPHI = 43 };
 enum { GQ = 0, GDQ = 7, GDDQ = 14, GPOS = 21, GIW = 24, GV = 27, GW = 30, GPHI = 33, GDPHI = 34, GDDPHI = 35 };
 enum { SQ = 0, SDQ = 7, SDDQ = 14, SJ = 21, SPHI = 28, SDPHI = 29, SDDPHI = 30, SJPHI = 31, SIOTA = 32 };
@@ -556,7 +557,12 @@ BMPC_D inline double red_min(const double *r) { double s = r[0];
 
 // Evaluate at Zs: kinematic records, node references, equality residuals Gd[N][36], inequality
 // values Hd[N][57]; returns the objective (wave-uniform).
-BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, const double *Zs, int oG, int oH) {
+// project (trial points of the line search after a rejected first trial; oracle/bmpc_oracle.c eval_values): the lifted variables
+// pos, i-omega, v of every node are overwritten in Zs by what their defining equalities give for the trial (q, dq), so those 12
+// residual rows are exactly zero.  One lane per node: a lane writes only its own node's entries and reads its neighbours' projected
+// values from the kinematics records of phase 1 (v of the previous node; the i-omega recursion as a prefix sum from node 0), never
+// from Zs -- no cross-lane dependence inside the phase.
+BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Zs, int oG, int oH, bool project) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
     double *L = W.L, *G = W.G;
     const double *PAR = L + L_PAR;
@@ -586,13 +592,23 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, const dou
         double fk = 0;
         if (lane < N) {
             const int k = lane;
-            const double *Zn = Zs + k * NZ, *kp = G + sc.KIN + k * KREC, *kv = G + sc.KIN + (N + k) * KREC;
+            double *Zn = Zs + k * NZ; const double *kp = G + sc.KIN + k * KREC, *kv = G + sc.KIN + (N + k) * KREC;
             double *gk = G + oG + k * NE, *rr = G + sc.REF + k * RREC;
-            for (int i = 0; i < 3; i++) {
-                gk[GPOS + i] = kp[KPOS + i] - Zn[ZPOS + i];
-                gk[GIW + i] = ndv(PAR, po, Zs, k, ZIW + i, po.p0 + 3 + i) + 0.5 * h * (kv[KV + 3 + i] + kp[KV + 3 + i]) - Zn[ZIW + i];
+            if (project) {
+                double iw[3] = {PAR[po.p0 + 3], PAR[po.p0 + 4], PAR[po.p0 + 5]};
+                for (int j = 0; j <= k; j++) {
+                    const double *kpj = G + sc.KIN + j * KREC, *kvj = G + sc.KIN + (N + j) * KREC;
+                    for (int i = 0; i < 3; i++) iw[i] = iw[i] + 0.5 * h * (kvj[KV + 3 + i] + kpj[KV + 3 + i]);
+                }
+                for (int i = 0; i < 3; i++) { Zn[ZPOS + i] = kp[KPOS + i]; gk[GPOS + i] = 0.0; Zn[ZIW + i] = iw[i]; gk[GIW + i] = 0.0; }
+                for (int i = 0; i < 6; i++) { Zn[ZV + i] = kp[KV + i]; gk[GV + i] = 0.0; }
+            } else {
+                for (int i = 0; i < 3; i++) {
+                    gk[GPOS + i] = kp[KPOS + i] - Zn[ZPOS + i];
+                    gk[GIW + i] = ndv(PAR, po, Zs, k, ZIW + i, po.p0 + 3 + i) + 0.5 * h * (kv[KV + 3 + i] + kp[KV + 3 + i]) - Zn[ZIW + i];
+                }
+                for (int i = 0; i < 6; i++) gk[GV + i] = kp[KV + i] - Zn[ZV + i];
             }
-            for (int i = 0; i < 6; i++) gk[GV + i] = kp[KV + i] - Zn[ZV + i];
             const double ph = ndv(PAR, po, Zs, k, ZPHI, po.phi0), dph = ndv(PAR, po, Zs, k, ZDPHI, po.phi0 + 1),
                          ddph = ndv(PAR, po, Zs, k, ZDDPHI, po.phi0 + 2), jp0 = ndv(PAR, po, Zs, k, ZJPHI, po.jerkphi), jp1 = Zn[ZJPHI];
             gk[GPHI] = ph + h * dph + h2 / 2 * ddph + h3 / 8 * jp0 + h3 / 24 * jp1 - Zn[ZPHI];
@@ -606,7 +622,7 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, const dou
             for (int c = 0; c < 3; c++) { epo[c] = sig * rr[REP + c] + (1 - sig) * dde * d[c]; ero[c] = sig * rr[RER + c] + (1 - sig) * rr[RERPAR + c]; }
             fk = w[1] * dot3(ero, ero) + w[0] * dot3(epo, epo);
             for (int c = 0; c < 6; c++) {
-                const double vp = ndv(PAR, po, Zs, k, ZV + c, po.v0 + c);
+                const double vp = (project && k > 0) ? G[sc.KIN + (k - 1) * KREC + KV + c] : ndv(PAR, po, Zs, k, ZV + c, po.v0 + c);
                 const double rv = Zn[ZV + c] - Zn[ZDPHI] * d[c], ra = (Zn[ZV + c] - vp) / h - Zn[ZDDPHI] * d[c];
                 fk += w[2] * rv * rv + w[5] * ra * ra;
             }
@@ -1717,7 +1733,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     double mu = warm ? BMPC_FMIN(o.mu_init, BMPC_FMAX(mu_state, o.mu_warm)) : o.mu_init; const double mu_min = o.tol * o.mu_min_fac;
     double delta_last = 0.0, filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0;
     BMPC_PROF(W, 15);
-    double fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN);
+    double fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);
     BMPC_PROF(W, 0);
     // Row pass "A" (57 rows per node, lane-strided, three rows in flight per lane): multipliers nu, barrier ratios
     // sigma = nu/t, 1/t, sigma*(h+t), and the inequality part of the KKT error.  first = initialisation of t, nu.
@@ -1777,7 +1793,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         for (;;) {   // monotone barrier update (Fiacco-McCormick, Ipopt constants)
             const double ec = BMPC_FMAX(cmax - mu, mu - cmin);
             const double Emu = BMPC_FMAX(BMPC_FMAX(ed / sd, ep), ec / scl);
-            if (Emu <= 10.0 * mu && mu > mu_min) mu = BMPC_FMAX(mu_min, BMPC_FMIN(0.2 * mu, BMPC_POW15(mu))); else break;
+            if (Emu <= KAPPA_EPS * mu && mu > mu_min) mu = BMPC_FMAX(mu_min, BMPC_FMIN(0.2 * mu, BMPC_POW15(mu))); else break;
         }
         // ---- Newton system: QP gradient, lifted residuals, Riccati ----
         BMPC_PROF(W, 2);
@@ -1889,7 +1905,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                 }
             LANES_END
             BMPC_PROF(W, 9);
-            ft = wave_eval(W, po, sc, W.Zt, sc.GT, sc.HT);
+            ft = wave_eval(W, po, sc, W.Zt, sc.GT, sc.HT, ls > 0);
             BMPC_PROF(W, 0);
             LANES_BEGIN
                 double th = 0, br = 0;
@@ -1922,7 +1938,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
                 } else okk = (tht <= (1 - 1e-5) * theta) || (phit <= phi0 - 1e-8 * theta);
             }
             if (okk) { accepted = true; break; }
-            alpha *= 0.5;
+            if (ls > 0) alpha *= 0.5;     // trial 1 repeats the step length of trial 0 with the lifted variables projected
         }
 #ifdef BMPC_EMU
         if (o.verbose) fprintf(stderr, "   alpha_p %.3e (max %.3e) alpha_d %.3e delta %.1e acc %d arm %d nfilt %d theta %.3e dphi %.3e\n", alpha, ap, ad, delta, (int)accepted, (int)armijo_step, nfilt, theta, dphi);

@@ -54,6 +54,7 @@ enum { IJU = 0, IJL = 8, IQU = 16, IQL = 23, IDQU = 30, IDQL = 37, IPHI0 = 44, I
 static const double Q_LIM_DEG[7] = {165, 115, 165, 115, 165, 115, 170};
 static const double DQ_LIM_DEG[7] = {85, 85, 100, 75, 130, 135, 135};
 #define U_LIM 35.0
+#define KAPPA_EPS 100.0 /* barrier problem "solved" when its KKT error <= KAPPA_EPS * mu (Ipopt barrier_tol_factor, default 10) */
 #define PI 3.14159265358979323846
 
 typedef struct {
@@ -361,14 +362,18 @@ static inline double nd_phi(const Par *P, const double *Z, int k, int d) {
  * function evaluation: f, equality residuals g[N][36], inequality values h[N][57]
  * (casadi_ocp_formulation.py:88-349)
  * ---------------------------------------------------------------------------------------- */
-static double eval_values(const Cfg *C, const Par *P, const double *Z, Kin *Kp, Kin *Kv, NodeRef *Rf, double *g, double *hin) {
+/* project != 0 (trial points of the line search after a rejected first trial): the lifted variables pos, i-omega and v of every
+ * node are overwritten IN Z by the values their defining equalities give for the trial (q, dq) -- pos = fk(q^), v = J(q^) dq^,
+ * i-omega by the trapezoidal recursion from node 0 -- so that those 12 residual rows vanish identically and the trial is judged
+ * on the linear residuals, the inequalities and the objective alone (an exact "second-order correction" of the lifted rows). */
+static double eval_values(const Cfg *C, const Par *P, double *Z, Kin *Kp, Kin *Kv, NodeRef *Rf, double *g, double *hin, int project) {
     const int N = C->N;
     const double h = C->h, h2 = h * h, h3 = h2 * h;
     const double *w = P->w;
     double f = 0;
     for (int k = 0; k < N; k++) {
         const double *q = nd_q(P, Z, k), *dq = nd_dq(P, Z, k), *ddq = nd_ddq(P, Z, k), *j0 = nd_j(P, Z, k);
-        const double *Zn = Z + k * NZ;
+        double *Zn = Z + k * NZ;
         double qn[7], dqn[7], ddqn[7];
         for (int i = 0; i < 7; i++) {   /* jerk_trajectory_casadi.py:78-175 closed form */
             qn[i] = q[i] + h * dq[i] + h2 / 2 * ddq[i] + h3 / 8 * j0[i] + h3 / 24 * Zn[ZJ + i];
@@ -390,6 +395,13 @@ static double eval_values(const Cfg *C, const Par *P, const double *Z, Kin *Kp, 
         }
         for (int i = 0; i < 6; i++) gk[GV + i] = Kp[k].v[i] - Zn[ZV + i];
         gk[GPHI] = phn - Zn[ZPHI]; gk[GDPHI] = dphn - Zn[ZDPHI]; gk[GDDPHI] = ddphn - Zn[ZDDPHI];
+        if (project) {
+            for (int i = 0; i < 3; i++) {
+                Zn[ZPOS + i] = Kp[k].pos[i]; gk[GPOS + i] = 0.0;
+                Zn[ZIW + i] = pk[3 + i] + 0.5 * h * (Kv[k].v[3 + i] + Kp[k].v[3 + i]); gk[GIW + i] = 0.0;   /* pk: node k, already projected */
+            }
+            for (int i = 0; i < 6; i++) { Zn[ZV + i] = Kp[k].v[i]; gk[GV + i] = 0.0; }
+        }
         /* node k+1 cost and inequalities */
         NodeRef *R = &Rf[k];
         node_ref(C, P, Zn + ZPOS, Zn + ZIW, Zn[ZPHI], R);
@@ -878,7 +890,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
     double mu = warm ? fmin(o->mu_init, fmax(state[N * NI], o->mu_warm)) : o->mu_init;
     double mu_min = o->tol * o->mu_min_fac, delta_last = 0.0;
     double filt_th[32], filt_ph[32], filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0;
-    W->f = eval_values(C, P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
+    W->f = eval_values(C, P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0);
     for (int i = 0; i < N * NI; i++) {
         const double tmin = (warm && state[i] > 0.0) ? fmin(mu / state[i], o->slack_push) : o->slack_push;
         W->t[i] = fmax(-W->hin[i], tmin); W->nu[i] = mu / W->t[i];
@@ -899,7 +911,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         for (;;) {
             kkt_errors(C, W, mu, &ed, &ep, &ecm, &sd, &sc);
             double Emu = fmax(fmax(ed / sd, ep), ecm / sc);
-            if (Emu <= 10.0 * mu && mu > mu_min) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5))); else break;
+            if (Emu <= KAPPA_EPS * mu && mu > mu_min) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5))); else break;
         }
         for (int i = 0; i < N * NI; i++) {
             sg[i] = W->nu[i] / W->t[i];
@@ -943,7 +955,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         for (int ls = 0; ls < 14; ls++) {
             for (int i = 0; i < N * NZ; i++) W->Zt[i] = W->Z[i] + alpha * W->dZ[i];
             for (int i = 0; i < N * NI; i++) W->tt[i] = W->t[i] + alpha * W->dt[i];
-            ft = eval_values(C, P, W->Zt, W->Kp, W->Kv, W->R, gt, ht);
+            ft = eval_values(C, P, W->Zt, W->Kp, W->Kv, W->R, gt, ht, ls > 0);
             double th = 0, br = 0;
             for (int i = 0; i < N * NE; i++) th += fabs(gt[i]);
             for (int i = 0; i < N * NI; i++) { th += fabs(ht[i] + W->tt[i]); br -= mu * log(W->tt[i]); }
@@ -958,7 +970,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
                 } else ok = (th <= (1 - 1e-5) * theta) || (phit <= phi0 - 1e-8 * theta);
             }
             if (ok) { accepted = 1; break; }
-            alpha *= 0.5;
+            if (ls > 0) alpha *= 0.5;   /* trial 1 repeats the step length of trial 0 with the lifted variables projected */
         }
         if (!accepted) { nfilt = 0; if (o->verbose) fprintf(stderr, "   line search failed: smallest step taken, filter reset\n"); }
         else if (!armijo_step && nfilt < 32) { filt_th[nfilt] = (1 - 1e-5) * theta; filt_ph[nfilt] = phi0 - 1e-8 * theta; nfilt++; }
@@ -1011,7 +1023,7 @@ int bmpc_oracle_eval(int N, int S, double h, const double *p, const double *x, d
     Par P; par_view(p, S, &P);
     Work *W = work_alloc(N);
     memcpy(W->Z, x, sizeof(double) * N * NZ);
-    *f = eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
+    *f = eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0);
     fill_g_ref(&C, &P, W->Z, W->g, W->R, g);
     work_free(W);
     return 0;
@@ -1023,7 +1035,7 @@ int bmpc_oracle_adjoint(int N, int S, double h, const double *p, const double *x
     Par P; par_view(p, S, &P);
     Work *W = work_alloc(N);
     memcpy(W->Z, x, sizeof(double) * N * NZ);
-    eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
+    eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0);
     adjoint(&C, &P, W, W->Z, nu, lam, Rj, gradZ);
     work_free(W);
     return 0;
@@ -1045,7 +1057,7 @@ int bmpc_oracle_newton_dir(int N, int S, double h, const double *p, const double
     Par P; par_view(p, S, &P);
     Work *W = work_alloc(N);
     memcpy(W->Z, x, sizeof(double) * N * NZ); memcpy(W->t, t, sizeof(double) * N * NI); memcpy(W->nu, nu, sizeof(double) * N * NI);
-    eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
+    eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0);
     adjoint(&C, &P, W, W->Z, W->nu, W->lam, W->Rj, W->gradZ);
     double *sg = (double *)malloc(N * NI * sizeof(double)), *nuh = (double *)malloc(N * NI * sizeof(double));
     for (int i = 0; i < N * NI; i++) { sg[i] = nu[i] / t[i]; nuh[i] = (mu + nu[i] * (W->hin[i] + t[i])) / t[i]; }
@@ -1075,7 +1087,7 @@ int bmpc_oracle_solve_warm(int N, int S, double h, const bmpc_oracle_opts *opts,
             SolveInfo info; Par P; par_view(p + (size_t)b * C.np, S, &P);
             solve_one(&C, p + (size_t)b * C.np, x0 + (size_t)b * nw, W, &info, state ? state + (size_t)b * (N * NI + 2) : NULL);
             /* refresh node data at the final point for the outputs */
-            W->f = eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
+            W->f = eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0);
             write_outputs(&C, &P, W, x ? x + (size_t)b * nw : NULL, g ? g + (size_t)b * ng : NULL,
                           lam_g ? lam_g + (size_t)b * ng : NULL, lam_x ? lam_x + (size_t)b * nw : NULL);
             if (f) f[b] = info.f; if (iters) iters[b] = info.iters; if (status) status[b] = info.status; if (kkt) kkt[b] = info.kkt;
@@ -1098,7 +1110,7 @@ int bmpc_oracle_debug_qp(int N, int S, double h, const double *p, const double *
     Par P; par_view(p, S, &P);
     Work *W = work_alloc(N);
     memcpy(W->Z, x, sizeof(double) * N * NZ); memcpy(W->t, t, sizeof(double) * N * NI); memcpy(W->nu, nu, sizeof(double) * N * NI);
-    eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin);
+    eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0);
     adjoint(&C, &P, W, W->Z, W->nu, W->lam, W->Rj, W->gradZ);
     double *sg = (double *)malloc(N * NI * sizeof(double)), *nuh = (double *)malloc(N * NI * sizeof(double));
     for (int i = 0; i < N * NI; i++) { sg[i] = nu[i] / t[i]; nuh[i] = (mu + nu[i] * (W->hin[i] + t[i])) / t[i]; }

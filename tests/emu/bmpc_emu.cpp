@@ -89,7 +89,7 @@ extern "C" int bmpc_emu_newton(int N, int S, double h, const bmpc::Opts *opts, c
     const bool zl = N <= 11; W.Zc = zl ? W.L + L_ZL : W.G + sc.Z; W.Zt = zl ? W.L + L_PB : W.G + sc.ZT; W.Dz = zl ? W.L + L_PB + 512 : W.G + sc.DZ;
     for (int i = 0; i < N * NZ; i++) W.Zc[i] = x[i];
     for (int i = 0; i < N * NI; i++) { W.G[sc.T + i] = t[i]; W.G[sc.NUm + i] = nu[i]; }
-    wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN);
+    wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);
     LaneRegs LRs[64];
     wave_adjoint(W, po, sc, sc.NUm, false, 0.0, LRs);
     for (int i = 0; i < N * NI; i++) { const double tt = W.G[sc.T + i], nn = W.G[sc.NUm + i]; W.G[sc.SG + i] = nn / tt; W.G[sc.TI + i] = 1.0 / tt; W.G[sc.SR + i] = nn / tt * (W.G[sc.HIN + i] + tt); }

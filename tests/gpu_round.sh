@@ -17,7 +17,7 @@ timeout -k 10 300 python bench.py --batch 8192 --no-cpu-baseline > gpurun_out/be
 cat gpurun_out/bench_${TAG}_B8192.json
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --no-cpu-baseline > $R/gpurun_out/prof_$TAG.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --no-cpu-baseline --workers 1 > $R/gpurun_out/prof_$TAG.log 2>&1
 cd $R
 find gpurun_out/prof_$TAG -name '*kernel_stats.csv' -exec cat {} \;
 timeout -k 10 300 python tests/gpu_profile_phases.py > gpurun_out/phases_$TAG.log 2>&1 || true

