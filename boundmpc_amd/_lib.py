@@ -18,7 +18,7 @@ SYMBOLS = ["bmpc_default_options", "bmpc_error_string", "bmpc_create", "bmpc_des
 class Options(ctypes.Structure):
     _fields_ = [("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("mu_init", ctypes.c_double),
                 ("mu_min_fac", ctypes.c_double), ("slack_push", ctypes.c_double),
-                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double)]
+                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double), ("stall_window", ctypes.c_int)]
 
 
 class BoundMPCHipError(RuntimeError):

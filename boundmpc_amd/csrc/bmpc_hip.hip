@@ -104,7 +104,7 @@ struct bmpc_handle {
 
 extern "C" int bmpc_default_options(bmpc_options *o) {
     if (!o) return BMPC_ERR_ARG;
-    o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0; o->mu_warm = 1e-4;
+    o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0; o->mu_warm = 1e-4; o->stall_window = 40;
     return BMPC_OK;
 }
 extern "C" const char *bmpc_error_string(int c) {
@@ -113,7 +113,7 @@ extern "C" const char *bmpc_error_string(int c) {
 }
 extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bmpc_handle **out) {
     if (!out || N < 1 || N > 32 || S < 2 || S > bmpc::SMAX || !(dt > 0)) return BMPC_ERR_ARG;
-    if (opts && (!(opts->tol > 0) || opts->max_iter < 0 || !(opts->mu_init > 0) || !(opts->slack_push > 0))) return BMPC_ERR_ARG;
+    if (opts && (!(opts->tol > 0) || opts->max_iter < 0 || opts->stall_window < 0 || (opts->stall_window & 1) || !(opts->mu_init > 0) || !(opts->slack_push > 0))) return BMPC_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BMPC_ERR_NOGPU;
     bmpc_handle *h = new (std::nothrow) bmpc_handle();
@@ -178,7 +178,7 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
                          double *lam_x, double *f, int *iters, int *status, double *kkt, hipStream_t st, bool timed) {
     KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
     a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
-    a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm;
+    a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = lam_g; a.lam_x = lam_x; a.f = f; a.kkt = kkt; a.iters = iters; a.status = status;
     a.state = state; a.latency_us = h->latency_us;
     a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter; a.prof = h->prof;

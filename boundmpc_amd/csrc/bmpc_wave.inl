@@ -107,7 +107,7 @@ enum { NC_HPP = 0, NC_HRR = 9, NC_HPF = 18, NC_HRF = 21, NC_SC = 24 /* hff,hdd,h
        NC_GL = 91 /* 44 */, NC_RL = 135 /* 9 */, NC_GY = 144 /* 14 */ };
 
 struct Opts {
-    double tol; int max_iter; double mu_init; double mu_min_fac; double slack_push; int exact_hessian; int verbose; double mu_warm;
+    double tol; int max_iter; double mu_init; double mu_min_fac; double slack_push; int exact_hessian; int verbose; double mu_warm; int stall_window;
 };
 
 // global scratch layout (doubles) for horizon N
@@ -1763,7 +1763,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
             L[L_KKP + lane] = ep; L[L_KKP + 64 + lane] = cmax; L[L_KKP + 128 + lane] = cmin; L[L_KKP + 192 + lane] = sn;
         LANES_END
     }
-    int it = 0, status = 1; double E0 = 0;
+    int it = 0, status = 1; double E0 = 0, ep_old = 0, ep_mid = 0;
     for (it = 0; it <= o.max_iter; it++) {
         BMPC_PROF(W, 10);
         wave_adjoint(W, po, sc, sc.NUm, false, 0.0, LRs);
@@ -1790,6 +1790,13 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
 #endif
         if (E0 <= o.tol) { status = 0; break; }
         if (it == o.max_iter) break;
+        // stalled primal feasibility -> status 2, numerical breakdown -> status 3 (oracle/bmpc_oracle.c solve_one)
+        if (it == 0) ep_old = ep_mid = 1e300;
+        else if (o.stall_window > 0 && it % (o.stall_window / 2) == 0) {
+            if (it >= o.stall_window && ep >= 0.9 * ep_old && ep > 1e-6) { status = 2; break; }
+            ep_old = ep_mid; ep_mid = ep;
+        }
+        if (!(ed < 1e12)) { status = 3; break; }
         for (;;) {   // monotone barrier update (Fiacco-McCormick, Ipopt constants)
             const double ec = BMPC_FMAX(cmax - mu, mu - cmin);
             const double Emu = BMPC_FMAX(BMPC_FMAX(ed / sd, ep), ec / scl);

@@ -14,12 +14,13 @@ NZ, NG = 44, 43
 
 
 class BatchedOCPSolver:
-    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=0.1, slack_push=1e-2, exact_hessian=True, mu_warm=1e-4):
+    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=0.1, slack_push=1e-2, exact_hessian=True, mu_warm=1e-4, stall_window=40):
         self._lib = _lib.load()
         o = _lib.Options()
         self._lib.bmpc_default_options(ctypes.byref(o))
         o.tol, o.max_iter, o.mu_init, o.slack_push, o.exact_hessian = tol, int(max_iter), mu_init, slack_push, int(exact_hessian)
         o.mu_warm = mu_warm
+        o.stall_window = int(stall_window)
         self._h = ctypes.c_void_p()
         _lib.check(self._lib.bmpc_create(int(N), int(S), float(dt), ctypes.byref(o), ctypes.byref(self._h)), "bmpc_create")
         self.N, self.S, self.dt = int(N), int(S), float(dt)
@@ -186,7 +187,7 @@ class StepGraph:
             pass
 
 
-_STATUS = {0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 3: "Error_In_Step_Computation"}
+_STATUS = {0: "Solve_Succeeded", 1: "Maximum_Iterations_Exceeded", 2: "Infeasible_Problem_Detected", 3: "Error_In_Step_Computation"}
 
 
 class NlpSolverShim:

@@ -22,7 +22,8 @@
  *   x0, x  [B][44*N]  stage variables z_k = [u(7) u_phi | q dq ddq | p(6) | v(6) | phi dphi ddphi] (:90-153)
  *   g      [B][43*N]  constraints in the reference's order/form (:272-349)
  *   lam_g  [B][43*N]  multipliers of g (sign: L = f + lam_g.g), lam_x [B][44*N] multipliers of lbx <= x <= ubx
- *   f, kkt [B], iters [B], status [B]  (0 converged, 1 max_iter reached, 3 numerical failure)
+ *   f, kkt [B], iters [B], status [B]  (0 converged, 1 max_iter reached, 2 stalled at a point of local infeasibility -- no progress
+ *                                        of the primal infeasibility over 40 iterations --, 3 numerical failure)
  * lbx/ubx/lbg/ubg are structural constants of the formulation (robot limits, 36 equalities
  * + 7 inequalities per stage) and do not cross the ABI per call; bmpc_get_bounds returns them.
  *
@@ -48,6 +49,8 @@ typedef struct {
     int exact_hessian;  /* 1: exact Lagrangian Hessian (reference uses CasADi's exact Hessian); 0: Gauss-Newton */
     int verbose;
     double mu_warm;     /* warm start (bmpc_solve_batch_warm): the barrier restarts at clamp(stored mu, mu_warm, mu_init); default 1e-4 */
+    int stall_window;   /* status 2 when the primal infeasibility made < 10 % progress over this many iterations (checked every
+                           stall_window/2 iterations); 0 = never; default 40 (reference: Ipopt's restoration phase / "local infeasibility") */
 } bmpc_options;
 
 enum { BMPC_OK = 0, BMPC_ERR_ARG = 1, BMPC_ERR_HIP = 2, BMPC_ERR_NOGPU = 4 };

@@ -66,6 +66,7 @@ typedef struct {
     int exact_hessian;   /* 1 */
     int verbose;
     double mu_warm;      /* warm start: barrier restarts at clamp(stored mu, mu_warm, mu_init) */
+    int stall_window;    /* 40; 0 = off */
 } bmpc_oracle_opts;
 
 typedef struct {
@@ -899,7 +900,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
     double *gf = (double *)malloc(N * NZ * sizeof(double)), *zero_nu = (double *)calloc(N * NI, sizeof(double));
     double *hdir = (double *)malloc(NI * sizeof(double)), *gt = (double *)malloc(N * NE * sizeof(double)), *ht = (double *)malloc(N * NI * sizeof(double));
     int it = 0, status = 1;
-    double E0 = 0;
+    double E0 = 0, ep_old = 0, ep_mid = 0;
     for (it = 0; it <= o->max_iter; it++) {
         adjoint(C, P, W, W->Z, W->nu, W->lam, W->Rj, W->gradZ);
         double ed, ep, ec0, ecm, sd, sc;
@@ -908,6 +909,16 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         if (o->verbose) fprintf(stderr, "it %3d f %.8e dual %.2e prim %.2e compl %.2e mu %.1e\n", it, W->f, ed, ep, ec0, mu);
         if (E0 <= o->tol) { status = 0; break; }
         if (it == o->max_iter) break;
+        /* stalled primal feasibility (what Ipopt reports as "converged to a point of local infeasibility" after its restoration
+         * phase): every stall_window/2 iterations the primal infeasibility is compared with its value stall_window iterations
+         * earlier; less than 10 % progress ends the solve with status 2.  Never fires on problems that converge in < 40 iterations.
+         * A dual residual beyond 1e12 is a numerical breakdown (status 3). */
+        if (it == 0) ep_old = ep_mid = 1e300;
+        else if (o->stall_window > 0 && it % (o->stall_window / 2) == 0) {
+            if (it >= o->stall_window && ep >= 0.9 * ep_old && ep > 1e-6) { status = 2; break; }
+            ep_old = ep_mid; ep_mid = ep;
+        }
+        if (!(ed < 1e12)) { status = 3; break; }
         for (;;) {
             kkt_errors(C, W, mu, &ed, &ep, &ecm, &sd, &sc);
             double Emu = fmax(fmax(ed / sd, ep), ecm / sc);
@@ -993,7 +1004,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
  * exported API (ctypes)
  * ---------------------------------------------------------------------------------------- */
 void bmpc_oracle_default_opts(bmpc_oracle_opts *o) {
-    o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0; o->mu_warm = 1e-4;
+    o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0; o->mu_warm = 1e-4; o->stall_window = 40;
 }
 
 static void write_outputs(const Cfg *C, const Par *P, Work *W, double *x, double *g, double *lam_g, double *lam_x) {

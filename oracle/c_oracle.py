@@ -17,7 +17,7 @@ NZ, NG, NE, NI = 44, 43, 36, 57
 class Opts(ctypes.Structure):
     _fields_ = [("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("mu_init", ctypes.c_double),
                 ("mu_min_fac", ctypes.c_double), ("slack_push", ctypes.c_double),
-                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double)]
+                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double), ("stall_window", ctypes.c_int)]
 
 
 def build(force=False):

@@ -14,12 +14,12 @@ _SRC = [os.path.join(_HERE, "bmpc_emu.cpp"), os.path.join(_HERE, "..", "..", "bo
 class Opts(ctypes.Structure):
     _fields_ = [("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("mu_init", ctypes.c_double),
                 ("mu_min_fac", ctypes.c_double), ("slack_push", ctypes.c_double),
-                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double)]
+                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double), ("stall_window", ctypes.c_int)]
 
 
 def build(force=False):
     if force or not os.path.exists(_LIB) or any(os.path.getmtime(_LIB) < os.path.getmtime(s) for s in _SRC):
-        subprocess.check_call(["g++", "-O2", "-fopenmp", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas",
+        subprocess.check_call(["g++", "-O2", "-fopenmp", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-Wno-enum-compare",
                                "-o", _LIB, _SRC[0]])
     return _LIB
 
@@ -36,7 +36,7 @@ def lib():
 
 
 def default_opts(**kw):
-    o = Opts(1e-8, 500, 0.1, 0.1, 1e-2, 1, 0, 1e-4)
+    o = Opts(1e-8, 500, 0.1, 0.1, 1e-2, 1, 0, 1e-4, 40)
     for k, v in kw.items():
         setattr(o, k, v)
     return o
