@@ -134,10 +134,12 @@ class StreamBatch:
 
     def tick(self, max_iter=0, warm_dual=False, simulate=True, stream=None, accept_capped=False):
         """pack -> solve -> post as three launches (see tick_graph for the captured form)."""
+        if max_iter and not warm_dual:
+            raise ValueError("an iteration cap needs the dual state (warm_dual=True): the multipliers must be shifted with the plan")
         self.pack(warm_dual, stream)
         out = dict(x=self.x, g=self.g, iters=self.iters, status=self.status, kkt=self.kkt)
         self.solver.solve_batch(self.p, self.x0, out=out, want=("g", "iters", "status", "kkt"), stream=stream,
-                                state=self.dual if (warm_dual or max_iter) else None, max_iter=max_iter)
+                                state=self.dual if warm_dual else None, max_iter=max_iter)
         self.post(simulate, stream, accept_capped)
 
     def tick_graph(self, max_iter=0, warm_dual=False, simulate=True, stream=None, accept_capped=False):

@@ -93,3 +93,105 @@ def test_device_pack_and_post_equal_cpu_build_of_the_same_text():
         np.testing.assert_allclose(sb.state.cpu().numpy()[0], ss_c, atol=1e-11, rtol=1e-11)
         np.testing.assert_allclose(sb.robot.cpu().numpy()[0], rb_c, atol=1e-12)
     sb.close(); solver.close()
+
+
+def test_fallback_replay_on_the_gpu_matches_host_mirror():
+    """SURVEY 8 row f3 on the device: solver failures forced on the GPU (a handle capped at 2 iterations ends with status 1 and a
+    grossly infeasible iterate) at ticks 3, 4 and 9 -- the device-side state machine (error count, replay of the previous plan from
+    index error_count, shortened trajectories; BoundMPC.py:465-506,514-524) against the host mirror BoundMPC.step() fed by the same
+    GPU solves through the nlpsol shim."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, NlpSolverShim, stream as bstream, workload
+    from boundmpc_amd.bound_mpc import integrate_joint
+    from boundmpc_amd.robot_model import RobotModel
+    fails = (3, 4, 9)
+    good, bad = BatchedOCPSolver(10, 4, 0.1), BatchedOCPSolver(10, 4, 0.1, max_iter=2)
+
+    class Switch:          # nlpsol-shaped: the capped handle at the failing ticks
+        def __init__(self):
+            self.calls, self.s = 0, [NlpSolverShim(good), NlpSolverShim(bad)]
+
+        def generate_dependencies(self, *a, **k):
+            pass
+
+        def __call__(self, **kw):
+            self.cur = self.s[1 if self.calls in fails else 0]
+            self.calls += 1
+            return self.cur(**kw)
+
+        def stats(self):
+            return self.cur.stats()
+    q0 = workload.random_q0(3, seed=5)[2]
+    mpc, p0fk = workload.make_mpc(q0, solver=Switch())
+    ref, _ = workload.make_mpc(q0)
+    sb = bstream.StreamBatch(good, [ref])
+    rm = RobotModel()
+    q, dq, ddq, jerk, v = q0.copy(), np.zeros(7), np.zeros(7), np.zeros(7), np.zeros(6)
+    x_phi_d = np.array([mpc.phi_max[0], 0, 0])
+    sb.set_robot(bstream.robot_record(q, dq, ddq, p0fk, v, x_phi_d, jerk)[None])
+    out = dict(x=sb.x, g=sb.g, iters=sb.iters, status=sb.status, kkt=sb.kkt)
+    seen = []
+    for t in range(14):
+        p_lie = rm.forward_kinematics(q, dq)[0]
+        traj, _, _, _, _ = mpc.step(q, dq, ddq, p_lie, v, x_phi_d, jerk)
+        sb.pack()
+        (bad if t in fails else good).solve_batch(sb.p, sb.x0, out=out, want=("g", "iters", "status", "kkt"))
+        sb.post(simulate=True)
+        torch.cuda.synchronize()
+        st = sb.state.cpu().numpy()[0]
+        td, fl = bstream.unpack_traj(sb.traj.cpu().numpy()[0], 10)
+        assert int(sb.status.cpu().numpy()[0]) == (1 if t in fails else 0)
+        assert int(st[bstream.SS["ERRCNT"]]) == mpc.error_count
+        assert fl["using_previous"] == (t in fails) and fl["n_valid"] == 10 - mpc.error_count
+        seen.append(mpc.error_count)
+        for k in ("q", "dq", "ddq", "dddq", "p", "v", "a", "phi", "dphi", "ddphi", "dddphi"):
+            np.testing.assert_allclose(td[k], traj[k], atol=2e-5 if k in ("dddq", "dddphi") else 2e-6, err_msg=f"tick {t} {k}")
+        jm = np.concatenate((jerk[:, None], traj["dddq"][:, :2]), axis=1)
+        q, dq, ddq, p_lie, v = integrate_joint(rm, jm, q, dq, ddq, mpc.dt)[:5]
+        jerk = traj["dddq"][:, 0].copy()
+        np.testing.assert_allclose(sb.robot.cpu().numpy()[0, :7], q, atol=1e-7)
+    assert seen[3] == 1 and seen[4] == 2 and seen[5] == 0 and seen[9] == 1
+    sb.close(); good.close(); bad.close()
+
+
+def test_256_streams_real_time_mode_tracks_the_converged_loops():
+    """BASELINE.json configs[4] at full width: 256 closed-loop streams (generator of configs[1], seed 3), the whole tick {pack, queue
+    reset, solve, post, plant} replayed from ONE hipGraph.  The real-time mode (KKT tolerance 1e-3, at most 7 iterations per tick,
+    cold duals, a capped iterate applied as it is) against the loops solved to 1e-8 every tick: joint deviation per stream."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, stream as bstream, workload
+    B, T = 256, 40
+    q0s = workload.random_q0(B, seed=3)
+    mpcs, recs = [], []
+    for q0 in q0s:
+        m, p0fk = workload.make_mpc(q0)
+        mpcs.append(m)
+        recs.append(bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([m.phi_max[0], 0.0, 0.0]), np.zeros(7)))
+    recs = np.stack(recs)
+    runs = {}
+    for name, slv, capped in (("converged", BatchedOCPSolver(10, 4, 0.1, max_iter=100), False),
+                              ("rt", BatchedOCPSolver(10, 4, 0.1, tol=1e-3, max_iter=7), True)):
+        sb = bstream.StreamBatch(slv, mpcs)
+        sb.set_robot(recs)
+        Q, ms = [], []
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for t in range(T):
+            if t == 0:      # cold start from rest: to tolerance in both runs
+                sb.tick(max_iter=100, warm_dual=True, simulate=True); sb.dual.zero_()
+            else:
+                e0.record(); sb.tick_graph(simulate=True, accept_capped=capped); e1.record(); e1.synchronize()
+                ms.append(e0.elapsed_time(e1))
+            Q.append(sb.robot[:, :7].clone())
+        runs[name] = (torch.stack(Q).cpu().numpy(), np.array(ms), float((sb.traj[:, -2] > 0.5).double().mean().item()),
+                      sb.state[:, bstream.SS["PHI"]].cpu().numpy())
+        sb.close(); slv.close()
+    Qc, msc, okc, phic = runs["converged"]
+    Qr, msr, okr, phir = runs["rt"]
+    per_stream = np.sqrt(np.mean((Qr - Qc) ** 2, axis=(0, 2)))
+    print(f"\\n256 streams: converged tick p50 {np.percentile(msc, 50):.2f} / p99 {np.percentile(msc, 99):.2f} ms; real-time mode p50 "
+          f"{np.percentile(msr, 50):.2f} / p99 {np.percentile(msr, 99):.2f} ms; per-stream RMS deviation median {np.median(per_stream):.2e}, "
+          f"p90 {np.percentile(per_stream, 90):.2e}, max {per_stream.max():.2e} rad")
+    assert okc == 1.0 and okr == 1.0
+    assert np.median(per_stream) <= 1e-2 and np.percentile(per_stream, 90) <= 5e-2
+    assert np.abs(phir - phic).max() < 0.05                    # same progress along the path
+    assert np.percentile(msr, 99) < np.percentile(msc, 50)      # the capped tick is bounded: its p99 is below the converged p50
