@@ -10,8 +10,9 @@ Same names, argument meaning and error behaviour, so `bound_mpc_node.py:304-305`
 `mpc.step(q, dq, ddq, p_lie, v, x_phi_d, jerk)` unchanged.  The one difference is what sits behind
 `self.solver`: the HIP batched solver (boundmpc_amd.solver.NlpSolverShim) instead of
 CasADi/Ipopt.  `solve()` / `pack()` are additions (the reference has no `solve`).
-The logging half of `compute_return_data` (BoundMPC.py:614-752, ref_data/err_data for RViz) is not
-rebuilt: `step` returns None for both, which the node treats as "logging off" (bound_mpc_node.py:306-307)."""
+The logging half of `compute_return_data` (BoundMPC.py:614-752: ref_data / err_data, consumed by the node's RViz / Logger
+branch bound_mpc_node.py:306-360) is produced when `params.real_time` is false, as in the reference; the values are pinned by
+fixture G10 (the reference's own numeric reference_function / error_function run on recorded ticks)."""
 import copy
 import time
 
@@ -262,7 +263,8 @@ class BoundMPC:
             jac_r.T.ravel(), jac_l.T.ravel(), p_ref.ravel(), dp_ref.ravel(), dp_normed_ref.ravel(),
             bp1.ravel(), bp2.ravel(), br1.ravel(), br2.ravel(), a4.T.ravel(), a3.T.ravel(), a2.T.ravel(), a1.T.ravel(),
             a0.T.ravel(), weights_current, phi_max, self.dphi_max, v_1.ravel(), v_2.ravel(), v_3.ravel(), qd)).astype(float)
-        aux = dict(p_ref=p_ref, dp_ref=dp_ref, phi_switch=phi_switch)
+        aux = dict(p_ref=p_ref, dp_ref=dp_ref, phi_switch=phi_switch, dp_normed_ref=dp_normed_ref, bp1=bp1, bp2=bp2, br1=br1, br2=br2,
+                   v1=v_1, v2=v_2, v3=v_3, jac_l=jac_l, jac_r=jac_r, a=(a4, a3, a2, a1, a0))
         return w0.tolist(), params, aux
 
     def solve(self, q0, dq0, ddq0, p0, v0, x_phi_d, jerk_current):
@@ -355,6 +357,7 @@ class BoundMPC:
         self._prev_w = w          # prev_acc / prev_jerk (:560-566) are only consumed after update(): computed lazily
         self.prev_acc = self.prev_jerk = None
         phi_opt = w[41, ec:]
+        iw_ref_before = np.copy(self.iw_ref)
         if phi_opt[0] > phi_switch[1]:                                     # :594-604
             self.pr_ref = R.from_matrix(self.ref_path.r[self.ref_path.sector + 1]).as_rotvec()
             self.pr_ref = integrate_rotation_reference(self.pr_ref, dp_ref[3:, 1], phi_switch[1], phi_opt[0])
@@ -368,7 +371,96 @@ class BoundMPC:
         self.dddphi_current = np.array([jerk_phi[0]])
         traj_data = {'p': w[29:35, ec:], 'v': vel, 'a': acc, 'q': w[8:15, ec:], 'dq': w[15:22, ec:], 'ddq': w[22:29, ec:],
                      'dddq': jerk, 'phi': phi_opt, 'dphi': w[42, ec:], 'ddphi': w[43, ec:], 'dddphi': jerk_phi}
-        return traj_data, None, None
+        if not self.log:
+            return traj_data, None, None
+        ref_data, err_data = self._logging_data(q0, dq0, p0, iw_ref_before, w[29:35, ec:], vel, phi_opt, w[42, ec:], aux)
+        return traj_data, ref_data, err_data
+
+    def _segment_rows(self, phi, phi_switch):
+        """Row picked by the reference's nested if_else selections at path parameter phi (bound_mpc_functions.py:13-40):
+        -> (row of S-row arrays, row of the two-row window used for bp1/bp2, row of the (S+1)-row tube coefficients)."""
+        S = self.nr_segs
+        seg = S - 1
+        for i in reversed(range(S - 1)):
+            if phi < phi_switch[i + 1]:
+                seg = i
+        return seg, min(seg, S - 2), seg          # tube rows: row S (phi beyond the window) is defined as row S-1 (DESIGN.md 2)
+
+    def _logging_data(self, q0, dq0, p0, iw_ref_before, traj, vel, phi_opt, dphi_opt, aux):
+        """ref_data / err_data of BoundMPC.py:614-752: per stage of the (re-integrated) plan the path reference with its tube
+        bounds and the position / orientation errors in the path frame, then the rotation references and orientation errors
+        recomputed from the integrated rotation reference (:712-752).  Lists of flat arrays, one entry per stage, same keys."""
+        n, dt, S = traj.shape[1], self.dt, self.nr_segs
+        p_ref, dp_ref, sw = aux["p_ref"], aux["dp_ref"], aux["phi_switch"]
+        jl, jr = aux["jac_l"], aux["jac_r"]
+        a4, a3, a2, a1, a0 = aux["a"]
+        # integrated angular velocity of the plan (trapezoid from the measured state, :574-586), sign flip after failures (:587-589)
+        iw = np.empty((6, n))
+        om_prev = (self.robot_model.jacobian_fk(np.asarray(q0, dtype=float)) @ np.asarray(dq0, dtype=float))[3:]
+        for i in range(n):
+            base = iw[3:, i - 1] if i > 0 else np.asarray(p0, dtype=float)[3:]
+            iw[3:, i] = base + 0.5 * dt * (om_prev + vel[3:, i])
+            om_prev = vel[3:, i].copy()
+        iw[:3] = traj[:3]
+        if self.error_count > 0 and np.linalg.norm(p0[3:] - iw[3:, 0]) > 3.1:
+            iw[3:] *= -1
+        ref_data = {k: [] for k in ("p", "dp", "ddp", "dp_normed", "r_par_bound", "bound_lower", "bound_upper", "e_p_off", "e_r_off",
+                                    "bp1", "bp2", "br1", "br2", "v1", "v2", "v3")}
+        err_data = {k: [] for k in ("e_p", "de_p", "e_p_par", "e_p_orth", "de_p_par", "de_p_orth", "e_r", "de_r", "e_r_par", "e_r_orth1",
+                                    "e_r_orth2")}
+        dtau0 = self.dtau_init[:, 0]
+        for i in range(n):
+            phi, dphi = phi_opt[i], dphi_opt[i]
+            seg, segb, sega = self._segment_rows(phi, sw)
+            x = phi - sw[seg]
+            dp_d = dp_ref[:, seg].copy()
+            p_d = dp_d * x + p_ref[:, seg]
+            b = (((a4[sega] * x + a3[sega]) * x + a2[sega]) * x + a1[sega]) * x + a0[sega]         # 9 tube channels
+            upper, lower = np.array([b[0], b[1], b[4], b[5]]), np.array([b[2], b[3], b[6], b[7]])
+            dn = aux["dp_normed_ref"][:, seg].copy()
+            br1, br2 = aux["br1"][:, seg].copy(), aux["br2"][:, seg].copy()
+            v1, v2, v3 = aux["v1"][:, seg].copy(), aux["v2"][:, seg].copy(), aux["v3"][:, seg].copy()
+            for k, val in (("p", p_d), ("dp", dp_d), ("ddp", 0 * dp_d), ("dp_normed", dn), ("r_par_bound", np.array([b[8]])),
+                           ("bound_lower", lower), ("bound_upper", upper), ("e_p_off", 0.5 * (upper[:2] + lower[:2])),
+                           ("e_r_off", 0.5 * (upper[2:] + lower[2:])), ("bp1", aux["bp1"][:, segb].copy()), ("bp2", aux["bp2"][:, segb].copy()),
+                           ("br1", br1), ("br2", br2), ("v1", v1), ("v2", v2), ("v3", v3)):
+                ref_data[k].append(val)
+            d = dp_d[:3]
+            e = iw[:3, i] - p_d[:3]
+            e_par = (d @ e) * d
+            de = vel[:3, i] - d * dphi
+            de_par = (d @ de) * d
+            e_r = dtau0 + jl @ (iw[3:, i] - p0[3:]) - jr @ (p_d[3:] - iw_ref_before)
+            de_r = jl @ vel[3:, i] - jr @ (dp_d[3:] * dphi)
+            dl = e_r - dtau0
+            for k, val in (("e_p", e), ("de_p", de), ("e_p_par", e_par), ("e_p_orth", e - e_par), ("de_p_par", de_par),
+                           ("de_p_orth", de - de_par), ("e_r", e_r.copy()), ("de_r", de_r),
+                           ("e_r_par", self.dtau_init_par[:, seg] + (dl @ v2) * dn),
+                           ("e_r_orth1", self.dtau_init_orth1[:, seg] + (dl @ v1) * br1),
+                           ("e_r_orth2", self.dtau_init_orth2[:, seg] + (dl @ v3) * br2)):
+                err_data[k].append(val)
+        # rotation reference integrated along the plan and the orientation error against it (:712-752)
+        rot_err = lambda rv, ref: R.from_matrix(R.from_rotvec(rv).as_matrix() @ R.from_rotvec(ref).as_matrix().T).as_rotvec()
+        ref_data["p"][0][3:] = self.pr_ref
+        pr = np.copy(self.pr_ref)
+        sec = self.ref_path.sector
+        for i in range(n - 1):
+            ref_data["p"][i][3:] = pr
+            err_data["e_r"][i] = rot_err(traj[3:, i], pr)
+            phi, nxt = phi_opt[i], phi_opt[i + 1]
+            if nxt > sw[1] and phi < sw[1]:
+                pr = integrate_rotation_reference(R.from_matrix(self.ref_path.r[sec + 1]).as_rotvec(), dp_ref[3:, 1], sw[1], nxt)
+            elif nxt > sw[2] and phi < sw[2]:
+                pr = integrate_rotation_reference(R.from_matrix(self.ref_path.r[sec + 2]).as_rotvec(), dp_ref[3:, 2], sw[2], nxt)
+            elif nxt > sw[2]:
+                pr = integrate_rotation_reference(pr, dp_ref[3:, 2], phi, nxt)
+            elif nxt > sw[1]:
+                pr = integrate_rotation_reference(pr, dp_ref[3:, 1], phi, nxt)
+            else:
+                pr = integrate_rotation_reference(pr, dp_ref[3:, 0], phi, nxt)
+        ref_data["p"][-1][3:] = pr
+        err_data["e_r"][-1] = rot_err(traj[3:, -1], pr)
+        return ref_data, err_data
 
 
 def structural_bounds(N):

@@ -85,6 +85,10 @@ class SX:
     def __repr__(self):
         return "SX(%r)" % (self.a,)
 
+    def __array__(self, dtype=None, copy=None):      # np.array(x), and assignment of a result into a numpy slice (numeric branches)
+        a = np.real(self.a) if self.a.dtype.kind == "c" else self.a
+        return a.astype(dtype) if dtype is not None else np.array(a)
+
     # ---- indexing ------------------------------------------------------------------------
     @staticmethod
     def _as_slice(k, n):
@@ -191,12 +195,15 @@ class SX:
     __hash__ = None
 
 
-class MX:      # isinstance() placeholders only
+class MX:      # isinstance() placeholder only
     pass
 
 
-class DM:
-    pass
+class DM(SX):
+    """What CasADi hands back when its functions are called with plain numbers (`ca.if_else(numpy_bool, numpy_row, numpy_row)` in the
+    numeric branches of reference_function / error_function, BoundMPC.py:614-752): a dense numeric matrix with the same indexing
+    rules as SX; a 1-D numpy array becomes a COLUMN.  `np.array(dm)` gives the 2-D array."""
+
 
 
 def _lift(f):
@@ -247,6 +254,8 @@ def if_else(c, a, b):
     if isinstance(c, SX):
         assert c.a.size == 1, "numeric SX: if_else needs a scalar condition"
         return SX(a) if np.real(c.a.item()) != 0 else SX(b)
+    if isinstance(a, np.ndarray) or isinstance(b, np.ndarray) or isinstance(a, SX) or isinstance(b, SX):
+        return DM(a) if bool(np.all(c)) else DM(b)      # numeric call: CasADi converts the branches to DM
     return a if c else b
 
 

@@ -189,3 +189,57 @@ def test_workload_generator_reproducible_and_exp1():
     d6 = np.load(os.path.join(G, "g6_pack_exp1_tick0.npz"))
     p, x0 = workload.pack_cold(workload.Q0_EXP1)
     np.testing.assert_allclose(p[d6["p_defined_mask"]], d6["p_f64"][d6["p_defined_mask"]], atol=1e-13)
+
+
+class _StubOk:
+    """nlpsol-shaped stub answering with a given x and success flag (a failure carries a grossly infeasible g)."""
+
+    def __init__(self):
+        self.ans, self.ok = None, True
+
+    def generate_dependencies(self, *a, **k):
+        pass
+
+    def __call__(self, x0=None, lbx=None, ubx=None, lbg=None, ubg=None, p=None):
+        x = np.asarray(self.ans, dtype=float)
+        g = np.zeros((len(lbg), 1)) if self.ok else np.ones((len(lbg), 1))
+        return {"x": x.reshape(-1, 1), "g": g, "f": 0.0, "lam_x": 0 * x, "lam_g": np.zeros(len(lbg))}
+
+    def stats(self):
+        return {"iter_count": 1, "success": self.ok, "return_status": "stub"}
+
+
+@pytest.mark.parametrize("which", [1, 2])
+def test_logging_dictionaries_g10(which):
+    """ref_data / err_data (BoundMPC.py:614-752) of the host mirror against what the reference's own compute_return_data produced
+    on the same ticks (fixture G10, tests/golden/make_g10.py): start of the path, ticks around every segment switch, the tick
+    after the integrated-omega unwrap, the end of the path, and one tick with a forced solver failure (shortened plan)."""
+    d6 = np.load(os.path.join(G, f"g6_pack_exp{which}_tick0.npz"))
+    d7 = np.load(os.path.join(G, f"g7_closedloop_exp{which}.npz"))
+    d10 = np.load(os.path.join(G, "g10_logging.npz"))
+    ticks, fail = [int(t) for t in d10[f"exp{which}_ticks"]], int(d10[f"exp{which}_fail_tick"])
+    keys_ref = ("p", "dp", "ddp", "dp_normed", "r_par_bound", "bound_lower", "bound_upper", "e_p_off", "e_r_off", "bp1", "bp2", "br1", "br2",
+                "v1", "v2", "v3")
+    keys_err = ("e_p", "de_p", "e_p_par", "e_p_orth", "de_p_par", "de_p_orth", "e_r", "de_r", "e_r_par", "e_r_orth1", "e_r_orth2")
+    checked = 0
+    for with_failure in (True, False):
+        stub = _StubOk()
+        mpc = BoundMPC(*_path_from(d6), p0=d6["p0fk"].copy(), params=workload.Params(weights=d6["weights_f64"], real_time=False), solver=stub)
+        assert mpc.log
+        x_phi_d = np.array([mpc.phi_max[0], 0, 0])
+        for t in range(len(d7["x"])):
+            if with_failure and t > fail:
+                break
+            stub.ans, stub.ok = d7["x"][t], not (with_failure and t == fail)
+            traj, ref, err, _, _ = mpc.step(d7["q"][t], d7["dq"][t], d7["ddq"][t], d7["p_lie"][t], d7["v"][t], x_phi_d, d7["jerk"][t])
+            if t in ticks and (t <= fail) == with_failure:
+                pre = f"exp{which}_t{t}_"
+                assert mpc.error_count == int(d10[pre + "error_count"]) == (1 if t == fail else 0)
+                n = d10[pre + "ref_p"].shape[0]
+                assert n == 10 - mpc.error_count == len(ref["p"]) == len(err["e_p"])
+                for k in keys_ref:
+                    np.testing.assert_allclose(np.array(ref[k]).reshape(n, -1), d10[pre + "ref_" + k], atol=1e-11, err_msg=f"tick {t} ref {k}")
+                for k in keys_err:
+                    np.testing.assert_allclose(np.array(err[k]).reshape(n, -1), d10[pre + "err_" + k], atol=1e-10, err_msg=f"tick {t} err {k}")
+                checked += 1
+    assert checked == len(ticks)
