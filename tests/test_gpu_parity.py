@@ -441,3 +441,15 @@ def test_bench_launches_its_own_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 256 and rec["value"] > 0
     assert rec["config"]["solved_fraction"] == 1.0
+
+
+def test_closed_loop_ticks_against_independent_scipy_solutions(solver):
+    """HIP solver against the independent SLSQP solutions of 15 warm-started closed-loop ticks (fixture g8_scipy_ticks: segment
+    switches, omega unwrap, active +-0.01 tube, phi_max active; see tests/test_oracle_golden.py)."""
+    d = np.load(os.path.join(G, "g8_scipy_ticks.npz"))
+    out = solver.solve_host(d["p"], d["x0"])
+    assert (out["status"] == 0).all()
+    dq = (out["x"] - d["x"]).reshape(-1, 10, 44)[:, :, 8:15]
+    rms = np.sqrt(np.mean(dq ** 2, axis=(1, 2)))
+    assert rms.max() < 5e-6 and np.median(rms) < 2e-7, rms
+    assert np.abs(out["f"] - d["f"]).max() < 1e-7

@@ -337,3 +337,18 @@ def test_g9_kkt_certificate_with_the_references_own_derivatives():
     g = G9["n10_g"][i].reshape(10, 43)
     assert np.abs(g[:, :36]).max() < 1e-8 and g[:, 36:].max() < 1e-8
     assert (lam_g.reshape(10, 43)[:, 36:] >= 0).all()
+
+
+def test_scipy_independent_solutions_of_closed_loop_ticks():
+    """Fixture g8_scipy_ticks (oracle/solve_scipy.py --ticks): scipy SLSQP on the numpy restatement, reference-form constraints, from
+    the x0 the reference's step() handed to the solver, for 15 warm-started closed-loop ticks -- segment switch inside the horizon
+    (exp1 45/46, exp2 13/29/40), the integrated-omega unwrap ticks (exp1 49, exp2 47), experiment 2's +-0.01 tube active (10, 12),
+    phi_max active (exp1 143).  The solver lands on the same minimisers (SLSQP stops at its own ~1e-6 accuracy on some)."""
+    d = np.load(os.path.join(G, "g8_scipy_ticks.npz"))
+    assert len(d["tick"]) == 15
+    out = c_oracle.solve(d["p"], d["x0"], 10, 4, 0.1, c_oracle.default_opts(tol=1e-8))
+    assert (out["status"] == 0).all()
+    dq = (out["x"] - d["x"]).reshape(-1, 10, 44)[:, :, 8:15]
+    rms = np.sqrt(np.mean(dq ** 2, axis=(1, 2)))
+    assert rms.max() < 5e-6 and np.median(rms) < 2e-7, rms       # north-star tolerance: 1e-4 rad RMS
+    assert np.abs(out["f"] - d["f"]).max() < 1e-7
