@@ -243,3 +243,40 @@ def test_logging_dictionaries_g10(which):
                     np.testing.assert_allclose(np.array(err[k]).reshape(n, -1), d10[pre + "err_" + k], atol=1e-10, err_msg=f"tick {t} err {k}")
                 checked += 1
     assert checked == len(ticks)
+
+
+def test_update_replanning_g11():
+    """Re-planning: BoundMPC.update() (BoundMPC.py:163-217) in the middle of a loop and the re-projected warm start of the ticks
+    after it (:335-369), against the reference's own (fixture G11, tests/golden/make_g11.py)."""
+    d6 = np.load(os.path.join(G, "g6_pack_exp1_tick0.npz"))
+    d7 = np.load(os.path.join(G, "g7_closedloop_exp1.npz"))
+    d = np.load(os.path.join(G, "g11_update.npz"))
+    T = int(d["t_update"])
+    stub = _Stub()
+    prm = workload.Params(weights=d["weights"], build=False)
+    mpc = BoundMPC(*_path_from(d6), p0=d6["p0fk"].copy(), params=prm, solver=stub)
+    x_phi_d = np.array([mpc.phi_max[0], 0, 0])
+    for t in range(T):
+        stub.ans = d7["x"][t]
+        mpc.step(d7["q"][t], d7["dq"][t], d7["ddq"][t], d7["p_lie"][t], d7["v"][t], x_phi_d, d7["jerk"][t])
+    L = lambda k: [np.array(v) for v in d["upd_" + k]]
+    mpc.update(L("p_via"), L("r_via"), [L("p_lower"), L("p_upper")], [L("r_lower"), L("r_upper")], L("bp1"), L("br1"), list(d["upd_s"]),
+               list(d["upd_e_p_min"]), list(d["upd_e_r_min"]), list(d["upd_e_p_max"]), list(d["upd_e_r_max"]),
+               d["upd_p"].copy(), d["upd_v"].copy(), d["upd_a"].copy(), d["upd_jerk"].copy(), p0=d["upd_p"].copy(), params=prm)
+    np.testing.assert_allclose([mpc.phi_current[0], mpc.dphi_current[0], mpc.ddphi_current[0], mpc.dddphi_current[0]], d["after_update_phi"], atol=1e-13)
+    np.testing.assert_allclose(mpc.pr_ref, d["after_update_pr_ref"], atol=1e-12)
+    np.testing.assert_allclose(mpc.iw_ref, d["after_update_iw_ref"], atol=1e-12)
+    assert abs(mpc.phi_max[0] - float(d["after_update_phi_max"])) < 1e-13
+    x_phi_d = np.array([mpc.phi_max[0], 0, 0])
+    mask = d6["p_defined_mask"]
+    for i in range(len(d["x"])):
+        stub.ans = d["x"][i]
+        traj, _, _, _, _ = mpc.step(d["q"][i], d["dq"][i], d["ddq"][i], d["p_lie"][i], d["v"][i], x_phi_d, d["jerk"][i])
+        x0, p = stub.last
+        np.testing.assert_allclose(p[mask], d["p"][i][mask], atol=5e-12, err_msg=f"p, tick {i} after update")
+        np.testing.assert_allclose(x0, d["x0"][i], atol=1e-12, err_msg=f"x0, tick {i} after update")
+        np.testing.assert_allclose(traj["q"], d["traj_q"][i], atol=1e-12)
+        np.testing.assert_allclose(traj["phi"], d["traj_phi"][i], atol=1e-12)
+        assert abs(mpc.phi_current[0] - d["phi_current"][i]) < 1e-13 and mpc.ref_path.sector == d["sector"][i]
+        np.testing.assert_allclose(mpc.pr_ref, d["pr_ref"][i], atol=1e-12)
+        np.testing.assert_allclose(mpc.iw_ref, d["iw_ref"][i], atol=1e-12)
