@@ -26,6 +26,12 @@ class BatchedOCPSolver:
         self.N, self.S, self.dt = int(N), int(S), float(dt)
         self.n_w, self.n_g, self.n_p = N * NZ, N * NG, 141 + 91 * S
         self.state_len = int(self._lib.bmpc_state_len(self._h))
+        # the handle's workspace, work queue and occupancy belong to the device that was current at bmpc_create
+        try:
+            import torch
+            self.device_index = torch.cuda.current_device() if torch.cuda.is_available() else None
+        except Exception:
+            self.device_index = None
 
     def close(self):
         if getattr(self, "_h", None):
@@ -83,6 +89,11 @@ class BatchedOCPSolver:
         B = p.shape[0]
         if p.shape != (B, self.n_p) or x0.shape != (B, self.n_w):
             raise ValueError(f"shape mismatch: p {tuple(p.shape)} x0 {tuple(x0.shape)}")
+        if not (p.is_contiguous() and x0.is_contiguous()):
+            raise ValueError("p and x0 must be contiguous (the kernel reads them asynchronously on the launch stream; a temporary copy "
+                             "made here could be recycled by the allocator before the kernel has run)")
+        if self.device_index is not None and (p.device.index != self.device_index or x0.device.index != self.device_index):
+            raise ValueError(f"p / x0 live on cuda:{p.device.index}, the solver handle was created on cuda:{self.device_index}")
         if state is not None and not (state.is_cuda and state.dtype == torch.float64 and state.is_contiguous()
                                       and state.shape == (B, self.state_len)):
             raise ValueError(f"state must be a contiguous float64 GPU tensor of shape ({B}, {self.state_len})")
@@ -95,7 +106,6 @@ class BatchedOCPSolver:
         from it and updates it in place; `max_iter` > 0 caps the Newton steps of this call (real-time iteration)."""
         import torch
         self._check_io(p, x0, state)
-        p, x0 = p.contiguous(), x0.contiguous()
         B = p.shape[0]
         o = out if out is not None else {}
         dev = p.device

@@ -2,12 +2,12 @@
 # Round-end measurement run on the GPU box: parity tests, smoke, the two bench
 # sizes, the rocprofv3 kernel-stats summary of the bench command, the in-kernel
 # phase profile.  Usage: bash tests/gpu_round.sh TAG
-set -e
+set -e -o pipefail
 TAG=${1:-r01_x}
 cd "${GRAFT_REPO_ROOT:-.}"
 R=$PWD
 mkdir -p gpurun_out
-timeout -k 10 500 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_$TAG.log 2>&1
+timeout -k 10 500 python -m pytest tests -m gpu -q > gpurun_out/pytest_gpu_$TAG.log 2>&1 || echo "pytest FAILED"
 tail -2 gpurun_out/pytest_gpu_$TAG.log
 timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke_$TAG.log 2>&1
 tail -1 gpurun_out/smoke_$TAG.log
