@@ -43,6 +43,7 @@ namespace bmpc {
 // dimensions and index maps
 // ----------------------------------------------------------------------------------------
 constexpr int NZ = 44, NG = 43, NE = 36, NS = 35, NU = 8, NW = 43, NI = 57, SMAX = 4, NPMAX = 141 + 91 * SMAX;
+#define GN_MU_GATE 0.05  // Gauss-Newton fallback of the inertia correction only while mu >= GN_MU_GATE (first barrier level)
 #define KAPPA_EPS 100.0   // barrier problem "solved" at KKT error <= KAPPA_EPS * mu (oracle/bmpc_oracle.c; Ipopt barrier_tol_factor)
 enum { ZJ = 0, ZJPHI = 7, ZQ = 8, ZDQ = 15, ZDDQ = 22, ZPOS = 29, ZIW = 32, ZV = 35, ZW = 38, ZPHI = 41, ZDPHI = 42, ZDDPHI = 43 };
 enum { GQ = 0, GDQ = 7, GDDQ = 14, GPOS = 21, GIW = 24, GV = 27, GW = 30, GPHI = 33, GDPHI = 34, GDDPHI = 35 };
@@ -1808,13 +1809,22 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         BMPC_PROF(W, 3);
         wave_prepare_rlv(W, sc);
         BMPC_PROF(W, 4);
-        double delta = 0.0; bool ok = false;
+        double delta = 0.0; bool ok = false, used_gn = false; const int ex_saved = W.o.exact_hessian;
         for (int tries = 0; tries < 40; tries++) {
             if (wave_backward_blk(W, po, sc, mu, delta, LRs)) { ok = true; break; }
+            // first barrier level only: one attempt with the Gauss-Newton Hessian before regularising (oracle/bmpc_oracle.c solve_one).
+            // The node records carry the exact-Hessian entries, so they are rebuilt with the flag off (same f, g, h); the flag stays
+            // off until the factorisation of this iteration has succeeded, the next evaluation restores the exact entries.
+            if (!used_gn && ex_saved && mu >= GN_MU_GATE) {
+                used_gn = true; W.o.exact_hessian = 0;
+                wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);
+                if (wave_backward_blk(W, po, sc, mu, 0.0, LRs)) { ok = true; break; }
+            }
             if (delta == 0.0) delta = delta_last > 0 ? BMPC_FMAX(1e-20, delta_last / 3.0) : 1e-4;
             else delta *= (delta_last > 0 ? 8.0 : 100.0);
             if (delta > 1e20) break;
         }
+        W.o.exact_hessian = ex_saved;
         if (!ok) { status = 3; break; }
         if (delta > 0) delta_last = delta;
         BMPC_PROF(W, 6);

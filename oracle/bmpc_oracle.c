@@ -54,6 +54,7 @@ enum { IJU = 0, IJL = 8, IQU = 16, IQL = 23, IDQU = 30, IDQL = 37, IPHI0 = 44, I
 static const double Q_LIM_DEG[7] = {165, 115, 165, 115, 165, 115, 170};
 static const double DQ_LIM_DEG[7] = {85, 85, 100, 75, 130, 135, 135};
 #define U_LIM 35.0
+#define GN_MU_GATE 0.05
 #define KAPPA_EPS 100.0 /* barrier problem "solved" when its KKT error <= KAPPA_EPS * mu (Ipopt barrier_tol_factor, default 10) */
 #define PI 3.14159265358979323846
 
@@ -929,9 +930,18 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
             nuh[i] = (mu + W->nu[i] * (W->hin[i] + W->t[i])) / W->t[i];
         }
         build_qp(C, P, W, sg, nuh);
-        double delta = 0.0; int ok = 0;
+        double delta = 0.0; int ok = 0, used_gn = 0;
         for (int tries = 0; tries < 40; tries++) {
             if (riccati(C, W, delta)) { ok = 1; break; }
+            /* far from the solution (first barrier level) an indefinite exact Hessian is mostly the kinematic curvature weighted with
+             * meaningless multipliers: try the Gauss-Newton Hessian (positive semidefinite by construction) once before regularising;
+             * the delta escalation below continues on it if that fails too.  Never taken once mu has dropped below GN_MU_GATE. */
+            if (!used_gn && C->o.exact_hessian && mu >= GN_MU_GATE) {
+                used_gn = 1;
+                Cfg Cgn = *C; Cgn.o.exact_hessian = 0;      /* C is shared between the OpenMP threads: never modified */
+                build_qp(&Cgn, P, W, sg, nuh);
+                if (riccati(C, W, 0.0)) { ok = 1; break; }
+            }
             if (delta == 0.0) delta = delta_last > 0 ? fmax(1e-20, delta_last / 3.0) : 1e-4;
             else delta *= (delta_last > 0 ? 8.0 : 100.0);
             if (delta > 1e20) break;
