@@ -1815,7 +1815,9 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
             // first barrier level only: one attempt with the Gauss-Newton Hessian before regularising (oracle/bmpc_oracle.c solve_one).
             // The node records carry the exact-Hessian entries, so they are rebuilt with the flag off (same f, g, h); the flag stays
             // off until the factorisation of this iteration has succeeded, the next evaluation restores the exact entries.
-            if (!used_gn && ex_saved && mu >= GN_MU_GATE) {
+            // Long horizons only (N > 11 <=> !ZLDS, a compile-time property of this instantiation): the short-horizon kernel never
+            // met the case on any test batch, and carrying the extra path there costs registers (scratch 44 -> 312 B/lane, +1.7 %).
+            if (!zlds && !used_gn && ex_saved && mu >= GN_MU_GATE) {
                 used_gn = true; W.o.exact_hessian = 0;
                 wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);
                 if (wave_backward_blk(W, po, sc, mu, 0.0, LRs)) { ok = true; break; }

@@ -15,16 +15,21 @@
  *
  * The reference hands this NLP to CasADi -> Ipopt -> MUMPS (third-party, pip `casadi`,
  * unpinned, absent from the image).  Ipopt cannot be run here and the
- * reference holds no solution vectors, so the SOLUTION is "parity unpinned" against Ipopt;
- * what is pinned: f and g against oracle/nlp.py (itself pinned on golden vectors from the
- * reference's numeric leaves), KKT residuals of every solution (computed here and
- * independently by complex-step in tests), and an independent scipy solve
- * (oracle/solve_scipy.py).
+ * reference holds no solution vectors, so the SOLUTION is "parity unpinned" against Ipopt.
+ * What is pinned: f, g, the bound vectors and the parameter order against the reference's own,
+ * unmodified setup_optimization_problem run with numbers in place of symbols (fixture G9,
+ * tests/golden/ref_nlp.py), exact derivatives of it by a complex step through the reference's
+ * code, the numeric leaves (G1-G5), packing / post-processing / logging / re-planning (G6, G7,
+ * G10, G11); solutions carry KKT certificates and agree with independent scipy SLSQP solves
+ * of tick 0 and of 15 warm-started closed-loop ticks (oracle/solve_scipy.py, fixtures g8_*).
  *
  * Solver: primal-dual interior point on the reference's multiple-shooting variables
  * (same cold start), exact Lagrangian Hessian, Newton system solved stage by stage with a
  * Riccati recursion on a 35-dimensional reduced node state (lifted variables pos/v and
- * the trapezoidal omega term eliminated node-locally), l1-merit backtracking line search.
+ * the trapezoidal omega term eliminated node-locally), monotone barrier, filter line search
+ * whose trials after a rejected first one re-project the lifted variables onto their defining
+ * equalities, Gauss-Newton fallback of the inertia correction on the first barrier level,
+ * stall detection (status 2).
  * The quadratic tube constraints  l^2 - w^2 <= 0  of the reference are handled in the
  * equivalent two-sided form  -w <= l <= w  (same feasible set, same minimisers); g and
  * lam_g are reported in the reference's squared form.
@@ -55,6 +60,7 @@ static const double Q_LIM_DEG[7] = {165, 115, 165, 115, 165, 115, 170};
 static const double DQ_LIM_DEG[7] = {85, 85, 100, 75, 130, 135, 135};
 #define U_LIM 35.0
 #define GN_MU_GATE 0.05
+#define GN_MIN_HORIZON 11 /* long horizons only (the kernel's N <= 11 instantiation does not carry the path) */
 #define KAPPA_EPS 100.0 /* barrier problem "solved" when its KKT error <= KAPPA_EPS * mu (Ipopt barrier_tol_factor, default 10) */
 #define PI 3.14159265358979323846
 
@@ -935,8 +941,9 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
             if (riccati(C, W, delta)) { ok = 1; break; }
             /* far from the solution (first barrier level) an indefinite exact Hessian is mostly the kinematic curvature weighted with
              * meaningless multipliers: try the Gauss-Newton Hessian (positive semidefinite by construction) once before regularising;
-             * the delta escalation below continues on it if that fails too.  Never taken once mu has dropped below GN_MU_GATE. */
-            if (!used_gn && C->o.exact_hessian && mu >= GN_MU_GATE) {
+             * the delta escalation below continues on it if that fails too.  Never taken once mu has dropped below GN_MU_GATE, and only for
+             * horizons N > GN_MIN_HORIZON (a cold start over a long horizon is what produces the case). */
+            if (N > GN_MIN_HORIZON && !used_gn && C->o.exact_hessian && mu >= GN_MU_GATE) {
                 used_gn = 1;
                 Cfg Cgn = *C; Cgn.o.exact_hessian = 0;      /* C is shared between the OpenMP threads: never modified */
                 build_qp(&Cgn, P, W, sg, nuh);
