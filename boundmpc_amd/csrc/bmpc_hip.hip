@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
 
 struct bmpc_handle {
     int N, S; double h; bmpc_options o;
-    int grid; long long scr_stride; double *scratch; int *counter; unsigned long long *prof;
+    int grid; long long scr_stride; double *scratch; int scr_waves; int graphs_alive; int *counter; unsigned long long *prof;
     int timing; hipEvent_t ev0, ev1; int have_ev;
     double *latency_us;
     double *stage_d; int *stage_i; int stage_cap;   // device staging of the host-buffer path
@@ -119,7 +119,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     bmpc_handle *h = new (std::nothrow) bmpc_handle();
     if (!h) return BMPC_ERR_ARG;
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->have_ev = 0; h->latency_us = nullptr;
-    h->scratch = nullptr; h->counter = nullptr; h->prof = nullptr; h->stage_d = nullptr; h->stage_i = nullptr; h->stage_cap = 0;
+    h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->prof = nullptr; h->stage_d = nullptr; h->stage_i = nullptr; h->stage_cap = 0;
     if (opts) h->o = *opts; else bmpc_default_options(&h->o);
     int dev = 0, per_cu = 0; hipDeviceProp_t prop;
     bool ok = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess;
@@ -129,8 +129,9 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
         if (per_cu < 1) per_cu = 1;
         h->grid = per_cu * prop.multiProcessorCount;
         h->scr_stride = bmpc::make_scr(N).size;
-        ok = hipMalloc(&h->scratch, sizeof(double) * (size_t)h->scr_stride * h->grid) == hipSuccess
-          && hipMalloc(&h->counter, sizeof(int)) == hipSuccess
+        // the per-wave workspace slabs (123 KB at N=10) are allocated on the first solve, for min(B, grid) waves, and grow on demand:
+        // a single-problem handle (the nlpsol shim of one BoundMPC object) holds one slab, not 1024
+        ok = hipMalloc(&h->counter, sizeof(int)) == hipSuccess
           && hipMalloc(&h->prof, 32 * sizeof(unsigned long long)) == hipSuccess
           && hipMemset(h->prof, 0, 32 * sizeof(unsigned long long)) == hipSuccess;
     }
@@ -173,6 +174,20 @@ extern "C" int bmpc_get_bounds(const bmpc_handle *h, double *lbx, double *ubx, d
     return BMPC_OK;
 }
 
+// workspace for `waves` resident waves; growing frees the old slabs, which no launch may still be using: the device is drained
+// first, and captured graphs (which carry the old address) forbid growth -- size the first solve / capture for the largest batch
+static int ensure_scratch(bmpc_handle *h, int waves) {
+    if (waves <= h->scr_waves) return BMPC_OK;
+    if (h->graphs_alive > 0 && h->scratch) {
+        fprintf(stderr, "boundmpc_hip: a larger batch needs a larger workspace, but %d captured graph(s) hold the current one\n", h->graphs_alive);
+        return BMPC_ERR_ARG;
+    }
+    if (h->scratch) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(h->scratch)); h->scratch = nullptr; h->scr_waves = 0; }
+    HIPCHK(hipMalloc(&h->scratch, sizeof(double) * (size_t)h->scr_stride * waves));
+    h->scr_waves = waves;
+    return BMPC_OK;
+}
+
 // fills the kernel arguments and enqueues {reset of the work-queue counter, solver kernel} on `st`
 static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g, double *lam_g,
                          double *lam_x, double *f, int *iters, int *status, double *kkt, hipStream_t st, bool timed) {
@@ -181,9 +196,10 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = lam_g; a.lam_x = lam_x; a.f = f; a.kkt = kkt; a.iters = iters; a.status = status;
     a.state = state; a.latency_us = h->latency_us;
+    const int grid = B < h->grid ? B : h->grid;
+    if (grid > h->scr_waves) return BMPC_ERR_ARG;      // callers reserve the workspace first (never inside a stream capture)
     a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter; a.prof = h->prof;
     HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), st));
-    const int grid = B < h->grid ? B : h->grid;
     if (timed) {
         if (!h->have_ev) { HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1)); h->have_ev = 1; }
         HIPCHK(hipEventRecord(h->ev0, st));
@@ -199,6 +215,7 @@ extern "C" int bmpc_solve_batch(bmpc_handle *h, int B, const double *p, const do
                                 double *f, int *iters, int *status, double *kkt, void *hip_stream) {
     if (!h || B < 0 || (B > 0 && (!p || !x0 || !x))) return BMPC_ERR_ARG;
     if (B == 0) return BMPC_OK;
+    { const int rc_ = ensure_scratch(h, B < h->grid ? B : h->grid); if (rc_ != BMPC_OK) return rc_; }
     return enqueue_solve(h, B, p, x0, nullptr, 0, x, g, lam_g, lam_x, f, iters, status, kkt, (hipStream_t)hip_stream, h->timing != 0);
 }
 
@@ -208,6 +225,7 @@ extern "C" int bmpc_solve_batch_warm(bmpc_handle *h, int B, const double *p, con
                                      double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, void *hip_stream) {
     if (!h || B < 0 || max_iter < 0 || (B > 0 && (!p || !x0 || !x || !state))) return BMPC_ERR_ARG;
     if (B == 0) return BMPC_OK;
+    { const int rc_ = ensure_scratch(h, B < h->grid ? B : h->grid); if (rc_ != BMPC_OK) return rc_; }
     return enqueue_solve(h, B, p, x0, state, max_iter, x, g, lam_g, lam_x, f, iters, status, kkt, (hipStream_t)hip_stream, h->timing != 0);
 }
 
@@ -217,6 +235,7 @@ struct bmpc_graph { bmpc_handle *h; hipGraph_t graph; hipGraphExec_t exec; };
 extern "C" int bmpc_graph_create(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g,
                                  double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, bmpc_graph **out) {
     if (!h || !out || B < 1 || max_iter < 0 || !p || !x0 || !x) return BMPC_ERR_ARG;
+    { const int rc_ = ensure_scratch(h, B < h->grid ? B : h->grid); if (rc_ != BMPC_OK) return rc_; }
     hipStream_t cs;
     HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     bmpc_graph *gr = new (std::nothrow) bmpc_graph();
@@ -232,7 +251,7 @@ extern "C" int bmpc_graph_create(bmpc_handle *h, int B, const double *p, const d
     if (rc == BMPC_OK && hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0) != hipSuccess) rc = BMPC_ERR_HIP;
     hipStreamDestroy(cs);
     if (rc != BMPC_OK) { if (gr->exec) hipGraphExecDestroy(gr->exec); if (gr->graph) hipGraphDestroy(gr->graph); delete gr; return rc; }
-    *out = gr;
+    *out = gr; h->graphs_alive++;
     return BMPC_OK;
 }
 extern "C" int bmpc_graph_launch(bmpc_graph *gr, void *hip_stream) {
@@ -248,6 +267,7 @@ extern "C" int bmpc_graph_launch(bmpc_graph *gr, void *hip_stream) {
 }
 extern "C" int bmpc_graph_destroy(bmpc_graph *gr) {
     if (!gr) return BMPC_ERR_ARG;
+    if (gr->h && gr->h->graphs_alive > 0) gr->h->graphs_alive--;
     hipGraphExecDestroy(gr->exec); hipGraphDestroy(gr->graph); delete gr;
     return BMPC_OK;
 }
@@ -344,6 +364,7 @@ extern "C" int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *pat
                                         double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj,
                                         int flags, bmpc_graph **out) {
     if (!h || !out || B < 1 || max_iter < 0 || path_entries < h->S + 1 || !path || !sstate || !robot || !p || !x0 || !x || !g || !status || !traj) return BMPC_ERR_ARG;
+    { const int rc_ = ensure_scratch(h, B < h->grid ? B : h->grid); if (rc_ != BMPC_OK) return rc_; }
     hipStream_t cs;
     HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     bmpc_graph *gr = new (std::nothrow) bmpc_graph();
@@ -361,7 +382,7 @@ extern "C" int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *pat
     if (rc == BMPC_OK && hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0) != hipSuccess) rc = BMPC_ERR_HIP;
     hipStreamDestroy(cs);
     if (rc != BMPC_OK) { if (gr->exec) hipGraphExecDestroy(gr->exec); if (gr->graph) hipGraphDestroy(gr->graph); delete gr; return rc; }
-    *out = gr;
+    *out = gr; h->graphs_alive++;
     return BMPC_OK;
 }
 

@@ -172,6 +172,20 @@ def test_edge_cases(solver):
     o = s3.solve_host(d["p"][:4], d["x0"][:4])
     assert (o["status"] == 1).all() and (o["iters"] == 3).all() and np.isfinite(o["x"]).all()
     s3.close()
+    # the workspace of a handle is sized by its first batch and grows with later ones; captured graphs pin it
+    from boundmpc_amd import BoundMPCHipError
+    sg = BatchedOCPSolver(10, 4, 0.1)
+    for B in (1, 70, 3):
+        o = sg.solve_host(d["p"][:B], d["x0"][:B])
+        assert (o["status"] == 0).all() and _rms_q(o["x"], d["x"][:B]) < TOL_Q_RMS
+    p4, x4 = torch.tensor(d["p"][:4], device="cuda"), torch.tensor(d["x0"][:4], device="cuda")
+    sg2 = BatchedOCPSolver(10, 4, 0.1)
+    gr = sg2.capture_step(p4, x4)
+    gr.launch(); torch.cuda.synchronize()
+    assert _rms_q(gr.out["x"].cpu().numpy(), d["x"][:4]) < TOL_Q_RMS
+    with pytest.raises(BoundMPCHipError):          # 2000 problems need more slabs than the graph's handle holds
+        sg2.solve_batch(torch.zeros((2000, 505), dtype=torch.float64, device="cuda"), torch.zeros((2000, 440), dtype=torch.float64, device="cuda"))
+    gr.close(); sg.close(); sg2.close()
     # wrong shapes / dtypes raise on the host side
     with pytest.raises(ValueError):
         solver.solve_batch(torch.zeros((2, 504), dtype=torch.float64, device="cuda"), torch.zeros((2, 440), dtype=torch.float64, device="cuda"))
