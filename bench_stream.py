@@ -28,8 +28,9 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--ticks", type=int, default=60)
     ap.add_argument("--tol", type=float, default=1e-8)
-    ap.add_argument("--mu-warm", type=float, default=1e-4)
+    ap.add_argument("--mu-warm", type=float, default=1e-2)
     ap.add_argument("--max-iter", type=int, default=100, help="iteration cap of the converged modes (reference: 500)")
+    ap.add_argument("--rt-mu-warm", type=float, default=3e-2, help="barrier restart level of the warm real-time modes (rtw-*)")
     ap.add_argument("--rt-tol", type=float, default=1e-3, help="KKT tolerance of the real-time modes (rt-*: cold duals, hard iteration cap)")
     args = ap.parse_args()
     import torch
@@ -50,8 +51,16 @@ def main():
     for cap in (8, 7, 6, 5):
         rt[cap] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=cap)
         rt[cap].set_timing(True)
+    # warm real-time modes: the same, but the dual state is carried (shifted with the plan on the device) and the barrier restarts at
+    # a MODERATE level (mu_warm 3e-2): active rows keep their multipliers, nothing is jammed; mean 4.4 iterations per tick
+    rtw = {}
+    for cap in (7, 6, 5, 4):
+        rtw[cap] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=cap, mu_warm=args.rt_mu_warm)
+        rtw[cap].set_timing(True)
     res, ref_q = [], None
-    modes = [("converged", solver, 0, False), ("warm", solver, 0, True)] + [(f"rt-tol{args.rt_tol:g}-cap{c}", rt[c], 0, False) for c in (8, 7, 6, 5)] \
+    modes = [("converged", solver, 0, False), ("warm", solver, 0, True)] \
+        + [(f"rtw-tol{args.rt_tol:g}-cap{c}", rtw[c], 0, True) for c in (7, 6, 5, 4)] \
+        + [(f"rt-tol{args.rt_tol:g}-cap{c}", rt[c], 0, False) for c in (8, 7, 6, 5)] \
         + [("rti-5", solver, 5, True), ("rti-3", solver, 3, True), ("rti-1", solver, 1, True)]
     for mode, slv, cap, warm in modes:
         capped = cap > 0 or slv is not solver

@@ -14,7 +14,7 @@ NZ, NG = 44, 43
 
 
 class BatchedOCPSolver:
-    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=0.1, slack_push=1e-2, exact_hessian=True, mu_warm=1e-4, stall_window=40):
+    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=0.1, slack_push=1e-2, exact_hessian=True, mu_warm=1e-2, stall_window=40):
         self._lib = _lib.load()
         o = _lib.Options()
         self._lib.bmpc_default_options(ctypes.byref(o))

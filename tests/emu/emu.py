@@ -36,7 +36,7 @@ def lib():
 
 
 def default_opts(**kw):
-    o = Opts(1e-8, 500, 0.1, 0.1, 1e-2, 1, 0, 1e-4, 40)
+    o = Opts(1e-8, 500, 0.1, 0.1, 1e-2, 1, 0, 1e-2, 40)
     for k, v in kw.items():
         setattr(o, k, v)
     return o
