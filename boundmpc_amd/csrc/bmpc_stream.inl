@@ -10,8 +10,12 @@
 //                joint and path states from the optimal jerks (:513-555), Cartesian trajectory (:568-587), advance of the
 //                path-parameter state and of the rotation reference (:594-611, util_functions.py:88-99), optional kinematic
 //                plant step (util_functions.py:152-161) so that a closed loop runs without leaving the device.
-// Not covered (stays on the host object boundmpc_amd.bound_mpc.BoundMPC): re-planning `update()` (BoundMPC.py:163-217,335-369)
-// and the RViz logging dictionaries.
+// Re-planning (BoundMPC.update, BoundMPC.py:163-217): the host writes the new path table and the handful of state scalars update()
+// sets (boundmpc_amd.stream.apply_update), and raises SS_UPDATED; from then on -- the reference never clears `self.updated` --
+// stream_pack takes the re-projection branch of step() (:335-369: the path-parameter states of the warm start are re-projected
+// from the Cartesian position / velocity / acceleration / jerk of the previous plan, no shift), for which stream_post keeps those
+// four 3 x N arrays of the last plan in the state (:557-566; J, dJ and the second time derivative of J of the geometric chain).
+// Not covered: the RViz logging dictionaries (host mirror).
 //
 // Rotation conversions follow scipy.spatial.transform.Rotation's algorithms (from_rotvec / as_matrix / from_matrix /
 // as_rotvec / as_euler('zyx')) so that the parameters agree with the host mirror to round-off.
@@ -30,7 +34,11 @@ enum { SS_SECTOR = 0, SS_HASPREV = 1, SS_ERRCNT = 2, SS_PHI = 3, SS_DPHI = 4, SS
 enum { RB_Q = 0, RB_DQ = 7, RB_DDQ = 14, RB_P = 21, RB_V = 27, RB_XPHID = 33, RB_JERK = 36, RB_LEN = 43 };
 // trajectory record: [q dq ddq dddq](7 x N each) [p v a](6 x N each) [phi dphi ddphi dddphi](N each) n_valid
 BMPC_HD inline int tr_len(int N) { return 4 * 7 * N + 3 * 6 * N + 4 * N + 4; }
-BMPC_HD inline int ss_len(int N) { return SS_PREV + 44 * N; }
+// after the previous solution: Cartesian [pos | vel | acc | jerk] (linear parts, 3 x N each, [c][i]) of the previous plan, then the
+// `updated` flag of the reference object
+BMPC_HD inline int ss_pc(int N) { return SS_PREV + 44 * N; }
+BMPC_HD inline int ss_updated(int N) { return SS_PREV + 56 * N; }
+BMPC_HD inline int ss_len(int N) { return SS_PREV + 56 * N + 2; }
 
 BMPC_HD inline double norm3(const double *a) { return BMPC_SQRT(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
 BMPC_HD inline double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -142,6 +150,50 @@ BMPC_HD inline void chain_step(double &x, double &dx, double &ddx, double up, do
 
 // iiwa14 geometric chain (RobotModel.py:9-16,62-116,254-563): EE pose [pos; rotvec], J (6x7 row-major), dJ
 struct Fk { double p[6], J[42], dJ[42]; };
+// Second time derivative of the LINEAR rows of J along a motion with joint velocity dq and acceleration ddq (what
+// RobotModel.ddjacobian_fk gives in rows 0..2, RobotModel.py:565-1053), for the geometric chain: with a_j the axes, r_j = p - o_j,
+// w_j = a_j x r_j (column j of J_v), omega_j = sum_{i<j} dq_i a_i:
+//   a_j' = omega_j x a_j,  r_j' = omega_j x r_j + sum_{i>=j} dq_i w_i,  w_j' = a_j' x r_j + a_j x r_j'   (= column j of dJ_v)
+//   a_j'' = omega_j' x a_j + omega_j x a_j',  r_j'' = omega_j' x r_j + omega_j x r_j' + sum_{i>=j} (ddq_i w_i + dq_i w_i'),
+//   w_j'' = a_j'' x r_j + 2 a_j' x r_j' + a_j x r_j''
+BMPC_HD inline void jacobian_lin_ddot(const double *q, const double *dq, const double *ddq, double *ddJ /* [3][7] */) {
+    const int ax[7] = {2, 1, 2, -1, 2, 1, 2};
+    const double pre[7] = {0.0, 0.1575 + 0.2025, 0.0, 0.2375 + 0.1825, 0.0, 0.2175 + 0.1825, 0.0};
+    const double tool = 0.081 + (0.071 + 0.145);
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0}, A[7][3], O[7][3], P[3];
+    for (int j = 0; j < 7; j++) {
+        for (int c = 0; c < 3; c++) { o[c] += R[c * 3 + 2] * pre[j]; O[j][c] = o[c]; }
+        double cs = BMPC_COS(q[j]), sn = BMPC_SIN(q[j]);
+        if (ax[j] == 2) {
+            for (int c = 0; c < 3; c++) { A[j][c] = R[c * 3 + 2]; const double c0 = R[c * 3], c1 = R[c * 3 + 1]; R[c * 3] = cs * c0 + sn * c1; R[c * 3 + 1] = -sn * c0 + cs * c1; }
+        } else {
+            const double sg = (double)ax[j]; sn *= sg;
+            for (int c = 0; c < 3; c++) { A[j][c] = sg * R[c * 3 + 1]; const double c0 = R[c * 3], c2 = R[c * 3 + 2]; R[c * 3] = cs * c0 - sn * c2; R[c * 3 + 2] = sn * c0 + cs * c2; }
+        }
+    }
+    for (int c = 0; c < 3; c++) P[c] = o[c] + R[c * 3 + 2] * tool;
+    double r[7][3], w[7][3], om[7][3], da[7][3], dr[7][3], dw[7][3], suf[3] = {0, 0, 0}, t[3];
+    for (int j = 0; j < 7; j++) { for (int c = 0; c < 3; c++) r[j][c] = P[c] - O[j][c]; cross3s(A[j], r[j], w[j]); }
+    { double acc[3] = {0, 0, 0}; for (int j = 0; j < 7; j++) { for (int c = 0; c < 3; c++) { om[j][c] = acc[c]; acc[c] += dq[j] * A[j][c]; } } }
+    for (int j = 6; j >= 0; j--) {                      // suffix sums of dq_i w_i (inclusive)
+        for (int c = 0; c < 3; c++) suf[c] += dq[j] * w[j][c];
+        cross3s(om[j], A[j], da[j]);
+        cross3s(om[j], r[j], t); for (int c = 0; c < 3; c++) dr[j][c] = t[c] + suf[c];
+        double u1[3], u2[3]; cross3s(da[j], r[j], u1); cross3s(A[j], dr[j], u2);
+        for (int c = 0; c < 3; c++) dw[j][c] = u1[c] + u2[c];
+    }
+    double dom[7][3];
+    { double acc[3] = {0, 0, 0}; for (int j = 0; j < 7; j++) { for (int c = 0; c < 3; c++) { dom[j][c] = acc[c]; acc[c] += ddq[j] * A[j][c] + dq[j] * da[j][c]; } } }
+    double suf2[3] = {0, 0, 0};
+    for (int j = 6; j >= 0; j--) {
+        for (int c = 0; c < 3; c++) suf2[c] += ddq[j] * w[j][c] + dq[j] * dw[j][c];
+        double dda[3], ddr[3], u1[3], u2[3], u3[3];
+        cross3s(dom[j], A[j], u1); cross3s(om[j], da[j], u2); for (int c = 0; c < 3; c++) dda[c] = u1[c] + u2[c];
+        cross3s(dom[j], r[j], u1); cross3s(om[j], dr[j], u2); for (int c = 0; c < 3; c++) ddr[c] = u1[c] + u2[c] + suf2[c];
+        cross3s(dda, r[j], u1); cross3s(da[j], dr[j], u2); cross3s(A[j], ddr, u3);
+        for (int c = 0; c < 3; c++) ddJ[c * 7 + j] = u1[c] + 2.0 * u2[c] + u3[c];
+    }
+}
 BMPC_HD inline void forward_kinematics(const double *q, const double *dq, Fk &F) {
     const int ax[7] = {2, 1, 2, -1, 2, 1, 2};
     const double pre[7] = {0.0, 0.1575 + 0.2025, 0.0, 0.2375 + 0.1825, 0.0, 0.2175 + 0.1825, 0.0};
@@ -301,14 +353,38 @@ BMPC_HD inline void stream_pack(int N, int S, const double *path, double *ss, co
         const double *pv = ss + SS_PREV;
         const double d[3] = {p0[3] - pv[32], p0[4] - pv[33], p0[5] - pv[34]};
         const bool unwrap = norm3(d) > 1.5;
+        const bool updated = ss[ss_updated(N)] > 0.5;                      // after update(): no shift, re-projection below (:335-375)
         for (int id = lane; id < 44 * N; id += nl) {
             const int k = id / 44, i = id % 44;
-            const int kk = k + 1 < N ? k + 1 : N - 1;                      // shift: row k takes (unwrapped) row k+1
+            const int kk = updated ? k : (k + 1 < N ? k + 1 : N - 1);      // shift: row k takes (unwrapped) row k+1
             double v = pv[kk * 44 + i];
             if (unwrap && i >= 32 && i < 35) { const int ks = kk < N - 1 ? kk : N - 2; v = p0[i - 29] + (pv[(ks + 1) * 44 + i] - pv[i]); }
             x0[id] = v;
         }
-        if (dual && dual[57 * N] > 0.0)
+        if (updated) {
+            BMPCS_SYNC();
+            // path-parameter states of every stage re-projected onto the first segment of the (new) window from the Cartesian
+            // position / velocity / acceleration / jerk of the previous plan (BoundMPC.py:335-369); one lane per stage
+            const double *e0 = path + sector * PT_LEN, *pc = ss + ss_pc(N);
+            const double sw0 = e0[PT_CUM], sw1 = path[(sector + 1) * PT_LEN + PT_CUM];
+            for (int k = lane; k < N; k += nl) {
+                double phik = sw0, dphik = 0, ddphik = 0, dddphik = 0;
+                for (int c = 0; c < 3; c++) {
+                    const double dn = e0[PT_DPN + c];
+                    phik += (pc[c * N + k] - e0[PT_P + c]) * dn; dphik += pc[(3 + c) * N + k] * dn;
+                    ddphik += pc[(6 + c) * N + k] * dn; dddphik += pc[(9 + c) * N + k] * dn;
+                }
+                double *z = x0 + k * 44;
+                if (phik > sw1 - 0.01) { z[41] = sw1 - 0.01; z[42] = 0.0; z[43] = 0.0; }
+                else if (phik < 0) {
+                    for (int j = 0; j < 7; j++) z[8 + j] = q0[j];
+                    z[41] = 0.0; z[42] = 0.0; z[43] = 0.0;
+                    for (int c = 0; c < 6; c++) z[29 + c] = p0[c];
+                    for (int c = 0; c < 4; c++) z[35 + c] = 0.0;
+                } else { z[41] = phik; z[42] = dphik; z[43] = ddphik; z[7] = dddphik; }
+            }
+        }
+        if (!updated && dual && dual[57 * N] > 0.0)
             for (int i = lane; i < 57; i += nl) for (int k = 0; k < N - 1; k++) dual[k * 57 + i] = dual[(k + 1) * 57 + i];
     }
     BMPCS_SYNC();
@@ -377,16 +453,35 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, doub
     if (ec >= N) return;                                          // step() returns None :504-506 (uniform over the lanes)
     // ---- phase 2: roles 0..n-1: Cartesian trajectory of one stage :568-587; role 32: rotation reference and path-parameter
     //      state :594-611; role 33: the node's kinematic plant step (util_functions.py:152-161) ----
-    for (int role = lane; role < 34; role += nl) {
-        if (role < n) {
-            const int i = role;
-            double q[7], dq[7], ddq[7];
-            for (int j = 0; j < 7; j++) { q[j] = Tq[j * N + i]; dq[j] = Tdq[j * N + i]; ddq[j] = Tddq[j * N + i]; }
+    // Roles 34..34+ec-1 (only while a previous plan is replayed): the leading, already executed columns of that plan, of which
+    // only the Cartesian derivatives for a later re-planning are kept.
+    double *pc = ss + ss_pc(N);
+    for (int role = lane; role < 34 + ec; role += nl) {
+        if (role < n || role >= 34) {
+            const bool lead = role >= 34;
+            const int i = lead ? 0 : role, col = lead ? role - 34 : ec + role;        // trajectory index / column of the plan
+            double q[7], dq[7], ddq[7], u[7];
+            for (int j = 0; j < 7; j++) {
+                if (lead) { q[j] = w[col * 44 + 8 + j]; dq[j] = w[col * 44 + 15 + j]; ddq[j] = w[col * 44 + 22 + j]; }
+                else { q[j] = Tq[j * N + i]; dq[j] = Tdq[j * N + i]; ddq[j] = Tddq[j * N + i]; }
+                u[j] = w[col * 44 + j];
+            }
             Fk F; forward_kinematics(q, dq, F);
-            for (int c = 0; c < 6; c++) {
+            if (!lead) for (int c = 0; c < 6; c++) {
                 double v = 0, a = 0;
                 for (int j = 0; j < 7; j++) { v += F.J[c * 7 + j] * dq[j]; a += F.J[c * 7 + j] * ddq[j] + F.dJ[c * 7 + j] * dq[j]; }
                 Tp[c * N + i] = F.p[c]; Tv[c * N + i] = v; Ta[c * N + i] = a;
+            }
+            // previous-plan arrays of BoundMPC.py:557-566 (linear rows): position of the re-integrated plan (the plan's own entry for
+            // a leading column), the SOLVER's velocity variables, J ddq + dJ dq, J u + dJ ddq + ddJ dq
+            double ddJ[21];
+            jacobian_lin_ddot(q, dq, ddq, ddJ);
+            for (int c = 0; c < 3; c++) {
+                double a = 0, jk = 0;
+                for (int j = 0; j < 7; j++) { a += F.J[c * 7 + j] * ddq[j] + F.dJ[c * 7 + j] * dq[j]; jk += F.J[c * 7 + j] * u[j] + F.dJ[c * 7 + j] * ddq[j] + ddJ[c * 7 + j] * dq[j]; }
+                pc[c * N + col] = lead ? w[col * 44 + 29 + c] : F.p[c];
+                pc[(3 + c) * N + col] = w[col * 44 + 35 + c];
+                pc[(6 + c) * N + col] = a; pc[(9 + c) * N + col] = jk;
             }
         } else if (role == 32) {
             const int sector = (int)ss[SS_SECTOR];

@@ -6,7 +6,8 @@ BoundMPC instance is stateful per trajectory").  The static part of a stream is 
 the dynamic part is the *stream state* (phi-state, rotation reference, window sector, error count, previous
 solution).  Per tick the device runs  pack -> solve -> post  (csrc/bmpc_stream.inl + the solver kernel),
 optionally as one captured hipGraph and optionally with the node's kinematic plant simulation, so a closed loop
-needs no host round trip.  Re-planning (`BoundMPC.update`) is not covered.
+needs no host round trip.  Re-planning (`BoundMPC.update`, BoundMPC.py:163-217): `StreamBatch.update` / `apply_update` write the
+new path table and the state scalars update() sets, from then on the device takes the re-projection branch of step() (:335-369).
 """
 import ctypes
 
@@ -21,6 +22,15 @@ PT = dict(P=0, IW=3, DPN=6, DR=9, RRV=12, PLO=15, PUP=17, RLO=19, RUP=21, BP1=23
 SS = dict(SECTOR=0, HASPREV=1, ERRCNT=2, PHI=3, DPHI=4, DDPHI=5, DDDPHI=6, PRREF=7, IWREF=10, PHIMAX=13, W=14, NENT=29, USINGPREV=30, VALID=31,
           PREV=32)
 RB = dict(Q=0, DQ=7, DDQ=14, P=21, V=27, XPHID=33, JERK=36, LEN=43)
+
+
+def ss_len(N):
+    """[header 32 | previous solution 44 N | Cartesian pos, vel, acc, jerk of the previous plan 4 x 3 x N | updated flag, pad]"""
+    return SS["PREV"] + 56 * N + 2
+
+
+def ss_updated(N):
+    return SS["PREV"] + 56 * N
 
 
 def path_table(rp, entries=None):
@@ -49,7 +59,7 @@ def path_table(rp, entries=None):
 
 def initial_state(mpc, N):
     """Stream state of a freshly constructed host `BoundMPC` (before its first step)."""
-    s = np.zeros(SS["PREV"] + 44 * N)
+    s = np.zeros(ss_len(N))
     s[SS["SECTOR"]] = mpc.ref_path.sector
     s[SS["PHI"]], s[SS["DPHI"]], s[SS["DDPHI"]], s[SS["DDDPHI"]] = mpc.phi_current[0], mpc.dphi_current[0], mpc.ddphi_current[0], mpc.dddphi_current[0]
     s[SS["PRREF"]:SS["PRREF"] + 3] = mpc.pr_ref
@@ -58,9 +68,34 @@ def initial_state(mpc, N):
     s[SS["W"]:SS["W"] + 15] = mpc.weights
     if mpc.prev_solution is not None:
         s[SS["HASPREV"]] = 1.0
-        s[SS["PREV"]:] = np.asarray(mpc.prev_solution, dtype=float).ravel()
+        s[SS["PREV"]:SS["PREV"] + 44 * N] = np.asarray(mpc.prev_solution, dtype=float).ravel()
     s[SS["ERRCNT"]] = mpc.error_count
     return s
+
+
+def apply_update(ss, N, S, pos_points, rot_points, pos_lim, rot_lim, bp1, br1, s, e_p_min, e_r_min, e_p_max, e_r_max, p, v, a, jerk, p0, weights,
+                 entries=None):
+    """Re-planning of one stream, the state part of BoundMPC.update() (BoundMPC.py:163-217) on the stream-state row `ss` (numpy,
+    modified in place): new path table (returned, [entries][48]) and window start, path-parameter state projected onto the new first
+    segment from the measured Cartesian state (p0, v, a, jerk), rotation reference, phi_max, weights, and the `updated` flag that
+    switches the device's warm start to the re-projection branch of step() for good (the reference never clears it).  The previous
+    solution, its Cartesian derivatives and the error count stay, as in the reference."""
+    from .reference_path import ReferencePath
+    from .bound_mpc import integrate_rotation_reference
+    rp = ReferencePath(pos_points, rot_points, pos_lim, rot_lim, bp1, br1, s, e_p_min, e_r_min, e_p_max, e_r_max, S)
+    T, M = path_table(rp, entries)
+    dp0 = rp.dp[0] / np.linalg.norm(rp.dp[0])
+    phi = float((np.asarray(p0, dtype=float)[:3] - np.asarray(pos_points[0], dtype=float)) @ dp0)
+    dpn = rp.dpd[:3, 0]
+    ss[SS["SECTOR"]] = rp.sector
+    ss[SS["PHI"]], ss[SS["DPHI"]], ss[SS["DDPHI"]], ss[SS["DDDPHI"]] = phi, float(v[:3] @ dpn), float(a[:3] @ dpn), float(jerk[:3] @ dpn)
+    ss[SS["PRREF"]:SS["PRREF"] + 3] = integrate_rotation_reference(R.from_matrix(rot_points[0]).as_rotvec(), rp.dr[0], 0.0, phi)
+    ss[SS["IWREF"]:SS["IWREF"] + 3] = rp.pd[3:, 0] + phi * rp.dpd[3:, 0]
+    ss[SS["PHIMAX"]] = rp.phi_max - 0.0001
+    ss[SS["W"]:SS["W"] + 15] = np.asarray(weights, dtype=float)
+    ss[SS["NENT"]] = M
+    ss[ss_updated(N)] = 1.0
+    return T, M
 
 
 def robot_record(q, dq, ddq, p_lie, v, x_phi_d, jerk):
@@ -91,7 +126,7 @@ class StreamBatch:
         lens = [ctypes.c_int() for _ in range(4)]
         _lib.check(solver._lib.bmpc_stream_lengths(solver._h, *[ctypes.byref(v) for v in lens]), "bmpc_stream_lengths")
         self.pt_len, self.ss_len, self.rb_len, self.tr_len = (v.value for v in lens)
-        assert self.pt_len == PT["LEN"] and self.rb_len == RB["LEN"] and self.ss_len == SS["PREV"] + 44 * self.N
+        assert self.pt_len == PT["LEN"] and self.rb_len == RB["LEN"] and self.ss_len == ss_len(self.N)
         self.entries = max(len(m.ref_path.p) for m in mpcs)
         tabs, states = [], []
         for m in mpcs:
@@ -112,6 +147,17 @@ class StreamBatch:
         self.kkt = torch.zeros((self.B,), dtype=torch.float64, device=device)
         self.traj = torch.zeros((self.B, self.tr_len), dtype=torch.float64, device=device)
         self._graphs = {}
+
+    def update(self, b, *args, **kw):
+        """Re-plan stream b: `apply_update` on a host copy of its state row, then the new table and state go back to the device
+        (a rare event; the per-tick work stays on the device).  Arguments as apply_update after (ss, N, S)."""
+        import torch
+        torch.cuda.synchronize(self.state.device)
+        row = self.state[b].cpu().numpy().copy()
+        T, M = apply_update(row, self.N, self.S, *args, entries=self.entries, **kw)
+        self.path[b].copy_(torch.as_tensor(T, dtype=torch.float64))
+        self.state[b].copy_(torch.as_tensor(row, dtype=torch.float64))
+        return float(row[SS["PHIMAX"]])
 
     def set_robot(self, rec):
         import torch

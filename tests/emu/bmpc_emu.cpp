@@ -50,6 +50,8 @@ extern "C" void bmpc_emu_stream_post(int N, int S, double h, const double *path,
     bmpcs::stream_post(N, S, h, path, ss, rb, x, g, status, traj, simulate, sh, 0, 1);
 }
 
+extern "C" void bmpc_emu_jacobian_lin_ddot(const double *q, const double *dq, const double *ddq, double *out) { bmpcs::jacobian_lin_ddot(q, dq, ddq, out); }
+
 extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, int B, const double *p, const double *x0, double *state, double *x, double *g,
                               double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, int lane_order, int nthreads) {
     if (S > bmpc::SMAX || S < 2 || N < 1 || N > 32) return 1;

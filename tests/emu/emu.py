@@ -81,3 +81,11 @@ def stream_post(N, S, h, path, ss, rb, x, g, status, simulate=True):
     lib().bmpc_emu_stream_post(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), _p(path), _p(ss), _p(rb), _p(x), _p(g), ctypes.c_int(int(status)),
                                _p(traj), ctypes.c_int(int(simulate)))
     return traj
+
+
+def jacobian_lin_ddot(q, dq, ddq):
+    """Second time derivative of the linear rows of the Jacobian (csrc/bmpc_stream.inl) -> [3][7]."""
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (q, dq, ddq)]
+    out = np.zeros((3, 7))
+    lib().bmpc_emu_jacobian_lin_ddot(_p(a[0]), _p(a[1]), _p(a[2]), _p(out))
+    return out

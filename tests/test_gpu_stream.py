@@ -75,7 +75,7 @@ def test_device_pack_and_post_equal_cpu_build_of_the_same_text():
     for t in range(0, 155, 7):
         rb = bstream.robot_record(d7["q"][t], d7["dq"][t], d7["ddq"][t], d7["p_lie"][t], d7["v"][t], xphid, d7["jerk"][t])
         if t:                                                    # state of the stream just before tick t
-            ss[bstream.SS["HASPREV"]] = 1; ss[bstream.SS["PREV"]:] = d7["x"][t - 1]
+            ss[bstream.SS["HASPREV"]] = 1; ss[bstream.SS["PREV"]:bstream.SS["PREV"] + 440] = d7["x"][t - 1]
             ss[bstream.SS["PHI"]], ss[bstream.SS["DPHI"]], ss[bstream.SS["DDPHI"]], ss[bstream.SS["DDDPHI"]] = (
                 d7["phi_current"][t - 1], d7["dphi_current"][t - 1], d7["ddphi_current"][t - 1], d7["dddphi_current"][t - 1])
             ss[7:10], ss[10:13] = d7["pr_ref"][t - 1], d7["iw_ref"][t - 1]
@@ -198,3 +198,46 @@ def test_256_streams_real_time_mode_tracks_the_converged_loops():
     assert np.median(per_stream) <= 1e-2 and (per_stream <= 1e-2).mean() >= 0.5
     assert np.abs(phir - phic).max() < 0.05                    # same progress along the path
     assert np.percentile(msr, 99) < np.percentile(msc, 50)      # the capped tick is bounded: its p99 is below the converged p50
+
+
+def test_replanning_on_the_device_matches_reference_update_g11():
+    """BoundMPC.update() for a stream on the GPU (StreamBatch.update: new table + state scalars from the host, the re-projected warm
+    starts and the Cartesian derivatives of the previous plan on the device) against the REFERENCE's own update()/step() (fixture G11)."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, stream as bstream
+    from oracle import c_oracle
+    (mpc, d6), _ = _mpcs()
+    d7 = np.load(os.path.join(G, "g7_closedloop_exp1.npz"))
+    d = np.load(os.path.join(G, "g11_update.npz"))
+    T_UPD = int(d["t_update"])
+    solver = BatchedOCPSolver(10, 4, 0.1)
+    sb = bstream.StreamBatch(solver, [mpc])
+    xphid = np.array([mpc.phi_max[0], 0, 0])
+
+    def feed(q, dq, ddq, p_lie, v, jerk, x, p_fix, status):
+        sb.set_robot(bstream.robot_record(q, dq, ddq, p_lie, v, xphid, jerk)[None])
+        sb.pack(); torch.cuda.synchronize()
+        p, x0 = sb.p.cpu().numpy()[0].copy(), sb.x0.cpu().numpy()[0].copy()
+        g = c_oracle.eval_fg(p_fix, x, 10, 4, 0.1)[1]
+        sb.x.copy_(torch.tensor(x[None])); sb.g.copy_(torch.tensor(g[None])); sb.status.fill_(int(status))
+        sb.post(simulate=False); torch.cuda.synchronize()
+        return p, x0
+    for t in range(T_UPD):
+        feed(d7["q"][t], d7["dq"][t], d7["ddq"][t], d7["p_lie"][t], d7["v"][t], d7["jerk"][t], d7["x"][t], d7["p"][t], 0)
+    L = lambda k: [np.array(v) for v in d["upd_" + k]]
+    phi_max = sb.update(0, L("p_via"), L("r_via"), [L("p_lower"), L("p_upper")], [L("r_lower"), L("r_upper")], L("bp1"), L("br1"), list(d["upd_s"]),
+                        list(d["upd_e_p_min"]), list(d["upd_e_r_min"]), list(d["upd_e_p_max"]), list(d["upd_e_r_max"]),
+                        d["upd_p"], d["upd_v"], d["upd_a"], d["upd_jerk"], d["upd_p"], d["weights"])
+    assert abs(phi_max - float(d["after_update_phi_max"])) < 1e-13
+    xphid = np.array([phi_max, 0, 0])
+    mask = d6["p_defined_mask"]
+    for i in range(len(d["x"])):
+        p, x0 = feed(d["q"][i], d["dq"][i], d["ddq"][i], d["p_lie"][i], d["v"][i], d["jerk"][i], d["x"][i], d["p"][i], int(d["status"][i]))
+        np.testing.assert_allclose(p[mask], d["p"][i][mask], atol=5e-11, rtol=1e-11, err_msg=f"p, tick {i} after update")
+        np.testing.assert_allclose(x0, d["x0"][i], atol=1e-11, err_msg=f"x0, tick {i} after update")
+        st = sb.state.cpu().numpy()[0]
+        td, _ = bstream.unpack_traj(sb.traj.cpu().numpy()[0], 10)
+        np.testing.assert_allclose(td["q"], d["traj_q"][i], atol=1e-11)
+        assert abs(st[bstream.SS["PHI"]] - d["phi_current"][i]) < 1e-11 and int(st[0]) == int(d["sector"][i])
+        np.testing.assert_allclose(st[10:13], d["iw_ref"][i], atol=1e-11)
+    sb.close(); solver.close()

@@ -152,3 +152,52 @@ def test_stream_matches_host_mirror_with_failures():
         jerk = traj["dddq"][:, 0].copy()
         np.testing.assert_allclose(rb[:7], q, atol=1e-7)
         np.testing.assert_allclose(rb[21:27], p_lie, atol=1e-7)
+
+
+def test_second_time_derivative_of_the_jacobian_g1():
+    """The closed form of d2/dt2 J_v for the geometric chain (csrc/bmpc_stream.inl, needed for the Cartesian jerk of the previous plan
+    after a re-planning) against the reference's Maple-generated ddjacobian_fk (RobotModel.py:565-1053) on 256 random states."""
+    d = np.load(os.path.join(G, "g1_kinematics.npz"))
+    for i in range(len(d["q"])):
+        np.testing.assert_allclose(emu.jacobian_lin_ddot(d["q"][i], d["dq"][i], d["ddq"][i]), d["ddjacobian_fk"][i][:3], atol=2e-14)
+
+
+def test_stream_replanning_matches_reference_update_g11():
+    """Re-planning on the stream functions: the recorded experiment-1 loop up to the tick of the update, `apply_update` (the state part
+    of BoundMPC.update), then the ticks after it -- whose warm start goes through the re-projection branch with the Cartesian
+    derivatives of the previous plan kept by stream_post -- against what the REFERENCE's own update()/step() produced (fixture G11)."""
+    mpc, d6 = _fixture_mpc(1, _Oracle())
+    d7 = np.load(os.path.join(G, "g7_closedloop_exp1.npz"))
+    d = np.load(os.path.join(G, "g11_update.npz"))
+    T_UPD = int(d["t_update"])
+    T, M = bstream.path_table(mpc.ref_path)
+    ss = bstream.initial_state(mpc, 10); ss[bstream.SS["NENT"]] = M
+    xphid = np.array([mpc.phi_max[0], 0, 0])
+    for t in range(T_UPD):          # open loop over the recorded ticks (states and solutions of G7)
+        rb = bstream.robot_record(d7["q"][t], d7["dq"][t], d7["ddq"][t], d7["p_lie"][t], d7["v"][t], xphid, d7["jerk"][t])
+        emu.stream_pack(10, 4, T, ss, rb)
+        g = c_oracle.eval_fg(d7["p"][t], d7["x"][t], 10, 4, 0.1)[1]
+        emu.stream_post(10, 4, 0.1, T, ss, rb, d7["x"][t], g, 0, simulate=False)
+    L = lambda k: [np.array(v) for v in d["upd_" + k]]
+    T2, M2 = bstream.apply_update(ss, 10, 4, L("p_via"), L("r_via"), [L("p_lower"), L("p_upper")], [L("r_lower"), L("r_upper")], L("bp1"), L("br1"),
+                                  list(d["upd_s"]), list(d["upd_e_p_min"]), list(d["upd_e_r_min"]), list(d["upd_e_p_max"]), list(d["upd_e_r_max"]),
+                                  d["upd_p"], d["upd_v"], d["upd_a"], d["upd_jerk"], d["upd_p"], d["weights"])
+    np.testing.assert_allclose(ss[3:7], d["after_update_phi"], atol=1e-13)
+    np.testing.assert_allclose(ss[7:10], d["after_update_pr_ref"], atol=1e-12)
+    np.testing.assert_allclose(ss[10:13], d["after_update_iw_ref"], atol=1e-12)
+    assert abs(ss[bstream.SS["PHIMAX"]] - float(d["after_update_phi_max"])) < 1e-13
+    xphid = np.array([ss[bstream.SS["PHIMAX"]], 0, 0])
+    mask = d6["p_defined_mask"]
+    for i in range(len(d["x"])):
+        rb = bstream.robot_record(d["q"][i], d["dq"][i], d["ddq"][i], d["p_lie"][i], d["v"][i], xphid, d["jerk"][i])
+        p, x0 = emu.stream_pack(10, 4, T2, ss, rb)
+        np.testing.assert_allclose(p[mask], d["p"][i][mask], atol=5e-11, rtol=1e-11, err_msg=f"p, tick {i} after update")
+        np.testing.assert_allclose(x0, d["x0"][i], atol=1e-11, err_msg=f"x0, tick {i} after update")
+        g = c_oracle.eval_fg(d["p"][i], d["x"][i], 10, 4, 0.1)[1]
+        tr = emu.stream_post(10, 4, 0.1, T2, ss, rb, d["x"][i], g, int(d["status"][i]), simulate=False)
+        td, fl = bstream.unpack_traj(tr, 10)
+        np.testing.assert_allclose(td["q"], d["traj_q"][i], atol=1e-12)
+        np.testing.assert_allclose(td["phi"], d["traj_phi"][i], atol=1e-12)
+        assert abs(ss[bstream.SS["PHI"]] - d["phi_current"][i]) < 1e-12 and int(ss[0]) == int(d["sector"][i])
+        _same_rotation(ss[7:10], d["pr_ref"][i], 1e-11)
+        np.testing.assert_allclose(ss[10:13], d["iw_ref"][i], atol=1e-12)
