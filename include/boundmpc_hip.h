@@ -116,7 +116,10 @@ int bmpc_graph_destroy(bmpc_graph *g);
  *   sstate [B][state]   phi-state, rotation reference, sector, error count, weights, previous solution
  *   robot  [B][robot]   q dq ddq p_lie v x_phi_d jerk  = the arguments of step()            (read; written when simulate)
  *   traj   [B][traj]    q dq ddq dddq (7 x N) | p v a (6 x N) | phi dphi ddphi dddphi (N) | n_valid using_previous success g_viol
- * Re-planning (BoundMPC.update, BoundMPC.py:163-217) is not covered: rebuild the table and state on the host. */
+ *   sstate row = [header 32 | previous solution 44 N | Cartesian pos, vel, acc, jerk of the previous plan 4 x 3 x N | updated flag, pad].
+ * Re-planning (BoundMPC.update, BoundMPC.py:163-217): the host writes the new path table and the state scalars update() sets and
+ * raises the `updated` flag (boundmpc_amd.stream.apply_update); bmpc_stream_pack then takes the re-projection branch of step()
+ * (BoundMPC.py:335-369) for good, as the reference does, from the arrays bmpc_stream_post keeps. */
 int bmpc_stream_lengths(const bmpc_handle *h, int *path_entry, int *state, int *robot, int *traj);
 int bmpc_stream_pack(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, const double *robot, double *p, double *x0,
                      double *dual_state, void *hip_stream);
