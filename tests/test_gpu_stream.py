@@ -241,3 +241,35 @@ def test_replanning_on_the_device_matches_reference_update_g11():
         assert abs(st[bstream.SS["PHI"]] - d["phi_current"][i]) < 1e-11 and int(st[0]) == int(d["sector"][i])
         np.testing.assert_allclose(st[10:13], d["iw_ref"][i], atol=1e-11)
     sb.close(); solver.close()
+
+
+@pytest.mark.parametrize("N,S", [(5, 2), (8, 3), (20, 4)])
+def test_device_tick_other_horizons_and_windows_g12(N, S):
+    """The whole device tick {pack, solve, post} for other (n, nr_segs) than the experiments': closed loop against the reference's own
+    step() driven with the CPU oracle (fixture G12) -- parameter layout 141 + 91 S, warm start 44 N, N <= 11 and N > 11 kernels."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, stream as bstream, workload
+    from boundmpc_amd.bound_mpc import BoundMPC
+    from tests.test_stream import _Oracle
+    d6 = np.load(os.path.join(G, "g6_pack_exp2_tick0.npz"))
+    d = np.load(os.path.join(G, "g12_pack_other_sizes.npz"))
+    k = f"n{N}s{S}_"
+    dt, mask = float(d[k + "dt"]), d[k + "mask"]
+    mk = lambda key: [np.array(v) for v in d6[key]]
+    mpc = BoundMPC(mk("p_via"), mk("r_via"), [mk("p_lower"), mk("p_upper")], [mk("r_lower"), mk("r_upper")], mk("bp1_in"), mk("br1_in"),
+                   list(d6["s_in"]), list(d6["e_p_min_in"]), list(d6["e_r_min_in"]), list(d6["e_p_max_in"]), list(d6["e_r_max_in"]),
+                   p0=d6["p0fk"].copy(), params=workload.Params(n=N, dt=dt, nr_segs=S, weights=d["weights"]), solver=_Oracle())
+    solver = BatchedOCPSolver(N, S, dt)
+    sb = bstream.StreamBatch(solver, [mpc])
+    sb.set_robot(bstream.robot_record(d[k + "q"][0], d[k + "dq"][0], d[k + "ddq"][0], d[k + "p_lie"][0], d[k + "v"][0],
+                                      np.array([mpc.phi_max[0], 0, 0]), d[k + "jerk"][0])[None])
+    for i in range(len(d[k + "x"])):
+        sb.tick(simulate=True); torch.cuda.synchronize()
+        # closed loops of two solvers: round-off of each solve (tol 1e-8) feeds the next tick, the jerk entries feel it most
+        np.testing.assert_allclose(sb.p.cpu().numpy()[0][mask], d[k + "p"][i][mask], atol=2e-4, err_msg=f"tick {i}")
+        np.testing.assert_allclose(sb.x0.cpu().numpy()[0], d[k + "x0"][i], atol=2e-4)
+        td, fl = bstream.unpack_traj(sb.traj.cpu().numpy()[0], N)
+        assert fl["success"] and fl["n_valid"] == N
+        np.testing.assert_allclose(td["q"], d[k + "traj_q"][i], atol=2e-6)
+        assert abs(sb.state.cpu().numpy()[0][bstream.SS["PHI"]] - d[k + "phi_current"][i]) < 1e-6
+    sb.close(); solver.close()

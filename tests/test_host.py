@@ -280,3 +280,28 @@ def test_update_replanning_g11():
         assert abs(mpc.phi_current[0] - d["phi_current"][i]) < 1e-13 and mpc.ref_path.sector == d["sector"][i]
         np.testing.assert_allclose(mpc.pr_ref, d["pr_ref"][i], atol=1e-12)
         np.testing.assert_allclose(mpc.iw_ref, d["iw_ref"][i], atol=1e-12)
+
+
+@pytest.mark.parametrize("N,S", [(5, 2), (8, 3), (20, 4)])
+def test_pack_and_postprocess_other_horizons_and_windows_g12(N, S):
+    """Host mirror against the reference's own step()/compute_return_data for other (n, nr_segs) than the experiments' (fixture G12,
+    experiment-2 path: asymmetric tubes, mixed bases): the 141 + 91 S parameter layout and the 44 N warm start, tick by tick."""
+    d6 = np.load(os.path.join(G, "g6_pack_exp2_tick0.npz"))
+    d = np.load(os.path.join(G, "g12_pack_other_sizes.npz"))
+    k = f"n{N}s{S}_"
+    dt, mask = float(d[k + "dt"]), d[k + "mask"]
+    stub = _Stub()
+    mpc = BoundMPC(*_path_from(d6), p0=d6["p0fk"].copy(), params=workload.Params(n=N, dt=dt, nr_segs=S, weights=d["weights"], build=False), solver=stub)
+    assert abs(mpc.phi_max[0] - float(d[k + "phi_max"])) < 1e-15 and len(d[k + "p"][0]) == 141 + 91 * S
+    x_phi_d = np.array([mpc.phi_max[0], 0, 0])
+    for i in range(len(d[k + "x"])):
+        stub.ans = d[k + "x"][i]
+        traj, _, _, _, _ = mpc.step(d[k + "q"][i], d[k + "dq"][i], d[k + "ddq"][i], d[k + "p_lie"][i], d[k + "v"][i], x_phi_d, d[k + "jerk"][i])
+        x0, p = stub.last
+        np.testing.assert_allclose(p[mask], d[k + "p"][i][mask], atol=2e-12, err_msg=f"p tick {i}")
+        np.testing.assert_allclose(x0, d[k + "x0"][i], atol=1e-14, err_msg=f"x0 tick {i}")
+        for kk in ("q", "p", "a", "phi"):
+            np.testing.assert_allclose(np.array(traj[kk]), d[k + "traj_" + kk][i], atol=1e-12, err_msg=f"traj {kk} tick {i}")
+        assert abs(mpc.phi_current[0] - d[k + "phi_current"][i]) < 1e-13 and mpc.ref_path.sector == d[k + "sector"][i]
+        np.testing.assert_allclose(mpc.pr_ref, d[k + "pr_ref"][i], atol=1e-12)
+        np.testing.assert_allclose(mpc.iw_ref, d[k + "iw_ref"][i], atol=1e-12)

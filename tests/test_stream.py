@@ -201,3 +201,31 @@ def test_stream_replanning_matches_reference_update_g11():
         assert abs(ss[bstream.SS["PHI"]] - d["phi_current"][i]) < 1e-12 and int(ss[0]) == int(d["sector"][i])
         _same_rotation(ss[7:10], d["pr_ref"][i], 1e-11)
         np.testing.assert_allclose(ss[10:13], d["iw_ref"][i], atol=1e-12)
+
+
+@pytest.mark.parametrize("N,S", [(5, 2), (8, 3), (20, 4)])
+def test_stream_functions_other_horizons_and_windows_g12(N, S):
+    """stream_pack / stream_post for other (n, nr_segs) against the reference's own step() (fixture G12), open loop over its ticks."""
+    d6 = np.load(os.path.join(G, "g6_pack_exp2_tick0.npz"))
+    d = np.load(os.path.join(G, "g12_pack_other_sizes.npz"))
+    k = f"n{N}s{S}_"
+    dt, mask = float(d[k + "dt"]), d[k + "mask"]
+    mk = lambda key: [np.array(v) for v in d6[key]]
+    mpc = BoundMPC(mk("p_via"), mk("r_via"), [mk("p_lower"), mk("p_upper")], [mk("r_lower"), mk("r_upper")], mk("bp1_in"), mk("br1_in"),
+                   list(d6["s_in"]), list(d6["e_p_min_in"]), list(d6["e_r_min_in"]), list(d6["e_p_max_in"]), list(d6["e_r_max_in"]),
+                   p0=d6["p0fk"].copy(), params=workload.Params(n=N, dt=dt, nr_segs=S, weights=d["weights"]), solver=_Oracle())
+    T, M = bstream.path_table(mpc.ref_path)
+    ss = bstream.initial_state(mpc, N); ss[bstream.SS["NENT"]] = M
+    xphid = np.array([mpc.phi_max[0], 0, 0])
+    for i in range(len(d[k + "x"])):
+        rb = bstream.robot_record(d[k + "q"][i], d[k + "dq"][i], d[k + "ddq"][i], d[k + "p_lie"][i], d[k + "v"][i], xphid, d[k + "jerk"][i])
+        p, x0 = emu.stream_pack(N, S, T, ss, rb)
+        np.testing.assert_allclose(p[mask], d[k + "p"][i][mask], atol=2e-11, rtol=1e-11, err_msg=f"tick {i}")
+        np.testing.assert_allclose(x0, d[k + "x0"][i], atol=1e-13)
+        g = c_oracle.eval_fg(d[k + "p"][i], d[k + "x"][i], N, S, dt)[1]
+        tr = emu.stream_post(N, S, dt, T, ss, rb.copy(), d[k + "x"][i], g, 0, simulate=False)
+        td, fl = bstream.unpack_traj(tr, N)
+        np.testing.assert_allclose(td["q"], d[k + "traj_q"][i], atol=1e-12)
+        np.testing.assert_allclose(td["p"], d[k + "traj_p"][i], atol=1e-11)
+        assert abs(ss[bstream.SS["PHI"]] - d[k + "phi_current"][i]) < 1e-12
+        _same_rotation(ss[7:10], d[k + "pr_ref"][i], 1e-11)
