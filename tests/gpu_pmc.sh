@@ -1,8 +1,9 @@
 #!/bin/bash
 # Diagnostic (GPU box): PMC counter passes over the bench command, one rocprofv3 run per counter group (no trace domains
-# combined with --pmc); stops at the first pass that fails or times out.  Usage: bash tests/gpu_pmc.sh TAG
+# combined with --pmc); stops at the first pass that fails or times out.  Usage: bash tests/gpu_pmc.sh TAG [extra bench.py arguments]
 set -u
-TAG=$1
+TAG=$1; shift
+EXTRA="$*"
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
@@ -13,7 +14,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
            "SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_MFMA_F64 SQ_ACTIVE_INST_FLAT SQ_INSTS_WAVE32_LDS"; do
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --workers 1 > $OUT/p$i.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --workers 1 $EXTRA > $OUT/p$i.log 2>&1
   rc=$?
   echo "pass $i ($grp) exit $rc"
   if [ $rc -ne 0 ]; then echo "stopping after failed pass $i"; break; fi

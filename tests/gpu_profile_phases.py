@@ -20,7 +20,8 @@ lib.bmpc_solve_batch.argtypes = [vp, ci] + [vp] * 11
 lib.bmpc_get_profile.argtypes = [vp, vp]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-P, X, _ = workload.make_batch(B, seed=0, N=N)
+TIGHT = len(sys.argv) > 3 and sys.argv[3] == "tight"
+P, X, _ = workload.make_batch(B, seed=0, N=N, tight=TIGHT)
 h = vp()
 assert lib.bmpc_create(N, 4, 0.1, None, ctypes.byref(h)) == 0
 p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
@@ -33,6 +34,6 @@ for rep in range(2):
     lib.bmpc_get_profile(h, vp(prof.ctypes.data))
 names = ["eval", "adjoint", "kkt+mu", "qp-gradient", "prepare-rlv", "bwd:node(after p5..)", "bwd:stage-in", "forward", "step-dirs", "ls-trial", "nu-update", "(merged into nc:p1)", "st:S1 M-blocks", "st:S3 schur", "(unused)", "load", "nc:p1 small blocks + stage data", "(merged)", "nc:p2+p3 A1/A2/mu/gl", "nc:p4 block add", "(merged into S0)", "st:S0 q~/PR/U/PE", "st:S0b Mci/m", "st:S2 chol+gains", "bwd:staging burst", "eval:kinematics (2N lanes)", "eval:node refs+objective (N lanes)", "adjoint:node gradients (N lanes)", "step-dirs: row loop", "step-dirs: grad.dz + theta loops"] + [""] * 2
 tot = float(prof.sum()); its = float(it.sum().item())
-print(f"B={B} N={N} wall {dt*1e3:.1f} ms, total iterations {its:.0f}, cycles/iteration (lane-0 stamps, profile build) {tot/its:.0f}")
+print(f"B={B} N={N}{' tight' if TIGHT else ''} wall {dt*1e3:.1f} ms, total iterations {its:.0f}, cycles/iteration (lane-0 stamps, profile build) {tot/its:.0f}")
 for n, c in zip(names, prof):
     if c: print(f"  {n:14s} {100.0*float(c)/tot:5.1f} %   {float(c)/its:9.0f} cycles/iter")
