@@ -112,6 +112,12 @@ def main():
                n10_g_names=np.array(r.g_names))
     # exact derivatives through the reference's code at three points (a solution incl. switch, a perturbed point, random)
     dsel = [tag.index("exp1_tick0_sol"), tag.index("exp2_tick7_pert"), tag.index("random1")]
+    # recorded SOLUTIONS whose KKT conditions the tests certify with these derivatives: ticks around a segment switch, the end of the
+    # path (phi_max active, sigmoid on), experiment 2 with its +-0.01 tube
+    for want in ("exp1_tick1_sol", "exp1_tick45_sol", "exp1_tick46_sol", "exp1_tick%d_sol" % (len(g7[1]["x"]) - 12), "exp2_tick0_sol", "exp2_tick13_sol",
+                 "exp2_tick14_sol", "exp2_tick%d_sol" % (len(g7[2]["x"]) // 2)):
+        if want in tag and tag.index(want) not in dsel:
+            dsel.append(tag.index(want))
     switch_sol = [i for i, t in enumerate(tag) if t.endswith("_sol") and t.startswith("exp1")
                   and len(set(np.searchsorted(P[i][89:94], X[i].reshape(10, 44)[:, 41], side="right"))) > 1]
     if switch_sol:

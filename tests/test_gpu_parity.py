@@ -473,3 +473,19 @@ def test_closed_loop_ticks_against_independent_scipy_solutions(solver):
     rms = np.sqrt(np.mean(dq ** 2, axis=(1, 2)))
     assert rms.max() < 5e-6 and np.median(rms) < 2e-7, rms
     assert np.abs(out["f"] - d["f"]).max() < 1e-7
+
+
+def test_kkt_certificate_with_the_references_own_derivatives(solver):
+    """HIP solutions of recorded closed-loop ticks (cold start, segment switch, end of path, experiment 2's tight tube) are KKT points of
+    the REFERENCE's NLP: stationarity with the gradient / Jacobian obtained by a complex step through the reference's own builder
+    (fixture G9) and the kernel's multipliers."""
+    from tests.test_oracle_golden import _g9_solution_cases, _kkt_residual_with_reference_derivatives
+    cases = _g9_solution_cases()
+    assert len(cases) >= 8
+    for i, j, which, tick in cases:
+        d = np.load(os.path.join(G, f"g7_closedloop_exp{which}.npz"))
+        out = solver.solve_host(d["p"][tick], d["x0"][tick])
+        assert out["status"][0] == 0
+        r = _kkt_residual_with_reference_derivatives(i, j, out["x"][0], out["lam_g"][0], out["lam_x"][0])
+        assert r < 2e-4, (which, tick, r)
+        assert (out["lam_g"][0].reshape(10, 43)[:, 36:] >= 0).all()
