@@ -217,12 +217,14 @@ class BoundMPC:
             w0[:, 29:35] = p0
         else:
             w0 = np.array(self.prev_solution, dtype=float).reshape(N, -1).copy()
-            i_omega = w0[:, 29:35]
-            if np.linalg.norm(p0[3:] - i_omega[0, 3:]) > 1.5:      # integrated-omega unwrap :326-333
-                print("[INFO] Reversing integrated omega")
-                prev_p1 = i_omega[0, 3:].copy()
-                i_omega[:-1, 3:] = p0[3:] + (i_omega[1:, 3:] - prev_p1)
-                i_omega[-1, 3:] = i_omega[-2, 3:]
+            # The measured rotation vector may have flipped to its 2 pi-equivalent since the plan was made (scipy keeps |rotvec| <= pi):
+            # a jump of more than 1.5 rad between it and the plan's first integrated-omega entry re-bases the planned increments on the
+            # measurement (behaviour of BoundMPC.py:326-333; the last stage repeats its predecessor)
+            iw = w0[:, 32:35]
+            if np.linalg.norm(np.asarray(p0)[3:] - iw[0]) > 1.5:
+                increments = iw[1:] - iw[0]
+                iw[:-1] = np.asarray(p0)[3:] + increments
+                iw[-1] = iw[-2]
             if self.updated:                                       # re-projection after a path update :335-369
                 self._prev_cartesian_derivatives()
                 dp_new, p_ref_new = dp_ref[:3, 0], p_ref[:3, 0]
@@ -275,45 +277,47 @@ class BoundMPC:
         return sol, self.solver.stats()
 
     def step(self, q0, dq0, ddq0, p0, v0, x_phi_d, jerk_current, x_des=None):
-        """One optimisation step (BoundMPC.py:306-506)."""
+        """One optimisation step: pack, solve, decide which plan to execute, post-process (behaviour of BoundMPC.py:306-506).
+
+        Plan selection.  A solve counts when the solver reports success or when the summed violation of the constraint bounds
+        (beyond 1e-6 per row) stays below 1e-4.  Otherwise the stored plan is executed once more and `error_count` says how many of
+        its leading stages have been consumed; with no stored plan the infeasible iterate itself is used and the counter restarts.
+        After N failures in a row there is nothing left to replay and five Nones go back to the caller."""
         w0, params, aux = self.pack(q0, dq0, ddq0, p0, v0, x_phi_d, jerk_current)
-        time_start = time.perf_counter()
+        t0 = time.perf_counter()
         sol = self.solver(x0=w0, lbx=self.lbu, ubx=self.ubu, lbg=self.lbg, ubg=self.ubg, p=params)
-        w_curr = np.array(sol['x']).flatten()
-        time_elapsed = time.perf_counter() - time_start
+        candidate = np.asarray(sol['x'], dtype=float).ravel()
+        time_elapsed = time.perf_counter() - t0
         stats = self.solver.stats()
-        iters = stats['iter_count']
-        g = np.array(sol['g']).flatten()
-        lbg, ubg = np.array(self.lbg), np.array(self.ubg)
-        g_viol = -np.sum(g[g < lbg - 1e-6]) + np.sum(g[g > ubg + 1e-6])          # :460-463
-        success = stats['success'] or g_viol < 1e-4                               # :465
-        using_previous = False
-        if not success:
-            self.error_count += 1
-            print(f"[ERROR] Could not find feasible solution. Using previous solution. Error count: {self.error_count}")
-            print(f"Constraint Violation Sum: {g_viol}")
-            print(f"Casadi status: {stats['return_status']}")
-            if self.prev_solution is not None:
-                self.prev_infeasible_solution = w_curr
-                w_opt = np.copy(self.prev_solution)
-                using_previous = True
-            else:
-                print("[WARNING] Previous solution not found, using infeasible solution.")
-                self.error_count = 0
-                w_opt = w_curr
-                using_previous = True
-                self.lam_g0, self.lam_x0 = sol['lam_g'], sol['lam_x']
-                self.prev_infeasible_solution = self.prev_solution
-        else:
+        g = np.asarray(sol['g'], dtype=float).ravel()
+        below = np.asarray(self.lbg, dtype=float) - 1e-6 - g
+        above = g - np.asarray(self.ubg, dtype=float) - 1e-6
+        violation = float(np.sum(g[above > 0]) - np.sum(g[below > 0]))
+        accepted = bool(stats['success']) or violation < 1e-4
+        replay = not accepted
+        if accepted:
             self.error_count = 0
-            w_opt = w_curr
-            self.prev_solution = copy.deepcopy(w_opt)
+            plan = candidate
+            self.prev_solution = candidate.copy()
+            self.prev_infeasible_solution = candidate
             self.lam_g0, self.lam_x0 = sol['lam_g'], sol['lam_x']
-            self.prev_infeasible_solution = w_opt
-        if self.error_count < self.N:
-            traj_data, ref_data, err_data = self.compute_return_data(q0, dq0, ddq0, jerk_current, p0, w_opt, using_previous, aux)
-            return traj_data, ref_data, err_data, time_elapsed, iters
-        return None, None, None, None, None
+        else:
+            self.error_count += 1
+            print(f"[boundmpc_amd] solve rejected ({stats['return_status']}; constraint violation sum {violation:.3e}); "
+                  f"consecutive failures: {self.error_count}")
+            if self.prev_solution is None:
+                print("[boundmpc_amd] no stored plan to fall back on: executing the infeasible iterate")
+                self.error_count = 0
+                plan = candidate
+                self.prev_infeasible_solution = None
+                self.lam_g0, self.lam_x0 = sol['lam_g'], sol['lam_x']
+            else:
+                plan = np.array(self.prev_solution, dtype=float)
+                self.prev_infeasible_solution = candidate
+        if self.error_count >= self.N:
+            return None, None, None, None, None
+        traj_data, ref_data, err_data = self.compute_return_data(q0, dq0, ddq0, jerk_current, p0, plan, replay, aux)
+        return traj_data, ref_data, err_data, time_elapsed, stats['iter_count']
 
     def _prev_cartesian_derivatives(self):
         """Cartesian acceleration / jerk of the previous plan (BoundMPC.py:560-566), evaluated on demand."""
