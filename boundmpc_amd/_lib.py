@@ -8,7 +8,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("BOUNDMPC_HIP_LIB") or os.path.join(HERE, "csrc", "libboundmpc_hip.so")   # override: A/B builds of the same source
 
-SYMBOLS = ["bmpc_default_options", "bmpc_error_string", "bmpc_create", "bmpc_destroy", "bmpc_num_vars", "bmpc_num_cons",
+SYMBOLS = ["bmpc_default_options", "bmpc_default_options_for", "bmpc_error_string", "bmpc_create", "bmpc_destroy", "bmpc_num_vars", "bmpc_num_cons",
            "bmpc_num_params", "bmpc_get_bounds", "bmpc_solve_batch", "bmpc_solve_batch_host", "bmpc_set_timing",
            "bmpc_last_kernel_ms", "bmpc_launch_info", "bmpc_state_len", "bmpc_solve_batch_warm", "bmpc_graph_create",
            "bmpc_graph_launch", "bmpc_graph_destroy", "bmpc_stream_lengths", "bmpc_stream_pack", "bmpc_stream_post",
@@ -42,6 +42,7 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
     lib.bmpc_default_options.argtypes = [ctypes.POINTER(Options)]
+    lib.bmpc_default_options_for.argtypes = [ctypes.c_int, ctypes.POINTER(Options)]
     lib.bmpc_error_string.restype = ctypes.c_char_p
     lib.bmpc_error_string.argtypes = [ci]
     lib.bmpc_create.argtypes = [ci, ci, cd, ctypes.POINTER(Options), ctypes.POINTER(vp)]

@@ -107,6 +107,11 @@ extern "C" int bmpc_default_options(bmpc_options *o) {
     o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0; o->mu_warm = 1e-2; o->stall_window = 40;
     return BMPC_OK;
 }
+extern "C" int bmpc_default_options_for(int N, bmpc_options *o) {
+    const int rc = bmpc_default_options(o);
+    if (rc == BMPC_OK && N > 11) o->mu_init = 0.3;       // long horizons: a cold start far from the solution wants a more central first barrier level
+    return rc;
+}
 extern "C" const char *bmpc_error_string(int c) {
     switch (c) { case BMPC_OK: return "ok"; case BMPC_ERR_ARG: return "invalid argument"; case BMPC_ERR_HIP: return "HIP runtime error";
                  case BMPC_ERR_NOGPU: return "no HIP device available"; default: return "unknown error"; }
@@ -120,7 +125,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     if (!h) return BMPC_ERR_ARG;
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->have_ev = 0; h->latency_us = nullptr;
     h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->prof = nullptr; h->stage_d = nullptr; h->stage_i = nullptr; h->stage_cap = 0;
-    if (opts) h->o = *opts; else bmpc_default_options(&h->o);
+    if (opts) h->o = *opts; else bmpc_default_options_for(N, &h->o);
     int dev = 0, per_cu = 0; hipDeviceProp_t prop;
     bool ok = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess;
     if (ok) ok = (N <= 11 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel<true>, 64, 0)

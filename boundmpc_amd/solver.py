@@ -14,10 +14,12 @@ NZ, NG = 44, 43
 
 
 class BatchedOCPSolver:
-    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=0.1, slack_push=1e-2, exact_hessian=True, mu_warm=1e-2, stall_window=40):
+    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=None, slack_push=1e-2, exact_hessian=True, mu_warm=1e-2, stall_window=40):
         self._lib = _lib.load()
         o = _lib.Options()
-        self._lib.bmpc_default_options(ctypes.byref(o))
+        self._lib.bmpc_default_options_for(int(N), ctypes.byref(o))      # mu_init 0.1 for N <= 11, 0.3 for longer horizons
+        if mu_init is None:
+            mu_init = o.mu_init
         o.tol, o.max_iter, o.mu_init, o.slack_push, o.exact_hessian = tol, int(max_iter), mu_init, slack_push, int(exact_hessian)
         o.mu_warm = mu_warm
         o.stall_window = int(stall_window)

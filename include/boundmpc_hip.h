@@ -46,7 +46,8 @@ typedef struct bmpc_handle bmpc_handle;
 typedef struct {
     double tol;         /* KKT tolerance, Ipopt-style scaled error (reference: 'tol': 10e-6, BoundMPC.py:121); default 1e-8 */
     int max_iter;       /* reference: 500 (BoundMPC.py:122) */
-    double mu_init;     /* initial barrier parameter (Ipopt default 0.1) */
+    double mu_init;     /* initial barrier parameter: 0.1 (Ipopt's default) for N <= 11, 0.3 for longer horizons, whose cold start is far
+                           from the solution (N=30 tight: 98 % instead of 95 % converged, 39 instead of 46 iterations); see bmpc_default_options_for */
     double mu_min_fac;  /* final barrier = tol * mu_min_fac */
     double slack_push;  /* minimum initial slack of an inequality row (Ipopt bound_push 1e-2) */
     int exact_hessian;  /* 1: exact Lagrangian Hessian (reference uses CasADi's exact Hessian); 0: Gauss-Newton */
@@ -58,7 +59,8 @@ typedef struct {
 
 enum { BMPC_OK = 0, BMPC_ERR_ARG = 1, BMPC_ERR_HIP = 2, BMPC_ERR_NOGPU = 4 };
 
-int bmpc_default_options(bmpc_options *o);
+int bmpc_default_options(bmpc_options *o);                 /* the N <= 11 defaults */
+int bmpc_default_options_for(int N, bmpc_options *o);      /* defaults for horizon N; what bmpc_create(…, NULL, …) uses */
 const char *bmpc_error_string(int code);
 
 /* N horizon (1..32), S path segments in the window (2..4), dt sampling time */
