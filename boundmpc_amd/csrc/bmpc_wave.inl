@@ -510,7 +510,10 @@ BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
     W.ca = 2 * L[L_PAR + po.w + 5] / (W.h * W.h); W.cb = 2 * L[L_PAR + po.w + 5] / W.h;
 }
 
-constexpr int RU = 6;   // rows of a lane-strided pass kept in flight per lane (loads of a batch are issued before their first use)
+#ifndef BMPC_RU
+#define BMPC_RU 9   // N=10: all 570 rows of a pass in one trip per lane (6: two trips; 10 starts to spill); +2 % (profiles/r02_n_rows_in_flight_ab.txt)
+#endif
+constexpr int RU = BMPC_RU;   // rows of a lane-strided pass kept in flight per lane (loads of a batch are issued before their first use)
 struct LaneRegs { double mc[16]; double pf[24]; };   // pf: software prefetch of the next stage's inputs (global -> registers -> LDS)   // a lane's 4x4 state block of M, kept in registers between the M and the Schur phases
 
 // ----------------------------------------------------------------------------------------
