@@ -83,6 +83,9 @@ def apply_update(ss, N, S, pos_points, rot_points, pos_lim, rot_lim, bp1, br1, s
     from .reference_path import ReferencePath
     from .bound_mpc import integrate_rotation_reference
     rp = ReferencePath(pos_points, rot_points, pos_lim, rot_lim, bp1, br1, s, e_p_min, e_r_min, e_p_max, e_r_max, S)
+    if entries is not None and len(rp.p) > entries:
+        raise ValueError(f"the new path has {len(rp.p)} table entries, the stream batch was built for {entries}: construct the StreamBatch "
+                         "with the longest path it will ever follow")
     T, M = path_table(rp, entries)
     dp0 = rp.dp[0] / np.linalg.norm(rp.dp[0])
     phi = float((np.asarray(p0, dtype=float)[:3] - np.asarray(pos_points[0], dtype=float)) @ dp0)
