@@ -43,7 +43,12 @@ namespace bmpc {
 // dimensions and index maps
 // ----------------------------------------------------------------------------------------
 constexpr int NZ = 44, NG = 43, NE = 36, NS = 35, NU = 8, NW = 43, NI = 57, SMAX = 4, NPMAX = 141 + 91 * SMAX;
-#define GN_MU_GATE 0.05  // Gauss-Newton fallback of the inertia correction only while mu >= GN_MU_GATE (first barrier level)
+#define GN_MU_GATE 0.05      // Gauss-Newton fallback of the inertia correction only while mu >= GN_MU_GATE (first barrier level)
+#define GN_PROBE 3           // while the fallback keeps being needed, every GN_PROBE-th iteration tries the exact Hessian again
+#define DELTA_FIRST 1e-3     // inertia correction constants of oracle/bmpc_oracle.c
+#define DELTA_UP_FIRST 10.0
+#define DELTA_KEEP_MIN 1e-5
+#define STALL_FACTOR 0.5     // stall test: primal infeasibility must halve per stall_window iterations
 #define KAPPA_EPS 100.0   // barrier problem "solved" at KKT error <= KAPPA_EPS * mu (oracle/bmpc_oracle.c; Ipopt barrier_tol_factor)
 enum { ZJ = 0, ZJPHI = 7, ZQ = 8, ZDQ = 15, ZDDQ = 22, ZPOS = 29, ZIW = 32, ZV = 35, ZW = 38, ZPHI = 41, ZDPHI = 42, ZDDPHI = 43 };
 enum { GQ = 0, GDQ = 7, GDDQ = 14, GPOS = 21, GIW = 24, GV = 27, GW = 30, GPHI = 33, GDPHI = 34, GDDPHI = 35 };
@@ -1735,7 +1740,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     const double mu_state = pr.state ? pr.state[ni] : 0.0;
     const bool warm = mu_state > 0.0;
     double mu = warm ? BMPC_FMIN(o.mu_init, BMPC_FMAX(mu_state, o.mu_warm)) : o.mu_init; const double mu_min = o.tol * o.mu_min_fac;
-    double delta_last = 0.0, filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0;
+    double delta_last = 0.0, delta_prev = 0.0, filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0, gn_run = 0;
     BMPC_PROF(W, 15);
     double fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);
     BMPC_PROF(W, 0);
@@ -1797,7 +1802,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         // stalled primal feasibility -> status 2, numerical breakdown -> status 3 (oracle/bmpc_oracle.c solve_one)
         if (it == 0) ep_old = ep_mid = 1e300;
         else if (o.stall_window > 0 && it % (o.stall_window / 2) == 0) {
-            if (it >= o.stall_window && ep >= 0.9 * ep_old && ep > 1e-6) { status = 2; break; }
+            if (it >= o.stall_window && ep >= STALL_FACTOR * ep_old && ep > 1e-6) { status = 2; break; }
             ep_old = ep_mid; ep_mid = ep;
         }
         if (!(ed < 1e12)) { status = 3; break; }
@@ -1812,26 +1817,38 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         BMPC_PROF(W, 3);
         wave_prepare_rlv(W, sc);
         BMPC_PROF(W, 4);
+        // Inertia control (oracle/bmpc_oracle.c solve_one).  A failed factorisation costs most of a Riccati sweep (the indefinite
+        // 8x8 block usually shows up at the first stages, the END of the backward sweep), so the attempts are chosen to fail rarely:
+        // an iteration that follows a regularised one starts from a third of its delta instead of 0; while the Gauss-Newton
+        // fallback (first barrier level, long horizons) keeps being needed, the following iterations start from the Gauss-Newton
+        // Hessian directly and only every GN_PROBE-th tries the exact one again.
         double delta = 0.0; bool ok = false, used_gn = false; const int ex_saved = W.o.exact_hessian;
+        if (delta_prev > 0.0) { delta = delta_prev / 3.0; if (delta < DELTA_KEEP_MIN) delta = 0.0; }
+        // The node records carry the exact-Hessian entries, so for the Gauss-Newton matrix they are rebuilt with the flag off (same
+        // f, g, h); the flag stays off until the factorisation of this iteration has succeeded, the next evaluation restores the
+        // exact entries.  Long horizons only (N > 11 <=> !ZLDS, a compile-time property of this instantiation): the short-horizon
+        // kernel never met the case on any test batch, and carrying the extra path there costs registers (scratch 44 -> 312 B/lane).
+        const bool gn_allowed = !zlds && ex_saved && mu >= GN_MU_GATE;
+        if (gn_allowed && gn_run > 0 && gn_run % GN_PROBE != GN_PROBE - 1) {
+            used_gn = true; W.o.exact_hessian = 0;
+            wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);
+        }
         for (int tries = 0; tries < 40; tries++) {
             if (wave_backward_blk(W, po, sc, mu, delta, LRs)) { ok = true; break; }
-            // first barrier level only: one attempt with the Gauss-Newton Hessian before regularising (oracle/bmpc_oracle.c solve_one).
-            // The node records carry the exact-Hessian entries, so they are rebuilt with the flag off (same f, g, h); the flag stays
-            // off until the factorisation of this iteration has succeeded, the next evaluation restores the exact entries.
-            // Long horizons only (N > 11 <=> !ZLDS, a compile-time property of this instantiation): the short-horizon kernel never
-            // met the case on any test batch, and carrying the extra path there costs registers (scratch 44 -> 312 B/lane, +1.7 %).
-            if (!zlds && !used_gn && ex_saved && mu >= GN_MU_GATE) {
+            if (gn_allowed && !used_gn) {
                 used_gn = true; W.o.exact_hessian = 0;
                 wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);
-                if (wave_backward_blk(W, po, sc, mu, 0.0, LRs)) { ok = true; break; }
+                if (wave_backward_blk(W, po, sc, mu, 0.0, LRs)) { ok = true; delta = 0.0; break; }
             }
-            if (delta == 0.0) delta = delta_last > 0 ? BMPC_FMAX(1e-20, delta_last / 3.0) : 1e-4;
-            else delta *= (delta_last > 0 ? 8.0 : 100.0);
+            if (delta == 0.0) delta = delta_last > 0 ? BMPC_FMAX(1e-20, delta_last / 3.0) : DELTA_FIRST;
+            else delta *= (delta_last > 0 ? 8.0 : DELTA_UP_FIRST);
             if (delta > 1e20) break;
         }
+        gn_run = (used_gn && ok) ? gn_run + 1 : 0;
         W.o.exact_hessian = ex_saved;
         if (!ok) { status = 3; break; }
         if (delta > 0) delta_last = delta;
+        delta_prev = delta;
         BMPC_PROF(W, 6);
         wave_forward(W, sc, LRs);
         BMPC_PROF(W, 7);

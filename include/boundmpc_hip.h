@@ -53,7 +53,7 @@ typedef struct {
     int exact_hessian;  /* 1: exact Lagrangian Hessian (reference uses CasADi's exact Hessian); 0: Gauss-Newton */
     int verbose;
     double mu_warm;     /* warm start (bmpc_solve_batch_warm): the barrier restarts at clamp(stored mu, mu_warm, mu_init); default 1e-2 (round 2: closed loops converge in 9.5 instead of 11.2 iterations with it; 1e-4 jams the iterate against moved constraints) */
-    int stall_window;   /* status 2 when the primal infeasibility made < 10 % progress over this many iterations (checked every
+    int stall_window;   /* status 2 when the primal infeasibility has not halved over this many iterations (checked every
                            stall_window/2 iterations); 0 = never; default 40 (reference: Ipopt's restoration phase / "local infeasibility") */
 } bmpc_options;
 

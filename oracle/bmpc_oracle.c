@@ -61,6 +61,11 @@ static const double DQ_LIM_DEG[7] = {85, 85, 100, 75, 130, 135, 135};
 #define U_LIM 35.0
 #define GN_MU_GATE 0.05
 #define GN_MIN_HORIZON 11 /* long horizons only (the kernel's N <= 11 instantiation does not carry the path) */
+#define DELTA_FIRST 1e-3   /* first regularisation tried by a solve, escalated by DELTA_UP_FIRST until the factorisation succeeds */
+#define DELTA_UP_FIRST 10.0
+#define DELTA_KEEP_MIN 1e-5  /* an iteration that follows a regularised one starts from a third of its delta (no attempt at 0) down to this */
+#define GN_PROBE 3         /* after a Gauss-Newton fallback the following iterations start from the Gauss-Newton Hessian; every GN_PROBE-th tries the exact one again */
+#define STALL_FACTOR 0.5
 #define KAPPA_EPS 100.0 /* barrier problem "solved" when its KKT error <= KAPPA_EPS * mu (Ipopt barrier_tol_factor, default 10) */
 #define PI 3.14159265358979323846
 
@@ -896,7 +901,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
     memcpy(W->Z, x0, sizeof(double) * N * NZ);
     const int warm = state && state[N * NI] > 0.0;
     double mu = warm ? fmin(o->mu_init, fmax(state[N * NI], o->mu_warm)) : o->mu_init;
-    double mu_min = o->tol * o->mu_min_fac, delta_last = 0.0;
+    double mu_min = o->tol * o->mu_min_fac, delta_last = 0.0, delta_prev = 0.0; int gn_run = 0;
     double filt_th[32], filt_ph[32], filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0;
     W->f = eval_values(C, P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0);
     for (int i = 0; i < N * NI; i++) {
@@ -918,11 +923,13 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         if (it == o->max_iter) break;
         /* stalled primal feasibility (what Ipopt reports as "converged to a point of local infeasibility" after its restoration
          * phase): every stall_window/2 iterations the primal infeasibility is compared with its value stall_window iterations
-         * earlier; less than 10 % progress ends the solve with status 2.  Never fires on problems that converge in < 40 iterations.
+         * earlier; a reduction by less than STALL_FACTOR ends the solve with status 2.  Never fires on problems that converge in < 40
+         * iterations.  (0.5: on the tight long-horizon batch the problems that creep on at 10-30 % per window end as status 2 anyway,
+         * after 150-320 iterations, and a batch launch lasts as long as its slowest problem.)
          * A dual residual beyond 1e12 is a numerical breakdown (status 3). */
         if (it == 0) ep_old = ep_mid = 1e300;
         else if (o->stall_window > 0 && it % (o->stall_window / 2) == 0) {
-            if (it >= o->stall_window && ep >= 0.9 * ep_old && ep > 1e-6) { status = 2; break; }
+            if (it >= o->stall_window && ep >= STALL_FACTOR * ep_old && ep > 1e-6) { status = 2; break; }
             ep_old = ep_mid; ep_mid = ep;
         }
         if (!(ed < 1e12)) { status = 3; break; }
@@ -936,25 +943,38 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
             nuh[i] = (mu + W->nu[i] * (W->hin[i] + W->t[i])) / W->t[i];
         }
         build_qp(C, P, W, sg, nuh);
+        /* Inertia control.  A failed factorisation costs most of a Riccati sweep (the indefinite 8x8 block usually shows up at the
+         * first stages, i.e. at the END of the backward sweep), so the attempts are chosen to fail rarely:
+         *  - an iteration that follows a regularised one does not try delta = 0 again but a third of the last delta (Ipopt's
+         *    kappa_w^-), until that drops below DELTA_KEEP_MIN;
+         *  - far from the solution (first barrier level, long horizons) an indefinite exact Hessian is mostly the kinematic
+         *    curvature weighted with meaningless multipliers: the Gauss-Newton Hessian (positive semidefinite by construction) is
+         *    tried once before regularising, and while that fallback keeps being needed the following iterations start from it
+         *    directly (every GN_PROBE-th tries the exact Hessian again).  Never below GN_MU_GATE, only for N > GN_MIN_HORIZON. */
         double delta = 0.0; int ok = 0, used_gn = 0;
+        if (delta_prev > 0.0) { delta = delta_prev / 3.0; if (delta < DELTA_KEEP_MIN) delta = 0.0; }
+        const int gn_allowed = N > GN_MIN_HORIZON && C->o.exact_hessian && mu >= GN_MU_GATE;
+        if (gn_allowed && gn_run > 0 && gn_run % GN_PROBE != GN_PROBE - 1) {
+            used_gn = 1;
+            Cfg Cgn = *C; Cgn.o.exact_hessian = 0;      /* C is shared between the OpenMP threads: never modified */
+            build_qp(&Cgn, P, W, sg, nuh);
+        }
         for (int tries = 0; tries < 40; tries++) {
             if (riccati(C, W, delta)) { ok = 1; break; }
-            /* far from the solution (first barrier level) an indefinite exact Hessian is mostly the kinematic curvature weighted with
-             * meaningless multipliers: try the Gauss-Newton Hessian (positive semidefinite by construction) once before regularising;
-             * the delta escalation below continues on it if that fails too.  Never taken once mu has dropped below GN_MU_GATE, and only for
-             * horizons N > GN_MIN_HORIZON (a cold start over a long horizon is what produces the case). */
-            if (N > GN_MIN_HORIZON && !used_gn && C->o.exact_hessian && mu >= GN_MU_GATE) {
+            if (gn_allowed && !used_gn) {
                 used_gn = 1;
-                Cfg Cgn = *C; Cgn.o.exact_hessian = 0;      /* C is shared between the OpenMP threads: never modified */
+                Cfg Cgn = *C; Cgn.o.exact_hessian = 0;
                 build_qp(&Cgn, P, W, sg, nuh);
-                if (riccati(C, W, 0.0)) { ok = 1; break; }
+                if (riccati(C, W, 0.0)) { ok = 1; delta = 0.0; break; }
             }
-            if (delta == 0.0) delta = delta_last > 0 ? fmax(1e-20, delta_last / 3.0) : 1e-4;
-            else delta *= (delta_last > 0 ? 8.0 : 100.0);
+            if (delta == 0.0) delta = delta_last > 0 ? fmax(1e-20, delta_last / 3.0) : DELTA_FIRST;
+            else delta *= (delta_last > 0 ? 8.0 : DELTA_UP_FIRST);
             if (delta > 1e20) break;
         }
+        gn_run = (used_gn && ok) ? gn_run + 1 : 0;
         if (!ok) { status = 3; break; }
         if (delta > 0) delta_last = delta;
+        delta_prev = delta;
         /* slack and multiplier directions, fraction to the boundary */
         double tau = fmax(0.99, 1.0 - mu), ap = 1.0, ad = 1.0, dbar = 0;
         for (int k = 0; k < N; k++) {
