@@ -153,3 +153,18 @@ def test_emu_newton_direction_equals_oracle_dense_solve(N):
     np.testing.assert_allclose(KT, Kg, atol=1e-12)
     np.testing.assert_allclose(scr[off["KF"]:off["KF"] + 8 * N], kff.ravel(), atol=1e-12)
     np.testing.assert_allclose(scr[off["DZ"]:off["DZ"] + 44 * N], dZ, atol=1e-12)
+
+
+def test_infeasible_problem_ends_as_status_2_in_oracle_and_emulator():
+    """phi_max < 0 <= phi (casadi_ocp_formulation.py:307-310 against the bound phi >= 0, :145-147): no feasible point.  The stall test
+    ends the solve with status 2 at the same iteration in both builds ("failure is data", BoundMPC.py:465-489); with the test switched
+    off the solve runs into the iteration cap (status 1)."""
+    d = np.load(os.path.join(G, "g7_closedloop_exp1.npz"))
+    p, x0 = d["p"][:2].copy(), d["x0"][:2].copy()
+    p[:, 460] = -1.0
+    o, e = c_oracle.solve(p, x0, 10, 4, 0.1), emu.solve(p, x0, 10, 4, 0.1)
+    assert (o["status"] == 2).all() and (e["status"] == 2).all()
+    assert (o["iters"] == e["iters"]).all() and (o["iters"] % 20 == 0).all() and (o["iters"] >= 40).all()
+    assert np.isfinite(o["x"]).all() and np.isfinite(e["x"]).all()
+    off = c_oracle.solve(p, x0, 10, 4, 0.1, c_oracle.default_opts(stall_window=0, max_iter=90))
+    assert (off["status"] == 1).all() and (off["iters"] == 90).all()

@@ -339,6 +339,21 @@ def test_gauss_newton_option_matches_oracle():
 
 
 @pytest.mark.gpu
+def test_infeasible_problem_ends_as_status_2_like_the_oracle(solver):
+    """phi_max < 0 <= phi: no feasible point.  Status 2 (stalled at a point of local infeasibility) at the oracle's iteration, finite outputs,
+    and the feasible problems of the same batch are not disturbed."""
+    from oracle import c_oracle
+    d = np.load(os.path.join(G, "g7_closedloop_exp1.npz"))
+    p, x0 = d["p"][:6].copy(), d["x0"][:6].copy()
+    p[1, 460] = p[4, 460] = -1.0
+    o, ref = solver.solve_host(p, x0), c_oracle.solve(p, x0, 10, 4, 0.1)
+    assert list(o["status"]) == [0, 2, 0, 0, 2, 0] == list(ref["status"])
+    assert np.abs(o["iters"] - ref["iters"]).max() <= 1 and np.isfinite(o["x"]).all()
+    ok = o["status"] == 0
+    assert _rms_q(o["x"][ok], d["x"][:6][ok]) < TOL_Q_RMS
+
+
+@pytest.mark.gpu
 def test_second_seed_against_oracle():
     """A second synthetic batch (seed 1, 512 problems): same statuses, iteration counts within one, joint trajectories within 1e-6 rad
     per problem of the CPU oracle (tests/gpu_soak.py runs the long version of this check)."""
