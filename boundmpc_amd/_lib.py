@@ -10,7 +10,7 @@ LIB_PATH = os.environ.get("BOUNDMPC_HIP_LIB") or os.path.join(HERE, "csrc", "lib
 
 SYMBOLS = ["bmpc_default_options", "bmpc_default_options_for", "bmpc_error_string", "bmpc_create", "bmpc_destroy", "bmpc_num_vars", "bmpc_num_cons",
            "bmpc_num_params", "bmpc_get_bounds", "bmpc_solve_batch", "bmpc_solve_batch_host", "bmpc_set_timing",
-           "bmpc_last_kernel_ms", "bmpc_launch_info", "bmpc_state_len", "bmpc_solve_batch_warm", "bmpc_graph_create",
+           "bmpc_last_kernel_ms", "bmpc_kernel_ms", "bmpc_launch_info", "bmpc_state_len", "bmpc_solve_batch_warm", "bmpc_graph_create",
            "bmpc_graph_launch", "bmpc_graph_destroy", "bmpc_stream_lengths", "bmpc_stream_pack", "bmpc_stream_post",
            "bmpc_stream_graph_create", "bmpc_set_latency_buffer"]
 
@@ -64,6 +64,7 @@ def load():
     lib.bmpc_set_latency_buffer.argtypes = [vp, vp]
     lib.bmpc_set_timing.argtypes = [vp, ci]
     lib.bmpc_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
+    lib.bmpc_kernel_ms.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float)]
     lib.bmpc_launch_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_longlong)]
     _lib = lib
     return lib

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
 struct bmpc_handle {
     int N, S; double h; bmpc_options o;
     int grid; long long scr_stride; double *scratch; int scr_waves; int graphs_alive; int *counter; unsigned long long *prof;
-    int timing; hipEvent_t ev0, ev1; int have_ev;
+    int timing; hipEvent_t *ev; int nev; long long n_timed;   // timing = number of launches whose {start, stop} event pairs are kept (ring)
     double *latency_us;
     double *stage_d; int *stage_i; int stage_cap;   // device staging of the host-buffer path
 };
@@ -123,7 +123,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BMPC_ERR_NOGPU;
     bmpc_handle *h = new (std::nothrow) bmpc_handle();
     if (!h) return BMPC_ERR_ARG;
-    h->N = N; h->S = S; h->h = dt; h->timing = 0; h->have_ev = 0; h->latency_us = nullptr;
+    h->N = N; h->S = S; h->h = dt; h->timing = 0; h->ev = nullptr; h->nev = 0; h->n_timed = 0; h->latency_us = nullptr;
     h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->prof = nullptr; h->stage_d = nullptr; h->stage_i = nullptr; h->stage_cap = 0;
     if (opts) h->o = *opts; else bmpc_default_options_for(N, &h->o);
     int dev = 0, per_cu = 0; hipDeviceProp_t prop;
@@ -150,7 +150,8 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
 }
 extern "C" int bmpc_destroy(bmpc_handle *h) {
     if (!h) return BMPC_ERR_ARG;
-    if (h->have_ev) { hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); }
+    for (int i = 0; i < 2 * h->nev; i++) hipEventDestroy(h->ev[i]);
+    delete[] h->ev;
     hipFree(h->scratch); hipFree(h->counter); hipFree(h->prof); hipFree(h->stage_d); hipFree(h->stage_i);
     delete h;
     return BMPC_OK;
@@ -193,6 +194,17 @@ static int ensure_scratch(bmpc_handle *h, int waves) {
     return BMPC_OK;
 }
 
+// event pair of the next timed launch (ring of h->timing pairs, created on first use)
+static int timing_slot(bmpc_handle *h, hipEvent_t **pair) {
+    if (h->nev < h->timing) {
+        hipEvent_t *ne = new hipEvent_t[2 * h->timing];
+        for (int i = 0; i < 2 * h->nev; i++) ne[i] = h->ev[i];
+        for (int i = 2 * h->nev; i < 2 * h->timing; i++) HIPCHK(hipEventCreate(&ne[i]));
+        delete[] h->ev; h->ev = ne; h->nev = h->timing;
+    }
+    *pair = h->ev + 2 * (h->n_timed % h->timing);
+    return BMPC_OK;
+}
 // fills the kernel arguments and enqueues {reset of the work-queue counter, solver kernel} on `st`
 static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g, double *lam_g,
                          double *lam_x, double *f, int *iters, int *status, double *kkt, hipStream_t st, bool timed) {
@@ -205,14 +217,12 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     if (grid > h->scr_waves) return BMPC_ERR_ARG;      // callers reserve the workspace first (never inside a stream capture)
     a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter; a.prof = h->prof;
     HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), st));
-    if (timed) {
-        if (!h->have_ev) { HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1)); h->have_ev = 1; }
-        HIPCHK(hipEventRecord(h->ev0, st));
-    }
+    hipEvent_t *pair = nullptr;
+    if (timed) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
     if (h->N <= 11) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, a);
     else hipLaunchKernelGGL(bmpc_solve_kernel<false>, dim3(grid), dim3(64), 0, st, a);
     HIPCHK(hipGetLastError());
-    if (timed) HIPCHK(hipEventRecord(h->ev1, st));
+    if (timed) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }
     return BMPC_OK;
 }
 
@@ -262,12 +272,10 @@ extern "C" int bmpc_graph_create(bmpc_handle *h, int B, const double *p, const d
 extern "C" int bmpc_graph_launch(bmpc_graph *gr, void *hip_stream) {
     if (!gr) return BMPC_ERR_ARG;
     bmpc_handle *h = gr->h; hipStream_t st = (hipStream_t)hip_stream;
-    if (h->timing) {
-        if (!h->have_ev) { HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1)); h->have_ev = 1; }
-        HIPCHK(hipEventRecord(h->ev0, st));
-    }
+    hipEvent_t *pair = nullptr;
+    if (h->timing) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
     HIPCHK(hipGraphLaunch(gr->exec, st));
-    if (h->timing) HIPCHK(hipEventRecord(h->ev1, st));
+    if (h->timing) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }
     return BMPC_OK;
 }
 extern "C" int bmpc_graph_destroy(bmpc_graph *gr) {
@@ -319,13 +327,19 @@ extern "C" int bmpc_solve_batch_host(bmpc_handle *h, int B, const double *p, con
 }
 
 extern "C" int bmpc_set_latency_buffer(bmpc_handle *h, double *latency_us) { if (!h) return BMPC_ERR_ARG; h->latency_us = latency_us; return BMPC_OK; }
-extern "C" int bmpc_set_timing(bmpc_handle *h, int enable) { if (!h) return BMPC_ERR_ARG; h->timing = enable ? 1 : 0; return BMPC_OK; }
-extern "C" int bmpc_last_kernel_ms(bmpc_handle *h, float *ms) {
-    if (!h || !ms || !h->have_ev) return BMPC_ERR_ARG;
-    HIPCHK(hipEventSynchronize(h->ev1));
-    HIPCHK(hipEventElapsedTime(ms, h->ev0, h->ev1));
+extern "C" int bmpc_set_timing(bmpc_handle *h, int keep) {
+    if (!h || keep < 0 || keep > 65536) return BMPC_ERR_ARG;
+    h->timing = keep; h->n_timed = 0;
     return BMPC_OK;
 }
+extern "C" int bmpc_kernel_ms(bmpc_handle *h, int back, float *ms) {
+    if (!h || !ms || back < 0 || h->timing <= 0 || back >= h->timing || back >= h->n_timed) return BMPC_ERR_ARG;
+    hipEvent_t *pair = h->ev + 2 * ((h->n_timed - 1 - back) % h->timing);
+    HIPCHK(hipEventSynchronize(pair[1]));
+    HIPCHK(hipEventElapsedTime(ms, pair[0], pair[1]));
+    return BMPC_OK;
+}
+extern "C" int bmpc_last_kernel_ms(bmpc_handle *h, float *ms) { return bmpc_kernel_ms(h, 0, ms); }
 // ---- receding-horizon streams: device-side packing / post-processing, one 64-lane wave per stream ----
 __global__ void __launch_bounds__(64) bmpc_stream_pack_kernel(int N, int S, int B, const double *path, int path_stride, double *ss, const double *rb,
                                                              double *p, double *x0, double *dual) {

@@ -58,18 +58,23 @@ class BatchedOCPSolver:
         self._lib.bmpc_launch_info(self._h, ctypes.byref(g), ctypes.byref(l), ctypes.byref(s))
         return dict(grid=g.value, lds_bytes=l.value, scratch_bytes=s.value)
 
-    def set_timing(self, on=True):
-        self._lib.bmpc_set_timing(self._h, int(on))
+    def set_timing(self, keep=1):
+        """HIP events around the solver kernel on its launch stream; the pairs of the last `keep` launches are kept (0/False = off)."""
+        _lib.check(self._lib.bmpc_set_timing(self._h, int(keep)), "bmpc_set_timing")
 
     def set_latency_buffer(self, buf):
         """buf: float64 GPU tensor [>= B] that receives each solve's in-kernel duration in microseconds, or None."""
         self._lat = buf          # keep it alive while registered
         _lib.check(self._lib.bmpc_set_latency_buffer(self._h, ctypes.c_void_p(buf.data_ptr()) if buf is not None else None), "bmpc_set_latency_buffer")
 
-    def last_kernel_ms(self):
+    def kernel_ms(self, back=0):
+        """duration of the launch `back` launches ago (waits for its stop event only)."""
         ms = ctypes.c_float()
-        _lib.check(self._lib.bmpc_last_kernel_ms(self._h, ctypes.byref(ms)), "bmpc_last_kernel_ms")
+        _lib.check(self._lib.bmpc_kernel_ms(self._h, int(back), ctypes.byref(ms)), "bmpc_kernel_ms")
         return ms.value
+
+    def last_kernel_ms(self):
+        return self.kernel_ms(0)
 
     # ---- dual state of a receding-horizon stream (bmpc_solve_batch_warm) ----
     def new_state(self, B, device="cuda"):

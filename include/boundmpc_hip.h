@@ -136,9 +136,12 @@ int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *path, int path
 int bmpc_solve_batch_host(bmpc_handle *h, int B, const double *p, const double *x0, double *x, double *g, double *lam_g, double *lam_x,
                           double *f, int *iters, int *status, double *kkt);
 
-/* Timing of the solver kernel with HIP events on the launch stream: enable, solve, then read the
- * duration of the last launch (synchronises on the stop event). */
-int bmpc_set_timing(bmpc_handle *h, int enable);
+/* Timing of the solver kernel with HIP events on the launch stream.  bmpc_set_timing(h, keep): the {start, stop} event pairs of the
+ * last `keep` launches are kept (0 = off; 1 = the last launch only), so a caller can enqueue a run of launches back to back and read
+ * the durations afterwards.  bmpc_kernel_ms(h, back, &ms): duration of the launch `back` launches ago (0 = the last; synchronises on
+ * its stop event); bmpc_last_kernel_ms = bmpc_kernel_ms(h, 0, .). */
+int bmpc_set_timing(bmpc_handle *h, int keep);
+int bmpc_kernel_ms(bmpc_handle *h, int back, float *ms);
 int bmpc_last_kernel_ms(bmpc_handle *h, float *ms);
 /* Per-solve latency: while a DEVICE buffer [>= B] is registered, every solve stores its own in-kernel duration in microseconds
  * (wall-clock counter read when a wavefront takes the problem from the queue and when it has written the outputs); NULL = off. */
