@@ -10,7 +10,7 @@ re-integration, phi / rotation-reference advance, kinematic plant step).  Timed 
 
 Modes: converged (solve to tol every tick, cold duals = what the reference does with Ipopt), warm (dual state carried),
 rt-tolX-capK (cold duals, loose tolerance X, at most K iterations per tick, a capped iterate is applied as it is), rtw-* (the same with
-the dual state carried),
+the dual state carried; rtgn-*: and the Gauss-Newton Hessian),
 rti-K (K Newton steps per tick from the carried primal-dual state).  For every mode the closed-loop result is compared
 with the converged loop: RMS joint deviation over all ticks, and path progress phi after the last tick.  Independently of how far
 the loops have drifted apart, every tick's applied plan is also compared with the converged solution OF THE SAME PROBLEM (same p,
@@ -61,10 +61,18 @@ def main():
     for cap in (7, 6, 5, 4, 3):
         rtw[cap] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=cap, mu_warm=args.rt_mu_warm)
         rtw[cap].set_timing(True)
+    # warm real-time modes with the Gauss-Newton Hessian (the classical choice of real-time iteration schemes): positive semidefinite by
+    # construction, so no tick ever repeats a Riccati sweep after a failed factorisation
+    rtgn = {}
+    for cap in (6, 5, 4, 3):
+        rtgn[cap] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=cap, mu_warm=args.rt_mu_warm, exact_hessian=False)
+        rtgn[cap].set_timing(True)
     evaluate = BatchedOCPSolver(10, 4, 0.1, max_iter=0)       # f, g at a given point (no iteration)
+    reference = BatchedOCPSolver(10, 4, 0.1, tol=args.tol, max_iter=args.max_iter)    # every tick's problem solved to tolerance, untimed
     res, ref_q = [], None
     modes = [("converged", solver, 0, False), ("warm", solver, 0, True)] \
         + [(f"rtw-tol{args.rt_tol:g}-cap{c}", rtw[c], 0, True) for c in (7, 6, 5, 4, 3)] \
+        + [(f"rtgn-tol{args.rt_tol:g}-cap{c}", rtgn[c], 0, True) for c in (6, 5, 4, 3)] \
         + [(f"rt-tol{args.rt_tol:g}-cap{c}", rt[c], 0, False) for c in (8, 7, 6, 5)] \
         + [("rti-5", solver, 5, True), ("rti-3", solver, 3, True), ("rti-1", solver, 1, True)]
     for mode, slv, cap, warm in modes:
@@ -74,6 +82,8 @@ def main():
         ms, its, Q, ok, wall, tick_dq, tick_df = [], [], [], [], [], [], []
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for t in range(T):
+            if os.environ.get("BENCH_STREAM_TRACE"):
+                print("trace", mode, t, file=sys.stderr, flush=True)
             # the first tick of every stream is its cold start from rest: solved to tolerance in all modes (not timed)
             if t == 0:
                 sb.tick(max_iter=100, warm_dual=True, simulate=True)
@@ -87,8 +97,13 @@ def main():
             ms.append(slv.last_kernel_ms())
             if t > 0 and mode != "converged":
                 # this tick's problem solved to 1e-8 from the same warm start (untimed): how far is the applied plan from its minimiser?
-                star = solver.solve_batch(sb.p, sb.x0, want=("f", "status"))
-                f_rt = evaluate.solve_batch(sb.p, sb.x, want=("f",))["f"]
+                # (its own handle and a full synchronisation: a first version launched these two solves asynchronously on the handle that
+                # also owns the tick's graph and, 80 ticks into the warm mode, ended in a GPU memory fault that neither the old benchmark
+                # nor a synchronised run shows -- DESIGN.md 8)
+                star = reference.solve_batch(sb.p, sb.x0, want=("f", "status"))
+                at_x = evaluate.solve_batch(sb.p, sb.x, want=("f",))
+                torch.cuda.synchronize()
+                f_rt = at_x["f"]
                 good = star["status"] == 0
                 d = (sb.x - star["x"]).reshape(B, 10, 44)[:, :, 8:15]
                 tick_dq.append(torch.sqrt((d * d).mean(dim=(1, 2)))[good].cpu().numpy())
