@@ -150,6 +150,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
 }
 extern "C" int bmpc_destroy(bmpc_handle *h) {
     if (!h) return BMPC_ERR_ARG;
+    hipDeviceSynchronize();        // launches are asynchronous: nothing of this handle may still be running on its workspace
     for (int i = 0; i < 2 * h->nev; i++) hipEventDestroy(h->ev[i]);
     delete[] h->ev;
     hipFree(h->scratch); hipFree(h->counter); hipFree(h->prof); hipFree(h->stage_d); hipFree(h->stage_i);
@@ -280,6 +281,7 @@ extern "C" int bmpc_graph_launch(bmpc_graph *gr, void *hip_stream) {
 }
 extern "C" int bmpc_graph_destroy(bmpc_graph *gr) {
     if (!gr) return BMPC_ERR_ARG;
+    hipDeviceSynchronize();        // a replay of this graph may still be in flight
     if (gr->h && gr->h->graphs_alive > 0) gr->h->graphs_alive--;
     hipGraphExecDestroy(gr->exec); hipGraphDestroy(gr->graph); delete gr;
     return BMPC_OK;

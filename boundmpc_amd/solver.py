@@ -142,6 +142,10 @@ class BatchedOCPSolver:
             _lib.check(self._lib.bmpc_solve_batch_warm(self._h, B, dp(p), dp(x0), dp(state), int(max_iter), dp(x), dp(ptr["g"]), dp(ptr["lam_g"]),
                                                        dp(ptr["lam_x"]), dp(ptr["f"]), dp(ptr["iters"]), dp(ptr["status"]), dp(ptr["kkt"]),
                                                        ctypes.c_void_p(st.cuda_stream)), "bmpc_solve_batch_warm")
+        # The launch is asynchronous: the kernel reads p / x0 / state and writes the outputs on the launch stream after this call has
+        # returned.  The handle keeps them alive until its next launch (a caller that passes temporaries or drops the returned dict would
+        # otherwise hand their memory back to the allocator while the kernel is still using it).
+        self._inflight = (p, x0, state, o)
         return o
 
     def capture_step(self, p, x0, state=None, max_iter=0, want=("iters", "status", "kkt")):

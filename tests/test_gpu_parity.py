@@ -280,7 +280,8 @@ def test_hip_graph_step_replays_and_matches_direct_launch(solver):
         og = graph.launch()
         torch.cuda.synchronize()
         xg, itg = og["x"].clone(), og["iters"].clone()
-        od = solver.solve_batch(p.clone(), x0.clone(), state=st_d, max_iter=3)
+        pc, xc = p.clone(), x0.clone()          # kept alive: the call is asynchronous and reads them on the launch stream
+        od = solver.solve_batch(pc, xc, state=st_d, max_iter=3)
         assert torch.equal(xg, od["x"]) and torch.equal(itg, od["iters"]) and torch.equal(st_g, st_d)
     graph.close()
     with pytest.raises(ValueError):
