@@ -60,11 +60,15 @@ extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, in
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
+    const bool poison = getenv("BMPC_EMU_POISON") != nullptr;
 #pragma omp parallel
     {
         std::vector<double> lds(bmpc::L_SIZE, 0.0), scr(sc.size, 0.0);
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < B; b++) {
+            // BMPC_EMU_POISON=1: LDS and workspace are filled with NaN before every problem -- a read of something this solve has not
+            // written (what a reused slab or LDS holds on the GPU) then shows up in the outputs
+            if (poison) { std::fill(lds.begin(), lds.end(), std::nan("")); std::fill(scr.begin(), scr.end(), std::nan("")); }
             bmpc::Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = scr.data();
             for (int i = 0; i < 64; i++) W.order[i] = lane_order == 0 ? i : (lane_order == 1 ? 63 - i : (i * 37 + 11) % 64);
             bmpc::Problem pr;

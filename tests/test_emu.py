@@ -168,3 +168,34 @@ def test_infeasible_problem_ends_as_status_2_in_oracle_and_emulator():
     assert np.isfinite(o["x"]).all() and np.isfinite(e["x"]).all()
     off = c_oracle.solve(p, x0, 10, 4, 0.1, c_oracle.default_opts(stall_window=0, max_iter=90))
     assert (off["status"] == 1).all() and (off["iters"] == 90).all()
+
+
+def test_no_solve_reads_what_it_has_not_written():
+    """LDS and the workspace slab are reused from problem to problem on the GPU.  With both filled with NaN before every problem
+    (BMPC_EMU_POISON) every output must stay bit-identical: cold solves, evaluation only (max_iter 0), capped Gauss-Newton ticks,
+    warm-started ticks, the long-horizon instantiation."""
+    from boundmpc_amd import workload
+    d = np.load(os.path.join(G, "g7_closedloop_exp1.npz"))
+
+    def run():
+        outs = []
+        P, X, _ = workload.make_batch(8, seed=0, N=10)
+        outs.append(emu.solve(P, X, 10, 4, 0.1, nthreads=4))
+        outs.append(emu.solve(P, X, 10, 4, 0.1, emu.default_opts(max_iter=0), nthreads=4))
+        outs.append(emu.solve(P, X, 10, 4, 0.1, emu.default_opts(exact_hessian=0, tol=1e-3, max_iter=4), nthreads=4))
+        st = np.zeros((1, c_oracle.state_len(10)))
+        for t in range(4):
+            outs.append(emu.solve(d["p"][t:t + 1], d["x0"][t:t + 1], 10, 4, 0.1, emu.default_opts(tol=1e-3, max_iter=4, mu_warm=3e-2), state=st, nthreads=1))
+            nu = st[0, :570].reshape(10, 57); nu[:-1] = nu[1:].copy()
+        P3, X3, _ = workload.make_batch(2, seed=2, N=30, tight=True)
+        outs.append(emu.solve(P3, X3, 30, 4, 0.1, nthreads=2))
+        return outs
+    plain = run()
+    os.environ["BMPC_EMU_POISON"] = "1"
+    try:
+        poisoned = run()
+    finally:
+        del os.environ["BMPC_EMU_POISON"]
+    for a, b in zip(plain, poisoned):
+        for k in ("x", "g", "lam_g", "lam_x", "f", "kkt", "iters", "status"):
+            assert np.array_equal(a[k], b[k], equal_nan=True), k
