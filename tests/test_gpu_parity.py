@@ -355,6 +355,37 @@ def test_infeasible_problem_ends_as_status_2_like_the_oracle(solver):
 
 
 @pytest.mark.gpu
+def test_two_handles_on_two_streams_overlap_and_stay_exact(solver):
+    """Independent batches in flight (bench.py --inflight 2): two handles, one HIP stream each, launches interleaved without host
+    synchronisation.  Every result is bit-identical to the same batch solved alone, and the kept event pairs give every launch's time."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    P, X, _ = workload.make_batch(512, seed=5, N=10)
+    p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
+    halves = [(p[:256].contiguous(), x0[:256].contiguous()), (p[256:].contiguous(), x0[256:].contiguous())]
+    alone = [solver.solve_batch(a, b)["x"].clone() for a, b in halves]
+    torch.cuda.synchronize()
+    hs = [BatchedOCPSolver(10, 4, 0.1), BatchedOCPSolver(10, 4, 0.1)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for h in hs:
+        h.set_timing(6)
+    outs = [{}, {}]
+    for rep in range(6):
+        for j in (0, 1):
+            streams[j].wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(streams[j]):
+                hs[j].solve_batch(*halves[j], out=outs[j])
+    torch.cuda.synchronize()
+    for j in (0, 1):
+        assert torch.equal(outs[j]["x"], alone[j]) and (outs[j]["status"] == 0).all()
+        times = [hs[j].kernel_ms(i) for i in range(6)]
+        assert all(0.5 < t < 50.0 for t in times), times
+        with pytest.raises(Exception):
+            hs[j].kernel_ms(6)                  # only the last six launches are kept
+        hs[j].close()
+
+
+@pytest.mark.gpu
 def test_second_seed_against_oracle():
     """A second synthetic batch (seed 1, 512 problems): same statuses, iteration counts within one, joint trajectories within 1e-6 rad
     per problem of the CPU oracle (tests/gpu_soak.py runs the long version of this check)."""
