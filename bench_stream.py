@@ -75,6 +75,10 @@ def main():
         + [(f"rtgn-tol{args.rt_tol:g}-cap{c}", rtgn[c], 0, True) for c in (6, 5, 4, 3)] \
         + [(f"rt-tol{args.rt_tol:g}-cap{c}", rt[c], 0, False) for c in (8, 7, 6, 5)] \
         + [("rti-5", solver, 5, True), ("rti-3", solver, 3, True), ("rti-1", solver, 1, True)]
+    # Everything below runs on an explicit HIP stream.  On the legacy null stream, a hipGraph replay followed by further kernel launches
+    # without a host synchronisation in between ended in a GPU memory fault on ROCm 7.2 (80 ticks into the warm mode, reproducibly); the
+    # same sequence with direct launches instead of the graph, or on any explicit stream, is clean.
+    torch.cuda.set_stream(torch.cuda.Stream())
     for mode, slv, cap, warm in modes:
         capped = cap > 0 or slv is not solver
         sb = bstream.StreamBatch(slv, mpcs)
@@ -97,9 +101,6 @@ def main():
             ms.append(slv.last_kernel_ms())
             if t > 0 and mode != "converged":
                 # this tick's problem solved to 1e-8 from the same warm start (untimed): how far is the applied plan from its minimiser?
-                # (its own handle and a full synchronisation: a first version launched these two solves asynchronously on the handle that
-                # also owns the tick's graph and, 80 ticks into the warm mode, ended in a GPU memory fault that neither the old benchmark
-                # nor a synchronised run shows -- DESIGN.md 8)
                 star = reference.solve_batch(sb.p, sb.x0, want=("f", "status"))
                 at_x = evaluate.solve_batch(sb.p, sb.x, want=("f",))
                 torch.cuda.synchronize()
