@@ -123,6 +123,8 @@ class StreamBatch:
     """B streams on the GPU.  `mpcs`: list of freshly constructed host `boundmpc_amd.bound_mpc.BoundMPC` objects (used only to
     read their path and initial state; they are not advanced)."""
 
+    _warned_null_stream = False
+
     def __init__(self, solver, mpcs, device="cuda"):
         import torch
         self.solver, self.B, self.N, self.S = solver, len(mpcs), solver.N, solver.S
@@ -204,7 +206,13 @@ class StreamBatch:
                 dp(self.dual) if warm_dual else None, int(max_iter), dp(self.x), dp(self.g), dp(self.iters), dp(self.status), dp(self.kkt),
                 dp(self.traj), int(bool(simulate)) | (2 if accept_capped else 0), ctypes.byref(g)), "bmpc_stream_graph_create")
             self._graphs[key] = g
-        _lib.check(self.solver._lib.bmpc_graph_launch(self._graphs[key], self._stream(stream)), "bmpc_graph_launch")
+        st = self._stream(stream)
+        if not st.value and not StreamBatch._warned_null_stream:
+            StreamBatch._warned_null_stream = True
+            import warnings
+            warnings.warn("hipGraph replay on the legacy null stream: keep a host synchronisation between the replay and further launches on that "
+                          "stream, or use an explicit stream (ROCm 7.2: the unsynchronised mix ended in a GPU memory fault, DESIGN.md section 8)")
+        _lib.check(self.solver._lib.bmpc_graph_launch(self._graphs[key], st), "bmpc_graph_launch")
 
     def close(self):
         for g in self._graphs.values():
