@@ -282,3 +282,43 @@ def test_device_tick_other_horizons_and_windows_g12(N, S):
         np.testing.assert_allclose(td["q"], d[k + "traj_q"][i], atol=2e-6)
         assert abs(sb.state.cpu().numpy()[0][bstream.SS["PHI"]] - d[k + "phi_current"][i]) < 1e-6
     sb.close(); solver.close()
+
+
+@pytest.mark.gpu
+def test_long_closed_loops_through_the_hard_part_of_the_path():
+    """64 random streams over 130 ticks (the benchmark stops at 60): later segments are harder, some streams stall and run their error
+    count past N (the reference's `step()` returns None from there on, BoundMPC.py:498-506).  Everything stays finite, the stalled
+    streams stop where they are, the others keep their progress; graph replays on an explicit stream."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, stream as bstream, workload
+    B, T = 64, 130
+    q0s = workload.random_q0(256, seed=3)[:B]
+    mpcs, recs = [], []
+    for q0 in q0s:
+        m, p0fk = workload.make_mpc(q0)
+        mpcs.append(m)
+        recs.append(bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([m.phi_max[0], 0.0, 0.0]), np.zeros(7)))
+    slv = BatchedOCPSolver(10, 4, 0.1, max_iter=100)
+    sb = bstream.StreamBatch(slv, mpcs)
+    sb.set_robot(np.stack(recs))
+    side = torch.cuda.Stream()
+    phis, ecs, oks = [], [], []
+    with torch.cuda.stream(side):
+        for t in range(T):
+            if t == 0:
+                sb.tick(max_iter=100, warm_dual=True, simulate=True)
+            else:
+                sb.tick_graph(warm_dual=True, simulate=True)
+            side.synchronize()
+            phis.append(sb.state[:, bstream.SS["PHI"]].cpu().numpy().copy())
+            ecs.append(sb.state[:, bstream.SS["ERRCNT"]].cpu().numpy().copy())
+            oks.append((sb.traj[:, -2] > 0.5).cpu().numpy().copy())
+            assert bool(torch.isfinite(sb.state).all()) and bool(torch.isfinite(sb.robot).all()) and bool(torch.isfinite(sb.x).all()), t
+    phis, ecs, oks = np.array(phis), np.array(ecs), np.array(oks)
+    assert np.diff(phis, axis=0).min() > -0.05, np.diff(phis, axis=0).min()   # no jump backwards (a stalled stream may creep back: dphi has no lower bound)
+    assert phis[-1].max() > 5.0 and np.median(phis[-1]) > 3.0       # the loops got through the later segments
+    assert oks.mean() > 0.9
+    stuck = ecs[-1] >= 10                                           # error count past N: no plan is returned any more
+    assert stuck.any(), ecs[-1].max()
+    assert np.abs(phis[-1][stuck] - phis[-5][stuck]).max() == 0.0   # ... and the stream stays where it is
+    sb.close(); slv.close()
