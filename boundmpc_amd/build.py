@@ -60,6 +60,108 @@ def lint_isa(asm_path):
     return hits
 
 
+_LOAD = re.compile(r"^(global_load|ds_read|scratch_load|flat_load|buffer_load)\w*\s+(v\[\d+:\d+\]|v\d+)")
+_VREG = re.compile(r"v\[(\d+):(\d+)\]|(?<![a-z_\d])v(\d+)(?!\d)")
+_REGION_END = ("s_and_saveexec", "s_andn2_saveexec", "s_or_saveexec", "s_xor_b64 exec", "s_endpgm", "s_branch", "s_setpc")
+_STORES = ("global_store", "ds_write", "scratch_store", "flat_store", "buffer_store", "global_atomic", "ds_add")
+
+
+def _vregs(text):
+    out = set()
+    for m in _VREG.finditer(text):
+        out |= set(range(int(m.group(1)), int(m.group(2)) + 1)) if m.group(1) else {int(m.group(3))}
+    return out
+
+
+def _defs_uses(s):
+    parts = s.split(None, 1)
+    if len(parts) < 2:
+        return set(), set()
+    mn, ops = parts[0], [o.strip() for o in parts[1].split(",")]
+    if mn.startswith(_STORES) or (mn.startswith(("s_", "v_cmp", "v_readlane", "v_readfirstlane")) and not mn.startswith("v_cmpx")):
+        return set(), set().union(*[_vregs(o) for o in ops])
+    d = _vregs(ops[0])
+    u = set().union(*[_vregs(o) for o in ops[1:]]) if len(ops) > 1 else set()
+    if mn.startswith(("v_fmac", "v_mac", "v_dot", "v_mfma", "v_writelane")):
+        u |= d
+    return d, u
+
+
+def lint_isa_masked_loads(asm_path, window=400):
+    """Second signature of the same toolchain's trouble with control flow (`cond ? state[i] : 0.0` on a possibly null
+    pointer compiled into an exec-masked load whose join lost the other arm): a register whose only definition near a join is a LOAD
+    executed under `s_and_saveexec` and which is READ after the matching `s_or_b64 exec, exec, ...` -- the lanes the mask switched
+    off read whatever the register held.  For every such region (single block, no nested control flow) the loaded registers must
+    have been written in the straight-line code ahead of the saveexec (the default arm: `v_mov`, `v_cndmask`, ...).
+    Returns [(function, line of the saveexec, registers, defined_earlier)]: `defined_earlier` says whether the function writes the
+    register anywhere before (in listing order) -- then the register may legitimately hold the default from further back (a long-lived
+    value) and the hit is only a candidate; with no earlier write at all the inactive lanes certainly read garbage."""
+    hits, func, lines = [], None, []
+
+    def flush():
+        n = len(lines)
+        seen = set()       # registers written so far in listing order
+        written_before = []
+        for (_, s, _) in lines:
+            written_before.append(set(seen))
+            seen |= _defs_uses(s)[0] if s else set()
+        for i, (ln, s, _) in enumerate(lines):
+            m = re.match(r"s_andn?2?_saveexec_b64 (s\[\d+:\d+\])", s)
+            if not m:
+                continue
+            save, loads, j, closed = m.group(1), set(), i + 1, False
+            while j < n and j < i + window:
+                sj = lines[j][1]
+                if sj.startswith("s_or_b64 exec, exec, " + save):
+                    closed = True
+                    break
+                if sj.startswith(_REGION_END):
+                    break
+                d, _u = _defs_uses(sj)
+                lm = _LOAD.match(sj)
+                if lm:
+                    loads |= _vregs(lm.group(2))
+                else:
+                    loads -= d          # recomputed inside the region: no longer a bare load result
+                j += 1
+            if not closed or not loads:
+                continue
+            pre, k = set(), i - 1
+            while k >= 0 and k > i - window:      # straight-line code ahead of the saveexec (up to the previous label / branch / join)
+                sk = lines[k][1]
+                if lines[k][2] or sk.startswith(("s_or_b64 exec", "s_cbranch", "s_branch")):
+                    break
+                pre |= _defs_uses(sk)[0]
+                k -= 1
+            cand = loads - pre
+            live, used, k = set(cand), set(), j + 1
+            while k < n and k < j + window and live:
+                sk = lines[k][1]
+                if lines[k][2] or sk.startswith(("s_endpgm", "s_branch", "s_setpc", "s_cbranch")):
+                    break
+                d, u = _defs_uses(sk)
+                used |= u & live
+                live -= d
+                k += 1
+            if used:
+                hits.append((func, ln, sorted(used), bool(used & written_before[i]) and used <= written_before[i]))
+
+    with open(asm_path) as f:
+        for n, raw in enumerate(f, 1):
+            s = raw.strip()
+            m = re.match(r"^(_Z\w+):", s)
+            if m:
+                flush(); func, lines = m.group(1), []
+                continue
+            if re.match(r"^(\.LBB\w+):", s):
+                lines.append((n, "", True))
+                continue
+            if s and s[0] not in ";.":
+                lines.append((n, s.split(";")[0].strip(), False))
+    flush()
+    return hits
+
+
 def build(force=False, verbose=False, lint=True):
     if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in SOURCES):
         return LIB
@@ -72,6 +174,15 @@ def build(force=False, verbose=False, lint=True):
         bad = lint_isa(asm)
         if bad:
             raise RuntimeError("ISA lint: register copies ahead of an exec-mask restore (compiler defect, results would be wrong): %r" % (bad,))
+        # masked loads read after their join: fatal in the solver kernels (their text has no conditional load by construction) and
+        # anywhere when the register has no earlier definition at all; other candidates are listed with verbose=True
+        ml = lint_isa_masked_loads(asm)
+        fatal = [h for h in ml if "bmpc_solve_kernel" in (h[0] or "") or not h[3]]
+        if verbose and ml:
+            print("ISA lint (masked loads read after the join), candidates:", ml)
+        if fatal:
+            raise RuntimeError("ISA lint: load under an exec mask whose result is read after the join without a default (results would be wrong "
+                               "for the masked-off lanes): %r" % (fatal,))
     # -amdgpu-sched-strategy=iterative-ilp: the solver runs at one wave per SIMD, so the scheduler should chase instruction-level
     # parallelism (loads hoisted ahead of their uses), not occupancy; measured 12.7 -> 10.8 ms at B=1024 (profiles/)
     cmd = [hipcc()] + FLAGS + ["-fPIC", "-shared", "-o", LIB, SOURCES[0]]

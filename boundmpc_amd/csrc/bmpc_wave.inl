@@ -118,7 +118,7 @@ struct Opts {
 
 // global scratch layout (doubles) for horizon N
 struct Scr {
-    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, NU2, size;
+    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, NU2, NCS, size;
 };
 BMPC_HD inline Scr make_scr(int N) {
     Scr s; int c = 0;
@@ -127,6 +127,7 @@ BMPC_HD inline Scr make_scr(int N) {
     s.DZ = c; c += N * NZ; s.DT = c; c += N * NI; s.DNU = c; c += N * NI; s.GH = c; c += N * NZ; s.GVP = c; c += N * 8;
     s.RJ = c; c += N * NU; s.KIN = c; c += 2 * N * KREC; s.REF = c; c += N * RREC; s.KT = c; c += N * NS * NU; s.KF = c; c += N * NU;
     s.RDY = c; c += N * 36; s.AES = c; c += N * 42; s.RLV = c; c += N * 12; s.SG = c; c += N * NI; s.TI = c; c += N * NI; s.SR = c; c += N * NI; s.NU2 = c; c += N * NI;   // NU2: second multiplier buffer (the update ping-pongs)
+    s.NCS = c; c += N * 32;   // small (pos, iw, phi) Hessian blocks of every stage (28 used), written by wave_stage_data_wide
     s.size = (c + 15) & ~15;
     return s;
 }
@@ -922,88 +923,6 @@ BMPC_D inline double node_q_row(const double *L, const double *K0, int r, double
     return base + (heavy ? (isq ? t1 : 0.0) + 0.5 * h * t2 + t3 - sW : 0.0);
 }
 
-// Stage data of Riccati stage k: defect vector rdyn (35) and the iota coupling AE (3x14), for one lane (predicated straight-line
-// code; runs inside phase 1 of the node cost, with which it shares no data).  The acceleration cross block XT = C^T Gv(K1)
-// (15x14, rank 6) is never formed: its consumers contract the two rank-6 factors on the fly (t6 in S0, chain-pair entries in S1).
-BMPC_D inline void stage_data_lane(Wave &W, const Scr &sc, int k, int lane) {
-    double *L = W.L, *G = W.G; const double h = W.h;
-    const double *K0 = L + W.oK0, *K1 = L + W.oK1, *KVk = L + W.oKV, *gk = L + L_ST + ST_G;
-    {
-        const bool on = lane < NS; const int r = on ? lane : 0;
-        const bool io = r >= SIOTA; const int c = io ? r - SIOTA : 0;
-        const int code = (int)L[L_ZMAP + r], gsrc = (code >> 8) & 255;
-        const double gval = gk[gsrc];
-        BMPC_ACC4_DECL(ia);
-#pragma unroll
-        for (int i = 0; i < 7; i++) { BMPC_ACC4(ia, i, K0[KD + (3 + c) * 7 + i] * gk[GQ + i]); BMPC_ACC4(ia, i + 1, K0[KA + c * 7 + i] * gk[GDQ + i]); }
-        const bool zero = ((code >> 16) & 1) != 0;                            // jerk states carry no defect
-        const double v = zero ? 0.0 : (io ? gval - 0.5 * h * BMPC_ACC4_SUM(ia) : gval);
-        L[L_RD + r] = v; G[sc.RDY + k * 36 + r] = v;
-    }
-    {
-        const bool on = lane < 42; const int ln = on ? lane : 0, a = ln / 14, y = ln % 14;
-        const int eb = y < 7 ? KD + (3 + a) * 7 + y : KA + a * 7 + y - 7;
-        const double v = k >= 1 ? 0.5 * h * (K1[eb] + KVk[eb]) : 0.0;
-        L[L_AE + ln] = v; G[sc.AES + k * 42 + ln] = v;
-    }
-}
-
-// Phase 1 of the node cost of stage k for one lane (predicated straight-line code): the stage data and the small Hessian blocks
-// over (pos, iw, phi).  It reads only the staging area and the record buffers of its stage and writes work areas nothing else
-// touches between S1 of the previous stage and phase 2, so it rides in the Schur phase of stage k+1 (after that stage's inputs
-// were replaced by this one's), where it fills the latency gaps of the matrix-core update.
-BMPC_D inline void node_cost_p1_lane(Wave &W, const POff &po, const Scr &sc, int k, int lane) {
-    const int N = W.N; const int ex = W.o.exact_hessian;
-    double *L = W.L;
-    const double *PAR = L + L_PAR, *w = PAR + po.w;
-    const double *ST = L + L_ST;
-    const double *rr = ST + ST_REF, *sgk = ST + ST_SG, *nuk = ST + ST_NU;
-    double *NC = L + L_NC;
-    const bool has_next = k < N - 1;
-    stage_data_lane(W, sc, k, lane);
-    // tube rows: barrier weights su, sl and the gradient pieces, shared by the three roles below
-    double su[5], sl[5], g3[5], w1[5];
-#pragma unroll
-    for (int m = 0; m < 5; m++) { su[m] = sgk[ITUBE + 2 * m]; sl[m] = sgk[ITUBE + 2 * m + 1]; g3[m] = rr[RGC + m * 4 + 3]; w1[m] = rr[RW1 + m]; }
-    {   // Hpp, Hrr: geometric part from the record + barrier terms of the tube rows
-        const bool on = lane >= 16 && lane < 16 + 9; const int ln = on ? lane - 16 : 0, a = ln / 3, b = ln % 3;
-        double hp = rr[RHPPG + a * 3 + b], hr = rr[RHRRG + a * 3 + b];
-#pragma unroll
-        for (int m = 0; m < 5; m++) {
-            const double gg = (su[m] + sl[m]) * rr[RGC + m * 4 + a] * rr[RGC + m * 4 + b];
-            if (m == 1 || m == 2) hp += gg; else hr += gg;
-        }
-        NC[NC_HPP + a * 3 + b] = hp; NC[NC_HRR + a * 3 + b] = hr;
-    }
-    {   // Hp,phi, Hr,phi
-        const bool on = lane >= 32 && lane < 35; const int a = on ? lane - 32 : 0;
-        double hp = rr[RHPFG + a], hr = rr[RHRFG + a];
-#pragma unroll
-        for (int m = 0; m < 5; m++) {
-            const double gpu_ = g3[m] - w1[m], gpl_ = -g3[m] - w1[m];
-            const double gg = su[m] * rr[RGC + m * 4 + a] * gpu_ - sl[m] * rr[RGC + m * 4 + a] * gpl_;
-            if (m == 1 || m == 2) hp += gg; else hr += gg;
-        }
-        NC[NC_HPF + a] = hp; NC[NC_HRF + a] = hr;
-    }
-    {   // H phi,phi and the scalar curvatures (every lane computes them, lane 40 stores)
-        const double dpdp = rr[RDPDP], exm = ex ? 1.0 : 0.0;
-        double hff = rr[RHFFG] + 2 * w[6] + sgk[IPHI0] + sgk[IPHIMAX];
-#pragma unroll
-        for (int m = 0; m < 5; m++) {
-            const double gpu_ = g3[m] - w1[m], gpl_ = -g3[m] - w1[m];
-            hff += su[m] * gpu_ * gpu_ + sl[m] * gpl_ * gpl_;
-            hff += exm * (nuk[ITUBE + 2 * m] * (rr[RC2 + m] - rr[RW2 + m]) + nuk[ITUBE + 2 * m + 1] * (-rr[RC2 + m] - rr[RW2 + m]));
-        }
-        {   // identical in every lane: unconditional stores
-            NC[NC_SC + 0] = hff;
-            NC[NC_SC + 1] = 2 * w[2] * dpdp + 2 * w[7] + sgk[IDPHIMAX];
-            NC[NC_SC + 2] = 2 * w[5] * dpdp + 2 * w[8];
-            NC[NC_SC + 3] = 2 * w[2] + W.ca * (has_next ? 2.0 : 1.0);
-        }
-    }
-}
-
 // Node cost in block form: Q~ of node k+1 (index k) added into PB / PCI / PII, q~ into PV.
 BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, int k, double mu, double delta) {
     const int N = W.N; const double h = W.h; const int ex = W.o.exact_hessian;
@@ -1014,8 +933,8 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
     double *NC = L + L_NC, *WY = L + L_WY, *KHP = L + L_KHP;
     const double *K0 = L + W.oK0, *KV1 = L + W.oKV1;
     const bool has_next = k < N - 1;
-    // (phase 1 -- stage data and the small Hessian blocks -- has already run: node_cost_p1_lane(), in the prologue of the sweep for
-    // the first stage and inside the Schur phase of the previous stage for all others)
+    // (stage data and the small Hessian blocks of this stage were computed for all stages at once by wave_stage_data_wide() and came into
+    // LDS with the stage's other inputs)
     BMPC_PROF(W, 16);
     // phase 2: A1 = Hpp Jp, A2 = (h/2) Hrr Ehat, curvature multipliers, prefix vectors of the curvature records
     LANES_BEGIN   // predicated straight-line code (see S0): all roles in one basic block, conditional stores only
@@ -1185,20 +1104,143 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
     BMPC_PROF(W, 20);
 }
 
-// lifted residuals r_pos (3), r_v (6) of every node: r = g_lifted - G g_y   (needed across neighbouring nodes)
-BMPC_D inline void wave_prepare_rlv(Wave &W, const Scr &sc) {
-    const int N = W.N; double *G = W.G;
+// Stage data of ALL Riccati stages in one wide pass, once per iterate and BEFORE the backward sweep (it replaces wave_prepare_rlv and
+// "phase 1 of the node cost" of rounds 1-2):
+//   * lifted residuals r_pos (3), r_v (6) of every node, r = g_lifted - G g_y (needed across neighbouring nodes) -> RLV,
+//   * the defect vectors rdyn (35: the residual row the row table names; iota rows g_iw - (h/2) Ehat g_y) -> RDY,
+//   * the iota couplings AE = (h/2)(Ehat(K1) + Ehat(KV_k)) (3 x 14) -> AES,
+//   * the small Hessian blocks over (pos, iw, phi): Hpp, Hrr, Hp,phi, Hr,phi, H phi,phi and the scalar curvatures -> NCS.
+// All of it depends on the iterate and the multipliers only, not on the recursion.  Inside the sweep (one stage's worth per phase, fused
+// into the Schur phase) this work ran as chains of dependent LDS round trips with nothing to overlap them: 2.4 k cycles per stage.  Here
+// one lane owns one (stage, entry) item, the items of all stages are independent, and every loop issues the loads of a whole batch of
+// trips before the first use (a dependent round trip to the workspace costs ~1 k cycles: what counts is how many there are, not how
+// many loads ride in each).  The results reach LDS with the other inputs of a stage through the register prefetch of the sweeps.
+// The acceleration cross block XT = C^T Gv(K1) (15x14, rank 6) is never formed: its consumers contract the two rank-6 factors on
+// the fly (t6 in S0, chain-pair entries in S1).
+BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) {
+    const int N = W.N; const double h = W.h; const int ex = W.o.exact_hessian;
+    double *L = W.L, *G = W.G;
+    const double *PAR = L + L_PAR, *w = PAR + po.w;
     LANES_BEGIN
-        for (int id = lane; id < N * 9; id += 64) {
-            const int k = id / 9, c9 = id - k * 9;
-            const double *gk = G + sc.G + k * NE, *kp = G + sc.KIN + k * KREC;
-            double r;
-            if (c9 < 3) { r = gk[GPOS + c9]; for (int i = 0; i < 7; i++) r -= kp[KW + c9 * 7 + i] * gk[GQ + i]; }
-            else {
-                const int c6 = c9 - 3; r = gk[GV + c6];
-                for (int i = 0; i < 7; i++) r -= kp[KD + c6 * 7 + i] * gk[GQ + i] + (c6 < 3 ? kp[KW + c6 * 7 + i] : kp[KA + (c6 - 3) * 7 + i]) * gk[GDQ + i];
+        {   // lifted residuals (rows 0..8 of a node's 12) and the iota rows of rdyn (rows 9..11): a residual minus two 7-term dot products
+            // of a record row with g_q and g_dq; the row kind selects bases and factors, not code (rows past the end repeat the last one)
+            constexpr int RL = 2;
+            for (int base = lane; base < N * 12; base += 64 * RL) {
+                double a1[RL][7], a2[RL][7], g1[RL][7], g2[RL][7], b0[RL];
+#pragma unroll
+                for (int u = 0; u < RL; u++) {
+                    const int id0 = base + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, c = id - 12 * k;
+                    const int c6 = c >= 3 ? (c < 9 ? c - 3 : c - 6) : 0;                       // velocity rows 0..5; iota rows use the rotational rows 3..5
+                    const int p1 = c < 3 ? KW + c * 7 : KD + c6 * 7;
+                    const int p2 = c < 3 ? KA : (c < 9 ? (c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7) : KA + (c - 9) * 7);
+                    const int bs = c < 3 ? GPOS + c : (c < 9 ? GV + c - 3 : GIW + c - 9);
+                    const double *kp = G + sc.KIN + k * KREC, *gk = G + sc.G + k * NE;
+                    b0[u] = gk[bs];
+#pragma unroll
+                    for (int i = 0; i < 7; i++) { a1[u][i] = kp[p1 + i]; a2[u][i] = kp[p2 + i]; g1[u][i] = gk[GQ + i]; g2[u][i] = gk[GDQ + i]; }
+                }
+#pragma unroll
+                for (int u = 0; u < RL; u++) {
+                    const int id0 = base + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, c = id - 12 * k;
+                    BMPC_ACC4_DECL(sa); BMPC_ACC4_DECL(sb);
+#pragma unroll
+                    for (int i = 0; i < 7; i++) { BMPC_ACC4(sa, i, a1[u][i] * g1[u][i]); BMPC_ACC4(sb, i, a2[u][i] * g2[u][i]); }
+                    const double s1 = BMPC_ACC4_SUM(sa), s2 = BMPC_ACC4_SUM(sb);
+                    const double m2 = c < 3 ? 0.0 : 1.0, f = c < 9 ? 1.0 : 0.5 * h;
+                    const double r = b0[u] - f * (s1 + m2 * s2);
+                    G[c < 9 ? sc.RLV + k * 12 + c : sc.RDY + k * 36 + SIOTA + (c - 9)] = r;      // a clamped duplicate rewrites the last row with the same value
+                }
             }
-            G[sc.RLV + k * 12 + c9] = r;
+        }
+        {   // chain rows of rdyn: the residual row the row table names (jerk states carry no defect)
+            constexpr int RA = 5;
+            for (int base = lane; base < N * 32; base += 64 * RA) {
+                double gv[RA];
+#pragma unroll
+                for (int u = 0; u < RA; u++) {
+                    const int id0 = base + 64 * u, id = id0 < N * 32 ? id0 : N * 32 - 1, k = id >> 5, r = id & 31;
+                    gv[u] = G[sc.G + k * NE + (((int)L[L_ZMAP + r] >> 8) & 255)];
+                }
+#pragma unroll
+                for (int u = 0; u < RA; u++) {
+                    const int id0 = base + 64 * u, id = id0 < N * 32 ? id0 : N * 32 - 1, k = id >> 5, r = id & 31;
+                    const bool zero = (((int)L[L_ZMAP + r] >> 16) & 1) != 0;
+                    G[sc.RDY + k * 36 + r] = zero ? 0.0 : gv[u];
+                }
+            }
+        }
+        {   // AE = (h/2) (Ehat(K1) + Ehat(KV_k)): record of the predicted point k-1 and of the velocity point of node k (stage 0: none)
+            constexpr int RB = 7;
+            for (int base = lane; base < N * 42; base += 64 * RB) {
+                double e1[RB], e2[RB];
+#pragma unroll
+                for (int u = 0; u < RB; u++) {
+                    const int id0 = base + 64 * u, id = id0 < N * 42 ? id0 : N * 42 - 1, k = id / 42, ln = id - 42 * k, a = ln / 14, y = ln - 14 * a;
+                    const int eb = y < 7 ? KD + (3 + a) * 7 + y : KA + a * 7 + y - 7, kp = k >= 1 ? k - 1 : 0;
+                    e1[u] = G[sc.KIN + kp * KREC + eb]; e2[u] = G[sc.KIN + (N + k) * KREC + eb];
+                }
+#pragma unroll
+                for (int u = 0; u < RB; u++) {
+                    const int id0 = base + 64 * u, id = id0 < N * 42 ? id0 : N * 42 - 1;
+                    const double v = 0.5 * h * (e1[u] + e2[u]);
+                    G[sc.AES + id] = id >= 42 ? v : 0.0;
+                }
+            }
+        }
+        {   // Hpp, Hrr (9 entries per stage): geometric part from the record + barrier terms of the tube rows
+            constexpr int RC = 2;
+            for (int base = lane; base < N * 9; base += 64 * RC) {
+                double h0[RC], h1[RC], ss[RC][5], ga[RC][5], gb[RC][5];
+#pragma unroll
+                for (int u = 0; u < RC; u++) {
+                    const int id0 = base + 64 * u, id = id0 < N * 9 ? id0 : N * 9 - 1, k = id / 9, ln = id - 9 * k, a = ln / 3, b = ln - 3 * a;
+                    const double *rr = G + sc.REF + k * RREC, *sgk = G + sc.SG + k * NI;
+                    h0[u] = rr[RHPPG + ln]; h1[u] = rr[RHRRG + ln];
+#pragma unroll
+                    for (int m = 0; m < 5; m++) { ss[u][m] = sgk[ITUBE + 2 * m] + sgk[ITUBE + 2 * m + 1]; ga[u][m] = rr[RGC + m * 4 + a]; gb[u][m] = rr[RGC + m * 4 + b]; }
+                }
+#pragma unroll
+                for (int u = 0; u < RC; u++) {
+                    const int id0 = base + 64 * u, id = id0 < N * 9 ? id0 : N * 9 - 1, k = id / 9, ln = id - 9 * k;
+                    double hp = h0[u], hr = h1[u];
+#pragma unroll
+                    for (int m = 0; m < 5; m++) {
+                        const double gg = ss[u][m] * ga[u][m] * gb[u][m];
+                        if (m == 1 || m == 2) hp += gg; else hr += gg;
+                    }
+                    G[sc.NCS + k * 32 + NC_HPP + ln] = hp; G[sc.NCS + k * 32 + NC_HRR + ln] = hr;
+                }
+            }
+        }
+        {   // Hp,phi, Hr,phi (3 entries per stage) and, on the lanes of entry 0, H phi,phi and the scalar curvatures (4 values)
+            for (int base = lane; base < N * 3; base += 64) {
+                const int id = base, k = id / 3, a = id - 3 * k;
+                const double *rr = G + sc.REF + k * RREC, *sgk = G + sc.SG + k * NI, *nuk = G + sc.NUm + k * NI;
+                double su[5], sl[5], g3[5], w1[5], ga[5], nu_u[5], nu_l[5], c2[5], w2[5];
+                const double hp0 = rr[RHPFG + a], hr0 = rr[RHRFG + a], dpdp = rr[RDPDP], hffg = rr[RHFFG];
+                const double s_phi0 = sgk[IPHI0], s_phimax = sgk[IPHIMAX], s_dphimax = sgk[IDPHIMAX];
+#pragma unroll
+                for (int m = 0; m < 5; m++) {
+                    su[m] = sgk[ITUBE + 2 * m]; sl[m] = sgk[ITUBE + 2 * m + 1]; g3[m] = rr[RGC + m * 4 + 3]; w1[m] = rr[RW1 + m]; ga[m] = rr[RGC + m * 4 + a];
+                    nu_u[m] = nuk[ITUBE + 2 * m]; nu_l[m] = nuk[ITUBE + 2 * m + 1]; c2[m] = rr[RC2 + m]; w2[m] = rr[RW2 + m];
+                }
+                double hp = hp0, hr = hr0;
+                const double exm = ex ? 1.0 : 0.0;
+                double hff = hffg + 2 * w[6] + s_phi0 + s_phimax;
+#pragma unroll
+                for (int m = 0; m < 5; m++) {
+                    const double gpu_ = g3[m] - w1[m], gpl_ = -g3[m] - w1[m];
+                    const double gg = su[m] * ga[m] * gpu_ - sl[m] * ga[m] * gpl_;
+                    if (m == 1 || m == 2) hp += gg; else hr += gg;
+                    hff += su[m] * gpu_ * gpu_ + sl[m] * gpl_ * gpl_;
+                    hff += exm * (nu_u[m] * (c2[m] - w2[m]) + nu_l[m] * (-c2[m] - w2[m]));
+                }
+                G[sc.NCS + k * 32 + NC_HPF + a] = hp; G[sc.NCS + k * 32 + NC_HRF + a] = hr;
+                // the four scalars: every lane of the stage has them, entry a writes scalar a (entry 0 also writes the fourth)
+                const double sc0 = hff, sc1 = 2 * w[2] * dpdp + 2 * w[7] + s_dphimax, sc2 = 2 * w[5] * dpdp + 2 * w[8], sc3 = 2 * w[2] + W.ca * (k < N - 1 ? 2.0 : 1.0);
+                G[sc.NCS + k * 32 + NC_SC + a] = a == 0 ? sc0 : (a == 1 ? sc1 : sc2);
+                G[sc.NCS + k * 32 + NC_SC + 3] = sc3;      // identical in the three lanes of a stage
+            }
         }
     LANES_END
 }
@@ -1219,6 +1261,7 @@ BMPC_D inline void backward_loads_lane(Wave &W, const Scr &sc, int k, double *pf
     const int kn = k < N - 1 ? k + 1 : k, kp = k >= 1 ? k - 1 : 0;
     const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, r2 = lane < RREC - 64 ? 64 + lane : RREC - 1;
     const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l12 = lane < 12 ? lane : 11;
+    const int l35 = lane < NS ? lane : NS - 1, l42 = lane < 42 ? lane : 41, l28 = lane < 28 ? lane : 27;
     // of the four kinematics records of a stage (node k, velocity point of node k+1, node k-1, velocity point of node k) the
     // first two are the last two of the previous stage (k+1): they stay in LDS, only the first stage of a sweep loads all four
     if (full) {
@@ -1228,10 +1271,11 @@ BMPC_D inline void backward_loads_lane(Wave &W, const Scr &sc, int k, double *pf
     pf[4] = G[sc.KIN + kp * KREC + lane]; pf[5] = G[sc.KIN + kp * KREC + l2];
     pf[6] = G[sc.KIN + (N + k) * KREC + lane]; pf[7] = G[sc.KIN + (N + k) * KREC + l2];
     pf[8] = G[sc.REF + k * RREC + lane]; pf[9] = G[sc.REF + k * RREC + r2];
-    pf[10] = 0.0; pf[11] = G[sc.GH + k * NZ + lz];
+    pf[10] = G[sc.RDY + k * 36 + l35]; pf[11] = G[sc.GH + k * NZ + lz];
     pf[12] = G[sc.SG + k * NI + li]; pf[13] = G[sc.NUm + k * NI + li];
     pf[14] = G[sc.G + k * NE + le]; pf[15] = G[sc.LAM + k * NE + le]; pf[16] = G[sc.LAM + kn * NE + le];
     pf[17] = G[sc.RLV + k * 12 + l12]; pf[18] = G[sc.RLV + kp * 12 + l12]; pf[19] = G[sc.RLV + kn * 12 + l12];
+    pf[20] = G[sc.AES + k * 42 + l42]; pf[21] = G[sc.NCS + k * 32 + l28];      // stage data of wave_stage_data_wide
 }
 // record buffers of stage k: (K0, K1) and (KV1, KV) swap roles from stage to stage
 BMPC_D inline void backward_buffers(int N, int k, int &oK0, int &oK1, int &oKV, int &oKV1) {
@@ -1243,6 +1287,7 @@ BMPC_D inline void backward_commit_lane(Wave &W, int k, const double *pf, int la
     int oK0, oK1, oKV, oKV1; backward_buffers(W.N, k, oK0, oK1, oKV, oKV1);
     const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, r2 = lane < RREC - 64 ? 64 + lane : RREC - 1;
     const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l12 = lane < 12 ? lane : 11;
+    const int l35 = lane < NS ? lane : NS - 1, l42 = lane < 42 ? lane : 41, l28 = lane < 28 ? lane : 27;
     if (first) { L[oK0 + lane] = pf[0]; L[oKV1 + lane] = pf[2]; L[oK0 + l2] = pf[1]; L[oKV1 + l2] = pf[3]; }
     L[oK1 + lane] = pf[4]; L[oKV + lane] = pf[6];
     L[oK1 + l2] = pf[5]; L[oKV + l2] = pf[7];
@@ -1251,6 +1296,7 @@ BMPC_D inline void backward_commit_lane(Wave &W, int k, const double *pf, int la
     L[L_ST + ST_SG + li] = pf[12]; L[L_ST + ST_NU + li] = pf[13];
     L[L_ST + ST_G + le] = pf[14]; L[L_ST + ST_LAM0 + le] = pf[15]; L[L_ST + ST_LAM1 + le] = pf[16];
     L[L_ST + ST_RLV0 + l12] = pf[17]; L[L_ST + ST_RLVM + l12] = pf[18]; L[L_ST + ST_RLVP + l12] = pf[19];
+    L[L_RD + l35] = pf[10]; L[L_AE + l42] = pf[20]; L[L_NC + NC_HPP + l28] = pf[21];
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1270,10 +1316,6 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
     LANES_BEGIN
         backward_commit_lane(W, N - 1, LR[LIDX].pf, lane, true);
         backward_loads_lane(W, sc, N >= 2 ? N - 2 : 0, LR[LIDX].pf, lane, false);
-    LANES_END
-    backward_buffers(N, N - 1, W.oK0, W.oK1, W.oKV, W.oKV1);
-    LANES_BEGIN
-        node_cost_p1_lane(W, po, sc, N - 1, lane);
     LANES_END
     for (int k = N - 1; k >= 0; k--) {
         BMPC_PROF(W, 6);
@@ -1517,7 +1559,6 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         LANES_END
         BMPC_PROF(W, 23);
         if (L[L_FLAG] == 0.0) return false;
-        if (k >= 1) backward_buffers(N, k - 1, W.oK0, W.oK1, W.oKV, W.oKV1);     // for phase 1 of the next stage's node cost, fused below
         // ---- S3: Schur complement, block lanes write the value function of node k ----
         if (k >= 1) {
             LANES_BEGIN
@@ -1572,6 +1613,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 #pragma unroll
                         for (int g = 0; g < f; g++) C[f][g] = C[g][f];
                 }
+                BMPC_PROF(W, 14);
                 // the small roles (chain x iota, iota x iota, gradient) are predicated and evaluated BEFORE any store of this phase,
                 // so that all LDS reads of the phase can be in flight together
                 const int lf = (lane & 31) >> 3, lii = lane & 7;
@@ -1592,6 +1634,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 double pvv = L[L_MV + pr_];
 #pragma unroll
                 for (int a = 0; a < NU; a++) pvv += L[L_GS + a * 36 + pr_] * L[L_KS + a * 36 + 35];
+                BMPC_PROF(W, 17);
                 // ---- stores ----
 #pragma unroll
                 for (int f = 0; f < 4; f++)
@@ -1600,7 +1643,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 L[L_PCI + pci(0, lf, lii)] = ci3[0]; L[L_PCI + pci(1, lf, lii)] = ci3[1]; L[L_PCI + pci(2, lf, lii)] = ci3[2];   // lanes >= 32 repeat lanes 0..31
                 L[onII ? L_PII + ib * 3 + ic : L_DUMMY] = pii; L[onII ? L_PII + ic * 3 + ib : L_DUMMY] = pii;
                 L[L_PV + pr_] = pvv;
-                node_cost_p1_lane(W, po, sc, k - 1, lane);      // phase 1 of the next stage's node cost
+                BMPC_PROF(W, 30);
             LANES_END
         }
         BMPC_PROF(W, 13);
@@ -1815,7 +1858,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         BMPC_PROF(W, 2);
         wave_adjoint(W, po, sc, sc.NUm, true, mu, LRs);
         BMPC_PROF(W, 3);
-        wave_prepare_rlv(W, sc);
+        wave_stage_data_wide(W, po, sc);
         BMPC_PROF(W, 4);
         // Inertia control (oracle/bmpc_oracle.c solve_one).  A failed factorisation costs most of a Riccati sweep (the indefinite
         // 8x8 block usually shows up at the first stages, the END of the backward sweep), so the attempts are chosen to fail rarely:
@@ -1832,12 +1875,14 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         if (gn_allowed && gn_run > 0 && gn_run % GN_PROBE != GN_PROBE - 1) {
             used_gn = true; W.o.exact_hessian = 0;
             wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);
+            wave_stage_data_wide(W, po, sc);
         }
         for (int tries = 0; tries < 40; tries++) {
             if (wave_backward_blk(W, po, sc, mu, delta, LRs)) { ok = true; break; }
             if (gn_allowed && !used_gn) {
                 used_gn = true; W.o.exact_hessian = 0;
                 wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);
+                wave_stage_data_wide(W, po, sc);
                 if (wave_backward_blk(W, po, sc, mu, 0.0, LRs)) { ok = true; delta = 0.0; break; }
             }
             if (delta == 0.0) delta = delta_last > 0 ? BMPC_FMAX(1e-20, delta_last / 3.0) : DELTA_FIRST;

@@ -41,6 +41,11 @@
 #ifdef _OPENMP
 #include <omp.h>
 #endif
+/* phase marks for the flop-counting build (oracle/flopcount.cpp compiles this text with a counting number type); no-ops here */
+#ifndef ORACLE_REGION
+#define ORACLE_REGION(id) ((void)0)
+#endif
+enum { REG_DRIVER = 0, REG_EVAL = 1, REG_ADJOINT = 2, REG_BUILD_QP = 3, REG_RICCATI = 4, REG_KKT = 5, REG_OUTPUT = 6 };
 
 #define NZ 44
 #define NG 43
@@ -903,7 +908,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
     double mu = warm ? fmin(o->mu_init, fmax(state[N * NI], o->mu_warm)) : o->mu_init;
     double mu_min = o->tol * o->mu_min_fac, delta_last = 0.0, delta_prev = 0.0; int gn_run = 0;
     double filt_th[32], filt_ph[32], filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0;
-    W->f = eval_values(C, P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0);
+    ORACLE_REGION(REG_EVAL); W->f = eval_values(C, P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0); ORACLE_REGION(REG_DRIVER);
     for (int i = 0; i < N * NI; i++) {
         const double tmin = (warm && state[i] > 0.0) ? fmin(mu / state[i], o->slack_push) : o->slack_push;
         W->t[i] = fmax(-W->hin[i], tmin); W->nu[i] = mu / W->t[i];
@@ -914,9 +919,9 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
     int it = 0, status = 1;
     double E0 = 0, ep_old = 0, ep_mid = 0;
     for (it = 0; it <= o->max_iter; it++) {
-        adjoint(C, P, W, W->Z, W->nu, W->lam, W->Rj, W->gradZ);
+        ORACLE_REGION(REG_ADJOINT); adjoint(C, P, W, W->Z, W->nu, W->lam, W->Rj, W->gradZ); ORACLE_REGION(REG_DRIVER);
         double ed, ep, ec0, ecm, sd, sc;
-        kkt_errors(C, W, 0.0, &ed, &ep, &ec0, &sd, &sc);
+        ORACLE_REGION(REG_KKT); kkt_errors(C, W, 0.0, &ed, &ep, &ec0, &sd, &sc); ORACLE_REGION(REG_DRIVER);
         E0 = fmax(fmax(ed / sd, ep), ec0 / sc);
         if (o->verbose) fprintf(stderr, "it %3d f %.8e dual %.2e prim %.2e compl %.2e mu %.1e\n", it, W->f, ed, ep, ec0, mu);
         if (E0 <= o->tol) { status = 0; break; }
@@ -934,7 +939,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         }
         if (!(ed < 1e12)) { status = 3; break; }
         for (;;) {
-            kkt_errors(C, W, mu, &ed, &ep, &ecm, &sd, &sc);
+            ORACLE_REGION(REG_KKT); kkt_errors(C, W, mu, &ed, &ep, &ecm, &sd, &sc); ORACLE_REGION(REG_DRIVER);
             double Emu = fmax(fmax(ed / sd, ep), ecm / sc);
             if (Emu <= KAPPA_EPS * mu && mu > mu_min) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5))); else break;
         }
@@ -942,7 +947,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
             sg[i] = W->nu[i] / W->t[i];
             nuh[i] = (mu + W->nu[i] * (W->hin[i] + W->t[i])) / W->t[i];
         }
-        build_qp(C, P, W, sg, nuh);
+        ORACLE_REGION(REG_BUILD_QP); build_qp(C, P, W, sg, nuh); ORACLE_REGION(REG_DRIVER);
         /* Inertia control.  A failed factorisation costs most of a Riccati sweep (the indefinite 8x8 block usually shows up at the
          * first stages, i.e. at the END of the backward sweep), so the attempts are chosen to fail rarely:
          *  - an iteration that follows a regularised one does not try delta = 0 again but a third of the last delta (Ipopt's
@@ -957,20 +962,23 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         if (gn_allowed && gn_run > 0 && gn_run % GN_PROBE != GN_PROBE - 1) {
             used_gn = 1;
             Cfg Cgn = *C; Cgn.o.exact_hessian = 0;      /* C is shared between the OpenMP threads: never modified */
-            build_qp(&Cgn, P, W, sg, nuh);
+            ORACLE_REGION(REG_BUILD_QP); build_qp(&Cgn, P, W, sg, nuh); ORACLE_REGION(REG_DRIVER);
         }
         for (int tries = 0; tries < 40; tries++) {
+            ORACLE_REGION(REG_RICCATI);
             if (riccati(C, W, delta)) { ok = 1; break; }
             if (gn_allowed && !used_gn) {
                 used_gn = 1;
                 Cfg Cgn = *C; Cgn.o.exact_hessian = 0;
-                build_qp(&Cgn, P, W, sg, nuh);
+                ORACLE_REGION(REG_BUILD_QP); build_qp(&Cgn, P, W, sg, nuh); ORACLE_REGION(REG_DRIVER);
+                ORACLE_REGION(REG_RICCATI);
                 if (riccati(C, W, 0.0)) { ok = 1; delta = 0.0; break; }
             }
             if (delta == 0.0) delta = delta_last > 0 ? fmax(1e-20, delta_last / 3.0) : DELTA_FIRST;
             else delta *= (delta_last > 0 ? 8.0 : DELTA_UP_FIRST);
             if (delta > 1e20) break;
         }
+        ORACLE_REGION(REG_DRIVER);
         gn_run = (used_gn && ok) ? gn_run + 1 : 0;
         if (!ok) { status = 3; break; }
         if (delta > 0) delta_last = delta;
@@ -991,7 +999,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         }
         /* filter line search (Waechter & Biegler 2006, Ipopt constants) on theta = ||c||_1 + ||h+t||_1 and
          * the barrier objective phi = f - mu sum log t */
-        adjoint(C, P, W, W->Z, zero_nu, gt, ht, gf); /* gf = grad f ; gt/ht scratch */
+        ORACLE_REGION(REG_ADJOINT); adjoint(C, P, W, W->Z, zero_nu, gt, ht, gf); ORACLE_REGION(REG_DRIVER); /* gf = grad f ; gt/ht scratch */
         double gfd = 0; for (int i = 0; i < N * NZ; i++) gfd += gf[i] * W->dZ[i];
         double theta = 0, bar = 0;
         for (int i = 0; i < N * NE; i++) theta += fabs(W->g[i]);
@@ -1003,7 +1011,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         for (int ls = 0; ls < 14; ls++) {
             for (int i = 0; i < N * NZ; i++) W->Zt[i] = W->Z[i] + alpha * W->dZ[i];
             for (int i = 0; i < N * NI; i++) W->tt[i] = W->t[i] + alpha * W->dt[i];
-            ft = eval_values(C, P, W->Zt, W->Kp, W->Kv, W->R, gt, ht, ls > 0);
+            ORACLE_REGION(REG_EVAL); ft = eval_values(C, P, W->Zt, W->Kp, W->Kv, W->R, gt, ht, ls > 0); ORACLE_REGION(REG_DRIVER);
             double th = 0, br = 0;
             for (int i = 0; i < N * NE; i++) th += fabs(gt[i]);
             for (int i = 0; i < N * NI; i++) { th += fabs(ht[i] + W->tt[i]); br -= mu * log(W->tt[i]); }
@@ -1135,9 +1143,11 @@ int bmpc_oracle_solve_warm(int N, int S, double h, const bmpc_oracle_opts *opts,
             SolveInfo info; Par P; par_view(p + (size_t)b * C.np, S, &P);
             solve_one(&C, p + (size_t)b * C.np, x0 + (size_t)b * nw, W, &info, state ? state + (size_t)b * (N * NI + 2) : NULL);
             /* refresh node data at the final point for the outputs */
+            ORACLE_REGION(REG_OUTPUT);
             W->f = eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0);
             write_outputs(&C, &P, W, x ? x + (size_t)b * nw : NULL, g ? g + (size_t)b * ng : NULL,
                           lam_g ? lam_g + (size_t)b * ng : NULL, lam_x ? lam_x + (size_t)b * nw : NULL);
+            ORACLE_REGION(REG_DRIVER);
             if (f) f[b] = info.f; if (iters) iters[b] = info.iters; if (status) status[b] = info.status; if (kkt) kkt[b] = info.kkt;
         }
         work_free(W);

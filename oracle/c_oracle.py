@@ -108,3 +108,41 @@ def solve(p, x0, N, S, h, opts=None, nthreads=0, state=None):
                             _p(p), _p(x0), _p(state) if state is not None else None, _p(out["x"]), _p(out["g"]), _p(out["lam_g"]), _p(out["lam_x"]),
                             _p(out["f"]), _p(out["iters"]), _p(out["status"]), _p(out["kkt"]), ctypes.c_int(nthreads))
     return out
+
+
+# ---- flop-counting build (oracle/flopcount.cpp): the same source text with a counting number type, one thread ----
+_FLOPS_LIB = os.path.join(_HERE, "libbmpc_oracle_flops.so")
+FLOP_REGIONS = ("driver (row passes, line-search bookkeeping)", "eval (kinematics, references, residuals)", "adjoint + gradients",
+                "build_qp (node Hessians, stage maps)", "riccati (factorise + forward)", "kkt errors", "outputs")
+_flib = None
+
+
+def build_flops(force=False):
+    srcs = [os.path.join(_HERE, "flopcount.cpp"), os.path.join(_HERE, "bmpc_oracle.c")]
+    if force or not os.path.exists(_FLOPS_LIB) or os.path.getmtime(_FLOPS_LIB) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libbmpc_oracle_flops.so"])
+    return _FLOPS_LIB
+
+
+def count_flops(p, x0, N, S, h, opts=None):
+    """Executed fp64 operations of the oracle's solve of the batch (p, x0), one thread.  Returns a dict: iterations (total
+    interior-point iterations), converged, flops (total), special (divisions, roots, transcendentals among them), per_region
+    [(name, flops, special)], flops_per_iteration.  Convention: oracle/flopcount.cpp header."""
+    global _flib
+    if _flib is None:
+        if not os.path.exists(_FLOPS_LIB):
+            build_flops()
+        _flib = ctypes.CDLL(_FLOPS_LIB)
+    p = np.ascontiguousarray(np.atleast_2d(p), dtype=np.float64)
+    x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
+    B = p.shape[0]
+    assert p.shape[1] == 141 + 91 * S and x0.shape == (B, N * NZ)
+    o = opts if opts is not None else default_opts(mu_init=0.3 if N > 11 else 0.1)
+    out = np.zeros(18, dtype=np.uint64)
+    rc = _flib.bmpc_oracle_count_flops(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(B), _p(p), _p(x0), _p(out))
+    assert rc == 0
+    fl, sp = out[2:10].astype(np.int64), out[10:18].astype(np.int64)
+    its = int(out[0])
+    return dict(iterations=its, converged=int(out[1]), flops=int(fl.sum()), special=int(sp.sum()),
+                per_region=[(FLOP_REGIONS[r], int(fl[r]), int(sp[r])) for r in range(len(FLOP_REGIONS))],
+                flops_per_iteration=float(fl.sum()) / max(its, 1))

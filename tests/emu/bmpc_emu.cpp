@@ -100,7 +100,7 @@ extern "C" int bmpc_emu_newton(int N, int S, double h, const bmpc::Opts *opts, c
     wave_adjoint(W, po, sc, sc.NUm, false, 0.0, LRs);
     for (int i = 0; i < N * NI; i++) { const double tt = W.G[sc.T + i], nn = W.G[sc.NUm + i]; W.G[sc.SG + i] = nn / tt; W.G[sc.TI + i] = 1.0 / tt; W.G[sc.SR + i] = nn / tt * (W.G[sc.HIN + i] + tt); }
     wave_adjoint(W, po, sc, sc.NUm, true, mu, LRs);
-    wave_prepare_rlv(W, sc);
+    wave_stage_data_wide(W, po, sc);
     bool ok = wave_backward_blk(W, po, sc, mu, delta, LRs);
     if (ok) wave_forward(W, sc, LRs);
     if (ok) for (int i = 0; i < N * NZ; i++) W.G[sc.DZ + i] = W.Dz[i];

@@ -89,3 +89,29 @@ def jacobian_lin_ddot(q, dq, ddq):
     out = np.zeros((3, 7))
     lib().bmpc_emu_jacobian_lin_ddot(_p(a[0]), _p(a[1]), _p(a[2]), _p(out))
     return out
+
+
+# ---- flop-counting build of the same kernel text (tests/emu/bmpc_emu_flops.cpp) ----
+_FLIB = os.path.join(_HERE, "libbmpc_emu_flops.so")
+_fl = None
+
+
+def count_flops(p, x0, N, S, h, opts=None):
+    """fp64 operations the kernel text executes (summed over the lanes of every phase) while solving the batch: dict with iterations,
+    converged, flops, special, flops_per_iteration, per_phase (slot id of tests/gpu_profile_phases.py -> flops)."""
+    global _fl
+    src = os.path.join(_HERE, "bmpc_emu_flops.cpp")
+    if not os.path.exists(_FLIB) or any(os.path.getmtime(_FLIB) < os.path.getmtime(s) for s in (src, _SRC[1])):
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-Wno-enum-compare", "-o", _FLIB, src])
+        _fl = None
+    if _fl is None:
+        _fl = ctypes.CDLL(_FLIB)
+    p = np.ascontiguousarray(np.atleast_2d(p), dtype=np.float64)
+    x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
+    o = opts if opts is not None else default_opts(mu_init=0.3 if N > 11 else 0.1)
+    out = np.zeros(36, dtype=np.uint64)
+    rc = _fl.bmpc_emu_count_flops(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(p.shape[0]), _p(p), _p(x0), _p(out))
+    assert rc == 0
+    its = int(out[0])
+    return dict(iterations=its, converged=int(out[1]), flops=int(out[2]), special=int(out[3]), flops_per_iteration=float(out[2]) / max(its, 1),
+                per_phase={i: int(out[4 + i]) for i in range(32) if out[4 + i]})

@@ -15,10 +15,23 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
         for r in range(4):
             o = s.solve_batch(p, x0); torch.cuda.synchronize(); ms.append(s.last_kernel_ms())
         it = o["iters"].float()
-        print(f"   B={B}: kernel ms {min(ms):.2f} (runs {['%.1f' % m for m in ms]})  -> {B/min(ms)*1e3:.0f} solves/s; iters mean {it.mean():.2f} max {int(it.max())}; ok {int((o['status']==0).sum())}", flush=True)
+        ref = os.environ.get("BMPC_AB_REF")
+        dev = ""
+        if ref:
+            f = f"{ref}_B{B}.npy"
+            xs = o["x"].cpu().numpy()
+            if os.path.exists(f):
+                xr = np.load(f); q = slice(8, 15)
+                d = (xs - xr).reshape(B, 10, 44)[:, :, 8:15]
+                dev = f"; vs first lib: joint RMS {np.sqrt((d ** 2).mean()):.2e} max {np.abs(d).max():.2e} rad"
+            else:
+                np.save(f, xs)
+        print(f"   B={B}: kernel ms {min(ms):.2f} (runs {['%.1f' % m for m in ms]})  -> {B/min(ms)*1e3:.0f} solves/s; iters mean {it.mean():.2f} max {int(it.max())}; ok {int((o['status']==0).sum())}{dev}", flush=True)
         s.close()
 else:
+    ref = os.path.join(ROOT, "gpurun_out", "ab_ref_%d" % os.getpid())
+    os.makedirs(os.path.dirname(ref), exist_ok=True)
     for lib in sys.argv[1:]:
         print(lib, flush=True)
-        env = dict(os.environ, BOUNDMPC_HIP_LIB=os.path.abspath(lib))
+        env = dict(os.environ, BOUNDMPC_HIP_LIB=os.path.abspath(lib), BMPC_AB_REF=ref)
         subprocess.call([sys.executable, os.path.abspath(__file__), "--child"], env=env)

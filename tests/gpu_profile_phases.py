@@ -10,7 +10,7 @@ from boundmpc_amd import workload, _lib
 csrc = os.path.join(ROOT, "boundmpc_amd", "csrc")
 prof_lib = os.path.join(ROOT, "gpurun_out", "libboundmpc_hip_prof.so")
 os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DBMPC_PROFILE", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
+subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DBMPC_PROFILE"] + os.environ.get("BMPC_PROF_DEFS", "").split() + ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
                        "-Wno-unused-variable", "-Wno-unused-value", "-Wno-duplicate-decl-specifier", "-o", prof_lib,
                        os.path.join(csrc, "bmpc_hip.hip")])
 lib = ctypes.CDLL(prof_lib)
@@ -32,8 +32,8 @@ for rep in range(2):
     assert lib.bmpc_solve_batch(h, B, vp(p.data_ptr()), vp(x0.data_ptr()), vp(x.data_ptr()), None, None, None, None, vp(it.data_ptr()), None, None, None) == 0
     torch.cuda.synchronize(); dt = time.time() - t
     lib.bmpc_get_profile(h, vp(prof.ctypes.data))
-names = ["eval", "adjoint", "kkt+mu", "qp-gradient", "prepare-rlv", "bwd:node(after p5..)", "bwd:stage-in", "forward", "step-dirs", "ls-trial", "nu-update", "(merged into nc:p1)", "st:S1 M-blocks", "st:S3 schur", "(unused)", "load", "nc:p1 small blocks + stage data", "(merged)", "nc:p2+p3 A1/A2/mu/gl", "nc:p4 block add", "(merged into S0)", "st:S0 q~/PR/U/PE", "st:S0b Mci/m", "st:S2 chol+gains", "bwd:staging burst", "eval:kinematics (2N lanes)", "eval:node refs+objective (N lanes)", "adjoint:node gradients (N lanes)", "step-dirs: row loop", "step-dirs: grad.dz + theta loops"] + [""] * 2
+names = ["eval", "adjoint", "kkt+mu", "qp-gradient", "prepare-rlv", "bwd:node(after p5..)", "bwd:stage-in", "forward", "step-dirs", "ls-trial", "nu-update", "(merged into nc:p1)", "st:S1 M-blocks", "st:S3d p1 of next stage", "st:S3a mfma + C", "load", "nc:p1 small blocks + stage data", "st:S3b small roles", "nc:p2+p3 A1/A2/mu/gl", "nc:p4 block add", "(merged into S0)", "st:S0 q~/PR/U/PE", "st:S0b Mci/m", "st:S2 chol+gains", "bwd:staging burst", "eval:kinematics (2N lanes)", "eval:node refs+objective (N lanes)", "adjoint:node gradients (N lanes)", "step-dirs: row loop", "step-dirs: grad.dz + theta loops", "st:S3c stores", ""]
 tot = float(prof.sum()); its = float(it.sum().item())
 print(f"B={B} N={N}{' tight' if TIGHT else ''} wall {dt*1e3:.1f} ms, total iterations {its:.0f}, cycles/iteration (lane-0 stamps, profile build) {tot/its:.0f}")
 for n, c in zip(names, prof):
-    if c: print(f"  {n:14s} {100.0*float(c)/tot:5.1f} %   {float(c)/its:9.0f} cycles/iter")
+    if c: print(f"  {n:28s} {100.0*float(c)/tot:5.1f} %   {float(c)/its:9.0f} cycles/iter")

@@ -13,13 +13,13 @@ timeout -k 10 200 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_ou
 tail -1 gpurun_out/smoke_$TAG.log
 timeout -k 10 400 python bench.py > gpurun_out/bench_${TAG}_B1024.json 2> gpurun_out/bench_err.log
 cat gpurun_out/bench_${TAG}_B1024.json
-timeout -k 10 300 python bench.py --batch 8192 --no-cpu-baseline > gpurun_out/bench_${TAG}_B8192.json 2>> gpurun_out/bench_err.log
+timeout -k 10 300 python bench.py --config 2 --no-cpu-baseline > gpurun_out/bench_${TAG}_B8192.json 2>> gpurun_out/bench_err.log
 cat gpurun_out/bench_${TAG}_B8192.json
 export TMPDIR=/tmp
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --no-cpu-baseline --workers 1 > $R/gpurun_out/prof_$TAG.log 2>&1
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_B8192 -- python3 $R/bench.py --batch 8192 --steps 5 --no-cpu-baseline --workers 1 > $R/gpurun_out/prof_${TAG}_B8192.log 2>&1
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_N30 -- python3 $R/bench.py --batch 2048 --horizon 30 --tight --steps 3 --warmup 1 --no-cpu-baseline --workers 1 > $R/gpurun_out/prof_${TAG}_N30.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_B8192 -- python3 $R/bench.py --config 2 --steps 5 --no-cpu-baseline --workers 1 > $R/gpurun_out/prof_${TAG}_B8192.log 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_N30 -- python3 $R/bench.py --config 3 --batch 2048 --steps 3 --warmup 1 --no-cpu-baseline --workers 1 > $R/gpurun_out/prof_${TAG}_N30.log 2>&1
 cd $R
 find gpurun_out/prof_$TAG -name '*kernel_stats.csv' -exec cat {} \;
 timeout -k 10 300 python tests/gpu_profile_phases.py > gpurun_out/phases_$TAG.log 2>&1 || true

@@ -69,3 +69,18 @@ def test_shard_range_covers_batch():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_rank_shards_of_the_global_batch_tile_it():
+    """bench.py --gpus N: rank r packs only rows shard_range(G, r, shards) of the global batch (workload.make_batch(rows=...));
+    the shards must tile the batch a single process would generate, in order, with no problem repeated."""
+    from boundmpc_amd import workload
+    from boundmpc_amd.distributed import shard_range
+    G_, shards = 24, 4
+    P, X, Q = workload.make_batch(G_, seed=1, workers=1)
+    parts = [workload.make_batch(G_, seed=1, workers=1, rows=shard_range(G_, r, shards)) for r in range(shards)]
+    np.testing.assert_array_equal(np.concatenate([a[0] for a in parts]), P)
+    np.testing.assert_array_equal(np.concatenate([a[1] for a in parts]), X)
+    assert len({tuple(q) for q in Q}) == G_
+    # the first rows of a larger draw are the smaller batch (so rank 0's shard of the 1024 x N batch is configs[1] itself)
+    np.testing.assert_array_equal(workload.random_q0(6, 0), workload.random_q0(24, 0)[:6])

@@ -427,6 +427,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k
+    # compute-side figure priced with the exact operation count of the instrumented oracle, not with a model
+    rf = d["roofline_fp64"]
+    assert rf["flops_per_iteration"] > 1e6 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "riccati (factorise + forward)" in rf["flops_per_iteration_by_phase"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["gpu_vs_cpu_sample_joint_rms_rad"] < 1e-6
 
 
@@ -508,6 +511,11 @@ def test_bench_launches_its_own_ranks():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["global_batch"] == 256 and rec["value"] > 0
     assert rec["config"]["solved_fraction"] == 1.0
+    # every rank solves its own shard of ONE global batch: the job's problems are all distinct, and the line carries the
+    # per-rank kernel times and the check that the gathered tensor holds each rank's solution at its place
+    assert rec["config"]["distinct_problems"] == 256
+    assert len(rec["per_rank"]["kernel_ms"]) == 2 and rec["per_rank"]["gathered_rows_equal_local_solution"] is True
+    assert rec["per_rank"]["kernel_ms_min"] <= rec["per_rank"]["kernel_ms_max"] and rec["same_batch_ms_per_step"] > 0
 
 
 def test_closed_loop_ticks_against_independent_scipy_solutions(solver):
