@@ -106,7 +106,9 @@ def lint_isa_masked_loads(asm_path, window=400):
             written_before.append(set(seen))
             seen |= _defs_uses(s)[0] if s else set()
         for i, (ln, s, _) in enumerate(lines):
-            m = re.match(r"s_andn?2?_saveexec_b64 (s\[\d+:\d+\])", s)
+            # only `if` regions without an else arm: an else arm (s_andn2_saveexec / s_or_saveexec on the xor-ed mask) complements a then
+            # arm that defined the register for the other lanes
+            m = re.match(r"s_and_saveexec_b64 (s\[\d+:\d+\])", s)
             if not m:
                 continue
             save, loads, j, closed = m.group(1), set(), i + 1, False

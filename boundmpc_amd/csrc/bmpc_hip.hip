@@ -94,6 +94,13 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
 
 struct bmpc_handle {
     int N, S; double h; bmpc_options o;
+    int dev;                 // device the handle was created on: workspace, work queue, events and streams of the handle live there
+    int refs; bool closed;   // one reference for the creator, one per captured graph (their kernels carry the workspace addresses);
+                             // bmpc_destroy closes the handle, the memory goes when the last reference does
+    // launches of one handle share its workspace and work queue, so they are ordered against each other whatever streams the
+    // caller uses: every launch records order_ev, a launch on another stream waits for it first
+    hipEvent_t order_ev, bridge_ev; bool order_valid; hipStream_t order_stream;
+    hipStream_t own_stream;  // graph replays requested on the legacy null stream run here, bracketed by events (bmpc_graph_launch)
     int grid; long long scr_stride; double *scratch; int scr_waves; int graphs_alive; int *counter; unsigned long long *prof;
     int timing; hipEvent_t *ev; int nev; long long n_timed;   // timing = number of launches whose {start, stop} event pairs are kept (ring)
     double *latency_us;
@@ -101,6 +108,33 @@ struct bmpc_handle {
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "boundmpc_hip: %s failed: %s\n", #x, hipGetErrorString(e_)); return BMPC_ERR_HIP; } } while (0)
+
+// makes the handle's device current for the scope (allocation, free and synchronisation act on the CURRENT device)
+struct DevGuard {
+    int prev; bool changed;
+    explicit DevGuard(int dev) : prev(dev), changed(false) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess; }
+    ~DevGuard() { if (changed) hipSetDevice(prev); }
+};
+static int order_before(bmpc_handle *h, hipStream_t st) {
+    if (h->order_valid && st != h->order_stream) HIPCHK(hipStreamWaitEvent(st, h->order_ev, 0));
+    return BMPC_OK;
+}
+static int order_after(bmpc_handle *h, hipStream_t st) {
+    HIPCHK(hipEventRecord(h->order_ev, st));
+    h->order_stream = st; h->order_valid = true;
+    return BMPC_OK;
+}
+static void handle_release(bmpc_handle *h) {
+    if (--h->refs > 0) return;
+    DevGuard dg(h->dev);
+    for (int i = 0; i < 2 * h->nev; i++) hipEventDestroy(h->ev[i]);
+    delete[] h->ev;
+    if (h->order_ev) hipEventDestroy(h->order_ev);
+    if (h->bridge_ev) hipEventDestroy(h->bridge_ev);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    hipFree(h->scratch); hipFree(h->counter); hipFree(h->prof); hipFree(h->stage_d); hipFree(h->stage_i);
+    delete h;
+}
 
 extern "C" int bmpc_default_options(bmpc_options *o) {
     if (!o) return BMPC_ERR_ARG;
@@ -125,9 +159,11 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     if (!h) return BMPC_ERR_ARG;
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->ev = nullptr; h->nev = 0; h->n_timed = 0; h->latency_us = nullptr;
     h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->prof = nullptr; h->stage_d = nullptr; h->stage_i = nullptr; h->stage_cap = 0;
+    h->dev = 0; h->refs = 1; h->closed = false; h->order_ev = nullptr; h->bridge_ev = nullptr; h->order_valid = false; h->order_stream = nullptr; h->own_stream = nullptr;
     if (opts) h->o = *opts; else bmpc_default_options_for(N, &h->o);
     int dev = 0, per_cu = 0; hipDeviceProp_t prop;
     bool ok = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess;
+    h->dev = dev;
     if (ok) ok = (N <= 11 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel<true>, 64, 0)
                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel<false>, 64, 0)) == hipSuccess;
     if (ok) {
@@ -138,10 +174,14 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
         // a single-problem handle (the nlpsol shim of one BoundMPC object) holds one slab, not 1024
         ok = hipMalloc(&h->counter, sizeof(int)) == hipSuccess
           && hipMalloc(&h->prof, 32 * sizeof(unsigned long long)) == hipSuccess
-          && hipMemset(h->prof, 0, 32 * sizeof(unsigned long long)) == hipSuccess;
+          && hipMemset(h->prof, 0, 32 * sizeof(unsigned long long)) == hipSuccess
+          && hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming) == hipSuccess
+          && hipEventCreateWithFlags(&h->bridge_ev, hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) {   // nothing half-built survives a failed create
         fprintf(stderr, "boundmpc_hip: bmpc_create failed: %s\n", hipGetErrorString(hipGetLastError()));
+        if (h->order_ev) hipEventDestroy(h->order_ev);
+        if (h->bridge_ev) hipEventDestroy(h->bridge_ev);
         hipFree(h->scratch); hipFree(h->counter); hipFree(h->prof); delete h;
         return BMPC_ERR_HIP;
     }
@@ -149,12 +189,15 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     return BMPC_OK;
 }
 extern "C" int bmpc_destroy(bmpc_handle *h) {
-    if (!h) return BMPC_ERR_ARG;
-    hipDeviceSynchronize();        // launches are asynchronous: nothing of this handle may still be running on its workspace
-    for (int i = 0; i < 2 * h->nev; i++) hipEventDestroy(h->ev[i]);
-    delete[] h->ev;
-    hipFree(h->scratch); hipFree(h->counter); hipFree(h->prof); hipFree(h->stage_d); hipFree(h->stage_i);
-    delete h;
+    if (!h || h->closed) return BMPC_ERR_ARG;
+    {
+        DevGuard dg(h->dev);
+        hipDeviceSynchronize();    // launches are asynchronous: nothing of this handle may still be running on its workspace
+    }
+    // captured graphs carry the addresses of the workspace and of the work queue: while one is alive the memory stays, the handle
+    // only stops accepting work (bmpc_graph_launch of such a graph returns BMPC_ERR_ARG); the last bmpc_graph_destroy frees it
+    h->closed = true;
+    handle_release(h);
     return BMPC_OK;
 }
 extern "C" int bmpc_num_vars(const bmpc_handle *h) { return h ? h->N * bmpc::NZ : -1; }
@@ -185,6 +228,7 @@ extern "C" int bmpc_get_bounds(const bmpc_handle *h, double *lbx, double *ubx, d
 // first, and captured graphs (which carry the old address) forbid growth -- size the first solve / capture for the largest batch
 static int ensure_scratch(bmpc_handle *h, int waves) {
     if (waves <= h->scr_waves) return BMPC_OK;
+    DevGuard dg(h->dev);
     if (h->graphs_alive > 0 && h->scratch) {
         fprintf(stderr, "boundmpc_hip: a larger batch needs a larger workspace, but %d captured graph(s) hold the current one\n", h->graphs_alive);
         return BMPC_ERR_ARG;
@@ -208,7 +252,9 @@ static int timing_slot(bmpc_handle *h, hipEvent_t **pair) {
 }
 // fills the kernel arguments and enqueues {reset of the work-queue counter, solver kernel} on `st`
 static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g, double *lam_g,
-                         double *lam_x, double *f, int *iters, int *status, double *kkt, hipStream_t st, bool timed) {
+                         double *lam_x, double *f, int *iters, int *status, double *kkt, hipStream_t st, bool timed, bool capturing = false) {
+    if (h->closed) return BMPC_ERR_ARG;
+    if (!capturing) { const int rc_ = order_before(h, st); if (rc_ != BMPC_OK) return rc_; }
     KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
     a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
     a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window;
@@ -224,6 +270,7 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     else hipLaunchKernelGGL(bmpc_solve_kernel<false>, dim3(grid), dim3(64), 0, st, a);
     HIPCHK(hipGetLastError());
     if (timed) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }
+    if (!capturing) return order_after(h, st);
     return BMPC_OK;
 }
 
@@ -260,30 +307,49 @@ extern "C" int bmpc_graph_create(bmpc_handle *h, int B, const double *p, const d
     int rc = BMPC_OK;
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = BMPC_ERR_HIP;
     if (rc == BMPC_OK) {
-        rc = enqueue_solve(h, B, p, x0, state, max_iter, x, g, lam_g, lam_x, f, iters, status, kkt, cs, false);
+        rc = enqueue_solve(h, B, p, x0, state, max_iter, x, g, lam_g, lam_x, f, iters, status, kkt, cs, false, true);
         hipError_t e = hipStreamEndCapture(cs, &gr->graph);       // always end the capture, also after an enqueue error
         if (rc == BMPC_OK && e != hipSuccess) rc = BMPC_ERR_HIP;
     }
     if (rc == BMPC_OK && hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0) != hipSuccess) rc = BMPC_ERR_HIP;
     hipStreamDestroy(cs);
     if (rc != BMPC_OK) { if (gr->exec) hipGraphExecDestroy(gr->exec); if (gr->graph) hipGraphDestroy(gr->graph); delete gr; return rc; }
-    *out = gr; h->graphs_alive++;
+    *out = gr; h->graphs_alive++; h->refs++;
     return BMPC_OK;
 }
 extern "C" int bmpc_graph_launch(bmpc_graph *gr, void *hip_stream) {
-    if (!gr) return BMPC_ERR_ARG;
+    if (!gr || !gr->h || gr->h->closed) return BMPC_ERR_ARG;
     bmpc_handle *h = gr->h; hipStream_t st = (hipStream_t)hip_stream;
+    // A replay requested on the LEGACY NULL STREAM does not run there: on ROCm 7.2 a graph replayed on the null stream, followed by
+    // further null-stream launches without a host synchronisation, ended in a GPU memory fault (tests/cabi/graph_nullstream.cpp).
+    // It runs on a non-blocking stream of the handle, bracketed by events: after everything the null stream holds so far, and the
+    // null stream's later work after it -- the ordering a caller expects from "launch on the null stream".
+    const bool bridged = st == nullptr;
+    if (bridged) {
+        DevGuard dg(h->dev);
+        if (!h->own_stream) HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventRecord(h->bridge_ev, nullptr));
+        HIPCHK(hipStreamWaitEvent(h->own_stream, h->bridge_ev, 0));
+        st = h->own_stream;
+    }
+    { const int rc_ = order_before(h, st); if (rc_ != BMPC_OK) return rc_; }
     hipEvent_t *pair = nullptr;
     if (h->timing) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
     HIPCHK(hipGraphLaunch(gr->exec, st));
     if (h->timing) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }
+    { const int rc_ = order_after(h, st); if (rc_ != BMPC_OK) return rc_; }
+    if (bridged) HIPCHK(hipStreamWaitEvent(nullptr, h->order_ev, 0));
     return BMPC_OK;
 }
 extern "C" int bmpc_graph_destroy(bmpc_graph *gr) {
     if (!gr) return BMPC_ERR_ARG;
-    hipDeviceSynchronize();        // a replay of this graph may still be in flight
-    if (gr->h && gr->h->graphs_alive > 0) gr->h->graphs_alive--;
+    bmpc_handle *h = gr->h;
+    {
+        DevGuard dg(h ? h->dev : 0);
+        hipDeviceSynchronize();        // a replay of this graph may still be in flight
+    }
     hipGraphExecDestroy(gr->exec); hipGraphDestroy(gr->graph); delete gr;
+    if (h) { if (h->graphs_alive > 0) h->graphs_alive--; handle_release(h); }     // the last reference of a closed handle frees it
     return BMPC_OK;
 }
 
@@ -347,14 +413,14 @@ __global__ void __launch_bounds__(64) bmpc_stream_pack_kernel(int N, int S, int 
                                                              double *p, double *x0, double *dual) {
     __shared__ double sh[bmpcs::SH_LEN];
     const int b = blockIdx.x;
-    bmpcs::stream_pack(N, S, path + (long long)b * path_stride, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
+    bmpcs::stream_pack(N, S, path + (long long)b * path_stride, path_stride / bmpcs::PT_LEN, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
                        p + (long long)b * (141 + 91 * S), x0 + (long long)b * 44 * N, dual ? dual + (long long)b * (57 * N + 2) : nullptr, sh, threadIdx.x, 64);
 }
 __global__ void __launch_bounds__(64) bmpc_stream_post_kernel(int N, int S, int B, double h, const double *path, int path_stride, double *ss, double *rb,
                                                              const double *x, const double *g, const int *status, double *traj, int flags) {
     __shared__ double sh[bmpcs::SH_LEN];
     const int b = blockIdx.x;
-    bmpcs::stream_post(N, S, h, path + (long long)b * path_stride, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
+    bmpcs::stream_post(N, S, h, path + (long long)b * path_stride, path_stride / bmpcs::PT_LEN, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
                        x + (long long)b * 44 * N, g + (long long)b * 43 * N, status[b], traj + (long long)b * bmpcs::tr_len(N), flags, sh, threadIdx.x, 64);
 }
 extern "C" int bmpc_stream_lengths(const bmpc_handle *h, int *path_entry, int *state, int *robot, int *traj) {
@@ -366,6 +432,7 @@ extern "C" int bmpc_stream_pack(bmpc_handle *h, int B, const double *path, int p
                                 double *dual_state, void *hip_stream) {
     if (!h || B < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !p || !x0))) return BMPC_ERR_ARG;
     if (B == 0) return BMPC_OK;
+    if (h->closed) return BMPC_ERR_ARG;
     hipLaunchKernelGGL(bmpc_stream_pack_kernel, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, path, path_entries * bmpcs::PT_LEN,
                        sstate, robot, p, x0, dual_state);
     HIPCHK(hipGetLastError());
@@ -395,7 +462,7 @@ extern "C" int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *pat
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = BMPC_ERR_HIP;
     if (rc == BMPC_OK) {
         rc = bmpc_stream_pack(h, B, path, path_entries, sstate, robot, p, x0, dual_state, cs);
-        if (rc == BMPC_OK) rc = enqueue_solve(h, B, p, x0, dual_state, max_iter, x, g, nullptr, nullptr, nullptr, iters, status, kkt, cs, false);
+        if (rc == BMPC_OK) rc = enqueue_solve(h, B, p, x0, dual_state, max_iter, x, g, nullptr, nullptr, nullptr, iters, status, kkt, cs, false, true);
         if (rc == BMPC_OK) rc = bmpc_stream_post(h, B, path, path_entries, sstate, robot, x, g, status, traj, flags, cs);
         hipError_t e = hipStreamEndCapture(cs, &gr->graph);
         if (rc == BMPC_OK && e != hipSuccess) rc = BMPC_ERR_HIP;
@@ -403,7 +470,7 @@ extern "C" int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *pat
     if (rc == BMPC_OK && hipGraphInstantiate(&gr->exec, gr->graph, nullptr, nullptr, 0) != hipSuccess) rc = BMPC_ERR_HIP;
     hipStreamDestroy(cs);
     if (rc != BMPC_OK) { if (gr->exec) hipGraphExecDestroy(gr->exec); if (gr->graph) hipGraphDestroy(gr->graph); delete gr; return rc; }
-    *out = gr; h->graphs_alive++;
+    *out = gr; h->graphs_alive++; h->refs++;
     return BMPC_OK;
 }
 

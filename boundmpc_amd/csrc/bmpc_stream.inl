@@ -247,14 +247,18 @@ enum { SH_DTAU = 0, SH_RTAU = 3, SH_JR = 12, SH_JL = 21, SH_PHISW = 30, SH_FLAG 
 
 // f1 + f3: pack one stream.  path [nent][PT_LEN], ss stream state, rb robot record, p [141+91 S], x0 [N][44],
 // dual (may be null): the solver's dual state [57 N + 2], shifted with the plan.
-BMPC_HD inline void stream_pack(int N, int S, const double *path, double *ss, const double *rb, double *p, double *x0, double *dual,
+// cap = entries the path table holds: the entry count and the window start read from the state row are clamped to it, so that a
+// corrupted state (a NaN, a row written by a racing update) cannot index outside the table.
+BMPC_HD inline void stream_pack(int N, int S, const double *path, int cap, double *ss, const double *rb, double *p, double *x0, double *dual,
                                 double *sh, int lane, int nl) {
-    const int nent = (int)ss[SS_NENT];
+    int nent = (int)ss[SS_NENT];
+    nent = nent > cap ? cap : nent; nent = nent < S + 1 ? S + 1 : nent;
     const double phi_cur = ss[SS_PHI];
     const double *q0 = rb + RB_Q, *p0 = rb + RB_P;
     const bool has_prev = ss[SS_HASPREV] > 0.5;
     // ReferencePath.update: slide the window while phi passed the first switch (every lane computes the same sector)
     int sector = (int)ss[SS_SECTOR];
+    sector = sector > nent - S - 1 ? nent - S - 1 : sector; sector = sector < 0 ? 0 : sector;
     while (sector + S + 1 < nent && phi_cur > path[(sector + 1) * PT_LEN + PT_CUM]) sector++;
     // ---- phase 0 (one lane): initial orientation error, its rotation matrix, SO(3) Jacobians ----
     if (lane == 0) {
@@ -394,7 +398,7 @@ BMPC_HD inline void stream_pack(int N, int S, const double *path, double *ss, co
 // f2 + f3: post-process one stream.  x [N][44] solver result, g [N][43], status; traj: trajectory record (tr_len(N));
 // flags bit 0: advance the robot record rb with the kinematic plant step of the node (util_functions.py:152-161);
 // bit 1: real-time-iteration mode -- an iteration-capped solve (status 1) counts as a usable plan (not in the reference).
-BMPC_HD inline void stream_post(int N, int S, double h, const double *path, double *ss, double *rb, const double *x, const double *g, int status,
+BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int cap, double *ss, double *rb, const double *x, const double *g, int status,
                                 double *traj, int flags, double *sh, int lane, int nl) {
     // ---- phase 0: feasibility rule :460-465 (strided partial sums, fixed-order total) ----
     {
@@ -484,7 +488,8 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, doub
                 pc[(6 + c) * N + col] = a; pc[(9 + c) * N + col] = jk;
             }
         } else if (role == 32) {
-            const int sector = (int)ss[SS_SECTOR];
+            int sector = (int)ss[SS_SECTOR];
+            sector = sector > cap - 2 ? cap - 2 : sector; sector = sector < 0 ? 0 : sector;       // clamped to the table (see stream_pack)
             const double *e0 = path + sector * PT_LEN, *e1 = path + (sector + 1) * PT_LEN;
             const double sw0 = e0[PT_CUM], sw1 = e1[PT_CUM], phi0 = Tphi[0];
             double prn[3];

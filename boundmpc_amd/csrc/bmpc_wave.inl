@@ -112,13 +112,18 @@ enum { ST_REF = 0, ST_Z = 108, ST_SG = 152, ST_NU = 212, ST_G = 272, ST_LAM0 = 3
 enum { NC_HPP = 0, NC_HRR = 9, NC_HPF = 18, NC_HRF = 21, NC_SC = 24 /* hff,hdd,hddd,cv */, NC_A1 = 28 /* Hpp*Jp 3x7 */, NC_A2 = 49 /* Hrr*Ehat 3x14 */,
        NC_GL = 91 /* 44 */, NC_RL = 135 /* 9 */, NC_GY = 144 /* 14 */ };
 
+// row of the NCS workspace array (one per stage): [0, 91) mirrors the LDS node-cost area L_NC (small blocks 28 | A1 21 | A2 42),
+// then the curvature multipliers (12 -> L_MU + 4), dp_d of the stage's node (6 -> ST_REF + RDP), the 12 non-trivial entries of
+// gl - g^ (rows pos 3, v 6, phi, dphi, ddphi of Z) and a zero word (what the other rows of gl add to g^)
+enum { NCS_MU = 91, NCS_RDP = 103, NCS_ADDV = 109, NCS_ZERO = 121, NCS_DUMMY = 122, NCS_STRIDE = 128 };
+
 struct Opts {
     double tol; int max_iter; double mu_init; double mu_min_fac; double slack_push; int exact_hessian; int verbose; double mu_warm; int stall_window;
 };
 
 // global scratch layout (doubles) for horizon N
 struct Scr {
-    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, NU2, NCS, size;
+    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, NU2, NCS, KHPG, size;
 };
 BMPC_HD inline Scr make_scr(int N) {
     Scr s; int c = 0;
@@ -127,7 +132,8 @@ BMPC_HD inline Scr make_scr(int N) {
     s.DZ = c; c += N * NZ; s.DT = c; c += N * NI; s.DNU = c; c += N * NI; s.GH = c; c += N * NZ; s.GVP = c; c += N * 8;
     s.RJ = c; c += N * NU; s.KIN = c; c += 2 * N * KREC; s.REF = c; c += N * RREC; s.KT = c; c += N * NS * NU; s.KF = c; c += N * NU;
     s.RDY = c; c += N * 36; s.AES = c; c += N * 42; s.RLV = c; c += N * 12; s.SG = c; c += N * NI; s.TI = c; c += N * NI; s.SR = c; c += N * NI; s.NU2 = c; c += N * NI;   // NU2: second multiplier buffer (the update ping-pongs)
-    s.NCS = c; c += N * 32;   // small (pos, iw, phi) Hessian blocks of every stage (28 used), written by wave_stage_data_wide
+    s.NCS = c; c += N * NCS_STRIDE;   // node-cost data of every stage (wave_stage_data_wide): see the NCS_* row layout
+    s.KHPG = c; c += 2 * N * 72;      // prefix vectors of the kinematic curvature, one row per kinematics record (kin_point)
     s.size = (c + 15) & ~15;
     return s;
 }
@@ -177,7 +183,7 @@ BMPC_D inline double ndv(const double *PAR, const POff &po, const double *Z, int
 // joint axes (z,y,z,-y,z,y,z), link offsets along local z (RobotModel.py:9-16).
 // Writes the record rec[KREC]: axes, J_v columns, D = d(J dq)/dq, pos, v = J dq, dq.
 // ----------------------------------------------------------------------------------------
-BMPC_D inline void kin_point(const double *q, const double *dq, double *rec) {
+BMPC_D inline void kin_point(const double *q, const double *dq, double *rec, double *hp) {
     const double preZ[7] = {0.0, 0.1575 + 0.2025, 0.0, 0.2375 + 0.1825, 0.0, 0.2175 + 0.1825, 0.0};
     const double toolZ = 0.081 + (0.071 + 0.145);
     double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, o[3] = {0, 0, 0}, O[7][3], a[7][3], w[7][3];
@@ -226,6 +232,19 @@ BMPC_D inline void kin_point(const double *q, const double *dq, double *rec) {
     }
     for (int c = 0; c < 3; c++) rec[KPOS + c] = pos[c];
     for (int c = 0; c < 6; c++) rec[KV + c] = v[c];
+    // prefix vectors of the kinematic curvature, hp = [Wlt 8x3 | Vge 7x3 | Wgt 7x3] (kh_qq): Wlt_j = sum_{m<j} dq_m a_m,
+    // Vge_j = sum_{m>=j} dq_m w_m, Wgt_j = sum_{m>j} dq_m a_m -- the lane has a, w, dq in registers here; until round 2 every Riccati
+    // stage rebuilt them from the record in LDS (node-cost phase 2)
+    {
+        double wl[3] = {0, 0, 0}, vg[3] = {0, 0, 0}, wg[3] = {0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 7; j++) { for (int c = 0; c < 3; c++) { hp[3 * j + c] = wl[c]; wl[c] += dq[j] * a[j][c]; } }
+        for (int c = 0; c < 3; c++) hp[21 + c] = wl[c];
+#pragma unroll
+        for (int j = 6; j >= 0; j--) {
+            for (int c = 0; c < 3; c++) { hp[45 + 3 * j + c] = wg[c]; vg[c] += dq[j] * w[j][c]; hp[24 + 3 * j + c] = vg[c]; wg[c] += dq[j] * a[j][c]; }
+        }
+    }
 }
 
 // one entry (ya,yb), ya<=yb, of the Hessian of  mu_p.pos + mu_v.(J_v dq) + mu_w.(J_w dq)  w.r.t. y=(q,dq);
@@ -594,7 +613,7 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
             } else {
                 for (int i = 0; i < 7; i++) { q[i] = ndv(PAR, po, Zs, k, ZQ + i, po.q0 + i); dq[i] = ndv(PAR, po, Zs, k, ZDQ + i, po.dq0 + i); }
             }
-            kin_point(q, dq, G + sc.KIN + lane * KREC);
+            kin_point(q, dq, G + sc.KIN + lane * KREC, G + sc.KHPG + lane * 72);
         }
     LANES_END
     BMPC_PROF(W, 25);
@@ -933,68 +952,9 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
     double *NC = L + L_NC, *WY = L + L_WY, *KHP = L + L_KHP;
     const double *K0 = L + W.oK0, *KV1 = L + W.oKV1;
     const bool has_next = k < N - 1;
-    // (stage data and the small Hessian blocks of this stage were computed for all stages at once by wave_stage_data_wide() and came into
-    // LDS with the stage's other inputs)
+    // (stage data, the small Hessian blocks, A1 / A2, the curvature multipliers and prefix vectors and gl of this stage were computed for
+    // all stages at once -- wave_stage_data_wide(), kin_point() -- and came into LDS with the stage's other inputs)
     BMPC_PROF(W, 16);
-    // phase 2: A1 = Hpp Jp, A2 = (h/2) Hrr Ehat, curvature multipliers, prefix vectors of the curvature records
-    LANES_BEGIN   // predicated straight-line code (see S0): all roles in one basic block, conditional stores only
-        {   // hp = [Wlt 8x3 | Vge 7x3 | Wgt 7x3] per record: one lane per (record, joint, component), three short sums each
-            const int rec = lane >> 5, jj = (lane >> 2) & 7, c4 = lane & 3; const bool on = ex && c4 < 3; const int c = c4 < 3 ? c4 : 0;
-            const double *R_ = rec ? KV1 : K0; double *hp = KHP + rec * 72;
-            double wlt = 0, vge = 0, wgt = 0;
-#pragma unroll
-            for (int m = 0; m < 7; m++) {
-                const double dqm = R_[KDQ + m], am = R_[KA + c * 7 + m], wm = R_[KW + c * 7 + m];
-                wlt += (m < jj ? dqm : 0.0) * am; vge += (m >= jj ? dqm : 0.0) * wm; wgt += (m > jj ? dqm : 0.0) * am;
-            }
-            {   // unconditional stores: lanes without a slot write to the dummy word
-                const int hb = L_KHP + rec * 72, j7 = jj < 7 ? jj : 0; const bool on7 = on && jj < 7;
-                L[on ? hb + 3 * jj + c : L_DUMMY] = wlt; L[on7 ? hb + 24 + 3 * j7 + c : L_DUMMY] = vge; L[on7 ? hb + 45 + 3 * j7 + c : L_DUMMY] = wgt;
-            }
-        }
-        {   // A1 = Hpp Jp (3 x 7)
-            const bool on = lane >= 16 && lane < 16 + 21; const int ln = on ? lane - 16 : 0, c = ln / 7, i = ln % 7; double sacc = 0;
-#pragma unroll
-            for (int b2 = 0; b2 < 3; b2++) sacc += NC[NC_HPP + c * 3 + b2] * K0[KW + b2 * 7 + i];
-            NC[NC_A1 + c * 7 + i] = sacc;
-        }
-        {   // A2 = (h/2) Hrr Ehat (3 x 14)
-            const bool on = lane < 42; const int ln = on ? lane : 0, c = ln / 14, y = ln % 14; double sacc = 0;
-            const int eb = y < 7 ? KD + 21 + y : KA + y - 7;                 // Ehat column y: rows at stride 7
-#pragma unroll
-            for (int b2 = 0; b2 < 3; b2++) sacc += NC[NC_HRR + c * 3 + b2] * K0[eb + b2 * 7];
-            NC[NC_A2 + c * 14 + y] = 0.5 * h * sacc;
-        }
-        {   // curvature multipliers mu_p, mu_v, mu_w (this node) and mu_w of the next node's velocity point
-            const bool on = lane >= 48 && lane < 60; const int ln = on ? lane - 48 : 0, c = ln % 3, g = ln / 3; const double *lam = ST + ST_LAM0;
-            const double lp = lam[GPOS + c], lv = lam[GV + c], lw = lam[GW + c], li = lam[GIW + c], ln1 = ST[ST_LAM1 + GIW + c];
-            // 0/1 factors instead of selects: a select between loaded values compiles into a branch nest with the loads inside
-            const double m0 = g == 0 ? 1.0 : 0.0, m1 = g == 1 ? 1.0 : 0.0, m2 = g == 2 ? 1.0 : 0.0, m3 = (g == 3 && has_next) ? 1.0 : 0.0;
-            const double v = m0 * lp + m1 * lv + m2 * (lw + 0.5 * h * li) + m3 * (0.5 * h * ln1);
-            L[L_MU + 4 + ln] = v;
-        }
-        // (same phase) Z-space gradient gl = g^ + H r + cross terms: reads only phase-1 results and the staging area (the row kinds
-        // select coefficients, not code paths)
-        {
-            const bool on = lane < NZ; const int z = on ? lane : 0;
-            const double *rl = ST + ST_RLV0, cv = NC[NC_SC + 3], *d = rr + RDP;
-            const bool isPos = z >= ZPOS && z < ZPOS + 3, isPhi = z == ZPHI, isV = z >= ZV && z < ZV + 6, isD = z == ZDPHI, isDD = z == ZDDPHI;
-            const int pa = isPos ? NC_HPP + (z - ZPOS) * 3 : NC_HPF;            // 3-vector that multiplies r_pos
-            const int c = isV ? z - ZV : 0;
-            double g = ST[ST_GH + z];
-            double sA = 0, s1 = 0, s2 = 0;
-#pragma unroll
-            for (int b2 = 0; b2 < 3; b2++) sA += NC[pa + b2] * rl[b2];
-#pragma unroll
-            for (int c6 = 0; c6 < 6; c6++) { s1 += d[c6] * rl[3 + c6]; s2 += d[c6] * ST[ST_RLVM + 3 + c6]; }
-            const double vm = k >= 1 ? ST[ST_RLVM + 3 + c] : 0.0, vp = has_next ? ST[ST_RLVP + 3 + c] : 0.0;
-            const double tV = cv * rl[3 + c] - W.ca * vm - W.ca * vp, tD = -2 * w[2] * s1, tDD = -W.cb * s1 + (k >= 1 ? W.cb * s2 : 0.0);
-            double addv = 0.0;
-            addv = isDD ? tDD : addv; addv = isD ? tD : addv; addv = isV ? tV : addv; addv = (isPos || isPhi) ? sA : addv;
-            g += addv;
-            NC[NC_GL + z] = g;
-        }
-    LANES_END
     BMPC_PROF(W, 18);
     // phase 4: one lane per chain pair adds its block of Q~ (and writes the predicted-point curvature to WY for q~).
     // Predicated: every lane evaluates the joint-pair block AND the joint/phi coupling on clamped chain indices (all loads up
@@ -1104,142 +1064,211 @@ BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, in
     BMPC_PROF(W, 20);
 }
 
-// Stage data of ALL Riccati stages in one wide pass, once per iterate and BEFORE the backward sweep (it replaces wave_prepare_rlv and
-// "phase 1 of the node cost" of rounds 1-2):
+// Node-cost data of ALL Riccati stages in wide passes, once per iterate and BEFORE the backward sweep (it replaces wave_prepare_rlv and
+// the node-cost phases 1 and 2 of rounds 1-2, which ran once per stage inside the sequential sweep):
 //   * lifted residuals r_pos (3), r_v (6) of every node, r = g_lifted - G g_y (needed across neighbouring nodes) -> RLV,
 //   * the defect vectors rdyn (35: the residual row the row table names; iota rows g_iw - (h/2) Ehat g_y) -> RDY,
 //   * the iota couplings AE = (h/2)(Ehat(K1) + Ehat(KV_k)) (3 x 14) -> AES,
-//   * the small Hessian blocks over (pos, iw, phi): Hpp, Hrr, Hp,phi, Hr,phi, H phi,phi and the scalar curvatures -> NCS.
-// All of it depends on the iterate and the multipliers only, not on the recursion.  Inside the sweep (one stage's worth per phase, fused
-// into the Schur phase) this work ran as chains of dependent LDS round trips with nothing to overlap them: 2.4 k cycles per stage.  Here
-// one lane owns one (stage, entry) item, the items of all stages are independent, and every loop issues the loads of a whole batch of
-// trips before the first use (a dependent round trip to the workspace costs ~1 k cycles: what counts is how many there are, not how
-// many loads ride in each).  The results reach LDS with the other inputs of a stage through the register prefetch of the sweeps.
+//   * the small Hessian blocks over (pos, iw, phi): Hpp, Hrr, Hp,phi, Hr,phi, H phi,phi and the scalar curvatures,
+//     A1 = Hpp Jp, A2 = (h/2) Hrr Ehat, the curvature multipliers, dp_d and the non-trivial entries of gl - g^ -> NCS (row layout: NCS_*).
+// All of it depends on the iterate and the multipliers only, not on the recursion.  Inside the sweep this work ran as predicated
+// roles (every lane executes every role: about half the lanes idle) in chains of dependent LDS round trips: 4.6 k cycles per stage.
+// Here one lane owns one (stage, entry) item, the items of all stages are independent and every lane has one.
+// What costs in a wide pass is the number of DEPENDENT round trips to the workspace (~1.7 k cycles each, measured; a load that rides
+// in a batch costs ~25): so each phase is written as batches -- all loads of all the item kinds of a batch first, then the
+// arithmetic and the stores -- two batches in the first phase (inputs written by earlier phases), two in the second (which reads what
+// the first wrote: a phase boundary).  One batch covers 10 stages; longer horizons loop.
+// The results reach LDS with the other inputs of a stage through the register prefetch of the sweeps.
 // The acceleration cross block XT = C^T Gv(K1) (15x14, rank 6) is never formed: its consumers contract the two rank-6 factors on
 // the fly (t6 in S0, chain-pair entries in S1).
 BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) {
     const int N = W.N; const double h = W.h; const int ex = W.o.exact_hessian;
     double *L = W.L, *G = W.G;
     const double *PAR = L + L_PAR, *w = PAR + po.w;
+    const int npass = (N + 9) / 10;
     LANES_BEGIN
-        {   // lifted residuals (rows 0..8 of a node's 12) and the iota rows of rdyn (rows 9..11): a residual minus two 7-term dot products
-            // of a record row with g_q and g_dq; the row kind selects bases and factors, not code (rows past the end repeat the last one)
-            constexpr int RL = 2;
-            for (int base = lane; base < N * 12; base += 64 * RL) {
-                double a1[RL][7], a2[RL][7], g1[RL][7], g2[RL][7], b0[RL];
+        for (int pass = 0; pass < npass; pass++) {
+            // ================= batch 1: lifted residuals + iota rows (R), curvature multipliers (M), chain rows of rdyn (Y), AE (E) ==========
+            constexpr int RR = 2, RM = 2, RY = 5, RE = 7;
+            double ra1[RR][7], ra2[RR][7], rg1[RR][7], rg2[RR][7], rb0[RR];
+            double ml[RM][5];
+            double yv[RY];
+            double e1[RE], e2[RE];
 #pragma unroll
-                for (int u = 0; u < RL; u++) {
-                    const int id0 = base + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, c = id - 12 * k;
-                    const int c6 = c >= 3 ? (c < 9 ? c - 3 : c - 6) : 0;                       // velocity rows 0..5; iota rows use the rotational rows 3..5
-                    const int p1 = c < 3 ? KW + c * 7 : KD + c6 * 7;
-                    const int p2 = c < 3 ? KA : (c < 9 ? (c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7) : KA + (c - 9) * 7);
-                    const int bs = c < 3 ? GPOS + c : (c < 9 ? GV + c - 3 : GIW + c - 9);
-                    const double *kp = G + sc.KIN + k * KREC, *gk = G + sc.G + k * NE;
-                    b0[u] = gk[bs];
+            for (int u = 0; u < RR; u++) {   // R: a residual minus two 7-term dot products of a record row with g_q, g_dq; the row kind selects bases
+                const int id0 = pass * 64 * RR + lane + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, c = id - 12 * k;
+                const int c6 = c >= 3 ? (c < 9 ? c - 3 : c - 6) : 0;                       // velocity rows 0..5; iota rows use the rotational rows 3..5
+                const int p1 = c < 3 ? KW + c * 7 : KD + c6 * 7;
+                const int p2 = c < 3 ? KA : (c < 9 ? (c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7) : KA + (c - 9) * 7);
+                const int bs = c < 3 ? GPOS + c : (c < 9 ? GV + c - 3 : GIW + c - 9);
+                const double *kp = G + sc.KIN + k * KREC, *gk = G + sc.G + k * NE;
+                rb0[u] = gk[bs];
 #pragma unroll
-                    for (int i = 0; i < 7; i++) { a1[u][i] = kp[p1 + i]; a2[u][i] = kp[p2 + i]; g1[u][i] = gk[GQ + i]; g2[u][i] = gk[GDQ + i]; }
-                }
+                for (int i = 0; i < 7; i++) { ra1[u][i] = kp[p1 + i]; ra2[u][i] = kp[p2 + i]; rg1[u][i] = gk[GQ + i]; rg2[u][i] = gk[GDQ + i]; }
+            }
 #pragma unroll
-                for (int u = 0; u < RL; u++) {
-                    const int id0 = base + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, c = id - 12 * k;
-                    BMPC_ACC4_DECL(sa); BMPC_ACC4_DECL(sb);
+            for (int u = 0; u < RM; u++) {   // M: mu_p, mu_v, mu_w of the node and mu_w of the next node's velocity point (item = 3 g + c)
+                const int id0 = pass * 64 * RM + lane + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, ln = id - 12 * k, c = ln % 3;
+                const int kn = k < N - 1 ? k + 1 : k;
+                const double *lam = G + sc.LAM + k * NE;
+                ml[u][0] = lam[GPOS + c]; ml[u][1] = lam[GV + c]; ml[u][2] = lam[GW + c]; ml[u][3] = lam[GIW + c]; ml[u][4] = G[sc.LAM + kn * NE + GIW + c];
+            }
 #pragma unroll
-                    for (int i = 0; i < 7; i++) { BMPC_ACC4(sa, i, a1[u][i] * g1[u][i]); BMPC_ACC4(sb, i, a2[u][i] * g2[u][i]); }
-                    const double s1 = BMPC_ACC4_SUM(sa), s2 = BMPC_ACC4_SUM(sb);
-                    const double m2 = c < 3 ? 0.0 : 1.0, f = c < 9 ? 1.0 : 0.5 * h;
-                    const double r = b0[u] - f * (s1 + m2 * s2);
-                    G[c < 9 ? sc.RLV + k * 12 + c : sc.RDY + k * 36 + SIOTA + (c - 9)] = r;      // a clamped duplicate rewrites the last row with the same value
-                }
+            for (int u = 0; u < RY; u++) {   // Y: chain rows of rdyn = the residual row the row table names
+                const int id0 = pass * 64 * RY + lane + 64 * u, id = id0 < N * 32 ? id0 : N * 32 - 1, k = id >> 5, r = id & 31;
+                yv[u] = G[sc.G + k * NE + (((int)L[L_ZMAP + r] >> 8) & 255)];
+            }
+#pragma unroll
+            for (int u = 0; u < RE; u++) {   // E: Ehat entries of the predicted point k-1 and of the velocity point of node k
+                const int id0 = pass * 64 * RE + lane + 64 * u, id = id0 < N * 42 ? id0 : N * 42 - 1, k = id / 42, ln = id - 42 * k, a = ln / 14, y = ln - 14 * a;
+                const int eb = y < 7 ? KD + (3 + a) * 7 + y : KA + a * 7 + y - 7, kp = k >= 1 ? k - 1 : 0;
+                e1[u] = G[sc.KIN + kp * KREC + eb]; e2[u] = G[sc.KIN + (N + k) * KREC + eb];
+            }
+            // ---- arithmetic and stores of batch 1 (a clamped duplicate rewrites the last item with the same value) ----
+#pragma unroll
+            for (int u = 0; u < RR; u++) {
+                const int id0 = pass * 64 * RR + lane + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, c = id - 12 * k;
+                BMPC_ACC4_DECL(sa); BMPC_ACC4_DECL(sb);
+#pragma unroll
+                for (int i = 0; i < 7; i++) { BMPC_ACC4(sa, i, ra1[u][i] * rg1[u][i]); BMPC_ACC4(sb, i, ra2[u][i] * rg2[u][i]); }
+                const double s1 = BMPC_ACC4_SUM(sa), s2 = BMPC_ACC4_SUM(sb);
+                const double m2 = c < 3 ? 0.0 : 1.0, f = c < 9 ? 1.0 : 0.5 * h;
+                G[c < 9 ? sc.RLV + k * 12 + c : sc.RDY + k * 36 + SIOTA + (c - 9)] = rb0[u] - f * (s1 + m2 * s2);
+            }
+#pragma unroll
+            for (int u = 0; u < RM; u++) {
+                const int id0 = pass * 64 * RM + lane + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, ln = id - 12 * k, g = ln / 3;
+                // 0/1 factors instead of selects between loaded values
+                const double m0 = g == 0 ? 1.0 : 0.0, m1 = g == 1 ? 1.0 : 0.0, m2 = g == 2 ? 1.0 : 0.0, m3 = (g == 3 && k < N - 1) ? 1.0 : 0.0;
+                G[sc.NCS + k * NCS_STRIDE + NCS_MU + ln] = m0 * ml[u][0] + m1 * ml[u][1] + m2 * (ml[u][2] + 0.5 * h * ml[u][3]) + m3 * (0.5 * h * ml[u][4]);
+            }
+#pragma unroll
+            for (int u = 0; u < RY; u++) {
+                const int id0 = pass * 64 * RY + lane + 64 * u, id = id0 < N * 32 ? id0 : N * 32 - 1, k = id >> 5, r = id & 31;
+                const bool zero = (((int)L[L_ZMAP + r] >> 16) & 1) != 0;                    // jerk states carry no defect
+                G[sc.RDY + k * 36 + r] = zero ? 0.0 : yv[u];
+            }
+#pragma unroll
+            for (int u = 0; u < RE; u++) {
+                const int id0 = pass * 64 * RE + lane + 64 * u, id = id0 < N * 42 ? id0 : N * 42 - 1;
+                const double v = 0.5 * h * (e1[u] + e2[u]);
+                G[sc.AES + id] = id >= 42 ? v : 0.0;                                          // stage 0 has no iota coupling
             }
         }
-        {   // chain rows of rdyn: the residual row the row table names (jerk states carry no defect)
-            constexpr int RA = 5;
-            for (int base = lane; base < N * 32; base += 64 * RA) {
-                double gv[RA];
-#pragma unroll
-                for (int u = 0; u < RA; u++) {
-                    const int id0 = base + 64 * u, id = id0 < N * 32 ? id0 : N * 32 - 1, k = id >> 5, r = id & 31;
-                    gv[u] = G[sc.G + k * NE + (((int)L[L_ZMAP + r] >> 8) & 255)];
-                }
-#pragma unroll
-                for (int u = 0; u < RA; u++) {
-                    const int id0 = base + 64 * u, id = id0 < N * 32 ? id0 : N * 32 - 1, k = id >> 5, r = id & 31;
-                    const bool zero = (((int)L[L_ZMAP + r] >> 16) & 1) != 0;
-                    G[sc.RDY + k * 36 + r] = zero ? 0.0 : gv[u];
-                }
-            }
-        }
-        {   // AE = (h/2) (Ehat(K1) + Ehat(KV_k)): record of the predicted point k-1 and of the velocity point of node k (stage 0: none)
-            constexpr int RB = 7;
-            for (int base = lane; base < N * 42; base += 64 * RB) {
-                double e1[RB], e2[RB];
-#pragma unroll
-                for (int u = 0; u < RB; u++) {
-                    const int id0 = base + 64 * u, id = id0 < N * 42 ? id0 : N * 42 - 1, k = id / 42, ln = id - 42 * k, a = ln / 14, y = ln - 14 * a;
-                    const int eb = y < 7 ? KD + (3 + a) * 7 + y : KA + a * 7 + y - 7, kp = k >= 1 ? k - 1 : 0;
-                    e1[u] = G[sc.KIN + kp * KREC + eb]; e2[u] = G[sc.KIN + (N + k) * KREC + eb];
-                }
-#pragma unroll
-                for (int u = 0; u < RB; u++) {
-                    const int id0 = base + 64 * u, id = id0 < N * 42 ? id0 : N * 42 - 1;
-                    const double v = 0.5 * h * (e1[u] + e2[u]);
-                    G[sc.AES + id] = id >= 42 ? v : 0.0;
-                }
-            }
-        }
-        {   // Hpp, Hrr (9 entries per stage): geometric part from the record + barrier terms of the tube rows
+        for (int pass = 0; pass < npass; pass++) {
+            // ================= batch 2: Hpp, Hrr (C, 9 entries per stage); Hp,phi, Hr,phi, H phi,phi, scalar curvatures, dp_d (D, 3 items per stage) =====
             constexpr int RC = 2;
-            for (int base = lane; base < N * 9; base += 64 * RC) {
-                double h0[RC], h1[RC], ss[RC][5], ga[RC][5], gb[RC][5];
+            double h0[RC], h1[RC], ss[RC][5], ga[RC][5], gb[RC][5];
 #pragma unroll
-                for (int u = 0; u < RC; u++) {
-                    const int id0 = base + 64 * u, id = id0 < N * 9 ? id0 : N * 9 - 1, k = id / 9, ln = id - 9 * k, a = ln / 3, b = ln - 3 * a;
-                    const double *rr = G + sc.REF + k * RREC, *sgk = G + sc.SG + k * NI;
-                    h0[u] = rr[RHPPG + ln]; h1[u] = rr[RHRRG + ln];
+            for (int u = 0; u < RC; u++) {
+                const int id0 = pass * 64 * RC + lane + 64 * u, id = id0 < N * 9 ? id0 : N * 9 - 1, k = id / 9, ln = id - 9 * k, a = ln / 3, b = ln - 3 * a;
+                const double *rr = G + sc.REF + k * RREC, *sgk = G + sc.SG + k * NI;
+                h0[u] = rr[RHPPG + ln]; h1[u] = rr[RHRRG + ln];
 #pragma unroll
-                    for (int m = 0; m < 5; m++) { ss[u][m] = sgk[ITUBE + 2 * m] + sgk[ITUBE + 2 * m + 1]; ga[u][m] = rr[RGC + m * 4 + a]; gb[u][m] = rr[RGC + m * 4 + b]; }
-                }
-#pragma unroll
-                for (int u = 0; u < RC; u++) {
-                    const int id0 = base + 64 * u, id = id0 < N * 9 ? id0 : N * 9 - 1, k = id / 9, ln = id - 9 * k;
-                    double hp = h0[u], hr = h1[u];
-#pragma unroll
-                    for (int m = 0; m < 5; m++) {
-                        const double gg = ss[u][m] * ga[u][m] * gb[u][m];
-                        if (m == 1 || m == 2) hp += gg; else hr += gg;
-                    }
-                    G[sc.NCS + k * 32 + NC_HPP + ln] = hp; G[sc.NCS + k * 32 + NC_HRR + ln] = hr;
-                }
+                for (int m = 0; m < 5; m++) { ss[u][m] = sgk[ITUBE + 2 * m] + sgk[ITUBE + 2 * m + 1]; ga[u][m] = rr[RGC + m * 4 + a]; gb[u][m] = rr[RGC + m * 4 + b]; }
             }
-        }
-        {   // Hp,phi, Hr,phi (3 entries per stage) and, on the lanes of entry 0, H phi,phi and the scalar curvatures (4 values)
-            for (int base = lane; base < N * 3; base += 64) {
-                const int id = base, k = id / 3, a = id - 3 * k;
-                const double *rr = G + sc.REF + k * RREC, *sgk = G + sc.SG + k * NI, *nuk = G + sc.NUm + k * NI;
-                double su[5], sl[5], g3[5], w1[5], ga[5], nu_u[5], nu_l[5], c2[5], w2[5];
-                const double hp0 = rr[RHPFG + a], hr0 = rr[RHRFG + a], dpdp = rr[RDPDP], hffg = rr[RHFFG];
-                const double s_phi0 = sgk[IPHI0], s_phimax = sgk[IPHIMAX], s_dphimax = sgk[IDPHIMAX];
+            const int idd0 = pass * 64 + lane, idd = idd0 < N * 3 ? idd0 : N * 3 - 1, kd = idd / 3, ad = idd - 3 * kd;
+            double su[5], sl[5], g3[5], w1[5], gd[5], nu_u[5], nu_l[5], c2[5], w2[5];
+            const double *rrd = G + sc.REF + kd * RREC, *sgd = G + sc.SG + kd * NI, *nud = G + sc.NUm + kd * NI;
+            const double hp0 = rrd[RHPFG + ad], hr0 = rrd[RHRFG + ad], dpdp = rrd[RDPDP], hffg = rrd[RHFFG];
+            const double s_phi0 = sgd[IPHI0], s_phimax = sgd[IPHIMAX], s_dphimax = sgd[IDPHIMAX];
+            const double dp_a = rrd[RDP + ad], dp_b = rrd[RDP + 3 + ad];
+#pragma unroll
+            for (int m = 0; m < 5; m++) {
+                su[m] = sgd[ITUBE + 2 * m]; sl[m] = sgd[ITUBE + 2 * m + 1]; g3[m] = rrd[RGC + m * 4 + 3]; w1[m] = rrd[RW1 + m]; gd[m] = rrd[RGC + m * 4 + ad];
+                nu_u[m] = nud[ITUBE + 2 * m]; nu_l[m] = nud[ITUBE + 2 * m + 1]; c2[m] = rrd[RC2 + m]; w2[m] = rrd[RW2 + m];
+            }
+            // ---- arithmetic and stores of batch 2 ----
+#pragma unroll
+            for (int u = 0; u < RC; u++) {
+                const int id0 = pass * 64 * RC + lane + 64 * u, id = id0 < N * 9 ? id0 : N * 9 - 1, k = id / 9, ln = id - 9 * k;
+                double hp = h0[u], hr = h1[u];
 #pragma unroll
                 for (int m = 0; m < 5; m++) {
-                    su[m] = sgk[ITUBE + 2 * m]; sl[m] = sgk[ITUBE + 2 * m + 1]; g3[m] = rr[RGC + m * 4 + 3]; w1[m] = rr[RW1 + m]; ga[m] = rr[RGC + m * 4 + a];
-                    nu_u[m] = nuk[ITUBE + 2 * m]; nu_l[m] = nuk[ITUBE + 2 * m + 1]; c2[m] = rr[RC2 + m]; w2[m] = rr[RW2 + m];
+                    const double gg = ss[u][m] * ga[u][m] * gb[u][m];
+                    if (m == 1 || m == 2) hp += gg; else hr += gg;
                 }
+                G[sc.NCS + k * NCS_STRIDE + NC_HPP + ln] = hp; G[sc.NCS + k * NCS_STRIDE + NC_HRR + ln] = hr;
+            }
+            {
                 double hp = hp0, hr = hr0;
                 const double exm = ex ? 1.0 : 0.0;
                 double hff = hffg + 2 * w[6] + s_phi0 + s_phimax;
 #pragma unroll
                 for (int m = 0; m < 5; m++) {
                     const double gpu_ = g3[m] - w1[m], gpl_ = -g3[m] - w1[m];
-                    const double gg = su[m] * ga[m] * gpu_ - sl[m] * ga[m] * gpl_;
+                    const double gg = su[m] * gd[m] * gpu_ - sl[m] * gd[m] * gpl_;
                     if (m == 1 || m == 2) hp += gg; else hr += gg;
                     hff += su[m] * gpu_ * gpu_ + sl[m] * gpl_ * gpl_;
                     hff += exm * (nu_u[m] * (c2[m] - w2[m]) + nu_l[m] * (-c2[m] - w2[m]));
                 }
-                G[sc.NCS + k * 32 + NC_HPF + a] = hp; G[sc.NCS + k * 32 + NC_HRF + a] = hr;
-                // the four scalars: every lane of the stage has them, entry a writes scalar a (entry 0 also writes the fourth)
-                const double sc0 = hff, sc1 = 2 * w[2] * dpdp + 2 * w[7] + s_dphimax, sc2 = 2 * w[5] * dpdp + 2 * w[8], sc3 = 2 * w[2] + W.ca * (k < N - 1 ? 2.0 : 1.0);
-                G[sc.NCS + k * 32 + NC_SC + a] = a == 0 ? sc0 : (a == 1 ? sc1 : sc2);
-                G[sc.NCS + k * 32 + NC_SC + 3] = sc3;      // identical in the three lanes of a stage
+                double *row = G + sc.NCS + kd * NCS_STRIDE;
+                row[NC_HPF + ad] = hp; row[NC_HRF + ad] = hr;
+                // the four scalars: every item of the stage has them, item a writes scalar a; the fourth, the zero word and dp_d ride along
+                const double sc1 = 2 * w[2] * dpdp + 2 * w[7] + s_dphimax, sc2 = 2 * w[5] * dpdp + 2 * w[8];
+                row[NC_SC + ad] = ad == 0 ? hff : (ad == 1 ? sc1 : sc2);
+                row[NC_SC + 3] = 2 * w[2] + W.ca * (kd < N - 1 ? 2.0 : 1.0);      // identical in the three items of a stage
+                row[NCS_ZERO] = 0.0;
+                row[NCS_RDP + ad] = dp_a; row[NCS_RDP + 3 + ad] = dp_b;
+            }
+        }
+    LANES_END
+    // ---- second phase: what needs the small blocks and the lifted residuals of the first ----
+    LANES_BEGIN
+        for (int pass = 0; pass < npass; pass++) {
+            // ================= batch 3: A1 = Hpp Jp (21), A2 = (h/2) Hrr Ehat (42): one 3-term product per entry =================
+            constexpr int RA = 10;
+            double cf[RA][3], kc[RA][3];
+#pragma unroll
+            for (int u = 0; u < RA; u++) {
+                const int id0 = pass * 64 * RA + lane + 64 * u, id = id0 < N * 63 ? id0 : N * 63 - 1, k = id / 63, e = id - 63 * k;
+                const bool isA1 = e < 21; const int e2 = isA1 ? 0 : e - 21;
+                const int c = isA1 ? e / 7 : e2 / 14, i = isA1 ? e - 7 * c : 0, y = isA1 ? 0 : e2 - 14 * c;
+                const int cb = isA1 ? NC_HPP + c * 3 : NC_HRR + c * 3, kb = isA1 ? KW + i : (y < 7 ? KD + 21 + y : KA + y - 7);
+                const double *row = G + sc.NCS + k * NCS_STRIDE, *K0 = G + sc.KIN + k * KREC;
+#pragma unroll
+                for (int b2 = 0; b2 < 3; b2++) { cf[u][b2] = row[cb + b2]; kc[u][b2] = K0[kb + b2 * 7]; }
+            }
+#pragma unroll
+            for (int u = 0; u < RA; u++) {
+                const int id0 = pass * 64 * RA + lane + 64 * u, id = id0 < N * 63 ? id0 : N * 63 - 1, k = id / 63, e = id - 63 * k;
+                double sacc = 0;
+#pragma unroll
+                for (int b2 = 0; b2 < 3; b2++) sacc += cf[u][b2] * kc[u][b2];
+                G[sc.NCS + k * NCS_STRIDE + NC_A1 + e] = e < 21 ? sacc : 0.5 * h * sacc;
+            }
+        }
+        for (int pass = 0; pass < npass; pass++) {
+            // ================= batch 4: the 12 rows of gl = g^ + H r + cross terms that differ from g^ (pos 3, v 6, phi, dphi, ddphi) =================
+            constexpr int RV = 2;
+            double nc3[RV][3], rl3[RV][3], rv0[RV], rvm[RV], rvp[RV], cvv[RV], dd[RV][6], r6[RV][6], m6[RV][6];
+#pragma unroll
+            for (int u = 0; u < RV; u++) {
+                const int id0 = pass * 64 * RV + lane + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, t = id - 12 * k;
+                const bool isPos = t < 3, isV = t >= 3 && t < 9;
+                const int c = isV ? t - 3 : 0, pa = isPos ? NC_HPP + t * 3 : NC_HPF;            // 3-vector that multiplies r_pos
+                const int kp = k >= 1 ? k - 1 : 0, kn = k < N - 1 ? k + 1 : k;
+                const double *row = G + sc.NCS + k * NCS_STRIDE, *rl = G + sc.RLV + k * 12, *rm = G + sc.RLV + kp * 12, *rp = G + sc.RLV + kn * 12;
+#pragma unroll
+                for (int b2 = 0; b2 < 3; b2++) { nc3[u][b2] = row[pa + b2]; rl3[u][b2] = rl[b2]; }
+                rv0[u] = rl[3 + c]; rvm[u] = rm[3 + c]; rvp[u] = rp[3 + c]; cvv[u] = row[NC_SC + 3];
+#pragma unroll
+                for (int c6 = 0; c6 < 6; c6++) { dd[u][c6] = row[NCS_RDP + c6]; r6[u][c6] = rl[3 + c6]; m6[u][c6] = rm[3 + c6]; }
+            }
+#pragma unroll
+            for (int u = 0; u < RV; u++) {
+                const int id0 = pass * 64 * RV + lane + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, t = id - 12 * k;
+                const bool isPos = t < 3, isV = t >= 3 && t < 9, isPhi = t == 9, isD = t == 10, isDD = t == 11;
+                double sA = 0, s1 = 0, s2 = 0;
+#pragma unroll
+                for (int b2 = 0; b2 < 3; b2++) sA += nc3[u][b2] * rl3[u][b2];
+#pragma unroll
+                for (int c6 = 0; c6 < 6; c6++) { s1 += dd[u][c6] * r6[u][c6]; s2 += dd[u][c6] * m6[u][c6]; }
+                const double vm = k >= 1 ? rvm[u] : 0.0, vp = k < N - 1 ? rvp[u] : 0.0;
+                const double tV = cvv[u] * rv0[u] - W.ca * vm - W.ca * vp, tD = -2 * w[2] * s1, tDD = -W.cb * s1 + (k >= 1 ? W.cb * s2 : 0.0);
+                double addv = 0.0;
+                addv = isDD ? tDD : addv; addv = isD ? tD : addv; addv = isV ? tV : addv; addv = (isPos || isPhi) ? sA : addv;
+                G[sc.NCS + k * NCS_STRIDE + NCS_ADDV + t] = addv;
             }
         }
     LANES_END
@@ -1259,9 +1288,9 @@ BMPC_D inline double gv_at(const double *rec, int c6, int y) {
 BMPC_D inline void backward_loads_lane(Wave &W, const Scr &sc, int k, double *pf, int lane, bool full) {
     const int N = W.N; const double *G = W.G;
     const int kn = k < N - 1 ? k + 1 : k, kp = k >= 1 ? k - 1 : 0;
-    const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, r2 = lane < RREC - 64 ? 64 + lane : RREC - 1;
-    const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l12 = lane < 12 ? lane : 11;
-    const int l35 = lane < NS ? lane : NS - 1, l42 = lane < 42 ? lane : 41, l28 = lane < 28 ? lane : 27;
+    const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1;
+    const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1;
+    const int l35 = lane < NS ? lane : NS - 1, l42 = lane < 42 ? lane : 41;
     // of the four kinematics records of a stage (node k, velocity point of node k+1, node k-1, velocity point of node k) the
     // first two are the last two of the previous stage (k+1): they stay in LDS, only the first stage of a sweep loads all four
     if (full) {
@@ -1270,12 +1299,19 @@ BMPC_D inline void backward_loads_lane(Wave &W, const Scr &sc, int k, double *pf
     }
     pf[4] = G[sc.KIN + kp * KREC + lane]; pf[5] = G[sc.KIN + kp * KREC + l2];
     pf[6] = G[sc.KIN + (N + k) * KREC + lane]; pf[7] = G[sc.KIN + (N + k) * KREC + l2];
-    pf[8] = G[sc.REF + k * RREC + lane]; pf[9] = G[sc.REF + k * RREC + r2];
+    // node-cost data of the stage (wave_stage_data_wide): NCS row (two slots), defects, iota couplings; gl = g^ + its non-trivial entries
+    pf[8] = G[sc.NCS + k * NCS_STRIDE + lane]; pf[9] = G[sc.NCS + k * NCS_STRIDE + 64 + lane];
     pf[10] = G[sc.RDY + k * 36 + l35]; pf[11] = G[sc.GH + k * NZ + lz];
-    pf[12] = G[sc.SG + k * NI + li]; pf[13] = G[sc.NUm + k * NI + li];
-    pf[14] = G[sc.G + k * NE + le]; pf[15] = G[sc.LAM + k * NE + le]; pf[16] = G[sc.LAM + kn * NE + le];
-    pf[17] = G[sc.RLV + k * 12 + l12]; pf[18] = G[sc.RLV + kp * 12 + l12]; pf[19] = G[sc.RLV + kn * 12 + l12];
-    pf[20] = G[sc.AES + k * 42 + l42]; pf[21] = G[sc.NCS + k * 32 + l28];      // stage data of wave_stage_data_wide
+    {   // rows pos (29..31), v (35..40), phi, dphi, ddphi (41..43) of Z have a non-trivial entry, the others add the zero word
+        const int t = lz >= ZV ? lz - ZV + 3 : lz - ZPOS; const bool sp = lz >= ZV || (lz >= ZPOS && lz < ZIW);
+        pf[13] = G[sc.NCS + k * NCS_STRIDE + (sp ? NCS_ADDV + t : NCS_ZERO)];
+    }
+    pf[12] = G[sc.SG + k * NI + li]; pf[14] = G[sc.G + k * NE + le];
+    // prefix vectors of the two curvature records (predicted point k, velocity point of node k+1): 2 x 72 doubles in three slots
+    pf[15] = G[sc.KHPG + k * 72 + lane];
+    pf[16] = G[lane < 8 ? sc.KHPG + k * 72 + 64 + lane : sc.KHPG + (N + kn) * 72 + lane - 8];
+    pf[17] = G[sc.KHPG + (N + kn) * 72 + 56 + (lane < 16 ? lane : 15)];
+    pf[20] = G[sc.AES + k * 42 + l42];
 }
 // record buffers of stage k: (K0, K1) and (KV1, KV) swap roles from stage to stage
 BMPC_D inline void backward_buffers(int N, int k, int &oK0, int &oK1, int &oKV, int &oKV1) {
@@ -1285,18 +1321,26 @@ BMPC_D inline void backward_buffers(int N, int k, int &oK0, int &oK1, int &oKV, 
 BMPC_D inline void backward_commit_lane(Wave &W, int k, const double *pf, int lane, bool first) {
     double *L = W.L;
     int oK0, oK1, oKV, oKV1; backward_buffers(W.N, k, oK0, oK1, oKV, oKV1);
-    const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1, r2 = lane < RREC - 64 ? 64 + lane : RREC - 1;
-    const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l12 = lane < 12 ? lane : 11;
-    const int l35 = lane < NS ? lane : NS - 1, l42 = lane < 42 ? lane : 41, l28 = lane < 28 ? lane : 27;
+    const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1;
+    const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1;
+    const int l35 = lane < NS ? lane : NS - 1, l42 = lane < 42 ? lane : 41;
     if (first) { L[oK0 + lane] = pf[0]; L[oKV1 + lane] = pf[2]; L[oK0 + l2] = pf[1]; L[oKV1 + l2] = pf[3]; }
     L[oK1 + lane] = pf[4]; L[oKV + lane] = pf[6];
     L[oK1 + l2] = pf[5]; L[oKV + l2] = pf[7];
-    L[L_ST + ST_REF + lane] = pf[8]; L[L_ST + ST_REF + r2] = pf[9];
-    L[L_ST + ST_GH + lz] = pf[11];
-    L[L_ST + ST_SG + li] = pf[12]; L[L_ST + ST_NU + li] = pf[13];
-    L[L_ST + ST_G + le] = pf[14]; L[L_ST + ST_LAM0 + le] = pf[15]; L[L_ST + ST_LAM1 + le] = pf[16];
-    L[L_ST + ST_RLV0 + l12] = pf[17]; L[L_ST + ST_RLVM + l12] = pf[18]; L[L_ST + ST_RLVP + l12] = pf[19];
-    L[L_RD + l35] = pf[10]; L[L_AE + l42] = pf[20]; L[L_NC + NC_HPP + l28] = pf[21];
+    L[L_NC + lane] = pf[8];
+    {   // second slot of the NCS row: the rest of the L_NC mirror, the curvature multipliers, dp_d (flat chain of selects on the address)
+        const int idx = 64 + lane;
+        int dst = L_DUMMY;
+        dst = idx < NCS_RDP + 6 ? L_ST + ST_REF + RDP + (idx - NCS_RDP) : dst;
+        dst = idx < NCS_RDP ? L_MU + 4 + (idx - NCS_MU) : dst;
+        dst = idx < NCS_MU ? L_NC + idx : dst;
+        L[dst] = pf[9];
+    }
+    L[L_RD + l35] = pf[10];
+    L[L_NC + NC_GL + lz] = pf[11] + pf[13];
+    L[L_ST + ST_SG + li] = pf[12]; L[L_ST + ST_G + le] = pf[14];
+    L[L_KHP + lane] = pf[15]; L[L_KHP + 64 + lane] = pf[16]; L[L_KHP + 128 + (lane < 16 ? lane : 15)] = pf[17];
+    L[L_AE + l42] = pf[20];
 }
 
 // ----------------------------------------------------------------------------------------

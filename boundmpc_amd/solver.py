@@ -28,6 +28,8 @@ class BatchedOCPSolver:
         self.N, self.S, self.dt = int(N), int(S), float(dt)
         self.n_w, self.n_g, self.n_p = N * NZ, N * NG, 141 + 91 * S
         self.state_len = int(self._lib.bmpc_state_len(self._h))
+        import weakref
+        self._children = weakref.WeakSet()      # captured graphs (StepGraph, StreamBatch): closed before the handle, see close()
         # the handle's workspace, work queue and occupancy belong to the device that was current at bmpc_create
         try:
             import torch
@@ -36,7 +38,14 @@ class BatchedOCPSolver:
             self.device_index = None
 
     def close(self):
+        """Destroys the captured graphs made from this handle first, then the handle (a graph destroyed later would still be safe --
+        the C handle is reference-counted by its graphs -- but could no longer launch)."""
         if getattr(self, "_h", None):
+            for c in list(getattr(self, "_children", ())):
+                try:
+                    c.close()
+                except Exception:
+                    pass
             self._lib.bmpc_destroy(self._h)
             self._h = None
 
@@ -189,6 +198,7 @@ class StepGraph:
         self._g = ctypes.c_void_p()
         _lib.check(solver._lib.bmpc_graph_create(solver._h, B, dp(p), dp(x0), dp(state), int(max_iter), dp(self.out["x"]), g("g"), g("lam_g"),
                                                  g("lam_x"), g("f"), g("iters"), g("status"), g("kkt"), ctypes.byref(self._g)), "bmpc_graph_create")
+        solver._children.add(self)
 
     def launch(self, stream=None):
         import torch

@@ -59,6 +59,9 @@ def path_table(rp, entries=None):
 
 def initial_state(mpc, N):
     """Stream state of a freshly constructed host `BoundMPC` (before its first step)."""
+    if getattr(mpc, "updated", False):
+        raise ValueError("the host BoundMPC has been re-planned (update()): its warm start re-projects from Cartesian arrays the stream state does not "
+                         "carry over; build the StreamBatch from a fresh object and call StreamBatch.update()")
     s = np.zeros(ss_len(N))
     s[SS["SECTOR"]] = mpc.ref_path.sector
     s[SS["PHI"]], s[SS["DPHI"]], s[SS["DDPHI"]], s[SS["DDDPHI"]] = mpc.phi_current[0], mpc.dphi_current[0], mpc.ddphi_current[0], mpc.dddphi_current[0]
@@ -123,8 +126,6 @@ class StreamBatch:
     """B streams on the GPU.  `mpcs`: list of freshly constructed host `boundmpc_amd.bound_mpc.BoundMPC` objects (used only to
     read their path and initial state; they are not advanced)."""
 
-    _warned_null_stream = False
-
     def __init__(self, solver, mpcs, device="cuda"):
         import torch
         self.solver, self.B, self.N, self.S = solver, len(mpcs), solver.N, solver.S
@@ -152,6 +153,7 @@ class StreamBatch:
         self.kkt = torch.zeros((self.B,), dtype=torch.float64, device=device)
         self.traj = torch.zeros((self.B, self.tr_len), dtype=torch.float64, device=device)
         self._graphs = {}
+        solver._children.add(self)
 
     def update(self, b, *args, **kw):
         """Re-plan stream b: `apply_update` on a host copy of its state row, then the new table and state go back to the device
@@ -206,13 +208,9 @@ class StreamBatch:
                 dp(self.dual) if warm_dual else None, int(max_iter), dp(self.x), dp(self.g), dp(self.iters), dp(self.status), dp(self.kkt),
                 dp(self.traj), int(bool(simulate)) | (2 if accept_capped else 0), ctypes.byref(g)), "bmpc_stream_graph_create")
             self._graphs[key] = g
-        st = self._stream(stream)
-        if not st.value and not StreamBatch._warned_null_stream:
-            StreamBatch._warned_null_stream = True
-            import warnings
-            warnings.warn("hipGraph replay on the legacy null stream: keep a host synchronisation between the replay and further launches on that "
-                          "stream, or use an explicit stream (ROCm 7.2: the unsynchronised mix ended in a GPU memory fault, DESIGN.md section 8)")
-        _lib.check(self.solver._lib.bmpc_graph_launch(self._graphs[key], st), "bmpc_graph_launch")
+        # (a replay requested on the legacy null stream is run by the library on a stream of the handle, bracketed by events:
+        # bmpc_graph_launch)
+        _lib.check(self.solver._lib.bmpc_graph_launch(self._graphs[key], self._stream(stream)), "bmpc_graph_launch")
 
     def close(self):
         for g in self._graphs.values():

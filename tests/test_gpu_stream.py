@@ -322,3 +322,44 @@ def test_long_closed_loops_through_the_hard_part_of_the_path():
     assert stuck.any(), ecs[-1].max()
     assert np.abs(phis[-1][stuck] - phis[-5][stuck]).max() == 0.0   # ... and the stream stays where it is
     sb.close(); slv.close()
+
+
+def test_graph_replays_mixed_with_direct_launches_on_the_null_stream(tmp_path):
+    """Torch-free reproducer of the round-2 fault, built with hipcc against the in-tree library: 256 problems x 200 rounds of
+    {bmpc_graph_launch(g, NULL), bmpc_solve_batch(..., NULL)} without a host synchronisation, outputs bit-identical to a synchronised solve;
+    part A checks the runtime's own ordering of a null-stream graph replay against null-stream launches with trivial kernels; the graph
+    outlives bmpc_destroy of its handle and then refuses to launch."""
+    import subprocess
+    from boundmpc_amd import LIB_PATH, workload
+    B, ticks = 256, 200
+    P, X, _ = workload.make_batch(B, seed=3)
+    prob = tmp_path / "problems.bin"
+    with open(prob, "wb") as fh:
+        P.astype(np.float64).tofile(fh); X.astype(np.float64).tofile(fh)
+    exe = tmp_path / "graph_nullstream"
+    libdir = os.path.dirname(os.path.realpath(LIB_PATH))
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O1", "--offload-arch=gfx950", "-o", str(exe), os.path.join(os.path.dirname(__file__), "cabi", "graph_nullstream.cpp"),
+                           "-L" + libdir, "-lboundmpc_hip", "-Wl,-rpath," + libdir], stderr=subprocess.DEVNULL)
+    r = subprocess.run(["timeout", "-k", "10", "120", str(exe), str(prob), str(B), str(ticks)], capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0, (r.stdout, r.stderr[-2000:])
+    assert r.stdout.strip() == "A broken=0 B mismatch=0 status=ok"
+
+
+def test_solver_close_destroys_its_graphs_first():
+    """BatchedOCPSolver.close() closes the StepGraph / StreamBatch objects made from it before the handle goes (graph destroy
+    touched a freed handle); closing them again afterwards is a no-op."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    P, X, _ = workload.make_batch(4, seed=5)
+    s = BatchedOCPSolver(10, 4, 0.1)
+    p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
+    st = torch.cuda.Stream()
+    g = s.capture_step(p, x0)
+    with torch.cuda.stream(st):
+        a = g.launch(stream=st)["x"].clone()
+    b = s.solve_batch(p, x0, stream=st)["x"].clone()          # direct launch on the same handle right behind the replay
+    st.synchronize()
+    assert torch.equal(a, b)
+    s.close()
+    assert g._g is None
+    g.close()
