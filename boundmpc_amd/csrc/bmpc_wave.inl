@@ -107,7 +107,7 @@ static_assert(32 * 57 <= (int)L_PV - (int)L_PB, "multiplier staging of the adjoi
 static_assert((int)L_BLK_END <= (int)L_PV, "block Riccati storage must fit into the retired PM/SR/RED region");
 // staging area inside L_ST: per-stage inputs of the sequential sweeps, loaded from the scratch slab in ONE burst per stage
 enum { ST_REF = 0, ST_Z = 108, ST_SG = 152, ST_NU = 212, ST_G = 272, ST_LAM0 = 308, ST_LAM1 = 344, ST_GH = 380, ST_RLVM = 424, ST_RLV0 = 436, ST_RLVP = 448,
-       /* forward sweep view */ ST_KT = 0, ST_KF = 280, ST_RDY = 288, ST_AES = 324, ST_RLVF = 366 };
+       /* forward sweep view */ ST_KT = 0, ST_KF = 280, ST_RDY = 288, ST_AES = 324, ST_RLVF = 366, ST_GHF = 378 /* 64: gradient entry of the lane's dZ component */ };
 // node-cost work area inside L_NC
 enum { NC_HPP = 0, NC_HRR = 9, NC_HPF = 18, NC_HRF = 21, NC_SC = 24 /* hff,hdd,hddd,cv */, NC_A1 = 28 /* Hpp*Jp 3x7 */, NC_A2 = 49 /* Hrr*Ehat 3x14 */,
        NC_GL = 91 /* 44 */, NC_RL = 135 /* 9 */, NC_GY = 144 /* 14 */ };
@@ -178,6 +178,25 @@ BMPC_D inline double ndv(const double *PAR, const POff &po, const double *Z, int
     return k ? Z[(k - 1) * NZ + zoff] : PAR[poff];
 }
 
+// sin and cos of a joint angle.  The library sincos() carries the full-range argument reduction (Payne-Hanek path, ~100 instructions a
+// call, 7 calls per evaluation point); joint angles are bounded (|q| < 3 rad inside the limits, RobotModel.py:20-28; a trial point of the
+// line search may leave them by a little), so a two-constant Cody-Waite reduction by pi/2 is exact here and the classical minimax
+// kernels on [-pi/4, pi/4] (the coefficients every libm descended from fdlibm uses) finish in ~30 instructions, error < 1 ulp
+// (tests/test_emu.py checks it against libm over [-50, 50]).
+BMPC_D inline void bmpc_sincos(double x, double *sn, double *cs) {
+    const double k = __builtin_rint(x * 6.36619772367581382433e-01);
+    const double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+    const double z = r * r;
+    const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double s = r + (z * r) * (-1.66666666666666324348e-01 + z * ps);
+    const double pc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 +
+                      z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double c = 1.0 - (0.5 * z - z * pc);
+    const int n = (int)k;
+    const double a = (n & 1) ? c : s, b = (n & 1) ? s : c;
+    *sn = (n & 2) ? -a : a; *cs = ((n + 1) & 2) ? -b : b;
+}
+
 // ----------------------------------------------------------------------------------------
 // kinematics of one evaluation point (sequential, one lane): iiwa14 as a geometric chain,
 // joint axes (z,y,z,-y,z,y,z), link offsets along local z (RobotModel.py:9-16).
@@ -191,7 +210,7 @@ BMPC_D inline void kin_point(const double *q, const double *dq, double *rec, dou
     for (int j = 0; j < 7; j++) {
         for (int i = 0; i < 3; i++) o[i] += R[i][2] * preZ[j];
         double s, c;
-        BMPC_SINCOS(q[j], &s, &c);
+        bmpc_sincos(q[j], &s, &c);
         if ((j & 1) == 0) {   // +z joints 0,2,4,6
             for (int i = 0; i < 3; i++) { a[j][i] = R[i][2]; O[j][i] = o[i]; }
             for (int i = 0; i < 3; i++) { double c0 = R[i][0], c1 = R[i][1]; R[i][0] = c * c0 + s * c1; R[i][1] = -s * c0 + c * c1; }
@@ -539,7 +558,7 @@ BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
 #define BMPC_RU 9   // N=10: all 570 rows of a pass in one trip per lane (6: two trips; 10 starts to spill); +2 % (profiles/r02_n_rows_in_flight_ab.txt)
 #endif
 constexpr int RU = BMPC_RU;   // rows of a lane-strided pass kept in flight per lane (loads of a batch are issued before their first use)
-struct LaneRegs { double mc[16]; double pf[24]; };   // pf: software prefetch of the next stage's inputs (global -> registers -> LDS)   // a lane's 4x4 state block of M, kept in registers between the M and the Schur phases
+struct LaneRegs { double mc[16]; double pf[24]; double ghd; };   // ghd: the lane's share of (QP gradient) . dZ, accumulated by the forward sweep   // pf: software prefetch of the next stage's inputs (global -> registers -> LDS)   // a lane's 4x4 state block of M, kept in registers between the M and the Schur phases
 
 // ----------------------------------------------------------------------------------------
 // wave-uniform deterministic reductions through LDS (RED has 6 x 64 slots)
@@ -1705,14 +1724,16 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
     pf[6] = G[sc.RDY + j * 36 + (lane < 36 ? lane : 35)]; \
     pf[7] = G[sc.AES + j * 42 + (lane < 42 ? lane : 41)]; \
     pf[8] = G[sc.RLV + j * 12 + (lane < 12 ? lane : 11)]; \
-    pf[9] = G[sc.KIN + j * KREC + lane]; pf[10] = G[sc.KIN + j * KREC + (lane < KREC - 64 ? 64 + lane : KREC - 1)]; }
+    pf[9] = G[sc.KIN + j * KREC + lane]; pf[10] = G[sc.KIN + j * KREC + (lane < KREC - 64 ? 64 + lane : KREC - 1)]; \
+    { const int t_ = lane < NZ ? lane : 0, r_ = t_ < NS ? t_ : 0; int z_ = (int)L[L_ZMAP + r_] & 255; z_ = t_ >= NS ? (t_ < NS + 3 ? ZPOS + t_ - NS : ZV + t_ - NS - 3) : z_; \
+      pf[11] = G[sc.GH + j * NZ + z_]; } }   /* the QP-gradient entry of the component of dZ this lane will write (forward_stage) */
 #define BMPC_FWD_COMMIT(j_, PO_) { const double *pf = LR[LIDX].pf + (PO_); const int odd_ = (j_) & 1; double *sb_ = L + (odd_ ? L_GS : L_ST), *kb_ = L + (odd_ ? L_K1 : L_K0); \
     _Pragma("unroll") for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; sb_[ST_KT + (id < NS * NU ? id : NS * NU - 1)] = pf[u]; } \
     sb_[ST_KF + (lane < NU ? lane : NU - 1)] = pf[5]; \
     sb_[ST_RDY + (lane < 36 ? lane : 35)] = pf[6]; \
     sb_[ST_AES + (lane < 42 ? lane : 41)] = pf[7]; \
     sb_[ST_RLVF + (lane < 12 ? lane : 11)] = pf[8]; \
-    kb_[lane] = pf[9]; kb_[lane < KREC - 64 ? 64 + lane : KREC - 1] = pf[10]; }
+    kb_[lane] = pf[9]; kb_[lane < KREC - 64 ? 64 + lane : KREC - 1] = pf[10]; sb_[ST_GHF + lane] = pf[11]; }
 // one stage of the forward sweep (three phases); PO = register set that holds the inputs of stage k+1
 template <int PO>
 BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
@@ -1769,6 +1790,7 @@ BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
             double fa = 0.0; fa = isV ? 1.0 : fa; fa = isIw ? 0.5 * h : fa; fa = isPos ? 1.0 : fa;
             const double v = addv + fa * (s1 + ((isIw || isV) ? 1.0 : 0.0) * s2);
             W.Dz[k * NZ + z] = v;
+            LR[LIDX].ghd += on ? sb[ST_GHF + lane] * v : 0.0;      // (QP gradient) . dZ for the line search, summed where dZ is made
         }
         { const int r = lane < 36 ? lane : 35; const double v = L[L_DSN + (r < NS ? r : 0)]; L[L_DS + r] = r < NS ? v : 0.0; }
         // inputs of stage k+1 into the other LDS buffer set (loaded two stages ago), then the loads of stage k+3 (clamped to the
@@ -1780,19 +1802,20 @@ BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
 BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
     const int N = W.N;
     double *L = W.L, *G = W.G;
-    static_assert(ST_RLVF + 12 <= 288 + 64 + 288, "second forward staging buffer must fit into the idle GS/R8/KS area");
+    static_assert(ST_GHF + 64 <= 288 + 64 + 288 && ST_GHF + 64 <= 460, "forward staging buffers must fit into L_ST and into the idle GS/R8/KS area");
     LANES_BEGIN
         if (lane < 36) L[L_DS + lane] = 0.0;
+        LR[LIDX].ghd = 0.0;
         BMPC_FWD_LOADS(0, 0)
-        BMPC_FWD_LOADS(1, 11)
+        BMPC_FWD_LOADS(1, 12)
     LANES_END
     LANES_BEGIN
         BMPC_FWD_COMMIT(0, 0)
         BMPC_FWD_LOADS(2, 0)
     LANES_END
     int k = 0;
-    for (; k + 1 < N; k += 2) { forward_stage<11>(W, sc, LR, k); forward_stage<0>(W, sc, LR, k + 1); }
-    if (k < N) forward_stage<11>(W, sc, LR, k);
+    for (; k + 1 < N; k += 2) { forward_stage<12>(W, sc, LR, k); forward_stage<0>(W, sc, LR, k + 1); }
+    if (k < N) forward_stage<12>(W, sc, LR, k);
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1866,17 +1889,18 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         BMPC_PROF(W, 1);
         // ---- KKT error (Ipopt-style scaling), deterministic reductions; the inequality part comes from row pass A ----
         LANES_BEGIN
-            double ed = 0, ep = L[L_KKP + lane], sl = 0;
+            double ed = 0, ep = L[L_KKP + lane], sl = 0, g1 = 0;
             for (int id = lane; id < N * NU; id += 64) { const double v = BMPC_FABS(G[sc.RJ + id]); ed = v > ed ? v : ed; }
             for (int base = lane; base < ne; base += 64 * RU) {
                 double gv[RU], lv[RU];
 #pragma unroll
                 for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < ne ? id0 : ne - 1; gv[u] = G[sc.G + id]; lv[u] = G[sc.LAM + id]; }
 #pragma unroll
-                for (int u = 0; u < RU; u++) { const bool ok_ = base + 64 * u < ne; const double v = ok_ ? BMPC_FABS(gv[u]) : 0.0; ep = v > ep ? v : ep; sl += ok_ ? BMPC_FABS(lv[u]) : 0.0; }
+                for (int u = 0; u < RU; u++) { const bool ok_ = base + 64 * u < ne; const double v = ok_ ? BMPC_FABS(gv[u]) : 0.0; ep = v > ep ? v : ep; g1 += v; sl += ok_ ? BMPC_FABS(lv[u]) : 0.0; }
             }
-            L[L_RED + lane] = ed; L[L_RED + 64 + lane] = ep; L[L_RED + 128 + lane] = sl;
+            L[L_RED + lane] = ed; L[L_RED + 64 + lane] = ep; L[L_RED + 128 + lane] = sl; L[L_RED + 192 + lane] = g1;
         LANES_END
+        const double theta_eq = red_sum(L + L_RED + 192);      // ||c||_1 of the current iterate, for the filter's theta (row pass B)
         const double ed = red_max(L + L_RED), ep = red_max(L + L_RED + 64), cmax = red_max(L + L_KKP + 64), cmin = red_min(L + L_KKP + 128),
                      sl = red_sum(L + L_RED + 128), sn = red_sum(L + L_KKP + 192);
         const double sd = BMPC_FMAX(100.0, (sl + sn) / (N * (NE + NI))) / 100.0, scl = BMPC_FMAX(100.0, sn / (N * NI)) / 100.0;
@@ -1993,21 +2017,10 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
             if (pd_ > 0.0) { const double a = tau * pn_ / pd_; ap = a < ap ? a : ap; }
             if (dd_ > 0.0) { const double a = tau * dn_ / dd_; adl = a < adl ? a : adl; }
             BMPC_PROF(W, 28);
-            double ghd = 0;
-            for (int base = lane; base < nw; base += 64 * RU) {
-                double gv[RU];
-#pragma unroll
-                for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < nw ? id0 : nw - 1; gv[u] = G[sc.GH + id] * W.Dz[id]; }
-#pragma unroll
-                for (int u = 0; u < RU; u++) ghd += base + 64 * u < nw ? gv[u] : 0.0;
-            }
-            for (int base = lane; base < ne; base += 64 * RU) {
-                double gv[RU];
-#pragma unroll
-                for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u; gv[u] = G[sc.G + (id0 < ne ? id0 : ne - 1)]; }
-#pragma unroll
-                for (int u = 0; u < RU; u++) th += base + 64 * u < ne ? BMPC_FABS(gv[u]) : 0.0;
-            }
+            // (QP gradient) . dZ was summed by the forward sweep (one entry per lane and stage), the 1-norm of the equality residuals by
+            // the KKT pass at the top of the iteration: no further trip to the workspace here
+            const double ghd = LRs[LIDX].ghd;
+            th += lane == 0 ? theta_eq : 0.0;
             BMPC_PROF(W, 29);
             L[L_RED + lane] = ap; L[L_RED + 64 + lane] = adl; L[L_RED + 128 + lane] = dbar; L[L_RED + 192 + lane] = ghd - nhd;
             L[L_RED + 256 + lane] = th; L[L_RED + 320 + lane] = bar;

@@ -113,5 +113,6 @@ extern "C" void bmpc_emu_scr_offsets(int N, int *out) {
     int v[] = {s.Z, s.ZT, s.T, s.TT, s.NUm, s.LAM, s.G, s.GT, s.HIN, s.HT, s.DZ, s.DT, s.DNU, s.GH, s.GVP, s.RJ, s.KIN, s.REF, s.KT, s.KF, s.RDY, s.AES, s.RLV, s.SG, s.TI, s.SR, s.size};
     for (unsigned i = 0; i < sizeof(v) / sizeof(int); i++) out[i] = v[i];
 }
+extern "C" void bmpc_emu_sincos(int n, const double *x, double *s, double *c) { for (int i = 0; i < n; i++) bmpc::bmpc_sincos(x[i], s + i, c + i); }
 extern "C" int bmpc_emu_lds_doubles() { return bmpc::L_SIZE; }
 extern "C" int bmpc_emu_scratch_doubles(int N) { return bmpc::make_scr(N).size; }

@@ -199,3 +199,19 @@ def test_no_solve_reads_what_it_has_not_written():
     for a, b in zip(plain, poisoned):
         for k in ("x", "g", "lam_g", "lam_x", "f", "kkt", "iters", "status"):
             assert np.array_equal(a[k], b[k], equal_nan=True), k
+
+
+def test_bounded_range_sincos_of_the_kinematics_against_libm():
+    """bmpc_sincos (csrc/bmpc_wave.inl): two-constant Cody-Waite reduction + the classical kernels on [-pi/4, pi/4], used for the joint
+    angles of the kinematic chain instead of the full-range library call.  Against libm: every quadrant, the reduction boundaries,
+    and far outside the joint range."""
+    import ctypes
+    emu.build()
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(-3.3, 3.3, 20000), rng.uniform(-50, 50, 20000), np.arange(-8, 9) * np.pi / 4, np.arange(-8, 9) * np.pi / 4 + 1e-9,
+                        np.array([0.0, 1e-300, -1e-300, 1e-9, 2.9670597283903604, -2.9670597283903604])])
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    emu.lib().bmpc_emu_sincos(ctypes.c_int(len(x)), vp(x), vp(s), vp(c))
+    assert np.abs(s - np.sin(x)).max() < 3e-16 and np.abs(c - np.cos(x)).max() < 3e-16
+    assert np.abs(s * s + c * c - 1).max() < 5e-16
