@@ -100,6 +100,7 @@ struct bmpc_handle {
     // launches of one handle share its workspace and work queue, so they are ordered against each other whatever streams the
     // caller uses: every launch records order_ev, a launch on another stream waits for it first
     hipEvent_t order_ev, bridge_ev; bool order_valid; hipStream_t order_stream;
+    double rt_viol_tol;      // acceptance threshold of stream_post in real-time mode (flag bit 1); default = the reference's 1e-4
     hipStream_t own_stream;  // graph replays requested on the legacy null stream run here, bracketed by events (bmpc_graph_launch)
     int grid; long long scr_stride; double *scratch; int scr_waves; int graphs_alive; int *counter; unsigned long long *prof;
     int timing; hipEvent_t *ev; int nev; long long n_timed;   // timing = number of launches whose {start, stop} event pairs are kept (ring)
@@ -143,7 +144,8 @@ extern "C" int bmpc_default_options(bmpc_options *o) {
 }
 extern "C" int bmpc_default_options_for(int N, bmpc_options *o) {
     const int rc = bmpc_default_options(o);
-    if (rc == BMPC_OK && N > 11) o->mu_init = 0.3;       // long horizons: a cold start far from the solution wants a more central first barrier level
+    if (rc == BMPC_OK && N > 11) { o->mu_init = 0.3; o->stall_window = 20; }   // long horizons: a cold start far from the solution wants a more central first barrier
+                                                                               // level; stalls are met by barrier restarts (bmpc_wave.inl), so they are looked for earlier
     return rc;
 }
 extern "C" const char *bmpc_error_string(int c) {
@@ -159,7 +161,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     if (!h) return BMPC_ERR_ARG;
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->ev = nullptr; h->nev = 0; h->n_timed = 0; h->latency_us = nullptr;
     h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->prof = nullptr; h->stage_d = nullptr; h->stage_i = nullptr; h->stage_cap = 0;
-    h->dev = 0; h->refs = 1; h->closed = false; h->order_ev = nullptr; h->bridge_ev = nullptr; h->order_valid = false; h->order_stream = nullptr; h->own_stream = nullptr;
+    h->rt_viol_tol = 1e-4; h->dev = 0; h->refs = 1; h->closed = false; h->order_ev = nullptr; h->bridge_ev = nullptr; h->order_valid = false; h->order_stream = nullptr; h->own_stream = nullptr;
     if (opts) h->o = *opts; else bmpc_default_options_for(N, &h->o);
     int dev = 0, per_cu = 0; hipDeviceProp_t prop;
     bool ok = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess;
@@ -414,14 +416,89 @@ __global__ void __launch_bounds__(64) bmpc_stream_pack_kernel(int N, int S, int 
     __shared__ double sh[bmpcs::SH_LEN];
     const int b = blockIdx.x;
     bmpcs::stream_pack(N, S, path + (long long)b * path_stride, path_stride / bmpcs::PT_LEN, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
-                       p + (long long)b * (141 + 91 * S), x0 + (long long)b * 44 * N, dual ? dual + (long long)b * (57 * N + 2) : nullptr, sh, threadIdx.x, 64);
+                       p + (long long)b * (141 + 91 * S), x0 + (long long)b * 44 * N, dual ? dual + (long long)b * (57 * N + 2) : nullptr, nullptr, sh, threadIdx.x, 64);
 }
 __global__ void __launch_bounds__(64) bmpc_stream_post_kernel(int N, int S, int B, double h, const double *path, int path_stride, double *ss, double *rb,
-                                                             const double *x, const double *g, const int *status, double *traj, int flags) {
+                                                             const double *x, const double *g, const int *status, double *traj, int flags, double rt_tol) {
     __shared__ double sh[bmpcs::SH_LEN];
     const int b = blockIdx.x;
     bmpcs::stream_post(N, S, h, path + (long long)b * path_stride, path_stride / bmpcs::PT_LEN, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
-                       x + (long long)b * 44 * N, g + (long long)b * 43 * N, status[b], traj + (long long)b * bmpcs::tr_len(N), flags, sh, threadIdx.x, 64);
+                       x + (long long)b * 44 * N, g + (long long)b * 43 * N, status[b], traj + (long long)b * bmpcs::tr_len(N), flags, rt_tol, sh, threadIdx.x, 64);
+}
+// ---- one closed-loop tick of a stream in ONE launch: {pack, solve, post} by the wave that owns the stream (N <= 11) ----
+// The three steps of a tick are each "one wave per stream" and strictly sequential per stream, so they need no grid-wide boundary
+// between them: as three kernels + the work-queue reset they cost three launch ramps, three drains and ~130 us of launch overhead
+// per tick at 1 kHz (profiles/r03_*_stream_trace.txt); here stream b is block b (B <= resident waves: no work queue, no reset node),
+// the stream functions use the reduction area of the solver's LDS, and the hand-over of p, x0 -> solver -> x, g, status goes through
+// global memory of the same wave in program order.
+struct SArgs {
+    const double *path; int path_stride; double *ss, *rb, *traj; int flags; double rt_tol;
+};
+__global__ void __launch_bounds__(64, 1) bmpc_stream_tick_kernel(KArgs a, SArgs s) {
+    __shared__ double lds[bmpc::L_SIZE];
+    const int b = blockIdx.x;
+    if (b >= a.B) return;
+    const int np = 141 + 91 * a.S, nw = a.N * bmpc::NZ, ng = a.N * bmpc::NG;
+    double *sh = lds + bmpc::L_RED;
+    static_assert(bmpcs::SH_LEN <= 6 * 64, "the stream functions' LDS words must fit into the solver's reduction area");
+    const double *path = s.path + (long long)b * s.path_stride;
+    double *ss = s.ss + (long long)b * bmpcs::ss_len(a.N), *rb = s.rb + (long long)b * bmpcs::RB_LEN;
+    double *p = const_cast<double *>(a.p) + (long long)b * np, *x0 = const_cast<double *>(a.x0) + (long long)b * nw;
+    double *dual = a.state ? a.state + (long long)b * (a.N * bmpc::NI + 2) : nullptr;
+    bmpcs::stream_pack(a.N, a.S, path, s.path_stride / bmpcs::PT_LEN, ss, rb, p, x0, dual, (s.flags & 2) ? a.x + (long long)b * nw : nullptr, sh, threadIdx.x, 64);
+    __syncthreads();
+    bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = a.scratch + (long long)b * a.scr_stride;
+    bmpc::Problem pr;
+    pr.p = p; pr.x0 = x0; pr.x = a.x + (long long)b * nw; pr.g = a.g + (long long)b * ng; pr.lam_g = nullptr; pr.lam_x = nullptr;
+    pr.f = nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr; pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status + b; pr.state = dual;
+    const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
+    bmpc::wave_solve<true>(W, pr);
+    __syncthreads();
+    if (a.latency_us && threadIdx.x == 0) a.latency_us[b] = (double)((long long)wall_clock64() - t0_) * 0.01;
+    bmpcs::stream_post(a.N, a.S, a.h, path, s.path_stride / bmpcs::PT_LEN, ss, rb, pr.x, pr.g, a.status[b], s.traj + (long long)b * bmpcs::tr_len(a.N), s.flags, s.rt_tol,
+                       sh, threadIdx.x, 64);
+}
+// enqueues the fused tick on `st` (direct launch or inside a capture)
+static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, double *p, double *x0, double *dual_state,
+                        int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj, int flags, hipStream_t st, bool capturing) {
+    if (h->closed) return BMPC_ERR_ARG;
+    if (!capturing) { const int rc_ = order_before(h, st); if (rc_ != BMPC_OK) return rc_; }
+    KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
+    a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
+    a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window;
+    a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = nullptr; a.lam_x = nullptr; a.f = nullptr; a.kkt = kkt; a.iters = iters; a.status = status;
+    a.state = dual_state; a.latency_us = h->latency_us;
+    if (B > h->scr_waves) return BMPC_ERR_ARG;
+    a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter; a.prof = h->prof;
+    SArgs s; s.path = path; s.path_stride = path_entries * bmpcs::PT_LEN; s.ss = sstate; s.rb = robot; s.traj = traj; s.flags = flags; s.rt_tol = h->rt_viol_tol;
+    const bool timed = !capturing && h->timing != 0;
+    hipEvent_t *pair = nullptr;
+    if (timed) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
+    hipLaunchKernelGGL(bmpc_stream_tick_kernel, dim3(B), dim3(64), 0, st, a, s);
+    HIPCHK(hipGetLastError());
+    if (timed) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }
+    if (!capturing) return order_after(h, st);
+    return BMPC_OK;
+}
+static bool tick_fusable(const bmpc_handle *h, int B) { return h->N <= 11 && B <= h->grid; }
+extern "C" int bmpc_stream_tick(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, double *p, double *x0,
+                                double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj, int flags,
+                                void *hip_stream) {
+    if (!h || B < 0 || max_iter < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !p || !x0 || !x || !g || !status || !traj))) return BMPC_ERR_ARG;
+    if (B == 0) return BMPC_OK;
+    { const int rc_ = ensure_scratch(h, B < h->grid ? B : h->grid); if (rc_ != BMPC_OK) return rc_; }
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (tick_fusable(h, B)) return enqueue_tick(h, B, path, path_entries, sstate, robot, p, x0, dual_state, max_iter, x, g, iters, status, kkt, traj, flags, st, false);
+    int rc = bmpc_stream_pack(h, B, path, path_entries, sstate, robot, p, x0, dual_state, st);
+    if (rc == BMPC_OK) rc = enqueue_solve(h, B, p, x0, dual_state, max_iter, x, g, nullptr, nullptr, nullptr, iters, status, kkt, st, h->timing != 0);
+    if (rc == BMPC_OK) rc = bmpc_stream_post(h, B, path, path_entries, sstate, robot, x, g, status, traj, flags, st);
+    return rc;
+}
+
+extern "C" int bmpc_stream_set_rt_feasibility_tol(bmpc_handle *h, double tol) {
+    if (!h || !(tol > 0)) return BMPC_ERR_ARG;
+    h->rt_viol_tol = tol;      // read at launch / capture time: re-capture a tick graph after changing it
+    return BMPC_OK;
 }
 extern "C" int bmpc_stream_lengths(const bmpc_handle *h, int *path_entry, int *state, int *robot, int *traj) {
     if (!h) return BMPC_ERR_ARG;
@@ -443,7 +520,7 @@ extern "C" int bmpc_stream_post(bmpc_handle *h, int B, const double *path, int p
     if (!h || B < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !x || !g || !status || !traj))) return BMPC_ERR_ARG;
     if (B == 0) return BMPC_OK;
     hipLaunchKernelGGL(bmpc_stream_post_kernel, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, h->h, path,
-                       path_entries * bmpcs::PT_LEN, sstate, robot, x, g, status, traj, flags);
+                       path_entries * bmpcs::PT_LEN, sstate, robot, x, g, status, traj, flags, h->rt_viol_tol);
     HIPCHK(hipGetLastError());
     return BMPC_OK;
 }
@@ -461,9 +538,12 @@ extern "C" int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *pat
     int rc = BMPC_OK;
     if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) rc = BMPC_ERR_HIP;
     if (rc == BMPC_OK) {
-        rc = bmpc_stream_pack(h, B, path, path_entries, sstate, robot, p, x0, dual_state, cs);
-        if (rc == BMPC_OK) rc = enqueue_solve(h, B, p, x0, dual_state, max_iter, x, g, nullptr, nullptr, nullptr, iters, status, kkt, cs, false, true);
-        if (rc == BMPC_OK) rc = bmpc_stream_post(h, B, path, path_entries, sstate, robot, x, g, status, traj, flags, cs);
+        if (tick_fusable(h, B)) rc = enqueue_tick(h, B, path, path_entries, sstate, robot, p, x0, dual_state, max_iter, x, g, iters, status, kkt, traj, flags, cs, true);
+        else {
+            rc = bmpc_stream_pack(h, B, path, path_entries, sstate, robot, p, x0, dual_state, cs);
+            if (rc == BMPC_OK) rc = enqueue_solve(h, B, p, x0, dual_state, max_iter, x, g, nullptr, nullptr, nullptr, iters, status, kkt, cs, false, true);
+            if (rc == BMPC_OK) rc = bmpc_stream_post(h, B, path, path_entries, sstate, robot, x, g, status, traj, flags, cs);
+        }
         hipError_t e = hipStreamEndCapture(cs, &gr->graph);
         if (rc == BMPC_OK && e != hipSuccess) rc = BMPC_ERR_HIP;
     }

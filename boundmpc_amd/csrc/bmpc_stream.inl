@@ -249,8 +249,13 @@ enum { SH_DTAU = 0, SH_RTAU = 3, SH_JR = 12, SH_JL = 21, SH_PHISW = 30, SH_FLAG 
 // dual (may be null): the solver's dual state [57 N + 2], shifted with the plan.
 // cap = entries the path table holds: the entry count and the window start read from the state row are clamped to it, so that a
 // corrupted state (a NaN, a row written by a racing update) cannot index outside the table.
+// xlast (may be null; real-time mode of the fused tick): the solver's iterate of the previous tick.  When the state row says it is
+// usable (stream_post sets the word behind the `updated` flag), the warm start shifts IT instead of the last ACCEPTED plan: an iterate
+// the acceptance rule rejected is not applied to the plant, but the iterations spent on it are not thrown away either -- the next
+// tick continues from it while the plant replays the accepted plan (the reference restarts from the last accepted plan, shifted once,
+// however many ticks ago that was: BoundMPC.py:322-375,468-489).
 BMPC_HD inline void stream_pack(int N, int S, const double *path, int cap, double *ss, const double *rb, double *p, double *x0, double *dual,
-                                double *sh, int lane, int nl) {
+                                const double *xlast, double *sh, int lane, int nl) {
     int nent = (int)ss[SS_NENT];
     nent = nent > cap ? cap : nent; nent = nent < S + 1 ? S + 1 : nent;
     const double phi_cur = ss[SS_PHI];
@@ -354,10 +359,10 @@ BMPC_HD inline void stream_pack(int N, int S, const double *path, int cap, doubl
             x0[id] = (i >= 8 && i < 15) ? q0[i - 8] : ((i >= 29 && i < 35) ? p0[i - 29] : 0.0);
         }
     } else {
-        const double *pv = ss + SS_PREV;
+        const bool updated = ss[ss_updated(N)] > 0.5;                      // after update(): no shift, re-projection below (:335-375)
+        const double *pv = (xlast && !updated && ss[ss_updated(N) + 1] > 0.5) ? xlast : ss + SS_PREV;
         const double d[3] = {p0[3] - pv[32], p0[4] - pv[33], p0[5] - pv[34]};
         const bool unwrap = norm3(d) > 1.5;
-        const bool updated = ss[ss_updated(N)] > 0.5;                      // after update(): no shift, re-projection below (:335-375)
         for (int id = lane; id < 44 * N; id += nl) {
             const int k = id / 44, i = id % 44;
             const int kk = updated ? k : (k + 1 < N ? k + 1 : N - 1);      // shift: row k takes (unwrapped) row k+1
@@ -397,9 +402,13 @@ BMPC_HD inline void stream_pack(int N, int S, const double *path, int cap, doubl
 
 // f2 + f3: post-process one stream.  x [N][44] solver result, g [N][43], status; traj: trajectory record (tr_len(N));
 // flags bit 0: advance the robot record rb with the kinematic plant step of the node (util_functions.py:152-161);
-// bit 1: real-time-iteration mode -- an iteration-capped solve (status 1) counts as a usable plan (not in the reference).
+// bit 1: real-time-iteration mode (not in the reference): the solver runs a fixed, small number of iterations per tick, so status 1 is the
+// normal outcome.  The reference's acceptance rule (BoundMPC.py:460-465: solver success OR summed violation of g beyond 1e-6 below
+// 1e-4) still decides -- with the threshold rt_tol in place of 1e-4 (bmpc_stream_set_rt_feasibility_tol; default 1e-4, the
+// reference's).  A capped iterate that fails it is NOT applied: the previous plan is replayed from its error count, as the reference
+// does after a failed solve (:468-489).  (Round 2 accepted every capped iterate unconditionally; closed loops then ran away.)
 BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int cap, double *ss, double *rb, const double *x, const double *g, int status,
-                                double *traj, int flags, double *sh, int lane, int nl) {
+                                double *traj, int flags, double rt_tol, double *sh, int lane, int nl) {
     // ---- phase 0: feasibility rule :460-465 (strided partial sums, fixed-order total) ----
     {
         double part = 0.0;
@@ -414,7 +423,7 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
     if (lane == 0) {
         double viol = 0.0;
         for (int l = 0; l < nl; l++) viol += sh[SH_RED + l];
-        const bool success = status == 0 || viol < 1e-4 || ((flags & 2) && status == 1);
+        const bool success = status == 0 || viol < ((flags & 2) ? rt_tol : 1e-4);
         int ec = (int)ss[SS_ERRCNT], using_prev = 0, use_prev_plan = 0;
         if (!success) {
             ec += 1; using_prev = 1;
@@ -451,6 +460,7 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
     BMPCS_SYNC();
     if (lane == 0) {
         ss[SS_ERRCNT] = (double)ec; ss[SS_USINGPREV] = (double)using_prev; ss[SS_VALID] = ec < N ? 1.0 : 0.0;
+        ss[ss_updated(N) + 1] = ((flags & 2) && status != 3) ? 1.0 : 0.0;      // real-time mode: the next warm start may continue from this iterate (stream_pack)
         if (success) ss[SS_HASPREV] = 1.0;
         traj[TRN - 4] = ec < N ? (double)n : 0.0; traj[TRN - 3] = (double)using_prev; traj[TRN - 2] = success ? 1.0 : 0.0; traj[TRN - 1] = sh[SH_FLAG + 4];
     }

@@ -49,6 +49,9 @@ constexpr int NZ = 44, NG = 43, NE = 36, NS = 35, NU = 8, NW = 43, NI = 57, SMAX
 #define DELTA_UP_FIRST 10.0
 #define DELTA_KEEP_MIN 1e-5
 #define STALL_FACTOR 0.5     // stall test: primal infeasibility must halve per stall_window iterations
+#define STALL_RESTARTS 3     // barrier restarts from a stalled iterate before status 2 (long horizons only; oracle/bmpc_oracle.c solve_one)
+#define STALL_RESTART_MU 3.0
+#define STALL_RESTART_PUSH 1e-1
 #define KAPPA_EPS 100.0   // barrier problem "solved" at KKT error <= KAPPA_EPS * mu (oracle/bmpc_oracle.c; Ipopt barrier_tol_factor)
 enum { ZJ = 0, ZJPHI = 7, ZQ = 8, ZDQ = 15, ZDDQ = 22, ZPOS = 29, ZIW = 32, ZV = 35, ZW = 38, ZPHI = 41, ZDPHI = 42, ZDDPHI = 43 };
 enum { GQ = 0, GDQ = 7, GDDQ = 14, GPOS = 21, GIW = 24, GV = 27, GW = 30, GPHI = 33, GDPHI = 34, GDDPHI = 35 };
@@ -1857,31 +1860,34 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     // Row pass "A" (57 rows per node, lane-strided, three rows in flight per lane): multipliers nu, barrier ratios
     // sigma = nu/t, 1/t, sigma*(h+t), and the inequality part of the KKT error.  first = initialisation of t, nu.
     double ad = 1.0;
-    for (int it_first = 1; it_first >= 1; it_first--) {
-        LANES_BEGIN
-            double ep = 0, cmax = -1e300, cmin = 1e300, sn = 0;
-            for (int base = lane; base < ni; base += 64 * RU) {
-                double hv[RU], tv[RU];
-#pragma unroll
-                for (int u = 0; u < RU; u++) {
-                    const int id = base + 64 * u; hv[u] = id < ni ? G[sc.HIN + id] : -1.0;
-                    const double ns = (warm && id < ni) ? pr.state[id] : 0.0;
-                    tv[u] = ns > 0.0 ? BMPC_FMIN(mu / ns, o.slack_push) : o.slack_push;
-                }
-#pragma unroll
-                for (int u = 0; u < RU; u++) {
-                    const int id = base + 64 * u;
-                    if (id < ni) {
-                        const double t = (-hv[u] > tv[u]) ? -hv[u] : tv[u], ti = 1.0 / t, nu = mu * ti, r = hv[u] + t;
-                        G[sc.T + id] = t; G[sc.NUm + id] = nu; G[sc.SG + id] = nu * ti; G[sc.TI + id] = ti; G[sc.SR + id] = nu * ti * r;
-                        const double v = BMPC_FABS(r), c = nu * t;
-                        ep = v > ep ? v : ep; cmax = c > cmax ? c : cmax; cmin = c < cmin ? c : cmin; sn += nu;
-                    }
-                }
-            }
-            L[L_KKP + lane] = ep; L[L_KKP + 64 + lane] = cmax; L[L_KKP + 128 + lane] = cmin; L[L_KKP + 192 + lane] = sn;
+    // Row pass "A0": slacks and multipliers from the inequality values -- at the start of the solve (warm: slack bounded from below by
+    // the stored multiplier) and again at every barrier restart of a stalled long-horizon solve (re-centred on a high barrier level).
+#define BMPC_ROWS_INIT(WARM_, PUSH_) \
+        LANES_BEGIN \
+            double ep = 0, cmax = -1e300, cmin = 1e300, sn = 0; \
+            for (int base = lane; base < ni; base += 64 * RU) { \
+                double hv[RU], tv[RU]; \
+_Pragma("unroll") \
+                for (int u = 0; u < RU; u++) { \
+                    const int id = base + 64 * u; hv[u] = id < ni ? G[sc.HIN + id] : -1.0; \
+                    const double ns = ((WARM_) && id < ni) ? pr.state[id] : 0.0; \
+                    tv[u] = ns > 0.0 ? BMPC_FMIN(mu / ns, (PUSH_)) : (PUSH_); \
+                } \
+_Pragma("unroll") \
+                for (int u = 0; u < RU; u++) { \
+                    const int id = base + 64 * u; \
+                    if (id < ni) { \
+                        const double t = (-hv[u] > tv[u]) ? -hv[u] : tv[u], ti = 1.0 / t, nu = mu * ti, r = hv[u] + t; \
+                        G[sc.T + id] = t; G[sc.NUm + id] = nu; G[sc.SG + id] = nu * ti; G[sc.TI + id] = ti; G[sc.SR + id] = nu * ti * r; \
+                        const double v = BMPC_FABS(r), c = nu * t; \
+                        ep = v > ep ? v : ep; cmax = c > cmax ? c : cmax; cmin = c < cmin ? c : cmin; sn += nu; \
+                    } \
+                } \
+            } \
+            L[L_KKP + lane] = ep; L[L_KKP + 64 + lane] = cmax; L[L_KKP + 128 + lane] = cmin; L[L_KKP + 192 + lane] = sn; \
         LANES_END
-    }
+    BMPC_ROWS_INIT(warm, o.slack_push)
+    int n_restart = 0, it_restart = 0;
     int it = 0, status = 1; double E0 = 0, ep_old = 0, ep_mid = 0;
     for (it = 0; it <= o.max_iter; it++) {
         BMPC_PROF(W, 10);
@@ -1913,7 +1919,19 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
         // stalled primal feasibility -> status 2, numerical breakdown -> status 3 (oracle/bmpc_oracle.c solve_one)
         if (it == 0) ep_old = ep_mid = 1e300;
         else if (o.stall_window > 0 && it % (o.stall_window / 2) == 0) {
-            if (it >= o.stall_window && ep >= STALL_FACTOR * ep_old && ep > 1e-6) { status = 2; break; }
+            if (it >= o.stall_window + it_restart && ep >= STALL_FACTOR * ep_old && ep > 1e-6) {
+                // Long horizons (a compile-time property of this instantiation, like the Gauss-Newton fallback): before giving up, restart
+                // the barrier from the CURRENT iterate -- slacks and multipliers re-centred on a high barrier level, filter and inertia
+                // history cleared -- at most STALL_RESTARTS times (oracle/bmpc_oracle.c solve_one has the numbers: the stalled
+                // problems of the tight 30-stage batch are feasible, their iterate is jammed at the first barrier level).
+                if (zlds || n_restart >= STALL_RESTARTS) { status = 2; break; }
+                n_restart++; it_restart = it;
+                mu = STALL_RESTART_MU;
+                BMPC_ROWS_INIT(false, STALL_RESTART_PUSH)
+                nfilt = 0; filt_mu = -1.0; theta_min = -1.0; delta_last = 0.0; delta_prev = 0.0; gn_run = 0;
+                ep_old = ep_mid = 1e300;
+                continue;
+            }
             ep_old = ep_mid; ep_mid = ep;
         }
         if (!(ed < 1e12)) { status = 3; break; }

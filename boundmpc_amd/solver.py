@@ -14,7 +14,7 @@ NZ, NG = 44, 43
 
 
 class BatchedOCPSolver:
-    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=None, slack_push=1e-2, exact_hessian=True, mu_warm=1e-2, stall_window=40):
+    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=None, slack_push=1e-2, exact_hessian=True, mu_warm=1e-2, stall_window=None):
         self._lib = _lib.load()
         o = _lib.Options()
         self._lib.bmpc_default_options_for(int(N), ctypes.byref(o))      # mu_init 0.1 for N <= 11, 0.3 for longer horizons
@@ -22,7 +22,8 @@ class BatchedOCPSolver:
             mu_init = o.mu_init
         o.tol, o.max_iter, o.mu_init, o.slack_push, o.exact_hessian = tol, int(max_iter), mu_init, slack_push, int(exact_hessian)
         o.mu_warm = mu_warm
-        o.stall_window = int(stall_window)
+        if stall_window is not None:
+            o.stall_window = int(stall_window)      # default: 40 for N <= 11, 20 for longer horizons (bmpc_default_options_for)
         self._h = ctypes.c_void_p()
         _lib.check(self._lib.bmpc_create(int(N), int(S), float(dt), ctypes.byref(o), ctypes.byref(self._h)), "bmpc_create")
         self.N, self.S, self.dt = int(N), int(S), float(dt)
@@ -66,6 +67,11 @@ class BatchedOCPSolver:
         g, l, s = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
         self._lib.bmpc_launch_info(self._h, ctypes.byref(g), ctypes.byref(l), ctypes.byref(s))
         return dict(grid=g.value, lds_bytes=l.value, scratch_bytes=s.value)
+
+    def set_rt_feasibility_tol(self, tol):
+        """Threshold of the reference's acceptance rule (summed violation of g, BoundMPC.py:462-465) that stream ticks in real-time mode
+        apply to an iteration-capped iterate (default 1e-4, the reference's).  Set it before the tick graph is captured."""
+        _lib.check(self._lib.bmpc_stream_set_rt_feasibility_tol(self._h, float(tol)), "bmpc_stream_set_rt_feasibility_tol")
 
     def set_timing(self, keep=1):
         """HIP events around the solver kernel on its launch stream; the pairs of the last `keep` launches are kept (0/False = off)."""

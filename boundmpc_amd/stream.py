@@ -185,10 +185,20 @@ class StreamBatch:
                                                      dp(self.g), dp(self.status), dp(self.traj), int(bool(simulate)) | (2 if accept_capped else 0),
                                                      self._stream(stream)), "bmpc_stream_post")
 
-    def tick(self, max_iter=0, warm_dual=False, simulate=True, stream=None, accept_capped=False):
-        """pack -> solve -> post as three launches (see tick_graph for the captured form)."""
+    def tick(self, max_iter=0, warm_dual=False, simulate=True, stream=None, accept_capped=False, fused=True):
+        """pack -> solve -> post of one tick: one fused launch (bmpc_stream_tick; N <= 11, B within the resident waves) or, with
+        fused=False, the three launches of the separate entry points (see tick_graph for the captured form).
+        accept_capped: real-time mode -- an iteration-capped iterate is judged by the reference's violation rule with the handle's
+        real-time threshold (BatchedOCPSolver.set_rt_feasibility_tol) and replaced by the previous plan if it fails."""
         if max_iter and not warm_dual:
             raise ValueError("an iteration cap needs the dual state (warm_dual=True): the multipliers must be shifted with the plan")
+        if fused:
+            dp = lambda t: ctypes.c_void_p(t.data_ptr())
+            _lib.check(self.solver._lib.bmpc_stream_tick(
+                self.solver._h, self.B, dp(self.path), self.entries, dp(self.state), dp(self.robot), dp(self.p), dp(self.x0),
+                dp(self.dual) if warm_dual else None, int(max_iter), dp(self.x), dp(self.g), dp(self.iters), dp(self.status), dp(self.kkt),
+                dp(self.traj), int(bool(simulate)) | (2 if accept_capped else 0), self._stream(stream)), "bmpc_stream_tick")
+            return
         self.pack(warm_dual, stream)
         out = dict(x=self.x, g=self.g, iters=self.iters, status=self.status, kkt=self.kkt)
         self.solver.solve_batch(self.p, self.x0, out=out, want=("g", "iters", "status", "kkt"), stream=stream,

@@ -94,8 +94,13 @@ int bmpc_solve_batch_warm(bmpc_handle *h, int B, const double *p, const double *
 
 /* The same step captured once into a hipGraph (work-queue reset + solver kernel) and replayed per tick with hipGraphLaunch: the
  * buffers are fixed at capture time, the caller refreshes their contents (p, x0, state) between launches.  state may be NULL
- * (cold starts).  One graph or solve in flight per handle.  A graph keeps the handle's workspace and the latency buffer registered
- * at capture time: destroy graphs before their handle, re-capture after bmpc_set_latency_buffer. */
+ * (cold starts).  Launches of one handle (direct or replayed) share its workspace and work queue: the library orders them against each
+ * other with an event whatever streams the caller uses, so they never overlap.  A graph keeps the handle's workspace and the latency
+ * buffer registered at capture time (re-capture after bmpc_set_latency_buffer) and holds a reference on the handle: bmpc_destroy of
+ * a handle with live graphs closes it (those graphs then refuse to launch, BMPC_ERR_ARG) and the last bmpc_graph_destroy frees it.
+ * bmpc_graph_launch(g, NULL): the replay runs on a non-blocking stream of the handle, ordered by events after the work the legacy
+ * null stream holds so far and before its later work (a graph replayed ON the null stream and followed by unsynchronised null-stream
+ * launches ended in a GPU memory fault on ROCm 7.2; tests/cabi/graph_nullstream.cpp). */
 typedef struct bmpc_graph bmpc_graph;
 int bmpc_graph_create(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g,
                       double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, bmpc_graph **out);
@@ -111,7 +116,10 @@ int bmpc_graph_destroy(bmpc_graph *g);
  *                       compute_return_data :513-611 (re-integration, Cartesian trajectory, advance of phi / rotation reference);
  *                       flags bit 0 (simulate): additionally advance the robot record like the node's kinematic simulation
  *                       (util_functions.py:152-161, bound_mpc_node.py:292-372); bit 1 (real-time iteration, not in the
- *                       reference): an iteration-capped solve (status 1) counts as a usable plan.
+ *                       reference: a fixed small number of solver iterations per tick, status 1 is the normal outcome): the
+ *                       reference's acceptance rule BoundMPC.py:460-465 decides with the threshold of
+ *                       bmpc_stream_set_rt_feasibility_tol in place of 1e-4; an iterate that fails it is not applied, the
+ *                       previous plan is replayed (BoundMPC.py:468-489).
  * All buffers are DEVICE doubles, one row per stream, row lengths from bmpc_stream_lengths:
  *   path   [B][path_entries][path_entry]  static via-point table (built on the host once per path; layout in
  *                                          boundmpc_amd/csrc/bmpc_stream.inl, builder boundmpc_amd.stream.path_table)
@@ -127,7 +135,17 @@ int bmpc_stream_pack(bmpc_handle *h, int B, const double *path, int path_entries
                      double *dual_state, void *hip_stream);
 int bmpc_stream_post(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, const double *x, const double *g,
                      const int *status, double *traj, int flags, void *hip_stream);
-/* one whole tick {pack, warm-started solve with max_iter (0 = options), post} captured into a hipGraph; launch with bmpc_graph_launch */
+/* Threshold on the summed violation of g (beyond 1e-6 per row) below which bmpc_stream_post applies an iteration-capped iterate in
+ * real-time mode (flags bit 1).  Default 1e-4 = the reference's rule (BoundMPC.py:462-465).  Read when a post is launched or captured. */
+int bmpc_stream_set_rt_feasibility_tol(bmpc_handle *h, double tol);
+/* One whole tick {pack, warm-started solve with max_iter (0 = options), post} of B streams.  For N <= 11 and B within the resident
+ * waves of the device (bmpc_launch_info: grid) it is ONE kernel launch: the wave that owns a stream packs its problem, solves it and
+ * post-processes the result (no work queue, no launch boundary between the steps); otherwise the three kernels are enqueued.
+ * Arguments as bmpc_stream_pack / bmpc_solve_batch_warm / bmpc_stream_post. */
+int bmpc_stream_tick(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, double *p, double *x0,
+                     double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj, int flags,
+                     void *hip_stream);
+/* the same tick captured into a hipGraph (one kernel node when it fuses); launch with bmpc_graph_launch */
 int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, double *p, double *x0,
                              double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj,
                              int flags, bmpc_graph **out);

@@ -71,6 +71,9 @@ static const double DQ_LIM_DEG[7] = {85, 85, 100, 75, 130, 135, 135};
 #define DELTA_KEEP_MIN 1e-5  /* an iteration that follows a regularised one starts from a third of its delta (no attempt at 0) down to this */
 #define GN_PROBE 3         /* after a Gauss-Newton fallback the following iterations start from the Gauss-Newton Hessian; every GN_PROBE-th tries the exact one again */
 #define STALL_FACTOR 0.5
+#define STALL_RESTARTS 3        /* barrier restarts from a stalled iterate before status 2 (long horizons only) */
+#define STALL_RESTART_MU 3.0
+#define STALL_RESTART_PUSH 1e-1
 #define KAPPA_EPS 100.0 /* barrier problem "solved" when its KKT error <= KAPPA_EPS * mu (Ipopt barrier_tol_factor, default 10) */
 #define PI 3.14159265358979323846
 
@@ -916,7 +919,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
     double *sg = (double *)malloc(N * NI * sizeof(double)), *nuh = (double *)malloc(N * NI * sizeof(double));
     double *gf = (double *)malloc(N * NZ * sizeof(double)), *zero_nu = (double *)calloc(N * NI, sizeof(double));
     double *hdir = (double *)malloc(NI * sizeof(double)), *gt = (double *)malloc(N * NE * sizeof(double)), *ht = (double *)malloc(N * NI * sizeof(double));
-    int it = 0, status = 1;
+    int it = 0, status = 1, n_restart = 0, it_restart = 0;
     double E0 = 0, ep_old = 0, ep_mid = 0;
     for (it = 0; it <= o->max_iter; it++) {
         ORACLE_REGION(REG_ADJOINT); adjoint(C, P, W, W->Z, W->nu, W->lam, W->Rj, W->gradZ); ORACLE_REGION(REG_DRIVER);
@@ -934,7 +937,21 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
          * A dual residual beyond 1e12 is a numerical breakdown (status 3). */
         if (it == 0) ep_old = ep_mid = 1e300;
         else if (o->stall_window > 0 && it % (o->stall_window / 2) == 0) {
-            if (it >= o->stall_window && ep >= STALL_FACTOR * ep_old && ep > 1e-6) { status = 2; break; }
+            if (it >= o->stall_window + it_restart && ep >= STALL_FACTOR * ep_old && ep > 1e-6) {
+                /* Long horizons: before giving up, restart the barrier from the CURRENT iterate -- slacks and multipliers re-centred on
+                 * a high barrier level (mu = STALL_RESTART_MU, slack push STALL_RESTART_PUSH), filter and inertia history cleared --
+                 * at most STALL_RESTARTS times.  On the tight 30-stage batch 3.1 % of the problems crawl at the first barrier level
+                 * with boundary-limited steps; with the stall test off 93 % of them do converge (after 130 iterations at the median):
+                 * they are feasible, the iterate is jammed.  From a re-centred iterate 94 % of them converge within ~50 further
+                 * iterations.  (What Ipopt's restoration phase is for; the kernel's N <= 11 instantiation does not carry the path.) */
+                if (N <= GN_MIN_HORIZON || n_restart >= STALL_RESTARTS) { status = 2; break; }
+                n_restart++; it_restart = it;
+                mu = STALL_RESTART_MU;
+                for (int i = 0; i < N * NI; i++) { W->t[i] = fmax(-W->hin[i], STALL_RESTART_PUSH); W->nu[i] = mu / W->t[i]; }
+                nfilt = 0; filt_mu = -1.0; theta_min = -1.0; delta_last = 0.0; delta_prev = 0.0; gn_run = 0;
+                ep_old = ep_mid = 1e300;
+                continue;
+            }
             ep_old = ep_mid; ep_mid = ep;
         }
         if (!(ed < 1e12)) { status = 3; break; }
