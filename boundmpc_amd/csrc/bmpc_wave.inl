@@ -425,57 +425,6 @@ BMPC_D inline void node_ref(const double *PAR, const POff &po, int S, const doub
 // tube row m uses pos (m = 1,2) or iw (m = 0,3,4) as its 3-vector variable
 BMPC_D inline int tube_voff(int m) { return (m == 1 || m == 2) ? ZPOS : ZIW; }
 
-// gradient of the node-local cost + sum_i nuv_i h_i w.r.t. Z_k (gz[44]) and v_prev (gvp[6])
-BMPC_D inline void node_grad(const double *PAR, const POff &po, double h, const double *Zn, const double *vprev, const double *rr,
-                             const double *nuv, double *gz, double *gvp) {
-    const double *w = PAR + po.w;
-    for (int i = 0; i < NZ; i++) gz[i] = 0;
-    const double *d = rr + RDP, *dh = rr + RDH, *ep = rr + REP, *er = rr + RER, *erpar = rr + RERPAR, *l2 = rr + RL2, *rrv = rr + RRR;
-    const double sig = rr[RSIG], sig1 = rr[RSIG1];
-    const double dde = dot3(d, ep), dd = dot3(d, d);
-    double epo[3], ero[3], eperp[3], erd[3];
-    for (int c = 0; c < 3; c++) {
-        eperp[c] = ep[c] - dde * d[c]; epo[c] = sig * ep[c] + (1 - sig) * dde * d[c];
-        erd[c] = er[c] - erpar[c]; ero[c] = sig * er[c] + (1 - sig) * erpar[c];
-    }
-    const double depo = dot3(d, epo), dhero = dot3(dh, ero);
-    double gphi = 0, gdphi = 0, gddphi = 0;
-    for (int c = 0; c < 3; c++) gz[ZPOS + c] += 2 * w[0] * (sig * epo[c] + (1 - sig) * depo * d[c]);
-    gphi += 2 * w[0] * (-(sig * depo + (1 - sig) * depo * dd) + sig1 * dot3(eperp, epo));
-    const double *jacl = PAR + po.jacl;
-    for (int c = 0; c < 3; c++) {
-        double s = 0;
-        for (int r = 0; r < 3; r++) s += sig * jacl[c * 3 + r] * ero[r];
-        gz[ZIW + c] += 2 * w[1] * (s + (1 - sig) * dhero * l2[c]);
-    }
-    gphi += 2 * w[1] * (-sig * dot3(rrv, ero) - (1 - sig) * rr[RV2RR] * dhero + sig1 * dot3(erd, ero));
-    for (int c = 0; c < 6; c++) {
-        const double rv = Zn[ZV + c] - Zn[ZDPHI] * d[c];
-        const double ra = (Zn[ZV + c] - vprev[c]) / h - Zn[ZDDPHI] * d[c];
-        gz[ZV + c] += 2 * w[2] * rv + 2 * w[5] * ra / h;
-        gdphi += -2 * w[2] * rv * d[c]; gddphi += -2 * w[5] * ra * d[c];
-        gvp[c] = -2 * w[5] * ra / h;
-    }
-    for (int i = 0; i < 7; i++) {
-        gz[ZQ + i] += 2 * w[10] * (Zn[ZQ + i] - PAR[po.qd + i]); gz[ZDQ + i] += 2 * w[11] * Zn[ZDQ + i];
-        gz[ZDDQ + i] += 2 * w[12] * Zn[ZDDQ + i]; gz[ZJ + i] += 2 * w[13] * Zn[ZJ + i];
-    }
-    gphi += -2 * w[6] * (PAR[po.xphid + 0] - Zn[ZPHI]);
-    gdphi += -2 * w[7] * (PAR[po.xphid + 1] - Zn[ZDPHI]);
-    gddphi += -2 * w[8] * (PAR[po.xphid + 2] - Zn[ZDDPHI]);
-    gz[ZJPHI] += 2 * w[9] * Zn[ZJPHI];
-    for (int i = 0; i < 8; i++) gz[ZJ + i] += nuv[IJU + i] - nuv[IJL + i];
-    for (int i = 0; i < 7; i++) { gz[ZQ + i] += nuv[IQU + i] - nuv[IQL + i]; gz[ZDQ + i] += nuv[IDQU + i] - nuv[IDQL + i]; }
-    gphi += -nuv[IPHI0] + nuv[IPHIMAX]; gdphi += nuv[IDPHIMAX];
-    for (int m = 0; m < 5; m++) {
-        const double nu_u = nuv[ITUBE + 2 * m], nu_l = nuv[ITUBE + 2 * m + 1];
-        const int vo = tube_voff(m);
-        for (int c = 0; c < 3; c++) gz[vo + c] += (nu_u - nu_l) * rr[RGC + m * 4 + c];
-        gphi += (nu_u - nu_l) * rr[RGC + m * 4 + 3] - (nu_u + nu_l) * rr[RW1 + m];
-    }
-    gz[ZPHI] += gphi; gz[ZDPHI] += gdphi; gz[ZDDPHI] += gddphi;
-}
-
 // Box rows (i < ITUBE) are +-Z[src] - lim: descriptor without memory accesses, so that a batch of rows can issue all its
 // loads first.  Tube rows (i >= ITUBE) read the node's reference record instead.
 BMPC_D inline void ineq_box_row(const double *PAR, const POff &po, int i, int &src, double &sgn, double &lim) {
@@ -733,6 +682,126 @@ BMPC_D inline void stage_mu(Wave &W, const double *lam, const double *kp, int la
     L[L_MU + ch] = ch < 7 ? s : lp; L[L_MU + 8 + ch] = ch < 7 ? s2 : ld;
 }
 
+// d(f + nu.h)/dZ of every node -> GH [N][44] (the reference's objective_function / error_function, casadi_ocp_formulation.py:227-265,
+// bound_mpc_functions.py:152-246, differentiated; multipliers nu of the 57 internal inequality rows staged in LDS at L_PB).
+// One lane per (node, component) item in four homogeneous kinds -- box rows (jerk, q, dq, ddq: weight x value + multiplier pair),
+// Cartesian-velocity rows (which also carry the acceleration term of the NEXT node: no second pass over GH), pos / iw rows, and the
+// three path-parameter rows -- instead of one lane per node running all 44 components in sequence on 10 of 64 lanes (rounds 1-2:
+// 9.3 k cycles per call + a read-modify-write pass over GH).  The only loads from the workspace are entries of the reference records,
+// issued together ahead of the arithmetic: one dependent round trip per call.
+BMPC_D inline void wave_node_grad_wide(Wave &W, const POff &po, const Scr &sc) {
+    const int N = W.N; const double h = W.h, hinv = 1.0 / h;
+    double *L = W.L, *G = W.G;
+    const double *PAR = L + L_PAR, *w = PAR + po.w, *Zs = W.Zc, *NUV = L + L_PB;
+    const int npass = (N + 9) / 10;
+    LANES_BEGIN
+        // item maps (one integer division each per call): v / pos+iw rows 6 per node, path-parameter rows 3 per node, box rows 29 per node
+        const int k6 = lane / 6, c6 = lane - 6 * k6, k3 = lane / 3, a3 = lane - 3 * k3, k29 = lane / 29, z29 = lane - 29 * k29;
+        for (int pass = 0; pass < npass; pass++) {
+            const int kv0 = 10 * pass + k6, kv = kv0 < N ? kv0 : N - 1, kn = kv < N - 1 ? kv + 1 : kv;
+            const int kf0 = 10 * pass + k3, kf = kf0 < N ? kf0 : N - 1;
+            const bool on6 = lane < 60, on3 = lane < 30;
+            // ---- loads from the workspace: reference-record entries of the items' nodes ----
+            const double *rv_ = G + sc.REF + kv * RREC, *rn_ = G + sc.REF + kn * RREC, *rf_ = G + sc.REF + kf * RREC;
+            const double dv = rv_[RDP + c6], dn = rn_[RDP + c6];                              // v rows: dp_d[c] of the node and of the next node
+            const int cc = c6 < 3 ? c6 : c6 - 3;                                              // pos / iw rows: coordinate
+            double pd[3], pdh[3], pep[3], per_[3], ppar[3], pl2[3], prr[3], pgc[5];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { pd[c] = rv_[RDP + c]; pdh[c] = rv_[RDH + c]; pep[c] = rv_[REP + c]; per_[c] = rv_[RER + c]; ppar[c] = rv_[RERPAR + c]; pl2[c] = rv_[RL2 + c]; prr[c] = rv_[RRR + c]; }
+#pragma unroll
+            for (int m = 0; m < 5; m++) pgc[m] = rv_[RGC + m * 4 + cc];
+            const double psig = rv_[RSIG];
+            double fd[6], fdh[3], fep[3], fer[3], fpar[3], frr[3], fg3[5], fw1[5];
+#pragma unroll
+            for (int c = 0; c < 6; c++) fd[c] = rf_[RDP + c];
+#pragma unroll
+            for (int c = 0; c < 3; c++) { fdh[c] = rf_[RDH + c]; fep[c] = rf_[REP + c]; fer[c] = rf_[RER + c]; fpar[c] = rf_[RERPAR + c]; frr[c] = rf_[RRR + c]; }
+#pragma unroll
+            for (int m = 0; m < 5; m++) { fg3[m] = rf_[RGC + m * 4 + 3]; fw1[m] = rf_[RW1 + m]; }
+            const double fsig = rf_[RSIG], fsig1 = rf_[RSIG1], fv2rr = rf_[RV2RR];
+            // ---- v rows: tracking of v_ref = dphi dp_d and a_ref = ddphi dp_d, plus the acceleration term of node k+1 (which holds v_k) ----
+            {
+                const double *Zn = Zs + kv * NZ, *Z1 = Zs + kn * NZ;
+                const double vk = Zn[ZV + c6], vp = kv ? Zs[(kv - 1) * NZ + ZV + c6] : PAR[po.v0 + c6];
+                const double rv = vk - Zn[ZDPHI] * dv, ra = (vk - vp) * hinv - Zn[ZDDPHI] * dv;
+                const double ra1 = (Z1[ZV + c6] - vk) * hinv - Z1[ZDDPHI] * dn;
+                const double gz = 2 * w[2] * rv + 2 * w[5] * ra * hinv;
+                const double gn = kv < N - 1 ? -2 * w[5] * ra1 * hinv : 0.0;
+                G[on6 ? sc.GH + kv * NZ + ZV + c6 : sc.GVP + 6] = gz + gn;      // lanes without an item write to a spare word
+            }
+            // ---- pos rows (c6 < 3) and iw rows (c6 >= 3): blended tracking errors + tube rows ----
+            {
+                const double *nuv = NUV + kv * NI;
+                const double dde = dot3(pd, pep), dd = dot3(pd, pd);
+                double epo[3], ero[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) { epo[c] = psig * pep[c] + (1 - psig) * dde * pd[c]; ero[c] = psig * per_[c] + (1 - psig) * ppar[c]; }
+                const double depo = dot3(pd, epo), dhero = dot3(pdh, ero);
+                const double *jacl = PAR + po.jacl;
+                double sj = 0;
+#pragma unroll
+                for (int r = 0; r < 3; r++) sj += psig * jacl[cc * 3 + r] * ero[r];
+                const double gpos = 2 * w[0] * (psig * epo[cc] + (1 - psig) * depo * pd[cc]);
+                const double giw = 2 * w[1] * (sj + (1 - psig) * dhero * pl2[cc]);
+                double tp = 0, ti = 0;
+#pragma unroll
+                for (int m = 0; m < 5; m++) {
+                    const double dnu = nuv[ITUBE + 2 * m] - nuv[ITUBE + 2 * m + 1];
+                    if (m == 1 || m == 2) tp += dnu * pgc[m]; else ti += dnu * pgc[m];
+                }
+                const bool isp = c6 < 3;
+                G[on6 ? sc.GH + kv * NZ + (isp ? ZPOS : ZIW) + cc : sc.GVP + 6] = isp ? gpos + tp : giw + ti;
+            }
+            // ---- path-parameter rows phi (a3 = 0), dphi (1), ddphi (2) ----
+            {
+                const double *Zn = Zs + kf * NZ, *nuv = NUV + kf * NI;
+                const double dde = dot3(fd, fep), dd = dot3(fd, fd);
+                double epo[3], ero[3], eperp[3], erd[3];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    eperp[c] = fep[c] - dde * fd[c]; epo[c] = fsig * fep[c] + (1 - fsig) * dde * fd[c];
+                    erd[c] = fer[c] - fpar[c]; ero[c] = fsig * fer[c] + (1 - fsig) * fpar[c];
+                }
+                const double depo = dot3(fd, epo), dhero = dot3(fdh, ero);
+                double gphi = 2 * w[0] * (-(fsig * depo + (1 - fsig) * depo * dd) + fsig1 * dot3(eperp, epo));
+                gphi += 2 * w[1] * (-fsig * dot3(frr, ero) - (1 - fsig) * fv2rr * dhero + fsig1 * dot3(erd, ero));
+                gphi += -2 * w[6] * (PAR[po.xphid + 0] - Zn[ZPHI]);
+                gphi += -nuv[IPHI0] + nuv[IPHIMAX];
+#pragma unroll
+                for (int m = 0; m < 5; m++) {
+                    const double nu_u = nuv[ITUBE + 2 * m], nu_l = nuv[ITUBE + 2 * m + 1];
+                    gphi += (nu_u - nu_l) * fg3[m] - (nu_u + nu_l) * fw1[m];
+                }
+                double gdphi = 0, gddphi = 0;
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    const double vk = Zn[ZV + c], vp = kf ? Zs[(kf - 1) * NZ + ZV + c] : PAR[po.v0 + c];
+                    const double rv = vk - Zn[ZDPHI] * fd[c], ra = (vk - vp) * hinv - Zn[ZDDPHI] * fd[c];
+                    gdphi += -2 * w[2] * rv * fd[c]; gddphi += -2 * w[5] * ra * fd[c];
+                }
+                gdphi += -2 * w[7] * (PAR[po.xphid + 1] - Zn[ZDPHI]) + nuv[IDPHIMAX];
+                gddphi += -2 * w[8] * (PAR[po.xphid + 2] - Zn[ZDDPHI]);
+                G[on3 ? sc.GH + kf * NZ + ZPHI + a3 : sc.GVP + 6] = a3 == 0 ? gphi : (a3 == 1 ? gdphi : gddphi);
+            }
+            // ---- box rows: jerk (8), q, dq, ddq (7 each): 2 weight (value - target) + upper - lower multiplier; two nodes per trip ----
+#pragma unroll
+            for (int u = 0; u < 5; u++) {
+                const int kb0 = 10 * pass + 2 * u + k29, kb = kb0 < N ? kb0 : N - 1, z = z29;
+                const bool on = lane < 58;
+                const double *Zn = Zs + kb * NZ, *nuv = NUV + kb * NI;
+                // kind of the component: weight index, target, multiplier rows (ddq has none: both indices point at a row pair that cancels)
+                const bool isJ = z < 7, isJp = z == 7, isQ = z >= ZQ && z < ZDQ, isDQ = z >= ZDQ && z < ZDDQ;
+                int wi = 12; wi = isDQ ? 11 : wi; wi = isQ ? 10 : wi; wi = isJp ? 9 : wi; wi = isJ ? 13 : wi;
+                int iu = IJU, il = IJU; iu = isDQ ? IDQU + z - ZDQ : iu; il = isDQ ? IDQL + z - ZDQ : il; iu = isQ ? IQU + z - ZQ : iu; il = isQ ? IQL + z - ZQ : il;
+                iu = (isJ || isJp) ? IJU + z : iu; il = (isJ || isJp) ? IJL + z : il;
+                const double tgt = (isQ ? 1.0 : 0.0) * PAR[po.qd + (isQ ? z - ZQ : 0)];      // clamped index + 0/1 factor: no load under a branch
+                const double v = 2 * w[wi] * (Zn[z] - tgt) + (nuv[iu] - nuv[il]);
+                G[on ? sc.GH + kb * NZ + z : sc.GVP + 6] = v;
+            }
+        }
+    LANES_END
+}
+
 // inputs of adjoint stage j: gradient row j, kinematics records of node j+1 (predicted point and velocity point); j = -1: record
 // of node 0.  Register set PO (0 or 5) of the lane's prefetch array; LDS buffer set by stage parity.
 #define BMPC_ADJ_LOADS(j_, PO_) { double *pf = LR[LIDX].pf + (PO_); const int j0 = (j_), j = j0 >= -1 ? j0 : -1, jc = j >= 0 ? j : 0, jr = j + 1 < N ? j + 1 : N - 1; \
@@ -834,21 +903,7 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
             for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < N * NI ? id0 : N * NI - 1; L[L_PB + id] = use_hat ? mu * a_[u] + b_[u] : a_[u]; }
         }
     LANES_END
-    LANES_BEGIN
-        if (lane < N) {
-            const int k = lane;
-            double nuv[NI], vprev[6];
-            for (int i = 0; i < NI; i++) nuv[i] = L[L_PB + k * NI + i];
-            for (int c = 0; c < 6; c++) vprev[c] = ndv(PAR, po, Zs, k, ZV + c, po.v0 + c);
-            double gz[NZ], gvp[6];
-            node_grad(PAR, po, h, Zs + k * NZ, vprev, G + sc.REF + k * RREC, nuv, gz, gvp);
-            for (int i = 0; i < NZ; i++) G[sc.GH + k * NZ + i] = gz[i];
-            for (int c = 0; c < 6; c++) G[sc.GVP + k * 8 + c] = gvp[c];
-        }
-    LANES_END
-    LANES_BEGIN
-        for (int id = lane; id < (N - 1) * 6; id += 64) { const int k = id / 6, c = id - k * 6; G[sc.GH + k * NZ + ZV + c] += G[sc.GVP + (k + 1) * 8 + c]; }
-    LANES_END
+    wave_node_grad_wide(W, po, sc);
     BMPC_PROF(W, 27);
     if (use_hat) return;   // QP gradient only
     // sequential sweep; lam_{k+1} lives in LDS (ping-pong ST_LAM0/ST_LAM1).  A blocking global load per stage would cost a full
