@@ -562,7 +562,12 @@ BMPC_D inline double red_min(const double *r) { double s = r[0];
 // residual rows are exactly zero.  One lane per node: a lane writes only its own node's entries and reads its neighbours' projected
 // values from the kinematics records of phase 1 (v of the previous node; the i-omega recursion as a prefix sum from node 0), never
 // from Zs -- no cross-lane dependence inside the phase.
-BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Zs, int oG, int oH, bool project) {
+// ls (trial points of the line search): the row pass also forms the trial slacks tt = t + alpha dt (-> TT) and the two sums the filter
+// needs -- theta = ||c||_1 + ||h + tt||_1 and the barrier term -mu sum log tt -- from the values it has in registers, and leaves their
+// per-lane parts in L_RED + 64 / + 128: the trial used to cost two more passes over the rows (slacks before, sums after the
+// evaluation), each a dependent round trip to the workspace.
+struct LsRows { double alpha, mu; };
+BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Zs, int oG, int oH, bool project, const LsRows *ls = nullptr) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
     double *L = W.L, *G = W.G;
     const double *PAR = L + L_PAR;
@@ -638,8 +643,9 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
     const double f = red_sum(L + L_RED);
     BMPC_PROF(W, 26);
     LANES_BEGIN   // inequality values, lane-strided rows, RU rows in flight: all loads of a batch are issued before the first use
+        double th = 0, br = 0;
         for (int base = lane; base < N * NI; base += 64 * RU) {
-            double zv[RU], rc[RU], rw[RU], sg[RU], lm[RU];
+            double zv[RU], rc[RU], rw[RU], sg[RU], lm[RU], tv[RU], dv[RU];
 #pragma unroll
             // rows past the end are clamped to the last row: they load, compute and store exactly what its owner does (no exec-mask
             // branch anywhere in the pass)
@@ -651,15 +657,34 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
                 zv[u] = Zs[k * NZ + (int)L[L_ROWT + 2 * NI + i]];
                 const double *rr = G + sc.REF + k * RREC;
                 rc[u] = rr[RC + m]; rw[u] = rr[RWD + m];
+                if (ls) { tv[u] = G[sc.T + id]; dv[u] = G[sc.DT + id]; }      // wave-uniform condition
             }
+            double tprod = 1.0;
 #pragma unroll
             for (int u = 0; u < RU; u++) {
                 const int id0 = base + 64 * u, id = id0 < N * NI ? id0 : N * NI - 1;
                 const int i = id % NI;
                 // 0/1 factors instead of a select between the two row formulas (their operands are loads: a select becomes a branch nest)
                 const double mt = i >= ITUBE ? 1.0 : 0.0, s2 = (i >= ITUBE && ((i - ITUBE) & 1)) ? -1.0 : 1.0;
-                G[oH + id] = mt * (s2 * rc[u] - rw[u]) + (1.0 - mt) * (sg[u] * zv[u] - lm[u]);
+                const double hv = mt * (s2 * rc[u] - rw[u]) + (1.0 - mt) * (sg[u] * zv[u] - lm[u]);
+                G[oH + id] = hv;
+                if (ls) {
+                    const double tt = tv[u] + ls->alpha * dv[u]; const bool ok_ = id0 < N * NI;
+                    G[sc.TT + id] = tt;
+                    th += ok_ ? BMPC_FABS(hv + tt) : 0.0; tprod *= ok_ ? tt : 1.0;
+                }
             }
+            if (ls) br -= ls->mu * BMPC_LOG(tprod);      // one log per batch of RU slacks: sum of logs = log of the product (t in [1e-12, 1e2])
+        }
+        if (ls) {
+            for (int base = lane; base < N * NE; base += 64 * RU) {
+                double gv[RU];
+#pragma unroll
+                for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u; gv[u] = G[oG + (id0 < N * NE ? id0 : N * NE - 1)]; }
+#pragma unroll
+                for (int u = 0; u < RU; u++) th += base + 64 * u < N * NE ? BMPC_FABS(gv[u]) : 0.0;
+            }
+            L[L_RED + 64 + lane] = th; L[L_RED + 128 + lane] = br;
         }
     LANES_END
     return f;
@@ -2110,38 +2135,12 @@ _Pragma("unroll") \
         for (int ls = 0; ls < 14; ls++) {
             LANES_BEGIN
                 for (int id = lane; id < nw; id += 64) W.Zt[id] = W.Zc[id] + alpha * W.Dz[id];
-                for (int base = lane; base < ni; base += 64 * RU) {
-                    double tv[RU], dv[RU];
-#pragma unroll
-                    for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1; tv[u] = G[sc.T + id]; dv[u] = G[sc.DT + id]; }
-#pragma unroll
-                    for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1; G[sc.TT + id] = tv[u] + alpha * dv[u]; }
-                }
             LANES_END
             BMPC_PROF(W, 9);
-            ft = wave_eval(W, po, sc, W.Zt, sc.GT, sc.HT, ls > 0);
+            const LsRows lsr = {alpha, mu};
+            ft = wave_eval(W, po, sc, W.Zt, sc.GT, sc.HT, ls > 0, &lsr);      // also: trial slacks -> TT, theta and barrier sums -> L_RED
             BMPC_PROF(W, 0);
-            LANES_BEGIN
-                double th = 0, br = 0;
-                for (int base = lane; base < ne; base += 64 * RU) {
-                    double gv[RU];
-#pragma unroll
-                    for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u; gv[u] = G[sc.GT + (id0 < ne ? id0 : ne - 1)]; }
-#pragma unroll
-                    for (int u = 0; u < RU; u++) th += base + 64 * u < ne ? BMPC_FABS(gv[u]) : 0.0;
-                }
-                for (int base = lane; base < ni; base += 64 * RU) {
-                    double tv[RU], hv[RU];
-#pragma unroll
-                    for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1; tv[u] = G[sc.TT + id]; hv[u] = G[sc.HT + id]; }
-                    double tprod = 1.0;
-#pragma unroll
-                    for (int u = 0; u < RU; u++) { const bool ok_ = base + 64 * u < ni; th += ok_ ? BMPC_FABS(hv[u] + tv[u]) : 0.0; tprod *= ok_ ? tv[u] : 1.0; }
-                    br -= mu * BMPC_LOG(tprod);
-                }
-                L[L_RED + lane] = th; L[L_RED + 64 + lane] = br;
-            LANES_END
-            const double tht = red_sum(L + L_RED), phit = ft + red_sum(L + L_RED + 64);
+            const double tht = red_sum(L + L_RED + 64), phit = ft + red_sum(L + L_RED + 128);
             bool okk = (phit - phit == 0.0) && tht <= theta_max;
             for (int j = 0; j < nfilt && okk; j++) if (!(tht < L[L_FILT + 2 * j] || phit < L[L_FILT + 2 * j + 1])) okk = false;
             armijo_step = false;

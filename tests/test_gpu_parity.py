@@ -127,7 +127,8 @@ def test_long_horizon_tight_tubes(solver):
         assert set(np.unique(st)) <= {0, 2, 3}, np.bincount(st)          # converged | stalled (local infeasibility) | numerical
         assert (st == 3).mean() <= 0.002
         ok = st == 0
-        assert ok.mean() > 0.85 and it.max() <= 400, (ok.mean(), it.max())   # reference iteration cap: 500 (BoundMPC.py:122)
+        # measured (round 3, barrier restarts of stalled solves): 99.76 % converged, slowest problem 190 iterations; reference cap: 500 (BoundMPC.py:122)
+        assert ok.mean() >= 0.995 and it.max() <= 260, (ok.mean(), it.max())
         assert (kkt[ok] <= 1e-8).all()
         g = o["g"].cpu().numpy()[ok].reshape(-1, 30, 43)
         assert np.abs(g[:, :, :36]).max() < 1e-6 and g[:, :, 36:].max() < 1e-6
@@ -143,7 +144,7 @@ def test_long_horizon_tight_tubes(solver):
         idx = np.arange(0, 8192, 32)
         ref = c_oracle.solve(P[idx], X[idx], 30, 4, 0.1)
         same = ref["status"] == st[idx]
-        assert same.mean() >= 0.98, same.mean()     # a solve that stalls at the 10 % threshold may fall on either side
+        assert same.mean() >= 0.99, same.mean()     # a solve whose last restart stalls at the threshold may fall on either side
         k = same & (ref["status"] == 0)
         # these are 40...120-iteration runs through nonconvex regions: round-off differences between the two implementations can
         # change an accepted step length somewhere, after which the iteration counts drift apart (and a problem with several
