@@ -186,8 +186,11 @@ BMPC_D inline double ndv(const double *PAR, const POff &po, const double *Z, int
 // line search may leave them by a little), so a two-constant Cody-Waite reduction by pi/2 is exact here and the classical minimax
 // kernels on [-pi/4, pi/4] (the coefficients every libm descended from fdlibm uses) finish in ~30 instructions, error < 1 ulp
 // (tests/test_emu.py checks it against libm over [-50, 50]).
+#ifndef BMPC_RINT
+#define BMPC_RINT(x) __builtin_rint(x)
+#endif
 BMPC_D inline void bmpc_sincos(double x, double *sn, double *cs) {
-    const double k = __builtin_rint(x * 6.36619772367581382433e-01);
+    const double k = BMPC_RINT(x * 6.36619772367581382433e-01);
     const double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
     const double z = r * r;
     const double ps = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));

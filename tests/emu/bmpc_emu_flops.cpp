@@ -53,6 +53,7 @@ using namespace fc;
 #define BMPC_FMAX(a, b) Real(std::fmax(Real(a).v, Real(b).v))
 #define BMPC_FMIN(a, b) Real(std::fmin(Real(a).v, Real(b).v))
 #define BMPC_POW15(x) ((x) * BMPC_SQRT(x))
+#define BMPC_RINT(x) Real(__builtin_rint(Real(x).v))
 #define BMPC_POW(x, y) (fc::cs(), Real(std::pow(Real(x).v, Real(y).v)))
 #define LANES_BEGIN for (int li_ = 0; li_ < 64; ++li_) { const int lane = W.order[li_]; (void)lane;
 #define LANES_END }

@@ -102,7 +102,7 @@ def count_flops(p, x0, N, S, h, opts=None):
     global _fl
     src = os.path.join(_HERE, "bmpc_emu_flops.cpp")
     if not os.path.exists(_FLIB) or any(os.path.getmtime(_FLIB) < os.path.getmtime(s) for s in (src, _SRC[1])):
-        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-Wno-enum-compare", "-o", _FLIB, src])
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-Wno-enum-compare", "-Wno-format", "-o", _FLIB, src])
         _fl = None
     if _fl is None:
         _fl = ctypes.CDLL(_FLIB)

@@ -14,7 +14,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_FLAT SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
            "SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_MFMA_F64 SQ_ACTIVE_INST_FLAT SQ_INSTS_WAVE32_LDS"; do
   i=$((i+1))
-  timeout -k 10 400 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --workers 1 $EXTRA > $OUT/p$i.log 2>&1
+  timeout -k 10 400 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --seed-sweep 0 --workers 1 $EXTRA > $OUT/p$i.log 2>&1
   rc=$?
   echo "pass $i ($grp) exit $rc"
   if [ $rc -ne 0 ]; then echo "stopping after failed pass $i"; break; fi
@@ -30,4 +30,7 @@ with open("$OUT/summary.txt", "w") as o:
     for k in sorted(tot):
         line = f"{k:32s} per-dispatch {tot[k]/n[k]:.6g}  (dispatches {n[k]})"
         print(line); o.write(line + "\n")
+# machine-readable copy for bench.py (profiles/pmc_current.json): per-dispatch means of every counter
+import json
+json.dump({k: tot[k] / n[k] for k in tot}, open("$OUT/summary.json", "w"), indent=1)
 PY

@@ -17,7 +17,7 @@ timeout -k 10 300 python bench.py --config 2 --no-cpu-baseline > gpurun_out/benc
 cat gpurun_out/bench_${TAG}_B8192.json
 export TMPDIR=/tmp
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --no-cpu-baseline --workers 1 > $R/gpurun_out/prof_$TAG.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --steps 5 --no-cpu-baseline --seed-sweep 0 --workers 1 > $R/gpurun_out/prof_$TAG.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_B8192 -- python3 $R/bench.py --config 2 --steps 5 --no-cpu-baseline --workers 1 > $R/gpurun_out/prof_${TAG}_B8192.log 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_N30 -- python3 $R/bench.py --config 3 --batch 2048 --steps 3 --warmup 1 --no-cpu-baseline --workers 1 > $R/gpurun_out/prof_${TAG}_N30.log 2>&1
 cd $R
