@@ -89,6 +89,7 @@ enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV
        L_K1 = L_K0 + KREC, L_KV = L_K1 + KREC, L_XT = L_KV + KREC, L_NC = L_XT + 15 * 14, L_WY = L_NC + 160, L_WV = L_WY + 196, L_TOT = L_WV + 196,
        L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_ZL = L_ST + 460, L_SIZE = L_ZL + 484 };
 enum { L_KKP = L_WY };
+enum { L_PP = L_PM };   // [4 fields][64 pairs] partial products of P rdyn (blk_add_lane -> S0), in the area the value-function blocks used to occupy
 enum { L_DUMMY = L_FLAG + 1 };   // write-only slot: target of the stores of lanes that have nothing to store (keeps phases branch-free)
 // row descriptors of the 57 internal inequality rows (box rows: +-Z[src] - lim), built once per problem: [sgn 57 | lim 57 | src 57]
 // integrator-chain coefficients CF[fr][fc] (4 x 5) as a table: chain_cf() with a lane-dependent argument compiles into a nest of
@@ -647,7 +648,11 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
     BMPC_PROF(W, 26);
     LANES_BEGIN   // inequality values, lane-strided rows, RU rows in flight: all loads of a batch are issued before the first use
         double th = 0, br = 0;
-        for (int base = lane; base < N * NI; base += 64 * RU) {
+        // wave-uniform trip counts (rows past the end are clamped duplicates): a lane-dependent loop exit makes the compiler restore the
+        // exec mask behind the loop, and that is where this toolchain has placed register copies under the stale mask (build.py lint_isa)
+        const int trips_i = (N * NI + 64 * RU - 1) / (64 * RU), trips_e = (N * NE + 64 * RU - 1) / (64 * RU);
+        for (int tr_ = 0; tr_ < trips_i; tr_++) {
+            const int base = lane + tr_ * 64 * RU;
             double zv[RU], rc[RU], rw[RU], sg[RU], lm[RU], tv[RU], dv[RU];
 #pragma unroll
             // rows past the end are clamped to the last row: they load, compute and store exactly what its owner does (no exec-mask
@@ -680,7 +685,8 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
             if (ls) br -= ls->mu * BMPC_LOG(tprod);      // one log per batch of RU slacks: sum of logs = log of the product (t in [1e-12, 1e2])
         }
         if (ls) {
-            for (int base = lane; base < N * NE; base += 64 * RU) {
+            for (int tr_ = 0; tr_ < trips_e; tr_++) {
+                const int base = lane + tr_ * 64 * RU;
                 double gv[RU];
 #pragma unroll
                 for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u; gv[u] = G[oG + (id0 < N * NE ? id0 : N * NE - 1)]; }
@@ -1047,126 +1053,126 @@ BMPC_D inline double node_q_row(const double *L, const double *K0, int r, double
     return base + (heavy ? (isq ? t1 : 0.0) + 0.5 * h * t2 + t3 - sW : 0.0);
 }
 
-// Node cost in block form: Q~ of node k+1 (index k) added into PB / PCI / PII, q~ into PV.
-BMPC_D inline void wave_node_cost_blk(Wave &W, const POff &po, const Scr &sc, int k, double mu, double delta) {
+// Node cost in block form, for ONE lane = one chain pair (i, l): the lane's 4x4 block of Q~ of node k+1 (index k) is added to the block
+// of the value function the lane holds IN REGISTERS (Pb, the lane's own orientation: Pb[f*4+g] = P[(f,i)][(g,l)]), the iota couplings and
+// the gradient go to LDS as before.  Since round 3 the value-function blocks of the chain part never touch LDS: the congruence F^T P F
+// (S1), the Schur update (S3) and this add are all lane-local; what crosses lanes -- P rdyn for the gradient recursion -- leaves as four
+// partial products per lane (PP), which S0 sums over the eight pairs of a chain.
+// Inputs of the call: C = the block the Schur phase of stage k+1 just produced (canonical orientation, i.e. of the pair (min, max)), or
+// zeros at the last stage; ci3 / pii / pvv = the Schur phase's iota-coupling entries and gradient entry of this lane (or zeros).
+// Predicated: every lane evaluates the joint-pair block AND the joint/phi coupling on clamped chain indices (all loads up front), the
+// pair kind only selects what is added where.  The stage's data (records oK0 / oKV1, staging area, NC, KHP, L_MU, RD) must be in LDS.
+BMPC_D inline void blk_add_lane(Wave &W, const POff &po, int k, double delta, int lane, int oK0, int oKV1, const double (&C)[4][4], const double (&ci3)[3],
+                                double pii, double pvv, double *Pb) {
     const int N = W.N; const double h = W.h; const int ex = W.o.exact_hessian;
     double *L = W.L;
     const double *PAR = L + L_PAR, *w = PAR + po.w;
     const double *ST = L + L_ST;
-    const double *rr = ST + ST_REF, *gk = ST + ST_G, *sgk = ST + ST_SG, *nuk = ST + ST_NU;
-    double *NC = L + L_NC, *WY = L + L_WY, *KHP = L + L_KHP;
-    const double *K0 = L + W.oK0, *KV1 = L + W.oKV1;
+    const double *rr = ST + ST_REF, *sgk = ST + ST_SG;
+    double *NC = L + L_NC, *KHP = L + L_KHP;
+    const double *K0 = L + oK0, *KV1 = L + oKV1;
     const bool has_next = k < N - 1;
-    // (stage data, the small Hessian blocks, A1 / A2, the curvature multipliers and prefix vectors and gl of this stage were computed for
-    // all stages at once -- wave_stage_data_wide(), kin_point() -- and came into LDS with the stage's other inputs)
-    BMPC_PROF(W, 16);
-    BMPC_PROF(W, 18);
-    // phase 4: one lane per chain pair adds its block of Q~ (and writes the predicted-point curvature to WY for q~).
-    // Predicated: every lane evaluates the joint-pair block AND the joint/phi coupling on clamped chain indices (all loads up
-    // front, one basic block), the pair kind only selects what is stored.
-    LANES_BEGIN
-        const int i = lane >> 3, l = lane & 7, ci = i < l ? i : l, cl = i < l ? l : i; const bool tr = i > l;
-        const bool both = cl < 7, mix = !both && ci < 7;
-        const int cic = ci < 7 ? ci : 0, clc = cl < 7 ? cl : 0;
-        const double *A1 = NC + NC_A1, *A2 = NC + NC_A2, cv = NC[NC_SC + 3], *d = rr + RDP;
-        double e[2][2], wpv[2][2], vf[2], vd[2], vdd[2];
-        // Gv columns of the two chains: [D | J] columns (q part f = 0, dq part f = 1)
-        double gi[2][6], gl_[2][6];
+    const int i = lane >> 3, l = lane & 7, ci = i < l ? i : l, cl = i < l ? l : i; const bool tr = i > l;
+    const bool both = cl < 7, mix = !both && ci < 7;
+    const int cic = ci < 7 ? ci : 0, clc = cl < 7 ? cl : 0;
+    const double *A1 = NC + NC_A1, *A2 = NC + NC_A2, cv = NC[NC_SC + 3], *d = rr + RDP;
+    double e[2][2], wpv[2][2], vf[2], vd[2], vdd[2];
+    // Gv columns of the two chains: [D | J] columns (q part f = 0, dq part f = 1)
+    double gi[2][6], gl_[2][6];
 #pragma unroll
-        for (int c6 = 0; c6 < 6; c6++) {
-            const int jo = c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7;
-            gi[0][c6] = K0[KD + c6 * 7 + cic]; gi[1][c6] = K0[jo + cic];
-            gl_[0][c6] = K0[KD + c6 * 7 + clc]; gl_[1][c6] = K0[jo + clc];
-        }
+    for (int c6 = 0; c6 < 6; c6++) {
+        const int jo = c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7;
+        gi[0][c6] = K0[KD + c6 * 7 + cic]; gi[1][c6] = K0[jo + cic];
+        gl_[0][c6] = K0[KD + c6 * 7 + clc]; gl_[1][c6] = K0[jo + clc];
+    }
 #pragma unroll
-        for (int f = 0; f < 2; f++) {
+    for (int f = 0; f < 2; f++) {
 #pragma unroll
-            for (int g = 0; g < 2; g++) {
-                const int b = g * 7 + clc;
-                double v = 0;
-                if (f == 0 && g == 0) for (int c = 0; c < 3; c++) v += K0[KW + c * 7 + cic] * A1[c * 7 + clc];
+        for (int g = 0; g < 2; g++) {
+            const int b = g * 7 + clc;
+            double v = 0;
+            if (f == 0 && g == 0) for (int c = 0; c < 3; c++) v += K0[KW + c * 7 + cic] * A1[c * 7 + clc];
 #pragma unroll
-                for (int c = 0; c < 3; c++) v += 0.5 * h * gi[f][3 + c] * A2[c * 14 + b];      // Ehat columns are the rotational rows 3..5 of Gv
-                double gv = 0;
+            for (int c = 0; c < 3; c++) v += 0.5 * h * gi[f][3 + c] * A2[c * 14 + b];      // Ehat columns are the rotational rows 3..5 of Gv
+            double gv = 0;
 #pragma unroll
-                for (int c6 = 0; c6 < 6; c6++) gv += gi[f][c6] * gl_[g][c6];
-                v += cv * gv;
-                double wp = 0, wn = 0;
-                if (ex && !(f == 1 && g == 1)) {
-                    if (f == 0 && g == 0) { wp = kh_qq(K0, KHP, L + L_MU + 4, L + L_MU + 7, L + L_MU + 10, cic, clc);
-                                            if (has_next) wn = kh_qq_w(KV1, KHP + 72, L + L_MU + 13, cic, clc); }
-                    else { const int qi = f == 0 ? cic : clc, dj = f == 0 ? clc : cic;
-                           wp = kh_qdq(K0, L + L_MU + 7, L + L_MU + 10, qi, dj);
-                           if (has_next) wn = kh_qdq_w(KV1, L + L_MU + 13, qi, dj); }
-                }
-                wpv[f][g] = wp;
-                e[f][g] = v + wp + wn;
+            for (int c6 = 0; c6 < 6; c6++) gv += gi[f][c6] * gl_[g][c6];
+            v += cv * gv;
+            double wp = 0, wn = 0;
+            if (ex && !(f == 1 && g == 1)) {
+                if (f == 0 && g == 0) { wp = kh_qq(K0, KHP, L + L_MU + 4, L + L_MU + 7, L + L_MU + 10, cic, clc);
+                                        if (has_next) wn = kh_qq_w(KV1, KHP + 72, L + L_MU + 13, cic, clc); }
+                else { const int qi = f == 0 ? cic : clc, dj = f == 0 ? clc : cic;
+                       wp = kh_qdq(K0, L + L_MU + 7, L + L_MU + 10, qi, dj);
+                       if (has_next) wn = kh_qdq_w(KV1, L + L_MU + 13, qi, dj); }
             }
-            // coupling of (q, dq) of chain ci with (phi, dphi, ddphi)
-            double f1 = 0, f2 = 0, dsum = 0;
-            if (f == 0) for (int c = 0; c < 3; c++) f1 += K0[KW + c * 7 + cic] * NC[NC_HPF + c];
-#pragma unroll
-            for (int c = 0; c < 3; c++) f2 += gi[f][3 + c] * NC[NC_HRF + c];
-#pragma unroll
-            for (int c6 = 0; c6 < 6; c6++) dsum += d[c6] * gi[f][c6];
-            vf[f] = f1 + 0.5 * h * f2; vd[f] = -2 * w[2] * dsum; vdd[f] = -W.cb * dsum;
+            wpv[f][g] = wp;
+            e[f][g] = v + wp + wn;
         }
-        const double dq0 = 2 * w[10] + sgk[IQU + cic] + sgk[IQL + cic] + delta, dq1 = 2 * w[11] + sgk[IDQU + cic] + sgk[IDQL + cic] + delta,
-                     dq2 = 2 * w[12] + delta, dq3 = 2 * w[13] + sgk[IJU + cic] + sgk[IJL + cic] + delta;
-        const double p0 = NC[NC_SC + 0] + delta, p1 = NC[NC_SC + 1] + delta, p2 = NC[NC_SC + 2] + delta, p3 = 2 * w[9] + sgk[IJU + 7] + sgk[IJL + 7] + delta;
-        // ---- stores: six read-modify-write adds per lane into its own pair's planes; the pair kind selects planes and values
-        //      (a lane with fewer than six contributions adds 0.0 to its (0,0) entry), so there is no branch on the kind ----
-        // ---- all stores of this phase are unconditional: a lane that has nothing to store for a role stores to / accumulates on
-        //      a dummy LDS slot (L_DUMMY) instead, so the phase has no exec-mask branch around its memory operations ----
-        {
+        // coupling of (q, dq) of chain ci with (phi, dphi, ddphi)
+        double f1 = 0, f2 = 0, dsum = 0;
+        if (f == 0) for (int c = 0; c < 3; c++) f1 += K0[KW + c * 7 + cic] * NC[NC_HPF + c];
 #pragma unroll
-            for (int f = 0; f < 2; f++)
+        for (int c = 0; c < 3; c++) f2 += gi[f][3 + c] * NC[NC_HRF + c];
 #pragma unroll
-                for (int g = 0; g < 2; g++) {
-                    const int a = f * 7 + cic, b = g * 7 + clc;
-                    const int o1 = both ? L_WY + a * 14 + b : L_DUMMY, o2 = both ? L_WY + b * 14 + a : L_DUMMY;
-                    L[o1] = wpv[f][g]; L[o2] = wpv[f][g];
-                }
+        for (int c6 = 0; c6 < 6; c6++) dsum += d[c6] * gi[f][c6];
+        vf[f] = f1 + 0.5 * h * f2; vd[f] = -2 * w[2] * dsum; vdd[f] = -W.cb * dsum;
+    }
+    const double dq0 = 2 * w[10] + sgk[IQU + cic] + sgk[IQL + cic] + delta, dq1 = 2 * w[11] + sgk[IDQU + cic] + sgk[IDQL + cic] + delta,
+                 dq2 = 2 * w[12] + delta, dq3 = 2 * w[13] + sgk[IJU + cic] + sgk[IJL + cic] + delta;
+    const double p0 = NC[NC_SC + 0] + delta, p1 = NC[NC_SC + 1] + delta, p2 = NC[NC_SC + 2] + delta, p3 = 2 * w[9] + sgk[IJU + 7] + sgk[IJL + 7] + delta;
+    // iota couplings of this lane's Schur entries: P[(f,i)][iota_a] += (h/2)(Hrr Ehat)[a][(f,i)] for (q, dq) rows of the joints, += Hr,phi for
+    // the phi row; P_ii += Hrr + delta I.  (Until round 3 these were read-modify-writes of other lanes' LDS entries in a phase of their own.)
+    const int lf = (lane & 31) >> 3, lii = lane & 7;
+    const bool yq = lf < 2 && lii < 7, yphi = lf == 0 && lii == 7;
+    const int a2i = yq ? lf * 7 + lii : 0;
+    const bool onII = lane >= 32 && lane < 32 + 6; const int t = onII ? lane - 32 : 0;
+    const int ib = t < 3 ? 0 : (t < 5 ? 1 : 2), ic = t < 3 ? t : (t < 5 ? t - 2 : 2);
+    double c3[3];
+#pragma unroll
+    for (int b2 = 0; b2 < 3; b2++) c3[b2] = ci3[b2] + (yq ? 1.0 : 0.0) * A2[b2 * 14 + a2i] + (yphi ? 1.0 : 0.0) * NC[NC_HRF + b2];
+    const double piin = pii + NC[NC_HRR + ib * 3 + ic] + (ib == ic ? delta : 0.0);
+    // ---- the lane's value-function block: Schur result (own orientation) + the planes of Q~ its pair kind touches (static plane
+    //      indices: the block lives in registers) ----
+    {
+        const bool dg = both && ci == cl, c77 = !both && !mix;
+        const double e00 = e[0][0] + (dg ? dq0 : 0.0), e11 = e[1][1] + (dg ? dq1 : 0.0), e01 = e[0][1], e10 = dg ? e[0][1] : e[1][0];
+        double add[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) add[q] = 0.0;
+        add[0] = both ? e00 : (mix ? vf[0] : p0);
+        add[1] = both ? (tr ? e10 : e01) : (mix ? (tr ? vf[1] : vd[0]) : 0.0);
+        add[2] = (mix && !tr) ? vdd[0] : 0.0;
+        add[4] = both ? (tr ? e01 : e10) : (mix ? (tr ? vd[0] : vf[1]) : 0.0);
+        add[5] = both ? e11 : (mix ? vd[1] : p1);
+        add[6] = (mix && !tr) ? vdd[1] : 0.0;
+        add[8] = (mix && tr) ? vdd[0] : 0.0;
+        add[9] = (mix && tr) ? vdd[1] : 0.0;
+        add[10] = both ? (dg ? dq2 : 0.0) : (c77 ? p2 : 0.0);
+        add[15] = both ? (dg ? dq3 : 0.0) : (c77 ? p3 : 0.0);
+#pragma unroll
+        for (int f = 0; f < 4; f++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) Pb[f * 4 + g] = (tr ? C[g][f] : C[f][g]) + add[f * 4 + g];
+    }
+    // ---- stores (all unconditional: a lane that has nothing to store for a role stores to the dummy word) ----
+#pragma unroll
+    for (int f = 0; f < 2; f++)
+#pragma unroll
+        for (int g = 0; g < 2; g++) {     // predicted-point curvature of the joint pairs, for q~ (node_q_row in S0)
+            const int a = f * 7 + cic, b = g * 7 + clc;
+            const int o1 = both ? L_WY + a * 14 + b : L_DUMMY, o2 = both ? L_WY + b * 14 + a : L_DUMMY;
+            L[o1] = wpv[f][g]; L[o2] = wpv[f][g];
         }
-        {
-            const bool dg = both && ci == cl, c77 = !both && !mix;
-            const double e00 = e[0][0] + (dg ? dq0 : 0.0), e11 = e[1][1] + (dg ? dq1 : 0.0), e01 = e[0][1], e10 = dg ? e[0][1] : e[1][0];
-            // plane ids (f*4+g) and values of the six adds; the (7,7) lane has four
-            const int pl[6] = { 0,
-                                both ? 1 : (mix ? (tr ? 4 : 1) : 5),
-                                both ? 4 : (mix ? (tr ? 8 : 2) : 10),
-                                both ? 5 : (mix ? (tr ? 1 : 4) : 15),
-                                both ? 10 : 5,
-                                both ? 15 : (tr ? 9 : 6) };
-            const double vl[6] = { both ? e00 : (mix ? vf[0] : p0),
-                                   both ? (tr ? e10 : e01) : (mix ? vd[0] : p1),
-                                   both ? (tr ? e01 : e10) : (mix ? vdd[0] : p2),
-                                   both ? e11 : (mix ? vf[1] : p3),
-                                   both ? (dg ? dq2 : 0.0) : (mix ? vd[1] : 0.0),
-                                   both ? (dg ? dq3 : 0.0) : (mix ? vdd[1] : 0.0) };
-            int ad[6]; double cur[6];
+    L[L_PCI + pci(0, lf, lii)] = c3[0]; L[L_PCI + pci(1, lf, lii)] = c3[1]; L[L_PCI + pci(2, lf, lii)] = c3[2];   // lanes >= 32 repeat lanes 0..31
+    L[onII ? L_PII + ib * 3 + ic : L_DUMMY] = piin; L[onII ? L_PII + ic * 3 + ib : L_DUMMY] = piin;
+    L[L_PV + (lane < NS ? lane : 0)] = pvv;
+    // partial products of P rdyn over the lane's pair: PP[f][pair] = sum_{g<3} P[(f,i)][(g,l)] rdyn[(g,l)] (rdyn of the jerk states is zero)
+    {
+        const double r0 = L[L_RD + srow(0, l)], r1 = L[L_RD + srow(1, l)], r2 = L[L_RD + srow(2, l)];
 #pragma unroll
-            for (int t = 0; t < 6; t++) { ad[t] = (c77 && t >= 4) ? L_DUMMY : L_PB + pl[t] * 64 + lane; cur[t] = L[ad[t]]; }
-#pragma unroll
-            for (int t = 0; t < 6; t++) L[ad[t]] = cur[t] + vl[t];
-        }
-        {   // iota couplings: 42 + 3 + 9 read-modify-write items, one per lane
-            const int t = lane;
-            const bool m1 = t < 42, m2 = t >= 42 && t < 45, m3 = t >= 45 && t < 54;
-            const int t1 = m1 ? t : 0, a1 = t1 / 14, y = t1 % 14, f1 = y / 7, ii = y % 7;
-            const int t2 = m2 ? t - 42 : 0, t3 = m3 ? t - 45 : 0, a3 = t3 / 3, b3 = t3 % 3;
-            int dst = L_DUMMY, src = NC_HRR + t3;           // flat chains of selects (a nested one compiles into a branch nest)
-            dst = m3 ? L_PII + t3 : dst;
-            dst = m2 ? L_PCI + pci(t2, 0, 7) : dst; src = m2 ? NC_HRF + t2 : src;
-            dst = m1 ? L_PCI + pci(a1, f1, ii) : dst; src = m1 ? NC_A2 + t1 : src;
-            const double add = NC[src] + ((m3 && a3 == b3) ? delta : 0.0);
-            const double cur = L[dst];
-            L[dst] = cur + ((m1 || m2 || m3) ? add : 0.0);
-        }
-    LANES_END
-    BMPC_PROF(W, 19);
-    // (the gradient q~ of this node is added where it is consumed: node_q_row() in S0 of the Riccati stage)
-    BMPC_PROF(W, 20);
+        for (int f = 0; f < 4; f++) L[L_PP + f * 64 + lane] = Pb[f * 4 + 0] * r0 + Pb[f * 4 + 1] * r1 + Pb[f * 4 + 2] * r2;
+    }
 }
 
 // Node-cost data of ALL Riccati stages in wide passes, once per iterate and BEFORE the backward sweep (it replaces wave_prepare_rlv and
@@ -1456,21 +1462,25 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
     double *L = W.L, *G = W.G;
     const double *PAR = L + L_PAR, *w = PAR + po.w;
     LANES_BEGIN
-        for (int id = lane; id < 1024 + 96 + 12; id += 64) L[L_PB + id] = 0.0;
+        for (int id = lane; id < 96 + 12; id += 64) L[L_PCI + id] = 0.0;
         if (lane < 36) L[L_PV + lane] = 0.0;
-    LANES_END
-    LANES_BEGIN
         backward_loads_lane(W, sc, N - 1, LR[LIDX].pf, lane, true);
     LANES_END
     LANES_BEGIN
         backward_commit_lane(W, N - 1, LR[LIDX].pf, lane, true);
         backward_loads_lane(W, sc, N >= 2 ? N - 2 : 0, LR[LIDX].pf, lane, false);
     LANES_END
+    backward_buffers(N, N - 1, W.oK0, W.oK1, W.oKV, W.oKV1);
+    LANES_BEGIN   // value function of the last node = its node cost: the block add on a zero block
+        const double Z4[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, Z3[3] = {0, 0, 0};
+        blk_add_lane(W, po, N - 1, delta, lane, W.oK0, W.oKV1, Z4, Z3, 0.0, 0.0, LR[LIDX].mc);
+    LANES_END
     for (int k = N - 1; k >= 0; k--) {
         BMPC_PROF(W, 6);
         backward_buffers(N, k, W.oK0, W.oK1, W.oKV, W.oKV1);
         BMPC_PROF(W, 24);
-        wave_node_cost_blk(W, po, sc, k, mu, delta);     // PB/PCI/PII/PV now hold the value function of node k+1
+        // (the lanes' register blocks + PCI / PII / PV hold the value function of node k+1 including its node cost: blk_add_lane, in the
+        // prologue for the last stage and at the end of the Schur phase of stage k+1 otherwise)
         BMPC_PROF(W, 5);
         BMPC_PROF(W, 11);
         // ---- S0: PR = P' rdyn + p ; C^T P_c,iota ; P_ii E ----
@@ -1483,9 +1493,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 const int code = (int)L[L_ZMAP + r], f = (code >> 17) & 7, i = (code >> 20) & 7;     // (field, chain) of the row, from the row table
                 BMPC_ACC4_DECL(pa);
 #pragma unroll
-                for (int l = 0; l < 8; l++)
-#pragma unroll
-                    for (int g = 0; g < 3; g++) BMPC_ACC4(pa, g, L[L_PB + pbi(f, g, i, l)] * L[L_RD + srow(g, l)]);   // rdyn of the jerk states (g = 3) is zero
+                for (int l = 0; l < 8; l++) BMPC_ACC4(pa, l, L[L_PP + f * 64 + i * 8 + l]);        // partial products of the eight pairs of chain i (blk_add_lane)
 #pragma unroll
                 for (int a = 0; a < 3; a++) BMPC_ACC4(pa, a, L[L_PCI + pci(a, f, i)] * L[L_RD + SIOTA + a]);
                 const double qr = node_q_row(L, L + W.oK0, r, h, W.o.exact_hessian);          // q~ of node k+1 joins the value-function gradient here
@@ -1578,10 +1586,13 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         LANES_BEGIN
             const int i = lane >> 3, l = lane & 7, ci = i < l ? i : l, cl = i < l ? l : i; const bool tr = i > l;
             double B[4][4], T[4][5], M5[5][5];
+            {   // the canonical pair's block from the lane's own registers (a mirrored lane holds the transpose)
+                const double *Pb = LR[LIDX].mc;
 #pragma unroll
-            for (int f = 0; f < 4; f++)
+                for (int f = 0; f < 4; f++)
 #pragma unroll
-                for (int g = 0; g < 4; g++) B[f][g] = L[L_PB + pbi(f, g, ci, cl)];
+                    for (int g = 0; g < 4; g++) B[f][g] = tr ? Pb[g * 4 + f] : Pb[f * 4 + g];
+            }
 #pragma unroll
             for (int f = 0; f < 4; f++) {
                 T[f][0] = B[f][0]; T[f][1] = h * B[f][0] + B[f][1]; T[f][2] = h2 / 2 * B[f][0] + h * B[f][1] + B[f][2];
@@ -1784,14 +1795,12 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 #pragma unroll
                 for (int a = 0; a < NU; a++) pvv += L[L_GS + a * 36 + pr_] * L[L_KS + a * 36 + 35];
                 BMPC_PROF(W, 17);
-                // ---- stores ----
-#pragma unroll
-                for (int f = 0; f < 4; f++)
-#pragma unroll
-                    for (int g = 0; g < 4; g++) L[L_PB + pbi(f, g, i, l)] = tr ? C[g][f] : C[f][g];
-                L[L_PCI + pci(0, lf, lii)] = ci3[0]; L[L_PCI + pci(1, lf, lii)] = ci3[1]; L[L_PCI + pci(2, lf, lii)] = ci3[2];   // lanes >= 32 repeat lanes 0..31
-                L[onII ? L_PII + ib * 3 + ic : L_DUMMY] = pii; L[onII ? L_PII + ic * 3 + ib : L_DUMMY] = pii;
-                L[L_PV + pr_] = pvv;
+                // ---- node cost of stage k-1 added to the block just formed (registers), iota couplings, gradient, partial products: no
+                //      store of the chain blocks any more ----
+                {
+                    int q0_, q1_, q2_, q3_; backward_buffers(N, k - 1, q0_, q1_, q2_, q3_);
+                    blk_add_lane(W, po, k - 1, delta, lane, q0_, q3_, C, ci3, pii, pvv, LR[LIDX].mc);
+                }
                 BMPC_PROF(W, 30);
             LANES_END
         }
