@@ -32,7 +32,9 @@
 #define LANES_END } __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 #define LIDX 0
 #define BMPC_WAVE_RED 1
+#ifndef BMPC_NO_MFMA
 #define BMPC_MFMA 1       // Schur update of the Riccati stage on the matrix cores (v_mfma_f64_16x16x4_f64)
+#endif
 #define BMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 #ifdef BMPC_MARKS

@@ -482,6 +482,12 @@ BMPC_D inline double chain_cf(double h, int fr, int fc) {
     return fc == 4 ? 1.0 : 0.0;
 }
 BMPC_D inline int srow(int f, int i) { return i < 7 ? f * 7 + i : 28 + f; }   // reduced-state index of (field, chain)
+// column of a reduced-state row in the jerk rows GS / gains KS of a Riccati stage: chain-major (the four fields of a chain are adjacent),
+// so that a chain-pair lane reads its 4 rows / 4 columns of the Schur update as contiguous words; iota rows and the gradient column keep
+// their index.  gcol: from (field, chain); pcol: from the reduced-state index; prow: back.
+BMPC_D inline int gcol(int f, int i) { return i * 4 + f; }
+BMPC_D inline int pcol(int r) { return r < 28 ? (r % 7) * 4 + r / 7 : r; }
+BMPC_D inline int prow(int c) { return c < 28 ? (c & 3) * 7 + (c >> 2) : c; }
 
 // per-problem tables and constants that depend only on the parameter vector (already in LDS)
 BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
@@ -1671,7 +1677,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 for (int g = 0; g < 4; g++) mc[f * 4 + g] = M5[f][g];
             // publish the jerk rows: GS[u_l][(f,i)] = own[f][4], R8[i][l] = M[u_i][u_l]
 #pragma unroll
-            for (int f = 0; f < 4; f++) L[L_GS + l * 36 + srow(f, i)] = tr ? M5[4][f] : M5[f][4];
+            for (int f = 0; f < 4; f++) L[L_GS + l * 36 + gcol(f, i)] = tr ? M5[4][f] : M5[f][4];
             L[L_R8 + i * 8 + l] = M5[4][4];
         LANES_END
         BMPC_PROF(W, 12);
@@ -1712,7 +1718,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                     kc[a] = sacc * dinv[a]; }
 #pragma unroll
                 for (int a = 0; a < NU; a++) L[L_KS + a * 36 + c] = kc[a];
-                const int gb = c < NS ? sc.KT + (k * NS + c) * NU : sc.KF + k * NU;
+                const int gb = c < NS ? sc.KT + (k * NS + prow(c)) * NU : sc.KF + k * NU;      // the forward sweep reads the gains by reduced-state index
 #pragma unroll
                 for (int a = 0; a < NU; a++) G[gb + a] = kc[a];
             }
@@ -1754,7 +1760,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 #pragma unroll
                     for (int f = 0; f < 4; f++)
 #pragma unroll
-                        for (int g = 0; g < 4; g++) C[f][g] = mc[f * 4 + g] + L[L_PB + srow(f, ci) * 32 + srow(g, cl)];
+                        for (int g = 0; g < 4; g++) C[f][g] = mc[f * 4 + g] + L[L_PB + gcol(f, ci) * 32 + gcol(g, cl)];
                 }
 #else
 #pragma unroll
@@ -1763,7 +1769,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                     for (int g = 0; g < 4; g++) {
                         double sacc = mc[f * 4 + g];
 #pragma unroll
-                        for (int a = 0; a < NU; a++) sacc += L[L_GS + a * 36 + srow(f, ci)] * L[L_KS + a * 36 + srow(g, cl)];
+                        for (int a = 0; a < NU; a++) sacc += L[L_GS + a * 36 + gcol(f, ci)] * L[L_KS + a * 36 + gcol(g, cl)];
                         C[f][g] = sacc;
                     }
 #endif
@@ -1782,7 +1788,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 for (int b2 = 0; b2 < 3; b2++) {
                     double sacc = L[L_MCI + mci(b2, lf, lii)];
 #pragma unroll
-                    for (int a = 0; a < NU; a++) sacc += L[L_GS + a * 36 + srow(lf, lii)] * L[L_KS + a * 36 + SIOTA + b2];
+                    for (int a = 0; a < NU; a++) sacc += L[L_GS + a * 36 + gcol(lf, lii)] * L[L_KS + a * 36 + SIOTA + b2];
                     ci3[b2] = sacc;
                 }
                 const bool onII = lane >= 32 && lane < 32 + 6; const int t = onII ? lane - 32 : 0;
@@ -1792,8 +1798,9 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 for (int a = 0; a < NU; a++) pii += L[L_GS + a * 36 + SIOTA + ib] * L[L_KS + a * 36 + SIOTA + ic];
                 const bool onPV = lane < NS; const int pr_ = onPV ? lane : 0;
                 double pvv = L[L_MV + pr_];
+                const int pc_ = pcol(pr_);
 #pragma unroll
-                for (int a = 0; a < NU; a++) pvv += L[L_GS + a * 36 + pr_] * L[L_KS + a * 36 + 35];
+                for (int a = 0; a < NU; a++) pvv += L[L_GS + a * 36 + pc_] * L[L_KS + a * 36 + 35];
                 BMPC_PROF(W, 17);
                 // ---- node cost of stage k-1 added to the block just formed (registers), iota couplings, gradient, partial products: no
                 //      store of the chain blocks any more ----
