@@ -149,10 +149,27 @@ struct Problem {           // per-problem global pointers
     double *state;         // optional dual state of a receding-horizon stream: [nu (N*57) | mu | iterations]; mu <= 0: cold start
 };
 
+// Workspace accessor: wave-uniform base (an SGPR pair on the GPU) plus an unsigned 32-bit BYTE offset.  Indexing a plain double * with
+// an int makes every access a sign extension + a 64-bit shift-add + a 64-bit address register pair; this form is the hardware's
+// "scalar base + 32-bit vector offset" addressing mode (the slab of one wave is far below 4 GB).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BMPC_ASSUME(c) __builtin_assume(c)
+#else
+#define BMPC_ASSUME(c)
+#endif
+struct GPtr {
+    char *b; int o;      // o: byte offset, never negative
+    // signed arithmetic (overflow undefined) plus the stated range lets the compiler split constant index parts off into the
+    // instruction's immediate field; with unsigned wrap-around semantics every access got an address add of its own
+    BMPC_D double &operator[](int i) const { const int off = o + i * (int)sizeof(double); BMPC_ASSUME(off >= 0); return *(double *)(b + (size_t)(unsigned)off); }
+    BMPC_D GPtr operator+(int i) const { GPtr r; r.b = b; r.o = o + i * (int)sizeof(double); BMPC_ASSUME(r.o >= 0); return r; }
+    BMPC_D double *ptr() const { return (double *)(b + o); }
+};
+BMPC_D inline GPtr make_gptr(double *base) { GPtr r; r.b = (char *)base; r.o = 0; return r; }
 struct Wave {
     int N, S; double h; Opts o;
     double *L;             // LDS base (L_SIZE doubles)
-    double *G;             // scratch base
+    GPtr G;                // scratch base (workspace slab of this wave)
     long long tprev;       // diagnostic build only (BMPC_PROFILE): last phase stamp
     double ca, cb;         // wave-uniform constants 2 w_a / h^2 and 2 w_a / h (w_a = weights[5]), hoisted out of the phases: a run-time
                            // fp64 division costs ~40 instructions
@@ -167,11 +184,11 @@ struct Wave {
 // ----------------------------------------------------------------------------------------
 // small helpers
 // ----------------------------------------------------------------------------------------
-BMPC_D inline void cross3(const double *a, const double *b, double *c) {
+template <class PA, class PB> BMPC_D inline void cross3(const PA a, const PB b, double *c) {
     double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
     c[0] = x; c[1] = y; c[2] = z;
 }
-BMPC_D inline double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <class PA, class PB> BMPC_D inline double dot3(const PA a, const PB b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 #define BMPC_DEG(x) ((x) * 3.14159265358979323846 / 180.0)
 BMPC_D inline double qlim(int i) { return (i == 0 || i == 2 || i == 4) ? BMPC_DEG(165.0) : (i == 6 ? BMPC_DEG(170.0) : BMPC_DEG(115.0)); }
 BMPC_D inline double dqlim(int i) { return i <= 1 ? BMPC_DEG(85.0) : (i == 2 ? BMPC_DEG(100.0) : (i == 3 ? BMPC_DEG(75.0) : (i == 4 ? BMPC_DEG(130.0) : BMPC_DEG(135.0)))); }
@@ -209,7 +226,7 @@ BMPC_D inline void bmpc_sincos(double x, double *sn, double *cs) {
 // joint axes (z,y,z,-y,z,y,z), link offsets along local z (RobotModel.py:9-16).
 // Writes the record rec[KREC]: axes, J_v columns, D = d(J dq)/dq, pos, v = J dq, dq.
 // ----------------------------------------------------------------------------------------
-BMPC_D inline void kin_point(const double *q, const double *dq, double *rec, double *hp) {
+template <class PR> BMPC_D inline void kin_point(const double *q, const double *dq, const PR rec, const PR hp) {
     const double preZ[7] = {0.0, 0.1575 + 0.2025, 0.0, 0.2375 + 0.1825, 0.0, 0.2175 + 0.1825, 0.0};
     const double toolZ = 0.081 + (0.071 + 0.145);
     double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, o[3] = {0, 0, 0}, O[7][3], a[7][3], w[7][3];
@@ -312,7 +329,7 @@ BMPC_D inline double kin_hess_entry(const double *rec, const double *mu_p, const
 // node quantities depending on (pos, iw, phi): segment, tubes, errors -> record rr[RREC]
 // (bound_mpc_functions.py:13-20,34-40,43-149,152-202; mpc_utils_casadi.py:6-10,52,163)
 // ----------------------------------------------------------------------------------------
-BMPC_D inline void node_ref(const double *PAR, const POff &po, int S, const double *pos, const double *iw, double phi, double *rr, int ex) {
+template <class PR> BMPC_D inline void node_ref(const double *PAR, const POff &po, int S, const double *pos, const double *iw, double phi, const PR rr, int ex) {
     const double *sw = PAR + po.sw;
     int seg = S - 1;
     for (int i = S - 2; i >= 0; i--) if (phi < sw[i + 1]) seg = i;
@@ -579,14 +596,14 @@ BMPC_D inline double red_min(const double *r) { double s = r[0];
 struct LsRows { double alpha, mu; };
 BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Zs, int oG, int oH, bool project, const LsRows *ls = nullptr) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
-    double *L = W.L, *G = W.G;
+    double *L = W.L; const GPtr G = W.G;
     const double *PAR = L + L_PAR;
     LANES_BEGIN
         if (lane < 2 * N) {
             const int k = lane < N ? lane : lane - N;
             double q[7], dq[7];
             if (lane < N) {   // predicted point of node k+1 (jerk_trajectory_casadi.py closed form; bound_mpc_functions.py:254-260)
-                double *gk = G + oG + k * NE;
+                const GPtr gk = G + oG + k * NE;
                 const double *Zn = Zs + k * NZ;
                 for (int i = 0; i < 7; i++) {
                     const double q0 = ndv(PAR, po, Zs, k, ZQ + i, po.q0 + i), d0 = ndv(PAR, po, Zs, k, ZDQ + i, po.dq0 + i),
@@ -607,12 +624,12 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
         double fk = 0;
         if (lane < N) {
             const int k = lane;
-            double *Zn = Zs + k * NZ; const double *kp = G + sc.KIN + k * KREC, *kv = G + sc.KIN + (N + k) * KREC;
-            double *gk = G + oG + k * NE, *rr = G + sc.REF + k * RREC;
+            double *Zn = Zs + k * NZ; const GPtr kp = G + sc.KIN + k * KREC, kv = G + sc.KIN + (N + k) * KREC;
+            const GPtr gk = G + oG + k * NE, rr = G + sc.REF + k * RREC;
             if (project) {
                 double iw[3] = {PAR[po.p0 + 3], PAR[po.p0 + 4], PAR[po.p0 + 5]};
                 for (int j = 0; j <= k; j++) {
-                    const double *kpj = G + sc.KIN + j * KREC, *kvj = G + sc.KIN + (N + j) * KREC;
+                    const GPtr kpj = G + sc.KIN + j * KREC, kvj = G + sc.KIN + (N + j) * KREC;
                     for (int i = 0; i < 3; i++) iw[i] = iw[i] + 0.5 * h * (kvj[KV + 3 + i] + kpj[KV + 3 + i]);
                 }
                 for (int i = 0; i < 3; i++) { Zn[ZPOS + i] = kp[KPOS + i]; gk[GPOS + i] = 0.0; Zn[ZIW + i] = iw[i]; gk[GIW + i] = 0.0; }
@@ -631,7 +648,7 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
             gk[GDDPHI] = ddph + h / 2 * (jp0 + jp1) - Zn[ZDDPHI];
             node_ref(PAR, po, W.S, Zn + ZPOS, Zn + ZIW, Zn[ZPHI], rr, W.o.exact_hessian);
             // objective of node k+1 (bound_mpc_functions.py:205-246; casadi_ocp_formulation.py:227-265)
-            const double *w = PAR + po.w, *d = rr + RDP;
+            const double *w = PAR + po.w; const GPtr d = rr + RDP;
             const double sig = rr[RSIG], dde = dot3(d, rr + REP);
             double epo[3], ero[3];
             for (int c = 0; c < 3; c++) { epo[c] = sig * rr[REP + c] + (1 - sig) * dde * d[c]; ero[c] = sig * rr[RER + c] + (1 - sig) * rr[RERPAR + c]; }
@@ -669,7 +686,7 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
                 const int m = i >= ITUBE ? (i - ITUBE) >> 1 : 0;
                 sg[u] = L[L_ROWT + i]; lm[u] = L[L_ROWT + NI + i];
                 zv[u] = Zs[k * NZ + (int)L[L_ROWT + 2 * NI + i]];
-                const double *rr = G + sc.REF + k * RREC;
+                const GPtr rr = G + sc.REF + k * RREC;
                 rc[u] = rr[RC + m]; rw[u] = rr[RWD + m];
                 if (ls) { tv[u] = G[sc.T + id]; dv[u] = G[sc.DT + id]; }      // wave-uniform condition
             }
@@ -731,7 +748,7 @@ BMPC_D inline void stage_mu(Wave &W, const double *lam, const double *kp, int la
 // issued together ahead of the arithmetic: one dependent round trip per call.
 BMPC_D inline void wave_node_grad_wide(Wave &W, const POff &po, const Scr &sc) {
     const int N = W.N; const double h = W.h, hinv = 1.0 / h;
-    double *L = W.L, *G = W.G;
+    double *L = W.L; const GPtr G = W.G;
     const double *PAR = L + L_PAR, *w = PAR + po.w, *Zs = W.Zc, *NUV = L + L_PB;
     const int npass = (N + 9) / 10;
     LANES_BEGIN
@@ -742,7 +759,7 @@ BMPC_D inline void wave_node_grad_wide(Wave &W, const POff &po, const Scr &sc) {
             const int kf0 = 10 * pass + k3, kf = kf0 < N ? kf0 : N - 1;
             const bool on6 = lane < 60, on3 = lane < 30;
             // ---- loads from the workspace: reference-record entries of the items' nodes ----
-            const double *rv_ = G + sc.REF + kv * RREC, *rn_ = G + sc.REF + kn * RREC, *rf_ = G + sc.REF + kf * RREC;
+            const GPtr rv_ = G + sc.REF + kv * RREC, rn_ = G + sc.REF + kn * RREC, rf_ = G + sc.REF + kf * RREC;
             const double dv = rv_[RDP + c6], dn = rn_[RDP + c6];                              // v rows: dp_d[c] of the node and of the next node
             const int cc = c6 < 3 ? c6 : c6 - 3;                                              // pos / iw rows: coordinate
             double pd[3], pdh[3], pep[3], per_[3], ppar[3], pl2[3], prr[3], pgc[5];
@@ -872,7 +889,7 @@ BMPC_D inline int adjoint_zcode(int z) {
 template <int PO>
 BMPC_D inline void adjoint_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
-    double *L = W.L, *G = W.G;
+    double *L = W.L; const GPtr G = W.G;
     const int odd = (N - 1 - k) & 1;
     double *lam1 = L + L_ST + (odd ? ST_LAM0 : ST_LAM1);     // lam_{k+1} (written one step earlier)
     double *lam0 = L + L_ST + (odd ? ST_LAM1 : ST_LAM0);     // lam_k (written now)
@@ -927,12 +944,12 @@ BMPC_D inline void adjoint_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
 // LAM[N][36], RJ[N][8]; GH receives d(f + nu.h)/dZ.
 BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU, bool use_hat, double mu, LaneRegs *LR) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
-    double *L = W.L, *G = W.G;
+    double *L = W.L; const GPtr G = W.G;
     const double *PAR = L + L_PAR, *Zs = W.Zc;
     // the multipliers of all rows are staged through LDS with coalesced loads (the value-function block area is free outside the
     // Riccati sweep): one lane per NODE would otherwise issue 57-114 scattered global loads of its own
     LANES_BEGIN
-        for (int base = lane; base < N * NI; base += 64 * RU) {
+        for (int tr_ = 0; tr_ < (N * NI + 64 * RU - 1) / (64 * RU); tr_++) { const int base = lane + tr_ * 64 * RU;      /* wave-uniform trip count */
             double a_[RU], b_[RU];
 #pragma unroll
             for (int u = 0; u < RU; u++) {
@@ -1200,7 +1217,7 @@ BMPC_D inline void blk_add_lane(Wave &W, const POff &po, int k, double delta, in
 // the fly (t6 in S0, chain-pair entries in S1).
 BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) {
     const int N = W.N; const double h = W.h; const int ex = W.o.exact_hessian;
-    double *L = W.L, *G = W.G;
+    double *L = W.L; const GPtr G = W.G;
     const double *PAR = L + L_PAR, *w = PAR + po.w;
     const int npass = (N + 9) / 10;
     LANES_BEGIN
@@ -1218,7 +1235,7 @@ BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) 
                 const int p1 = c < 3 ? KW + c * 7 : KD + c6 * 7;
                 const int p2 = c < 3 ? KA : (c < 9 ? (c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7) : KA + (c - 9) * 7);
                 const int bs = c < 3 ? GPOS + c : (c < 9 ? GV + c - 3 : GIW + c - 9);
-                const double *kp = G + sc.KIN + k * KREC, *gk = G + sc.G + k * NE;
+                const GPtr kp = G + sc.KIN + k * KREC, gk = G + sc.G + k * NE;
                 rb0[u] = gk[bs];
 #pragma unroll
                 for (int i = 0; i < 7; i++) { ra1[u][i] = kp[p1 + i]; ra2[u][i] = kp[p2 + i]; rg1[u][i] = gk[GQ + i]; rg2[u][i] = gk[GDQ + i]; }
@@ -1227,7 +1244,7 @@ BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) 
             for (int u = 0; u < RM; u++) {   // M: mu_p, mu_v, mu_w of the node and mu_w of the next node's velocity point (item = 3 g + c)
                 const int id0 = pass * 64 * RM + lane + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, ln = id - 12 * k, c = ln % 3;
                 const int kn = k < N - 1 ? k + 1 : k;
-                const double *lam = G + sc.LAM + k * NE;
+                const GPtr lam = G + sc.LAM + k * NE;
                 ml[u][0] = lam[GPOS + c]; ml[u][1] = lam[GV + c]; ml[u][2] = lam[GW + c]; ml[u][3] = lam[GIW + c]; ml[u][4] = G[sc.LAM + kn * NE + GIW + c];
             }
 #pragma unroll
@@ -1279,14 +1296,14 @@ BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) 
 #pragma unroll
             for (int u = 0; u < RC; u++) {
                 const int id0 = pass * 64 * RC + lane + 64 * u, id = id0 < N * 9 ? id0 : N * 9 - 1, k = id / 9, ln = id - 9 * k, a = ln / 3, b = ln - 3 * a;
-                const double *rr = G + sc.REF + k * RREC, *sgk = G + sc.SG + k * NI;
+                const GPtr rr = G + sc.REF + k * RREC, sgk = G + sc.SG + k * NI;
                 h0[u] = rr[RHPPG + ln]; h1[u] = rr[RHRRG + ln];
 #pragma unroll
                 for (int m = 0; m < 5; m++) { ss[u][m] = sgk[ITUBE + 2 * m] + sgk[ITUBE + 2 * m + 1]; ga[u][m] = rr[RGC + m * 4 + a]; gb[u][m] = rr[RGC + m * 4 + b]; }
             }
             const int idd0 = pass * 64 + lane, idd = idd0 < N * 3 ? idd0 : N * 3 - 1, kd = idd / 3, ad = idd - 3 * kd;
             double su[5], sl[5], g3[5], w1[5], gd[5], nu_u[5], nu_l[5], c2[5], w2[5];
-            const double *rrd = G + sc.REF + kd * RREC, *sgd = G + sc.SG + kd * NI, *nud = G + sc.NUm + kd * NI;
+            const GPtr rrd = G + sc.REF + kd * RREC, sgd = G + sc.SG + kd * NI, nud = G + sc.NUm + kd * NI;
             const double hp0 = rrd[RHPFG + ad], hr0 = rrd[RHRFG + ad], dpdp = rrd[RDPDP], hffg = rrd[RHFFG];
             const double s_phi0 = sgd[IPHI0], s_phimax = sgd[IPHIMAX], s_dphimax = sgd[IDPHIMAX];
             const double dp_a = rrd[RDP + ad], dp_b = rrd[RDP + 3 + ad];
@@ -1319,7 +1336,7 @@ BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) 
                     hff += su[m] * gpu_ * gpu_ + sl[m] * gpl_ * gpl_;
                     hff += exm * (nu_u[m] * (c2[m] - w2[m]) + nu_l[m] * (-c2[m] - w2[m]));
                 }
-                double *row = G + sc.NCS + kd * NCS_STRIDE;
+                const GPtr row = G + sc.NCS + kd * NCS_STRIDE;
                 row[NC_HPF + ad] = hp; row[NC_HRF + ad] = hr;
                 // the four scalars: every item of the stage has them, item a writes scalar a; the fourth, the zero word and dp_d ride along
                 const double sc1 = 2 * w[2] * dpdp + 2 * w[7] + s_dphimax, sc2 = 2 * w[5] * dpdp + 2 * w[8];
@@ -1342,7 +1359,7 @@ BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) 
                 const bool isA1 = e < 21; const int e2 = isA1 ? 0 : e - 21;
                 const int c = isA1 ? e / 7 : e2 / 14, i = isA1 ? e - 7 * c : 0, y = isA1 ? 0 : e2 - 14 * c;
                 const int cb = isA1 ? NC_HPP + c * 3 : NC_HRR + c * 3, kb = isA1 ? KW + i : (y < 7 ? KD + 21 + y : KA + y - 7);
-                const double *row = G + sc.NCS + k * NCS_STRIDE, *K0 = G + sc.KIN + k * KREC;
+                const GPtr row = G + sc.NCS + k * NCS_STRIDE, K0 = G + sc.KIN + k * KREC;
 #pragma unroll
                 for (int b2 = 0; b2 < 3; b2++) { cf[u][b2] = row[cb + b2]; kc[u][b2] = K0[kb + b2 * 7]; }
             }
@@ -1365,7 +1382,7 @@ BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) 
                 const bool isPos = t < 3, isV = t >= 3 && t < 9;
                 const int c = isV ? t - 3 : 0, pa = isPos ? NC_HPP + t * 3 : NC_HPF;            // 3-vector that multiplies r_pos
                 const int kp = k >= 1 ? k - 1 : 0, kn = k < N - 1 ? k + 1 : k;
-                const double *row = G + sc.NCS + k * NCS_STRIDE, *rl = G + sc.RLV + k * 12, *rm = G + sc.RLV + kp * 12, *rp = G + sc.RLV + kn * 12;
+                const GPtr row = G + sc.NCS + k * NCS_STRIDE, rl = G + sc.RLV + k * 12, rm = G + sc.RLV + kp * 12, rp = G + sc.RLV + kn * 12;
 #pragma unroll
                 for (int b2 = 0; b2 < 3; b2++) { nc3[u][b2] = row[pa + b2]; rl3[u][b2] = rl[b2]; }
                 rv0[u] = rl[3 + c]; rvm[u] = rm[3 + c]; rvp[u] = rp[3 + c]; cvv[u] = row[NC_SC + 3];
@@ -1403,7 +1420,7 @@ BMPC_D inline double gv_at(const double *rec, int c6, int y) {
 // a neighbour node that does not exist is replaced by the nearest one -- its data is masked by the consumers), and the commit
 // stores to the same clamped slots (identical values), so neither has a single exec-mask branch.
 BMPC_D inline void backward_loads_lane(Wave &W, const Scr &sc, int k, double *pf, int lane, bool full) {
-    const int N = W.N; const double *G = W.G;
+    const int N = W.N; const GPtr G = W.G;
     const int kn = k < N - 1 ? k + 1 : k, kp = k >= 1 ? k - 1 : 0;
     const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1;
     const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1;
@@ -1465,7 +1482,7 @@ BMPC_D inline void backward_commit_lane(Wave &W, int k, const double *pf, int la
 // ----------------------------------------------------------------------------------------
 BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, double mu, double delta, LaneRegs *LR) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
-    double *L = W.L, *G = W.G;
+    double *L = W.L; const GPtr G = W.G;
     const double *PAR = L + L_PAR, *w = PAR + po.w;
     LANES_BEGIN
         for (int id = lane; id < 96 + 12; id += 64) L[L_PCI + id] = 0.0;
@@ -1688,6 +1705,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 backward_commit_lane(W, k - 1, LR[LIDX].pf, lane, false);
                 backward_loads_lane(W, sc, k >= 2 ? k - 2 : 0, LR[LIDX].pf, lane, false);
             }
+            BMPC_PROF(W, 19);
             double Lc[NU][NU], dinv[NU]; bool pd = true;
 #pragma unroll
             for (int a = 0; a < NU; a++) {
@@ -1700,6 +1718,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                     else Lc[a][b] = sacc * dinv[b];
                 }
             }
+            BMPC_PROF(W, 20);
             L[L_FLAG] = pd ? 1.0 : 0.0;            // identical in every lane
             {   // gains: one column per lane (lanes >= 36 repeat column 0: identical values, duplicate stores; when the block is not
                 // positive definite the values are discarded with the whole sweep)
@@ -1718,9 +1737,12 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                     kc[a] = sacc * dinv[a]; }
 #pragma unroll
                 for (int a = 0; a < NU; a++) L[L_KS + a * 36 + c] = kc[a];
-                const int gb = c < NS ? sc.KT + (k * NS + prow(c)) * NU : sc.KF + k * NU;      // the forward sweep reads the gains by reduced-state index
+                // gains to the workspace for the forward sweep, control-major ([control][reduced-state index], 8 x 35 per stage): the 36
+                // column lanes write neighbouring words of one row per store instruction (measured neutral against the state-major
+                // layout: the stores ride behind the triangular solves either way); the feed-forward column goes to KF
+                const int gcoff = c < NS ? sc.KT + k * NS * NU + prow(c) : sc.KF + k * NU, gstr = c < NS ? NS : 1;
 #pragma unroll
-                for (int a = 0; a < NU; a++) G[gb + a] = kc[a];
+                for (int a = 0; a < NU; a++) G[gcoff + a * gstr] = kc[a];
             }
         LANES_END
         BMPC_PROF(W, 23);
@@ -1840,13 +1862,13 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 template <int PO>
 BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
     const int N = W.N; const double h = W.h;
-    double *L = W.L, *G = W.G;
+    double *L = W.L; const GPtr G = W.G;
     const double *sb = L + ((k & 1) ? L_GS : L_ST), *K0 = L + ((k & 1) ? L_K1 : L_K0);
     LANES_BEGIN   // du = kff + K ds: partial sums on all 64 lanes (control u = lane & 7, every 8th state b), reduced by the consumers
         {
             const int u = lane & 7, part = lane >> 3; double acc = 0.0;
 #pragma unroll
-            for (int j = 0; j < 5; j++) { const int b0 = part + 8 * j, b = b0 < NS ? b0 : NS - 1; const double pr_ = sb[ST_KT + b * NU + u] * L[L_DS + b]; acc += b0 < NS ? pr_ : 0.0; }
+            for (int j = 0; j < 5; j++) { const int b0 = part + 8 * j, b = b0 < NS ? b0 : NS - 1; const double pr_ = sb[ST_KT + u * NS + b] * L[L_DS + b]; acc += b0 < NS ? pr_ : 0.0; }
             L[L_RED + part * 8 + u] = acc;
         }
     LANES_END
@@ -1903,7 +1925,7 @@ BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
 }
 BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
     const int N = W.N;
-    double *L = W.L, *G = W.G;
+    double *L = W.L; const GPtr G = W.G;
     static_assert(ST_GHF + 64 <= 288 + 64 + 288 && ST_GHF + 64 <= 460, "forward staging buffers must fit into L_ST and into the idle GS/R8/KS area");
     LANES_BEGIN
         if (lane < 36) L[L_DS + lane] = 0.0;
@@ -1928,7 +1950,7 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
 template <bool ZLDS>
 BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     const int N = W.N, S = W.S;
-    double *L = W.L, *G = W.G;
+    double *L = W.L; const GPtr G = W.G;
     const POff po = make_poff(S);
     Scr sc = make_scr(N);
     const Opts &o = W.o;
@@ -1940,7 +1962,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
 #endif
     // ---- coalesced load of the parameter vector into LDS and of x0 into the iterate ----
     constexpr bool zlds = ZLDS;
-    if (ZLDS) { W.Zc = L + L_ZL; W.Zt = L + L_PB; W.Dz = L + L_PB + 512; } else { W.Zc = G + sc.Z; W.Zt = G + sc.ZT; W.Dz = G + sc.DZ; }
+    if (ZLDS) { W.Zc = L + L_ZL; W.Zt = L + L_PB; W.Dz = L + L_PB + 512; } else { W.Zc = (G + sc.Z).ptr(); W.Zt = (G + sc.ZT).ptr(); W.Dz = (G + sc.DZ).ptr(); }
     LANES_BEGIN
         for (int id = lane; id < np; id += 64) L[L_PAR + id] = pr.p[id];
         for (int id = lane; id < nw; id += 64) W.Zc[id] = pr.x0[id];
@@ -1964,7 +1986,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
 #define BMPC_ROWS_INIT(WARM_, PUSH_) \
         LANES_BEGIN \
             double ep = 0, cmax = -1e300, cmin = 1e300, sn = 0; \
-            for (int base = lane; base < ni; base += 64 * RU) { \
+            for (int tr_ = 0; tr_ < (ni + 64 * RU - 1) / (64 * RU); tr_++) { const int base = lane + tr_ * 64 * RU;      /* wave-uniform trip count */ \
                 double hv[RU], tv[RU]; \
 _Pragma("unroll") \
                 for (int u = 0; u < RU; u++) { \
@@ -1996,7 +2018,7 @@ _Pragma("unroll") \
         LANES_BEGIN
             double ed = 0, ep = L[L_KKP + lane], sl = 0, g1 = 0;
             for (int id = lane; id < N * NU; id += 64) { const double v = BMPC_FABS(G[sc.RJ + id]); ed = v > ed ? v : ed; }
-            for (int base = lane; base < ne; base += 64 * RU) {
+            for (int tr_ = 0; tr_ < (ne + 64 * RU - 1) / (64 * RU); tr_++) { const int base = lane + tr_ * 64 * RU;      /* wave-uniform trip count */
                 double gv[RU], lv[RU];
 #pragma unroll
                 for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < ne ? id0 : ne - 1; gv[u] = G[sc.G + id]; lv[u] = G[sc.LAM + id]; }
@@ -2086,7 +2108,7 @@ _Pragma("unroll") \
         const double tau = BMPC_FMAX(0.99, 1.0 - mu);
         LANES_BEGIN
             double ap = 1.0, adl = 1.0, dbar = 0, nhd = 0, th = 0, bar = 0, pn_ = 1.0, pd_ = 0.0, dn_ = 1.0, dd_ = 0.0;
-            for (int base = lane; base < ni; base += 64 * RU) {
+            for (int tr_ = 0; tr_ < (ni + 64 * RU - 1) / (64 * RU); tr_++) { const int base = lane + tr_ * 64 * RU;      /* wave-uniform trip count */
                 double tv[RU], nv[RU], hv[RU], sg[RU], tiv[RU], sr[RU], hd[RU], tprod = 1.0;
 #pragma unroll
                 for (int u = 0; u < RU; u++) {   // rows past the end are clamped to the last row (branch-free); their contributions are masked below
@@ -2104,7 +2126,7 @@ _Pragma("unroll") \
                         // between loaded values would put the loads under an exec-mask branch)
                         const bool tube = i >= ITUBE; const int m = tube ? (i - ITUBE) >> 1 : 0, ti = tube ? 1 : 0; const double mt = tube ? 1.0 : 0.0;
                         const double sgn = L[L_ROWT + i]; const int src = (int)L[L_ROWT + 2 * NI + i];
-                        const double *rr = G + sc.REF + k * RREC, *dz = W.Dz + k * NZ;
+                        const GPtr rr = G + sc.REF + k * RREC; const double *dz = W.Dz + k * NZ;
                         const int vo = src + ti * (tube_voff(m) - src);
                         c0[u] = mt * rr[RGC + m * 4 + 0] + (1.0 - mt) * sgn; c1[u] = mt * rr[RGC + m * 4 + 1]; c2[u] = mt * rr[RGC + m * 4 + 2];
                         c3[u] = mt * rr[RGC + m * 4 + 3]; w1[u] = mt * rr[RW1 + m];
@@ -2192,7 +2214,7 @@ _Pragma("unroll") \
         fval = ft;
         LANES_BEGIN
             double ep = 0, cmax = -1e300, cmin = 1e300, sn = 0;
-            for (int base = lane; base < ni; base += 64 * RU) {
+            for (int tr_ = 0; tr_ < (ni + 64 * RU - 1) / (64 * RU); tr_++) { const int base = lane + tr_ * 64 * RU;      /* wave-uniform trip count */
                 double tv[RU], nv[RU], dv[RU], hv[RU];
 #pragma unroll
                 for (int u = 0; u < RU; u++) {   // loads on clamped rows (branch-free)
@@ -2221,7 +2243,7 @@ _Pragma("unroll") \
         if (pr.x) for (int id = lane; id < nw; id += 64) pr.x[id] = W.Zc[id];
         for (int id = lane; id < N * NG; id += 64) {
             const int k = id / NG, i = id - k * NG;
-            const double *Zn = W.Zc + k * NZ, *rr = G + sc.REF + k * RREC, *nu = G + sc.NUm + k * NI;
+            const double *Zn = W.Zc + k * NZ; const GPtr rr = G + sc.REF + k * RREC, nu = G + sc.NUm + k * NI;
             double gv, lv;
             if (i < NE) { gv = G[sc.G + k * NE + i]; lv = G[sc.LAM + k * NE + i]; }
             else if (i == 36) { gv = Zn[ZPHI] - PAR[po.phimax]; lv = nu[IPHIMAX]; }
@@ -2231,7 +2253,7 @@ _Pragma("unroll") \
             if (pr.lam_g) pr.lam_g[id] = lv;
         }
         if (pr.lam_x) for (int id = lane; id < nw; id += 64) {
-            const int k = id / NZ, z = id - k * NZ; const double *nu = G + sc.NUm + k * NI; double v = 0;
+            const int k = id / NZ, z = id - k * NZ; const GPtr nu = G + sc.NUm + k * NI; double v = 0;
             if (z < 8) v = nu[IJU + z] - nu[IJL + z]; else if (z < ZDQ) v = nu[IQU + z - ZQ] - nu[IQL + z - ZQ];
             else if (z < ZDDQ) v = nu[IDQU + z - ZDQ] - nu[IDQL + z - ZDQ]; else if (z == ZPHI) v = -nu[IPHI0];
             pr.lam_x[id] = v;

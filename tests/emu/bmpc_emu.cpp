@@ -69,7 +69,7 @@ extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, in
             // BMPC_EMU_POISON=1: LDS and workspace are filled with NaN before every problem -- a read of something this solve has not
             // written (what a reused slab or LDS holds on the GPU) then shows up in the outputs
             if (poison) { std::fill(lds.begin(), lds.end(), std::nan("")); std::fill(scr.begin(), scr.end(), std::nan("")); }
-            bmpc::Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = scr.data();
+            bmpc::Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = bmpc::make_gptr(scr.data());
             for (int i = 0; i < 64; i++) W.order[i] = lane_order == 0 ? i : (lane_order == 1 ? 63 - i : (i * 37 + 11) % 64);
             bmpc::Problem pr;
             pr.p = p + (size_t)b * np; pr.x0 = x0 + (size_t)b * nw;
@@ -88,11 +88,11 @@ extern "C" int bmpc_emu_newton(int N, int S, double h, const bmpc::Opts *opts, c
     using namespace bmpc;
     const Scr sc = make_scr(N); const POff po = make_poff(S);
     std::vector<double> lds(L_SIZE, 0.0), scr(sc.size, 0.0);
-    Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = scr.data();
+    Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = bmpc::make_gptr(scr.data());
     for (int i = 0; i < 64; i++) W.order[i] = i;
     for (int i = 0; i < po.size; i++) W.L[L_PAR + i] = p[i];
     wave_init_tables(W, po);
-    const bool zl = N <= 11; W.Zc = zl ? W.L + L_ZL : W.G + sc.Z; W.Zt = zl ? W.L + L_PB : W.G + sc.ZT; W.Dz = zl ? W.L + L_PB + 512 : W.G + sc.DZ;
+    const bool zl = N <= 11; W.Zc = zl ? W.L + L_ZL : (W.G + sc.Z).ptr(); W.Zt = zl ? W.L + L_PB : (W.G + sc.ZT).ptr(); W.Dz = zl ? W.L + L_PB + 512 : (W.G + sc.DZ).ptr();
     for (int i = 0; i < N * NZ; i++) W.Zc[i] = x[i];
     for (int i = 0; i < N * NI; i++) { W.G[sc.T + i] = t[i]; W.G[sc.NUm + i] = nu[i]; }
     wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);

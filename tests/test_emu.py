@@ -149,7 +149,7 @@ def test_emu_newton_direction_equals_oracle_dense_solve(N):
     rc2 = CO.bmpc_oracle_debug_qp(N, S, ctypes.c_double(h), P(p), P(x), P(t), P(nu), ctypes.c_double(mu), 1, ctypes.c_double(delta), P(Qt), P(qt),
                                   P(Xt), P(A), P(rd), P(T), P(rl), P(Kg), P(kff), P(dZ))
     assert rc == 0 and rc2 == 0
-    KT = scr[off["KT"]:off["KT"] + N * 35 * 8].reshape(N, 35, 8).transpose(0, 2, 1)
+    KT = scr[off["KT"]:off["KT"] + N * 35 * 8].reshape(N, 8, 35)      # control-major since round 3
     np.testing.assert_allclose(KT, Kg, atol=1e-12)
     np.testing.assert_allclose(scr[off["KF"]:off["KF"] + 8 * N], kff.ravel(), atol=1e-12)
     np.testing.assert_allclose(scr[off["DZ"]:off["DZ"] + 44 * N], dZ, atol=1e-12)
