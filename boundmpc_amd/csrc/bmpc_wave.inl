@@ -536,6 +536,7 @@ BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
 #ifndef BMPC_RU
 #define BMPC_RU 9   // N=10: all 570 rows of a pass in one trip per lane (6: two trips; 10 starts to spill); +2 % (profiles/r02_n_rows_in_flight_ab.txt)
 #endif
+static_assert(64 * BMPC_RU >= 32 * 8, "the first batch of a row pass must cover the N * NU <= 256 jerk-gradient entries (KKT pass)");
 constexpr int RU = BMPC_RU;   // rows of a lane-strided pass kept in flight per lane (loads of a batch are issued before their first use)
 struct LaneRegs { double mc[16]; double pf[24]; double ghd; };   // ghd: the lane's share of (QP gradient) . dZ, accumulated by the forward sweep   // pf: software prefetch of the next stage's inputs (global -> registers -> LDS)   // a lane's 4x4 state block of M, kept in registers between the M and the Schur phases
 
@@ -635,11 +636,20 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
                 for (int i = 0; i < 3; i++) { Zn[ZPOS + i] = kp[KPOS + i]; gk[GPOS + i] = 0.0; Zn[ZIW + i] = iw[i]; gk[GIW + i] = 0.0; }
                 for (int i = 0; i < 6; i++) { Zn[ZV + i] = kp[KV + i]; gk[GV + i] = 0.0; }
             } else {
+                // all twelve record entries first, then the stores: a store between two loads of the workspace makes the second load wait
+                // for it (they may alias as far as the compiler knows), and this block was twelve dependent round trips
+                double kpos[3], kvel[6], kvw[3];
+#pragma unroll
+                for (int i = 0; i < 3; i++) { kpos[i] = kp[KPOS + i]; kvw[i] = kv[KV + 3 + i]; }
+#pragma unroll
+                for (int i = 0; i < 6; i++) kvel[i] = kp[KV + i];
+#pragma unroll
                 for (int i = 0; i < 3; i++) {
-                    gk[GPOS + i] = kp[KPOS + i] - Zn[ZPOS + i];
-                    gk[GIW + i] = ndv(PAR, po, Zs, k, ZIW + i, po.p0 + 3 + i) + 0.5 * h * (kv[KV + 3 + i] + kp[KV + 3 + i]) - Zn[ZIW + i];
+                    gk[GPOS + i] = kpos[i] - Zn[ZPOS + i];
+                    gk[GIW + i] = ndv(PAR, po, Zs, k, ZIW + i, po.p0 + 3 + i) + 0.5 * h * (kvw[i] + kvel[3 + i]) - Zn[ZIW + i];
                 }
-                for (int i = 0; i < 6; i++) gk[GV + i] = kp[KV + i] - Zn[ZV + i];
+#pragma unroll
+                for (int i = 0; i < 6; i++) gk[GV + i] = kvel[i] - Zn[ZV + i];
             }
             const double ph = ndv(PAR, po, Zs, k, ZPHI, po.phi0), dph = ndv(PAR, po, Zs, k, ZDPHI, po.phi0 + 1),
                          ddph = ndv(PAR, po, Zs, k, ZDDPHI, po.phi0 + 2), jp0 = ndv(PAR, po, Zs, k, ZJPHI, po.jerkphi), jp1 = Zn[ZJPHI];
@@ -674,6 +684,18 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
         // wave-uniform trip counts (rows past the end are clamped duplicates): a lane-dependent loop exit makes the compiler restore the
         // exec mask behind the loop, and that is where this toolchain has placed register copies under the stale mask (build.py lint_isa)
         const int trips_i = (N * NI + 64 * RU - 1) / (64 * RU), trips_e = (N * NE + 64 * RU - 1) / (64 * RU);
+        double the = 0;
+        if (ls) {   // 1-norm of the equality residuals (written by the node phase): read ahead of this pass's stores, which its loads would
+                    // otherwise have to wait for
+            for (int tr_ = 0; tr_ < trips_e; tr_++) {
+                const int base = lane + tr_ * 64 * RU;
+                double gv[RU];
+#pragma unroll
+                for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u; gv[u] = G[oG + (id0 < N * NE ? id0 : N * NE - 1)]; }
+#pragma unroll
+                for (int u = 0; u < RU; u++) the += base + 64 * u < N * NE ? BMPC_FABS(gv[u]) : 0.0;
+            }
+        }
         for (int tr_ = 0; tr_ < trips_i; tr_++) {
             const int base = lane + tr_ * 64 * RU;
             double zv[RU], rc[RU], rw[RU], sg[RU], lm[RU], tv[RU], dv[RU];
@@ -707,17 +729,7 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
             }
             if (ls) br -= ls->mu * BMPC_LOG(tprod);      // one log per batch of RU slacks: sum of logs = log of the product (t in [1e-12, 1e2])
         }
-        if (ls) {
-            for (int tr_ = 0; tr_ < trips_e; tr_++) {
-                const int base = lane + tr_ * 64 * RU;
-                double gv[RU];
-#pragma unroll
-                for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u; gv[u] = G[oG + (id0 < N * NE ? id0 : N * NE - 1)]; }
-#pragma unroll
-                for (int u = 0; u < RU; u++) th += base + 64 * u < N * NE ? BMPC_FABS(gv[u]) : 0.0;
-            }
-            L[L_RED + 64 + lane] = th; L[L_RED + 128 + lane] = br;
-        }
+        if (ls) { L[L_RED + 64 + lane] = th + the; L[L_RED + 128 + lane] = br; }
     LANES_END
     return f;
 }
@@ -2017,11 +2029,16 @@ _Pragma("unroll") \
         // ---- KKT error (Ipopt-style scaling), deterministic reductions; the inequality part comes from row pass A ----
         LANES_BEGIN
             double ed = 0, ep = L[L_KKP + lane], sl = 0, g1 = 0;
-            for (int id = lane; id < N * NU; id += 64) { const double v = BMPC_FABS(G[sc.RJ + id]); ed = v > ed ? v : ed; }
+            // the jerk-gradient entries ride in the first batch of the residual rows (one round trip to the workspace for the whole pass;
+            // clamped duplicates do not change a maximum)
+            const int nrj = N * NU;
             for (int tr_ = 0; tr_ < (ne + 64 * RU - 1) / (64 * RU); tr_++) { const int base = lane + tr_ * 64 * RU;      /* wave-uniform trip count */
-                double gv[RU], lv[RU];
+                double gv[RU], lv[RU], rj[RU];
 #pragma unroll
-                for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < ne ? id0 : ne - 1; gv[u] = G[sc.G + id]; lv[u] = G[sc.LAM + id]; }
+                for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < ne ? id0 : ne - 1; gv[u] = G[sc.G + id]; lv[u] = G[sc.LAM + id];
+                                               rj[u] = G[sc.RJ + (id0 < nrj ? id0 : nrj - 1)]; }
+#pragma unroll
+                for (int u = 0; u < RU; u++) { const double v = BMPC_FABS(rj[u]); ed = v > ed ? v : ed; }
 #pragma unroll
                 for (int u = 0; u < RU; u++) { const bool ok_ = base + 64 * u < ne; const double v = ok_ ? BMPC_FABS(gv[u]) : 0.0; ep = v > ep ? v : ep; g1 += v; sl += ok_ ? BMPC_FABS(lv[u]) : 0.0; }
             }
