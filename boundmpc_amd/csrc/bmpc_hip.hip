@@ -155,7 +155,7 @@ extern "C" const char *bmpc_error_string(int c) {
                  case BMPC_ERR_NOGPU: return "no HIP device available"; default: return "unknown error"; }
 }
 extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bmpc_handle **out) {
-    if (!out || N < 1 || N > 32 || S < 2 || S > bmpc::SMAX || !(dt > 0)) return BMPC_ERR_ARG;
+    if (!out || N < 1 || N > bmpc::NMAX || S < 2 || S > bmpc::SMAX || !(dt > 0)) return BMPC_ERR_ARG;
     if (opts && (!(opts->tol > 0) || opts->max_iter < 0 || opts->stall_window < 0 || (opts->stall_window & 1) || !(opts->mu_init > 0) || !(opts->slack_push > 0))) return BMPC_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BMPC_ERR_NOGPU;
@@ -487,6 +487,7 @@ extern "C" int bmpc_stream_tick(bmpc_handle *h, int B, const double *path, int p
                                 double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj, int flags,
                                 void *hip_stream) {
     if (!h || B < 0 || max_iter < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !p || !x0 || !x || !g || !status || !traj))) return BMPC_ERR_ARG;
+    if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // the stream kernels place one lane per stage below fixed roles at lanes 32..: horizons up to 32
     if (B == 0) return BMPC_OK;
     { const int rc_ = ensure_scratch(h, B < h->grid ? B : h->grid); if (rc_ != BMPC_OK) return rc_; }
     hipStream_t st = (hipStream_t)hip_stream;
@@ -510,6 +511,7 @@ extern "C" int bmpc_stream_lengths(const bmpc_handle *h, int *path_entry, int *s
 extern "C" int bmpc_stream_pack(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, const double *robot, double *p, double *x0,
                                 double *dual_state, void *hip_stream) {
     if (!h || B < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !p || !x0))) return BMPC_ERR_ARG;
+    if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // the stream kernels place one lane per stage below fixed roles at lanes 32..: horizons up to 32
     if (B == 0) return BMPC_OK;
     if (h->closed) return BMPC_ERR_ARG;
     hipLaunchKernelGGL(bmpc_stream_pack_kernel, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, path, path_entries * bmpcs::PT_LEN,
@@ -520,6 +522,7 @@ extern "C" int bmpc_stream_pack(bmpc_handle *h, int B, const double *path, int p
 extern "C" int bmpc_stream_post(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, const double *x, const double *g,
                                 const int *status, double *traj, int flags, void *hip_stream) {
     if (!h || B < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !x || !g || !status || !traj))) return BMPC_ERR_ARG;
+    if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // the stream kernels place one lane per stage below fixed roles at lanes 32..: horizons up to 32
     if (B == 0) return BMPC_OK;
     hipLaunchKernelGGL(bmpc_stream_post_kernel, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, h->h, path,
                        path_entries * bmpcs::PT_LEN, sstate, robot, x, g, status, traj, flags, h->rt_viol_tol);
@@ -531,6 +534,7 @@ extern "C" int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *pat
                                         double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj,
                                         int flags, bmpc_graph **out) {
     if (!h || !out || B < 1 || max_iter < 0 || path_entries < h->S + 1 || !path || !sstate || !robot || !p || !x0 || !x || !g || !status || !traj) return BMPC_ERR_ARG;
+    if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // the stream kernels place one lane per stage below fixed roles at lanes 32..: horizons up to 32
     { const int rc_ = ensure_scratch(h, B < h->grid ? B : h->grid); if (rc_ != BMPC_OK) return rc_; }
     hipStream_t cs;
     HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));

@@ -23,6 +23,7 @@
 #pragma once
 
 namespace bmpcs {
+constexpr int STREAM_NMAX = 32;      // one lane per stage below the fixed roles at lanes 32.. (stream_post)
 
 // path table entry (one per via-point slot), doubles
 enum { PT_P = 0, PT_IW = 3, PT_DPN = 6, PT_DR = 9, PT_RRV = 12, PT_PLO = 15, PT_PUP = 17, PT_RLO = 19, PT_RUP = 21, PT_BP1 = 23, PT_BP2 = 26,

@@ -42,7 +42,7 @@ namespace bmpc {
 // ----------------------------------------------------------------------------------------
 // dimensions and index maps
 // ----------------------------------------------------------------------------------------
-constexpr int NZ = 44, NG = 43, NE = 36, NS = 35, NU = 8, NW = 43, NI = 57, SMAX = 4, NPMAX = 141 + 91 * SMAX;
+constexpr int NZ = 44, NG = 43, NE = 36, NS = 35, NU = 8, NW = 43, NI = 57, SMAX = 4, NPMAX = 141 + 91 * SMAX, NMAX = 40;
 #define GN_MU_GATE 0.05      // Gauss-Newton fallback of the inertia correction only while mu >= GN_MU_GATE (first barrier level)
 #define GN_PROBE 3           // while the fallback keeps being needed, every GN_PROBE-th iteration tries the exact Hessian again
 #define DELTA_FIRST 1e-3     // inertia correction constants of oracle/bmpc_oracle.c
@@ -107,7 +107,7 @@ static_assert(8 + 3 * 57 <= 15 * 14, "row table must fit into the retired XT are
 //   MCI [3][5][8]  C^T P_c,iota, then M_c,iota in place ;  PE [3][14] = P_ii E ;  KHP [2][72] prefix vectors of the kinematic curvature
 enum { L_PB = L_PM, L_PCI = L_PB + 1024, L_PII = L_PCI + 96, L_GS = L_PII + 12, L_R8 = L_GS + 288, L_KS = L_R8 + 64, L_MCI = L_KS + 288,
        L_PE = L_MCI + 120, L_BLK_END = L_PE + 42, L_KHP = L_WV /* 144 of the 196 */ };
-static_assert(32 * 57 <= (int)L_PV - (int)L_PB, "multiplier staging of the adjoint must fit into the block area");
+static_assert(10 * 57 <= (int)L_PV - (int)L_PB, "multiplier staging of the adjoint (ten nodes per pass) must fit into the block area");
 static_assert((int)L_BLK_END <= (int)L_PV, "block Riccati storage must fit into the retired PM/SR/RED region");
 // staging area inside L_ST: per-stage inputs of the sequential sweeps, loaded from the scratch slab in ONE burst per stage
 enum { ST_REF = 0, ST_Z = 108, ST_SG = 152, ST_NU = 212, ST_G = 272, ST_LAM0 = 308, ST_LAM1 = 344, ST_GH = 380, ST_RLVM = 424, ST_RLV0 = 436, ST_RLVP = 448,
@@ -536,7 +536,8 @@ BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
 #ifndef BMPC_RU
 #define BMPC_RU 9   // N=10: all 570 rows of a pass in one trip per lane (6: two trips; 10 starts to spill); +2 % (profiles/r02_n_rows_in_flight_ab.txt)
 #endif
-static_assert(64 * BMPC_RU >= 32 * 8, "the first batch of a row pass must cover the N * NU <= 256 jerk-gradient entries (KKT pass)");
+static_assert(64 * BMPC_RU >= 40 * 8, "the first batch of a row pass must cover the N * NU <= 320 jerk-gradient entries (KKT pass)");
+static_assert(64 * BMPC_RU >= 10 * 57, "one batch must cover the 570 multiplier rows of a ten-node pass (wave_node_grad_wide)");
 constexpr int RU = BMPC_RU;   // rows of a lane-strided pass kept in flight per lane (loads of a batch are issued before their first use)
 struct LaneRegs { double mc[16]; double pf[24]; double ghd; };   // ghd: the lane's share of (QP gradient) . dZ, accumulated by the forward sweep   // pf: software prefetch of the next stage's inputs (global -> registers -> LDS)   // a lane's 4x4 state block of M, kept in registers between the M and the Schur phases
 
@@ -600,10 +601,13 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
     double *L = W.L; const GPtr G = W.G;
     const double *PAR = L + L_PAR;
     LANES_BEGIN
-        if (lane < 2 * N) {
-            const int k = lane < N ? lane : lane - N;
+        // one lane per kinematics point: 2 N points, in chunks of 64 (one chunk up to N = 32; the loop count is wave-uniform)
+        for (int pt0 = 0; pt0 < 2 * N; pt0 += 64) {
+        const int pt = pt0 + lane;
+        if (pt < 2 * N) {
+            const int k = pt < N ? pt : pt - N;
             double q[7], dq[7];
-            if (lane < N) {   // predicted point of node k+1 (jerk_trajectory_casadi.py closed form; bound_mpc_functions.py:254-260)
+            if (pt < N) {   // predicted point of node k+1 (jerk_trajectory_casadi.py closed form; bound_mpc_functions.py:254-260)
                 const GPtr gk = G + oG + k * NE;
                 const double *Zn = Zs + k * NZ;
                 for (int i = 0; i < 7; i++) {
@@ -617,7 +621,8 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
             } else {
                 for (int i = 0; i < 7; i++) { q[i] = ndv(PAR, po, Zs, k, ZQ + i, po.q0 + i); dq[i] = ndv(PAR, po, Zs, k, ZDQ + i, po.dq0 + i); }
             }
-            kin_point(q, dq, G + sc.KIN + lane * KREC, G + sc.KHPG + lane * 72);
+            kin_point(q, dq, G + sc.KIN + pt * KREC, G + sc.KHPG + pt * 72);
+        }
         }
     LANES_END
     BMPC_PROF(W, 25);
@@ -758,15 +763,32 @@ BMPC_D inline void stage_mu(Wave &W, const double *lam, const double *kp, int la
 // three path-parameter rows -- instead of one lane per node running all 44 components in sequence on 10 of 64 lanes (rounds 1-2:
 // 9.3 k cycles per call + a read-modify-write pass over GH).  The only loads from the workspace are entries of the reference records,
 // issued together ahead of the arithmetic: one dependent round trip per call.
-BMPC_D inline void wave_node_grad_wide(Wave &W, const POff &po, const Scr &sc) {
+BMPC_D inline void wave_node_grad_wide(Wave &W, const POff &po, const Scr &sc, int oNU, bool use_hat, double mu) {
     const int N = W.N; const double h = W.h, hinv = 1.0 / h;
     double *L = W.L; const GPtr G = W.G;
-    const double *PAR = L + L_PAR, *w = PAR + po.w, *Zs = W.Zc, *NUV = L + L_PB;
+    const double *PAR = L + L_PAR, *w = PAR + po.w, *Zs = W.Zc;
     const int npass = (N + 9) / 10;
+    for (int pass = 0; pass < npass; pass++) {
+    // the multipliers of the pass's ten nodes (570 rows: one batch) are staged through LDS with coalesced loads (the value-function block
+    // area is free outside the Riccati sweep): one lane per item would otherwise issue scattered global loads of its own.  use_hat: the
+    // multiplier estimate mu / t + (nu / t) r of the QP gradient instead of the stored multiplier.
+    LANES_BEGIN
+        const int first = pass * 10 * NI, last = N * NI - 1;
+        double a_[RU], b_[RU];
+#pragma unroll
+        for (int u = 0; u < RU; u++) {
+            const int id0 = first + lane + 64 * u, id = id0 < last ? id0 : last;
+            a_[u] = G[(use_hat ? sc.TI : oNU) + id]; b_[u] = G[sc.SR + id];
+        }
+#pragma unroll
+        for (int u = 0; u < RU; u++) { const int j0 = lane + 64 * u, j = j0 < 10 * NI ? j0 : 10 * NI - 1; const double v = use_hat ? mu * a_[u] + b_[u] : a_[u];
+                                       L[j0 < 10 * NI ? L_PB + j : L_DUMMY] = v; }
+    LANES_END
+    const double *NUV = L + L_PB - pass * 10 * NI;      // row k of the staged block: NUV + k NI for the nodes 10 pass .. 10 pass + 9
     LANES_BEGIN
         // item maps (one integer division each per call): v / pos+iw rows 6 per node, path-parameter rows 3 per node, box rows 29 per node
         const int k6 = lane / 6, c6 = lane - 6 * k6, k3 = lane / 3, a3 = lane - 3 * k3, k29 = lane / 29, z29 = lane - 29 * k29;
-        for (int pass = 0; pass < npass; pass++) {
+        {
             const int kv0 = 10 * pass + k6, kv = kv0 < N ? kv0 : N - 1, kn = kv < N - 1 ? kv + 1 : kv;
             const int kf0 = 10 * pass + k3, kf = kf0 < N ? kf0 : N - 1;
             const bool on6 = lane < 60, on3 = lane < 30;
@@ -869,6 +891,7 @@ BMPC_D inline void wave_node_grad_wide(Wave &W, const POff &po, const Scr &sc) {
             }
         }
     LANES_END
+    }
 }
 
 // inputs of adjoint stage j: gradient row j, kinematics records of node j+1 (predicted point and velocity point); j = -1: record
@@ -958,21 +981,7 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
     double *L = W.L; const GPtr G = W.G;
     const double *PAR = L + L_PAR, *Zs = W.Zc;
-    // the multipliers of all rows are staged through LDS with coalesced loads (the value-function block area is free outside the
-    // Riccati sweep): one lane per NODE would otherwise issue 57-114 scattered global loads of its own
-    LANES_BEGIN
-        for (int tr_ = 0; tr_ < (N * NI + 64 * RU - 1) / (64 * RU); tr_++) { const int base = lane + tr_ * 64 * RU;      /* wave-uniform trip count */
-            double a_[RU], b_[RU];
-#pragma unroll
-            for (int u = 0; u < RU; u++) {
-                const int id0 = base + 64 * u, id = id0 < N * NI ? id0 : N * NI - 1;
-                a_[u] = G[(use_hat ? sc.TI : oNU) + id]; b_[u] = G[sc.SR + id];
-            }
-#pragma unroll
-            for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < N * NI ? id0 : N * NI - 1; L[L_PB + id] = use_hat ? mu * a_[u] + b_[u] : a_[u]; }
-        }
-    LANES_END
-    wave_node_grad_wide(W, po, sc);
+    wave_node_grad_wide(W, po, sc, oNU, use_hat, mu);
     BMPC_PROF(W, 27);
     if (use_hat) return;   // QP gradient only
     // sequential sweep; lam_{k+1} lives in LDS (ping-pong ST_LAM0/ST_LAM1).  A blocking global load per stage would cost a full
@@ -2192,7 +2201,8 @@ _Pragma("unroll") \
         double alpha = ap, ft = 0; bool accepted = false, armijo_step = false;
         for (int ls = 0; ls < 14; ls++) {
             LANES_BEGIN
-                for (int id = lane; id < nw; id += 64) W.Zt[id] = W.Zc[id] + alpha * W.Dz[id];
+                // wave-uniform trip count, clamped index (the lanes past the end rewrite the last entry with the same value)
+                for (int t_ = 0; t_ < (nw + 63) / 64; t_++) { const int id0 = lane + 64 * t_, id = id0 < nw ? id0 : nw - 1; W.Zt[id] = W.Zc[id] + alpha * W.Dz[id]; }
             LANES_END
             BMPC_PROF(W, 9);
             const LsRows lsr = {alpha, mu};
@@ -2224,7 +2234,7 @@ _Pragma("unroll") \
         // accept the last trial: iterate (LDS copy or slab swap), slab swaps for t / g / h; then row pass "A" with the multiplier update
         if (zlds) {
             LANES_BEGIN
-                for (int id = lane; id < nw; id += 64) W.Zc[id] = W.Zt[id];
+                for (int t_ = 0; t_ < (nw + 63) / 64; t_++) { const int id0 = lane + 64 * t_, id = id0 < nw ? id0 : nw - 1; W.Zc[id] = W.Zt[id]; }
             LANES_END
         } else { double *t_ = W.Zc; W.Zc = W.Zt; W.Zt = t_; }
         { int t_; t_ = sc.T; sc.T = sc.TT; sc.TT = t_; t_ = sc.G; sc.G = sc.GT; sc.GT = t_; t_ = sc.HIN; sc.HIN = sc.HT; sc.HT = t_; }

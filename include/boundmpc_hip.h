@@ -63,7 +63,8 @@ int bmpc_default_options(bmpc_options *o);                 /* the N <= 11 defaul
 int bmpc_default_options_for(int N, bmpc_options *o);      /* defaults for horizon N; what bmpc_create(…, NULL, …) uses */
 const char *bmpc_error_string(int code);
 
-/* N horizon (1..32), S path segments in the window (2..4), dt sampling time */
+/* N horizon (1..40; the closed-loop stream entry points bmpc_stream_* accept N <= 32 and return BMPC_ERR_ARG above), S path segments in
+ * the window (2..4), dt sampling time */
 int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bmpc_handle **out);
 int bmpc_destroy(bmpc_handle *h);
 

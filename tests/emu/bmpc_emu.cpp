@@ -54,7 +54,7 @@ extern "C" void bmpc_emu_jacobian_lin_ddot(const double *q, const double *dq, co
 
 extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, int B, const double *p, const double *x0, double *state, double *x, double *g,
                               double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, int lane_order, int nthreads) {
-    if (S > bmpc::SMAX || S < 2 || N < 1 || N > 32) return 1;
+    if (S > bmpc::SMAX || S < 2 || N < 1 || N > bmpc::NMAX) return 1;
     const bmpc::Scr sc = bmpc::make_scr(N);
     const int np = 141 + 91 * S, nw = N * bmpc::NZ, ng = N * bmpc::NG;
 #ifdef _OPENMP

@@ -215,3 +215,17 @@ def test_bounded_range_sincos_of_the_kinematics_against_libm():
     emu.lib().bmpc_emu_sincos(ctypes.c_int(len(x)), vp(x), vp(s), vp(c))
     assert np.abs(s - np.sin(x)).max() < 3e-16 and np.abs(c - np.cos(x)).max() < 3e-16
     assert np.abs(s * s + c * c - 1).max() < 5e-16
+
+def test_emu_long_horizon_above_32_stages_equals_oracle():
+    """N = 40: the kinematics points take two chunks of lanes and the multiplier staging four passes (bmpc_wave.inl wave_eval,
+    wave_node_grad_wide); the lane program against the scalar oracle, problem by problem."""
+    from boundmpc_amd import workload
+    from oracle import c_oracle
+    N = 40
+    P, X, _ = workload.make_batch(3, seed=5, N=N)
+    r = c_oracle.solve(P, X, N, 4, 0.1, opts=c_oracle.default_opts(mu_init=0.3, stall_window=20), nthreads=3)
+    e = emu.solve(P, X, N, 4, 0.1, opts=emu.default_opts(mu_init=0.3, stall_window=20), nthreads=3)
+    assert (r["status"] == 0).all() and (e["status"] == 0).all()
+    assert (r["iters"] == e["iters"]).all()
+    d = (e["x"] - r["x"]).reshape(-1, N, 44)[:, :, 8:15]
+    assert np.abs(d).max() < 1e-8

@@ -545,3 +545,23 @@ def test_kkt_certificate_with_the_references_own_derivatives(solver):
         r = _kkt_residual_with_reference_derivatives(i, j, out["x"][0], out["lam_g"][0], out["lam_x"][0])
         assert r < 2e-4, (which, tick, r)
         assert (out["lam_g"][0].reshape(10, 43)[:, 36:] >= 0).all()
+
+def test_horizon_limits_of_the_handle():
+    """bmpc_create accepts N = 1..40 (BoundMPC.py:35 makes the horizon a parameter); the stream entry points, whose kernels place one lane
+    per stage below fixed roles, refuse N > 32 instead of computing something else."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, BoundMPCHipError
+    with pytest.raises(BoundMPCHipError):
+        BatchedOCPSolver(41, 4, 0.1)
+    s = BatchedOCPSolver(40, 4, 0.1)
+    try:
+        from boundmpc_amd import workload
+        P, X, _ = workload.make_batch(8, seed=3, N=40)
+        o = s.solve_batch(torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda"))
+        assert int((o["status"] == 0).sum()) == 8
+        import ctypes
+        buf = torch.zeros(64, dtype=torch.float64, device="cuda"); vp = ctypes.c_void_p(buf.data_ptr())
+        rc = s._lib.bmpc_stream_pack(s._h, 1, vp, 5, vp, vp, vp, vp, None, None)      # refused before anything is launched
+        assert rc == 1, rc      # BMPC_ERR_ARG
+    finally:
+        s.close()
