@@ -168,7 +168,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     int dev = 0, per_cu = 0; hipDeviceProp_t prop;
     bool ok = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess;
     h->dev = dev;
-    if (ok) ok = (N <= 11 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel<true>, 64, 0)
+    if (ok) ok = ((N <= 11 && S <= bmpc::SMAX_ZLDS) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel<true>, 64, 0)
                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bmpc_solve_kernel<false>, 64, 0)) == hipSuccess;
     if (ok) {
         if (per_cu < 1) per_cu = 1;
@@ -270,7 +270,7 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), st));
     hipEvent_t *pair = nullptr;
     if (timed) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
-    if (h->N <= 11) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, a);
+    if (h->N <= 11 && h->S <= bmpc::SMAX_ZLDS) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, a);      // iterate in LDS; else in the workspace (long horizons, S > 4)
     else hipLaunchKernelGGL(bmpc_solve_kernel<false>, dim3(grid), dim3(64), 0, st, a);
     HIPCHK(hipGetLastError());
     if (timed) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }
@@ -482,7 +482,7 @@ static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entr
     if (!capturing) return order_after(h, st);
     return BMPC_OK;
 }
-static bool tick_fusable(const bmpc_handle *h, int B) { return h->N <= 11 && B <= h->grid; }
+static bool tick_fusable(const bmpc_handle *h, int B) { return h->N <= 11 && h->S <= bmpc::SMAX_ZLDS && B <= h->grid; }
 extern "C" int bmpc_stream_tick(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, double *p, double *x0,
                                 double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj, int flags,
                                 void *hip_stream) {

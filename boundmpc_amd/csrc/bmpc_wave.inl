@@ -42,7 +42,7 @@ namespace bmpc {
 // ----------------------------------------------------------------------------------------
 // dimensions and index maps
 // ----------------------------------------------------------------------------------------
-constexpr int NZ = 44, NG = 43, NE = 36, NS = 35, NU = 8, NW = 43, NI = 57, SMAX = 4, NPMAX = 141 + 91 * SMAX, NMAX = 40;
+constexpr int NZ = 44, NG = 43, NE = 36, NS = 35, NU = 8, NW = 43, NI = 57, SMAX = 6, SMAX_ZLDS = 4, NPMAX = 141 + 91 * SMAX, NMAX = 40;
 #define GN_MU_GATE 0.05      // Gauss-Newton fallback of the inertia correction only while mu >= GN_MU_GATE (first barrier level)
 #define GN_PROBE 3           // while the fallback keeps being needed, every GN_PROBE-th iteration tries the exact Hessian again
 #define DELTA_FIRST 1e-3     // inertia correction constants of oracle/bmpc_oracle.c
@@ -82,8 +82,22 @@ BMPC_HD inline POff make_poff(int S) {
     o.qd = c; c += 7; o.size = c;
     return o;
 }
+// LDS-relative offsets (index into L, from L_PAR = 0) of the parameter arrays; see the note at the LDS layout
+BMPC_HD inline int poff_split(int S) { return S <= SMAX_ZLDS ? (1 << 30) : make_poff(S).a[3]; }
+BMPC_HD inline int lds_index_of_p(int S, int id, int lzl) { const int sp = poff_split(S); return id < sp ? id : id - sp + lzl; }
+BMPC_HD inline POff make_poff_lds(int S, int lzl) {
+    POff o = make_poff(S);
+    if (S > SMAX_ZLDS) {
+        const int sh = lzl - o.a[3];
+        o.a[3] += sh; o.a[4] += sh; o.w += sh; o.phimax += sh; o.dphimax += sh; o.v1 += sh; o.v2 += sh; o.v3 += sh; o.qd += sh;
+    }
+    return o;
+}
 
 // LDS layout (doubles)
+// The parameter vector occupies [L_PAR, L_PAR + 512): 141 + 91 S <= 505 doubles up to S = 4.  Handles with 5 or 6 path segments run the
+// instantiation that keeps the iterate in the workspace (wave_solve<false>), whose iterate area L_ZL (484 doubles) is free: the tail of p
+// from a[3] on (27 S + 42 <= 204 doubles) lives there, and the offsets of make_poff_lds point at it.  lds_index maps an index of p.
 enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV = L_RED + 6 * 64, L_PR = L_PV + 36, L_QT = L_PR + 36,
        L_RD = L_QT + 36, L_DS = L_RD + 36, L_DSN = L_DS + 36, L_DU = L_DSN + 36, L_MV = L_DU + 8, L_AE = L_MV + 44, L_K0 = L_AE + 42,
        L_K1 = L_K0 + KREC, L_KV = L_K1 + KREC, L_XT = L_KV + KREC, L_NC = L_XT + 15 * 14, L_WY = L_NC + 160, L_WV = L_WY + 196, L_TOT = L_WV + 196,
@@ -1972,7 +1986,7 @@ template <bool ZLDS>
 BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     const int N = W.N, S = W.S;
     double *L = W.L; const GPtr G = W.G;
-    const POff po = make_poff(S);
+    const POff po = make_poff_lds(S, L_ZL);      // LDS-relative (S > 4: the tail of p sits in the free iterate area, ZLDS is false then)
     Scr sc = make_scr(N);
     const Opts &o = W.o;
     const int np = po.size, nw = N * NZ, ni = N * NI, ne = N * NE;
@@ -1983,9 +1997,10 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
 #endif
     // ---- coalesced load of the parameter vector into LDS and of x0 into the iterate ----
     constexpr bool zlds = ZLDS;
+    const bool longh = !ZLDS && N > 11;      // long-horizon rules of the algorithm (oracle/bmpc_oracle.c): the instantiation without the LDS iterate also serves S > 4 at short horizons
     if (ZLDS) { W.Zc = L + L_ZL; W.Zt = L + L_PB; W.Dz = L + L_PB + 512; } else { W.Zc = (G + sc.Z).ptr(); W.Zt = (G + sc.ZT).ptr(); W.Dz = (G + sc.DZ).ptr(); }
     LANES_BEGIN
-        for (int id = lane; id < np; id += 64) L[L_PAR + id] = pr.p[id];
+        for (int id = lane; id < np; id += 64) L[L_PAR + (ZLDS ? id : lds_index_of_p(S, id, L_ZL))] = pr.p[id];
         for (int id = lane; id < nw; id += 64) W.Zc[id] = pr.x0[id];
     LANES_END
     wave_init_tables(W, po);
@@ -2071,7 +2086,7 @@ _Pragma("unroll") \
                 // the barrier from the CURRENT iterate -- slacks and multipliers re-centred on a high barrier level, filter and inertia
                 // history cleared -- at most STALL_RESTARTS times (oracle/bmpc_oracle.c solve_one has the numbers: the stalled
                 // problems of the tight 30-stage batch are feasible, their iterate is jammed at the first barrier level).
-                if (zlds || n_restart >= STALL_RESTARTS) { status = 2; break; }
+                if (!longh || n_restart >= STALL_RESTARTS) { status = 2; break; }
                 n_restart++; it_restart = it;
                 mu = STALL_RESTART_MU;
                 BMPC_ROWS_INIT(false, STALL_RESTART_PUSH)
@@ -2104,7 +2119,7 @@ _Pragma("unroll") \
         // f, g, h); the flag stays off until the factorisation of this iteration has succeeded, the next evaluation restores the
         // exact entries.  Long horizons only (N > 11 <=> !ZLDS, a compile-time property of this instantiation): the short-horizon
         // kernel never met the case on any test batch, and carrying the extra path there costs registers (scratch 44 -> 312 B/lane).
-        const bool gn_allowed = !zlds && ex_saved && mu >= GN_MU_GATE;
+        const bool gn_allowed = longh && ex_saved && mu >= GN_MU_GATE;
         if (gn_allowed && gn_run > 0 && gn_run % GN_PROBE != GN_PROBE - 1) {
             used_gn = true; W.o.exact_hessian = 0;
             wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);

@@ -64,7 +64,8 @@ int bmpc_default_options_for(int N, bmpc_options *o);      /* defaults for horiz
 const char *bmpc_error_string(int code);
 
 /* N horizon (1..40; the closed-loop stream entry points bmpc_stream_* accept N <= 32 and return BMPC_ERR_ARG above), S path segments in
- * the window (2..4), dt sampling time */
+ * the window (2..6; with 5 or 6 the iterate lives in the workspace instead of LDS at every horizon, as it does for N > 11, and stream ticks are
+ * not fused into one launch), dt sampling time */
 int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bmpc_handle **out);
 int bmpc_destroy(bmpc_handle *h);
 

@@ -77,7 +77,7 @@ extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, in
             pr.lam_g = lam_g ? lam_g + (size_t)b * ng : nullptr; pr.lam_x = lam_x ? lam_x + (size_t)b * nw : nullptr;
             pr.f = f ? f + b : nullptr; pr.kkt = kkt ? kkt + b : nullptr; pr.iters = iters ? iters + b : nullptr; pr.status = status ? status + b : nullptr;
             pr.state = state ? state + (size_t)b * (N * bmpc::NI + 2) : nullptr;
-            if (N <= 11) bmpc::wave_solve<true>(W, pr); else bmpc::wave_solve<false>(W, pr);
+            if (N <= 11 && S <= bmpc::SMAX_ZLDS) bmpc::wave_solve<true>(W, pr); else bmpc::wave_solve<false>(W, pr);
         }
     }
     return 0;
@@ -86,13 +86,13 @@ extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, in
 extern "C" int bmpc_emu_newton(int N, int S, double h, const bmpc::Opts *opts, const double *p, const double *x, const double *t, const double *nu,
                                double mu, double delta, double *scratch_out, double *lds_out) {
     using namespace bmpc;
-    const Scr sc = make_scr(N); const POff po = make_poff(S);
+    const Scr sc = make_scr(N); const POff po = make_poff_lds(S, L_ZL);
     std::vector<double> lds(L_SIZE, 0.0), scr(sc.size, 0.0);
     Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = bmpc::make_gptr(scr.data());
     for (int i = 0; i < 64; i++) W.order[i] = i;
-    for (int i = 0; i < po.size; i++) W.L[L_PAR + i] = p[i];
+    for (int i = 0; i < po.size; i++) W.L[L_PAR + lds_index_of_p(S, i, L_ZL)] = p[i];
     wave_init_tables(W, po);
-    const bool zl = N <= 11; W.Zc = zl ? W.L + L_ZL : (W.G + sc.Z).ptr(); W.Zt = zl ? W.L + L_PB : (W.G + sc.ZT).ptr(); W.Dz = zl ? W.L + L_PB + 512 : (W.G + sc.DZ).ptr();
+    const bool zl = N <= 11 && S <= bmpc::SMAX_ZLDS; W.Zc = zl ? W.L + L_ZL : (W.G + sc.Z).ptr(); W.Zt = zl ? W.L + L_PB : (W.G + sc.ZT).ptr(); W.Dz = zl ? W.L + L_PB + 512 : (W.G + sc.DZ).ptr();
     for (int i = 0; i < N * NZ; i++) W.Zc[i] = x[i];
     for (int i = 0; i < N * NI; i++) { W.G[sc.T + i] = t[i]; W.G[sc.NUm + i] = nu[i]; }
     wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);

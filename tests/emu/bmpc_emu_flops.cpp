@@ -65,7 +65,7 @@ using namespace fc;
 
 // out[0] = total iterations, out[1] = converged solves, out[2] = flops, out[3] = divisions/roots/transcendentals among them, out[4..35] = flops per phase slot
 extern "C" int bmpc_emu_count_flops(int N, int S, double h, const bmpc::Opts *opts, int B, const double *p, const double *x0, unsigned long long *out) {
-    if (S > bmpc::SMAX || S < 2 || N < 1 || N > 32) return 1;
+    if (S > bmpc::SMAX || S < 2 || N < 1 || N > bmpc::NMAX) return 1;
     const bmpc::Scr sc = bmpc::make_scr(N);
     const int np = 141 + 91 * S, nw = N * bmpc::NZ;
     fc::g_flops = fc::g_special = fc::g_mark = 0; for (int i = 0; i < 32; i++) fc::g_phase[i] = 0;
@@ -77,7 +77,7 @@ extern "C" int bmpc_emu_count_flops(int N, int S, double h, const bmpc::Opts *op
         bmpc::Problem pr; int it = 0, st = 0;
         pr.p = (const Real *)p + (size_t)b * np; pr.x0 = (const Real *)x0 + (size_t)b * nw;
         pr.x = x.data(); pr.g = nullptr; pr.lam_g = nullptr; pr.lam_x = nullptr; pr.f = nullptr; pr.kkt = nullptr; pr.iters = &it; pr.status = &st; pr.state = nullptr;
-        if (N <= 11) bmpc::wave_solve<true>(W, pr); else bmpc::wave_solve<false>(W, pr);
+        if (N <= 11 && S <= bmpc::SMAX_ZLDS) bmpc::wave_solve<true>(W, pr); else bmpc::wave_solve<false>(W, pr);
         its += (unsigned long long)it; okc += st == 0;
     }
     out[0] = its; out[1] = okc; out[2] = fc::g_flops; out[3] = fc::g_special;

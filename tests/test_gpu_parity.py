@@ -438,7 +438,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 # G9: f and g of the HIP kernel at fixed points against the values the reference's own builder produced there
 # (tests/golden/make_g9.py).  A handle with max_iter = 0 evaluates the NLP at x0 and returns (status 1, x = x0).
 # ---------------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("key,N,S,h", [("n10", 10, 4, 0.1), ("n30", 30, 4, 0.1), ("n3s2", 3, 2, 0.05), ("n5s3", 5, 3, 0.05)])
+@pytest.mark.parametrize("key,N,S,h", [("n10", 10, 4, 0.1), ("n30", 30, 4, 0.1), ("n3s2", 3, 2, 0.05), ("n5s3", 5, 3, 0.05), ("n4s5", 4, 5, 0.05)])
 def test_g9_kernel_f_and_g_equal_the_reference_nlp(key, N, S, h):
     from boundmpc_amd import BatchedOCPSolver
     d = np.load(os.path.join(G, "g9_nlp.npz"))
@@ -553,6 +553,8 @@ def test_horizon_limits_of_the_handle():
     from boundmpc_amd import BatchedOCPSolver, BoundMPCHipError
     with pytest.raises(BoundMPCHipError):
         BatchedOCPSolver(41, 4, 0.1)
+    with pytest.raises(BoundMPCHipError):
+        BatchedOCPSolver(10, 7, 0.1)      # nr_segs: 2..6 (BoundMPC.py:62 makes it a parameter)
     s = BatchedOCPSolver(40, 4, 0.1)
     try:
         from boundmpc_amd import workload
@@ -565,3 +567,27 @@ def test_horizon_limits_of_the_handle():
         assert rc == 1, rc      # BMPC_ERR_ARG
     finally:
         s.close()
+
+@pytest.mark.parametrize("N,S", [(10, 5), (10, 6), (20, 6)])
+def test_five_and_six_path_segments_against_the_oracle(N, S):
+    """nr_segs > 4: the parameter vector no longer fits the 512-double LDS window; its tail lives in the iterate area and the iterate in
+    the workspace (bmpc_wave.inl make_poff_lds).  256 random problems against the oracle, problem by problem."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    from oracle import c_oracle
+    B = 256
+    P, X, _ = workload.make_batch(B, seed=41 + S, N=N, S=S)
+    assert P.shape[1] == 141 + 91 * S
+    s = BatchedOCPSolver(N, S, 0.1)
+    try:
+        o = s.solve_batch(torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda"))
+        st, it, x = o["status"].cpu().numpy(), o["iters"].cpu().numpy(), o["x"].cpu().numpy()
+    finally:
+        s.close()
+    ref = c_oracle.solve(P, X, N, S, 0.1, nthreads=16)
+    assert (st == ref["status"]).all() and (st == 0).all()
+    d = (x - ref["x"]).reshape(-1, N, 44)[:, :, 8:15]
+    per = np.sqrt((d ** 2).mean(axis=(1, 2)))
+    assert (per > 1e-6).sum() <= (1 if N > 11 else 0), float(per.max())
+    assert np.sqrt((d[per <= 1e-6] ** 2).mean()) < 1e-7
+    assert (np.abs(it - ref["iters"]) <= 2).mean() >= 0.97
