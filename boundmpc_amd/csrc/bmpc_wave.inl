@@ -598,6 +598,32 @@ BMPC_D inline double red_min(const double *r) { double s = r[0];
 //                                   the wave program
 // ========================================================================================
 
+// kinematics of point pt (pt < N: predicted point of node pt+1, with the dynamics residuals of q, dq, ddq; pt >= N: velocity point of node
+// pt - N): record -> KIN, curvature prefix vectors -> KHPG
+BMPC_D inline void eval_kin_lane(Wave &W, const POff &po, const Scr &sc, const double *Zs, int oG, int pt) {
+    const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
+    const GPtr G = W.G; const double *PAR = W.L + L_PAR;
+    if (pt < 2 * N) {
+        const int k = pt < N ? pt : pt - N;
+        double q[7], dq[7];
+        if (pt < N) {   // predicted point of node k+1 (jerk_trajectory_casadi.py closed form; bound_mpc_functions.py:254-260)
+            const GPtr gk = G + oG + k * NE;
+            const double *Zn = Zs + k * NZ;
+            for (int i = 0; i < 7; i++) {
+                const double q0 = ndv(PAR, po, Zs, k, ZQ + i, po.q0 + i), d0 = ndv(PAR, po, Zs, k, ZDQ + i, po.dq0 + i),
+                             dd0 = ndv(PAR, po, Zs, k, ZDDQ + i, po.ddq0 + i), j0 = ndv(PAR, po, Zs, k, ZJ + i, po.jerk + i), j1 = Zn[ZJ + i];
+                q[i] = q0 + h * d0 + h2 / 2 * dd0 + h3 / 8 * j0 + h3 / 24 * j1;
+                dq[i] = d0 + h * dd0 + h2 / 3 * j0 + h2 / 6 * j1;
+                const double ddqn = dd0 + h / 2 * (j0 + j1);
+                gk[GQ + i] = q[i] - Zn[ZQ + i]; gk[GDQ + i] = dq[i] - Zn[ZDQ + i]; gk[GDDQ + i] = ddqn - Zn[ZDDQ + i];
+            }
+        } else {
+            for (int i = 0; i < 7; i++) { q[i] = ndv(PAR, po, Zs, k, ZQ + i, po.q0 + i); dq[i] = ndv(PAR, po, Zs, k, ZDQ + i, po.dq0 + i); }
+        }
+        kin_point(q, dq, G + sc.KIN + pt * KREC, G + sc.KHPG + pt * 72);
+    }
+}
+
 // Evaluate at Zs: kinematic records, node references, equality residuals Gd[N][36], inequality
 // values Hd[N][57]; returns the objective (wave-uniform).
 // project (trial points of the line search after a rejected first trial; oracle/bmpc_oracle.c eval_values): the lifted variables
@@ -614,31 +640,15 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
     double *L = W.L; const GPtr G = W.G;
     const double *PAR = L + L_PAR;
+    // one lane per kinematics point: 2 N points; the points past the first 64 (N > 32 only) take a second phase
     LANES_BEGIN
-        // one lane per kinematics point: 2 N points, in chunks of 64 (one chunk up to N = 32; the loop count is wave-uniform)
-        for (int pt0 = 0; pt0 < 2 * N; pt0 += 64) {
-        const int pt = pt0 + lane;
-        if (pt < 2 * N) {
-            const int k = pt < N ? pt : pt - N;
-            double q[7], dq[7];
-            if (pt < N) {   // predicted point of node k+1 (jerk_trajectory_casadi.py closed form; bound_mpc_functions.py:254-260)
-                const GPtr gk = G + oG + k * NE;
-                const double *Zn = Zs + k * NZ;
-                for (int i = 0; i < 7; i++) {
-                    const double q0 = ndv(PAR, po, Zs, k, ZQ + i, po.q0 + i), d0 = ndv(PAR, po, Zs, k, ZDQ + i, po.dq0 + i),
-                                 dd0 = ndv(PAR, po, Zs, k, ZDDQ + i, po.ddq0 + i), j0 = ndv(PAR, po, Zs, k, ZJ + i, po.jerk + i), j1 = Zn[ZJ + i];
-                    q[i] = q0 + h * d0 + h2 / 2 * dd0 + h3 / 8 * j0 + h3 / 24 * j1;
-                    dq[i] = d0 + h * dd0 + h2 / 3 * j0 + h2 / 6 * j1;
-                    const double ddqn = dd0 + h / 2 * (j0 + j1);
-                    gk[GQ + i] = q[i] - Zn[ZQ + i]; gk[GDQ + i] = dq[i] - Zn[ZDQ + i]; gk[GDDQ + i] = ddqn - Zn[ZDDQ + i];
-                }
-            } else {
-                for (int i = 0; i < 7; i++) { q[i] = ndv(PAR, po, Zs, k, ZQ + i, po.q0 + i); dq[i] = ndv(PAR, po, Zs, k, ZDQ + i, po.dq0 + i); }
-            }
-            kin_point(q, dq, G + sc.KIN + pt * KREC, G + sc.KHPG + pt * 72);
-        }
-        }
+        eval_kin_lane(W, po, sc, Zs, oG, lane);
     LANES_END
+    if (2 * N > 64) {
+        LANES_BEGIN
+            eval_kin_lane(W, po, sc, Zs, oG, 64 + lane);
+        LANES_END
+    }
     BMPC_PROF(W, 25);
     LANES_BEGIN
         double fk = 0;
