@@ -72,7 +72,7 @@ extern "C" int bmpc_emu_count_flops(int N, int S, double h, const bmpc::Opts *op
     std::vector<Real> lds(bmpc::L_SIZE, Real(0.0)), scr(sc.size, Real(0.0)), x(nw);
     unsigned long long its = 0, okc = 0;
     for (int b = 0; b < B; b++) {
-        bmpc::Wave W; W.N = N; W.S = S; W.h = Real(h); W.o = *opts; W.L = lds.data(); W.G = scr.data();
+        bmpc::Wave W; W.N = N; W.S = S; W.h = Real(h); W.o = *opts; W.L = lds.data(); W.G = bmpc::make_gptr(scr.data());
         for (int i = 0; i < 64; i++) W.order[i] = i;
         bmpc::Problem pr; int it = 0, st = 0;
         pr.p = (const Real *)p + (size_t)b * np; pr.x0 = (const Real *)x0 + (size_t)b * nw;

@@ -229,3 +229,13 @@ def test_emu_long_horizon_above_32_stages_equals_oracle():
     assert (r["iters"] == e["iters"]).all()
     d = (e["x"] - r["x"]).reshape(-1, N, 44)[:, :, 8:15]
     assert np.abs(d).max() < 1e-8
+
+def test_flop_counting_build_of_the_kernel_text_runs_the_same_iterations():
+    """tests/emu/bmpc_emu_flops.cpp compiles the kernel text with a counting number type (profiles/flops_current.json comes from it):
+    it must keep building with the kernel and take the same number of iterations as the plain emulator."""
+    from boundmpc_amd import workload
+    P, X, _ = workload.make_batch(2, seed=0)
+    e = emu.solve(P, X, 10, 4, 0.1)
+    c = emu.count_flops(P, X, 10, 4, 0.1)
+    assert c["iterations"] == int(e["iters"].sum()) and c["converged"] == 2
+    assert 1.0e6 < c["flops_per_iteration"] < 2.5e6
