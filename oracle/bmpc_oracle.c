@@ -937,7 +937,8 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
          * A dual residual beyond 1e12 is a numerical breakdown (status 3). */
         if (it == 0) ep_old = ep_mid = 1e300;
         else if (o->stall_window > 0 && it % (o->stall_window / 2) == 0) {
-            if (it >= o->stall_window + it_restart && ep >= STALL_FACTOR * ep_old && ep > 1e-6) {
+            /* (the floor of the test scales with the tolerance: a solve that is asked for 1e-5 and sits at 1e-5 is converging, not stalled) */
+            if (it >= o->stall_window + it_restart && ep >= STALL_FACTOR * ep_old && ep > fmax(1e-6, 10.0 * o->tol)) {
                 /* Long horizons: before giving up, restart the barrier from the CURRENT iterate -- slacks and multipliers re-centred on
                  * a high barrier level (mu = STALL_RESTART_MU, slack push STALL_RESTART_PUSH), filter and inertia history cleared --
                  * at most STALL_RESTARTS times.  On the tight 30-stage batch 3.1 % of the problems crawl at the first barrier level
