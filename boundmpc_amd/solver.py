@@ -14,12 +14,14 @@ NZ, NG = 44, 43
 
 
 class BatchedOCPSolver:
-    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=None, slack_push=1e-2, exact_hessian=True, mu_warm=1e-2, stall_window=None):
+    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=None, slack_push=None, exact_hessian=True, mu_warm=1e-2, stall_window=None):
         self._lib = _lib.load()
         o = _lib.Options()
-        self._lib.bmpc_default_options_for(int(N), ctypes.byref(o))      # mu_init 0.1 for N <= 11, 0.3 for longer horizons
+        self._lib.bmpc_default_options_for(int(N), ctypes.byref(o))      # mu_init 0.1 / slack_push 1e-2 for N <= 11, 3.0 / 0.1 for longer horizons
         if mu_init is None:
             mu_init = o.mu_init
+        if slack_push is None:
+            slack_push = o.slack_push
         o.tol, o.max_iter, o.mu_init, o.slack_push, o.exact_hessian = tol, int(max_iter), mu_init, slack_push, int(exact_hessian)
         o.mu_warm = mu_warm
         if stall_window is not None:

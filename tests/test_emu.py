@@ -223,8 +223,8 @@ def test_emu_long_horizon_above_32_stages_equals_oracle():
     from oracle import c_oracle
     N = 40
     P, X, _ = workload.make_batch(3, seed=5, N=N)
-    r = c_oracle.solve(P, X, N, 4, 0.1, opts=c_oracle.default_opts(mu_init=0.3, stall_window=20), nthreads=3)
-    e = emu.solve(P, X, N, 4, 0.1, opts=emu.default_opts(mu_init=0.3, stall_window=20), nthreads=3)
+    r = c_oracle.solve(P, X, N, 4, 0.1, opts=c_oracle.default_opts(mu_init=3.0, slack_push=0.1, stall_window=20), nthreads=3)
+    e = emu.solve(P, X, N, 4, 0.1, opts=emu.default_opts(mu_init=3.0, slack_push=0.1, stall_window=20), nthreads=3)
     assert (r["status"] == 0).all() and (e["status"] == 0).all()
     assert (r["iters"] == e["iters"]).all()
     d = (e["x"] - r["x"]).reshape(-1, N, 44)[:, :, 8:15]
