@@ -10,7 +10,7 @@
 
 #include "../../include/boundmpc_hip.h"
 
-#define BMPC_HD __host__ __device__
+#define BMPC_HD __host__ __device__ __forceinline__
 #define BMPC_D __device__ __forceinline__
 #define BMPC_SINCOS(x, s, c) sincos(x, s, c)
 #define BMPC_EXP(x) exp(x)

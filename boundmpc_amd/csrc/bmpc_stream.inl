@@ -162,6 +162,7 @@ BMPC_HD inline void jacobian_lin_ddot(const double *q, const double *dq, const d
     const double pre[7] = {0.0, 0.1575 + 0.2025, 0.0, 0.2375 + 0.1825, 0.0, 0.2175 + 0.1825, 0.0};
     const double tool = 0.081 + (0.071 + 0.145);
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0}, A[7][3], O[7][3], P[3];
+#pragma unroll
     for (int j = 0; j < 7; j++) {
         for (int c = 0; c < 3; c++) { o[c] += R[c * 3 + 2] * pre[j]; O[j][c] = o[c]; }
         double cs = BMPC_COS(q[j]), sn = BMPC_SIN(q[j]);
@@ -174,8 +175,12 @@ BMPC_HD inline void jacobian_lin_ddot(const double *q, const double *dq, const d
     }
     for (int c = 0; c < 3; c++) P[c] = o[c] + R[c * 3 + 2] * tool;
     double r[7][3], w[7][3], om[7][3], da[7][3], dr[7][3], dw[7][3], suf[3] = {0, 0, 0}, t[3];
+#pragma unroll
     for (int j = 0; j < 7; j++) { for (int c = 0; c < 3; c++) r[j][c] = P[c] - O[j][c]; cross3s(A[j], r[j], w[j]); }
-    { double acc[3] = {0, 0, 0}; for (int j = 0; j < 7; j++) { for (int c = 0; c < 3; c++) { om[j][c] = acc[c]; acc[c] += dq[j] * A[j][c]; } } }
+    { double acc[3] = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 7; j++) { for (int c = 0; c < 3; c++) { om[j][c] = acc[c]; acc[c] += dq[j] * A[j][c]; } } }
+#pragma unroll
     for (int j = 6; j >= 0; j--) {                      // suffix sums of dq_i w_i (inclusive)
         for (int c = 0; c < 3; c++) suf[c] += dq[j] * w[j][c];
         cross3s(om[j], A[j], da[j]);
@@ -184,8 +189,11 @@ BMPC_HD inline void jacobian_lin_ddot(const double *q, const double *dq, const d
         for (int c = 0; c < 3; c++) dw[j][c] = u1[c] + u2[c];
     }
     double dom[7][3];
-    { double acc[3] = {0, 0, 0}; for (int j = 0; j < 7; j++) { for (int c = 0; c < 3; c++) { dom[j][c] = acc[c]; acc[c] += ddq[j] * A[j][c] + dq[j] * da[j][c]; } } }
+    { double acc[3] = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < 7; j++) { for (int c = 0; c < 3; c++) { dom[j][c] = acc[c]; acc[c] += ddq[j] * A[j][c] + dq[j] * da[j][c]; } } }
     double suf2[3] = {0, 0, 0};
+#pragma unroll
     for (int j = 6; j >= 0; j--) {
         for (int c = 0; c < 3; c++) suf2[c] += ddq[j] * w[j][c] + dq[j] * dw[j][c];
         double dda[3], ddr[3], u1[3], u2[3], u3[3];
@@ -200,6 +208,7 @@ BMPC_HD inline void forward_kinematics(const double *q, const double *dq, Fk &F)
     const double pre[7] = {0.0, 0.1575 + 0.2025, 0.0, 0.2375 + 0.1825, 0.0, 0.2175 + 0.1825, 0.0};
     const double tool = 0.081 + (0.071 + 0.145);
     double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0}, A[7][3], O[7][3];
+#pragma unroll
     for (int j = 0; j < 7; j++) {
         for (int c = 0; c < 3; c++) { o[c] += R[c * 3 + 2] * pre[j]; O[j][c] = o[c]; }
         double cs = BMPC_COS(q[j]), sn = BMPC_SIN(q[j]);
@@ -213,14 +222,17 @@ BMPC_HD inline void forward_kinematics(const double *q, const double *dq, Fk &F)
     for (int c = 0; c < 3; c++) F.p[c] = o[c] + R[c * 3 + 2] * tool;
     mat_to_rotvec(R, F.p + 3);
     double Wc[7][3];
+#pragma unroll
     for (int j = 0; j < 7; j++) {
         const double r[3] = {F.p[0] - O[j][0], F.p[1] - O[j][1], F.p[2] - O[j][2]};
         cross3s(A[j], r, Wc[j]);
         for (int c = 0; c < 3; c++) { F.J[c * 7 + j] = Wc[j][c]; F.J[(3 + c) * 7 + j] = A[j][c]; }
     }
     for (int i = 0; i < 42; i++) F.dJ[i] = 0.0;
+#pragma unroll
     for (int i = 0; i < 7; i++) {
         const double f = dq[i];
+#pragma unroll
         for (int j = 0; j < 7; j++) {
             double v[3];
             if (i <= j) cross3s(A[i], Wc[j], v); else cross3s(A[j], Wc[i], v);
