@@ -8,7 +8,7 @@ from boundmpc_amd import BatchedOCPSolver, workload
 from oracle import c_oracle
 worst = 0.0
 BIG = len(sys.argv) > 1 and sys.argv[1] == "big"      # ~50 000 problems instead of ~5 000
-CASES = ((10, False, 4096, tuple(range(10, 20))), (30, True, 2048, (5, 6)), (5, False, 1024, (6,)), (20, False, 1024, (7,)), (16, True, 1024, (8,))) if BIG \
+CASES = ((10, False, 4096, tuple(range(10, 20))), (30, True, 2048, (5, 6)), (5, False, 1024, (6,)), (20, False, 1024, (7,)), (16, True, 1024, (8,)), (40, False, 512, (9,)), (36, True, 256, (3,))) if BIG \
     else ((10, False, 1024, (1, 2, 3, 4)), (30, True, 128, (5,)), (5, False, 256, (6,)))
 for (N, tight, B, seeds) in CASES:
     s = BatchedOCPSolver(N, 4, 0.1)
