@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Fixture G12: packing and post-processing for other horizons / window sizes than the experiments' (N=10, S=4).
 
-The reference's own BoundMPC (stub solver, as for G6/G7) is constructed with (n, nr_segs) = (5, 2), (8, 3), (20, 4) on the
+The reference's own BoundMPC (stub solver, as for G6/G7) is constructed with (n, nr_segs) = (5, 2), (8, 3), (20, 4), (6, 5), (12, 6) on the
 experiment-2 path (asymmetric tubes, mixed bases) and driven in closed loop for a few ticks, the CPU oracle standing where Ipopt would:
 recorded per tick: the arguments of step(), (x0, p) handed to the solver, the solution used, traj_data and the advanced state.
 Build container only:  python tests/golden/make_g12.py"""
@@ -25,7 +25,7 @@ def main():
     rm = RobotModel()
     w = get_default_weights()
     out = {}
-    for (N, S, dt, ticks) in ((5, 2, 0.1, 12), (8, 3, 0.08, 16), (20, 4, 0.1, 8)):
+    for (N, S, dt, ticks) in ((5, 2, 0.1, 12), (8, 3, 0.08, 16), (20, 4, 0.1, 8), (6, 5, 0.1, 10), (12, 6, 0.1, 6)):
         setup = mg.experiment_setup(2, RobotModel, get_default_path, R)
         mpc, stub = mg.make_mpc(B, setup, w, n=N, dt=dt, nr_segs=S)
         mask = mg.UNDEF_MASK(S)

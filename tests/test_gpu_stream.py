@@ -259,7 +259,7 @@ def test_replanning_on_the_device_matches_reference_update_g11():
     sb.close(); solver.close()
 
 
-@pytest.mark.parametrize("N,S", [(5, 2), (8, 3), (20, 4)])
+@pytest.mark.parametrize("N,S", [(5, 2), (8, 3), (20, 4), (6, 5), (12, 6)])
 def test_device_tick_other_horizons_and_windows_g12(N, S):
     """The whole device tick {pack, solve, post} for other (n, nr_segs) than the experiments': closed loop against the reference's own
     step() driven with the CPU oracle (fixture G12) -- parameter layout 141 + 91 S, warm start 44 N, N <= 11 and N > 11 kernels."""

@@ -286,7 +286,7 @@ def test_update_replanning_g11():
         np.testing.assert_allclose(mpc.iw_ref, d["iw_ref"][i], atol=1e-12)
 
 
-@pytest.mark.parametrize("N,S", [(5, 2), (8, 3), (20, 4)])
+@pytest.mark.parametrize("N,S", [(5, 2), (8, 3), (20, 4), (6, 5), (12, 6)])
 def test_pack_and_postprocess_other_horizons_and_windows_g12(N, S):
     """Host mirror against the reference's own step()/compute_return_data for other (n, nr_segs) than the experiments' (fixture G12,
     experiment-2 path: asymmetric tubes, mixed bases): the 141 + 91 S parameter layout and the 44 N warm start, tick by tick."""

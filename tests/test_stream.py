@@ -203,7 +203,7 @@ def test_stream_replanning_matches_reference_update_g11():
         np.testing.assert_allclose(ss[10:13], d["iw_ref"][i], atol=1e-12)
 
 
-@pytest.mark.parametrize("N,S", [(5, 2), (8, 3), (20, 4)])
+@pytest.mark.parametrize("N,S", [(5, 2), (8, 3), (20, 4), (6, 5), (12, 6)])
 def test_stream_functions_other_horizons_and_windows_g12(N, S):
     """stream_pack / stream_post for other (n, nr_segs) against the reference's own step() (fixture G12), open loop over its ticks."""
     d6 = np.load(os.path.join(G, "g6_pack_exp2_tick0.npz"))
