@@ -175,7 +175,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
         if (per_cu < 1) per_cu = 1;
         h->grid = per_cu * prop.multiProcessorCount;
         h->scr_stride = bmpc::make_scr(N).size;
-        // the per-wave workspace slabs (123 KB at N=10) are allocated on the first solve, for min(B, grid) waves, and grow on demand:
+        // the per-wave workspace slabs (148 KB at N=10, 444 KB at N=30) are allocated on the first solve, for min(B, grid) waves, and grow on demand:
         // a single-problem handle (the nlpsol shim of one BoundMPC object) holds one slab, not 1024
         ok = hipMalloc(&h->counter, sizeof(int)) == hipSuccess
           && hipMalloc(&h->prof, 32 * sizeof(unsigned long long)) == hipSuccess
