@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("BOUNDMPC_HIP_LIB") or os.path.join(HERE, "csrc", "lib
 SYMBOLS = ["bmpc_default_options", "bmpc_default_options_for", "bmpc_error_string", "bmpc_create", "bmpc_destroy", "bmpc_num_vars", "bmpc_num_cons",
            "bmpc_num_params", "bmpc_get_bounds", "bmpc_solve_batch", "bmpc_solve_batch_host", "bmpc_set_timing",
            "bmpc_last_kernel_ms", "bmpc_kernel_ms", "bmpc_launch_info", "bmpc_state_len", "bmpc_solve_batch_warm", "bmpc_graph_create",
-           "bmpc_graph_launch", "bmpc_graph_destroy", "bmpc_stream_lengths", "bmpc_stream_pack", "bmpc_stream_post",
+           "bmpc_graph_launch", "bmpc_graph_destroy", "bmpc_stream_lengths", "bmpc_stream_pack", "bmpc_stream_pack_rt", "bmpc_stream_post",
            "bmpc_stream_graph_create", "bmpc_set_latency_buffer", "bmpc_stream_set_rt_feasibility_tol", "bmpc_stream_tick"]
 
 
@@ -59,6 +59,7 @@ def load():
     lib.bmpc_graph_destroy.argtypes = [vp]
     lib.bmpc_stream_lengths.argtypes = [vp] + [ctypes.POINTER(ci)] * 4
     lib.bmpc_stream_pack.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp]
+    lib.bmpc_stream_pack_rt.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp]
     lib.bmpc_stream_post.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp]
     lib.bmpc_stream_set_rt_feasibility_tol.argtypes = [vp, cd]
     lib.bmpc_stream_tick.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp]

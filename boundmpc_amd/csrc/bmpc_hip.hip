@@ -118,14 +118,28 @@ struct DevGuard {
     explicit DevGuard(int dev) : prev(dev), changed(false) { if (hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess; }
     ~DevGuard() { if (changed) hipSetDevice(prev); }
 };
+// A stream the CALLER is capturing (e.g. a torch CUDA graph around solve_batch / stream_tick) takes neither: waiting there on an event
+// recorded outside the capture invalidates the capture, and recording order_ev inside it would turn it into a captured event that later
+// direct launches then wait on.  Ordering of such launches against the handle's other work is the caller's (include/boundmpc_hip.h).
+static bool caller_is_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
 static int order_before(bmpc_handle *h, hipStream_t st) {
+    if (caller_is_capturing(st)) return BMPC_OK;
     if (h->order_valid && st != h->order_stream) HIPCHK(hipStreamWaitEvent(st, h->order_ev, 0));
     return BMPC_OK;
 }
 static int order_after(bmpc_handle *h, hipStream_t st) {
+    if (caller_is_capturing(st)) return BMPC_OK;
     HIPCHK(hipEventRecord(h->order_ev, st));
     h->order_stream = st; h->order_valid = true;
     return BMPC_OK;
+}
+// host wait for the last launch of THIS handle (every launch records order_ev): what teardown and workspace growth need -- not a
+// device-wide drain, which would stall every other stream and handle of the process
+static void wait_for_handle(bmpc_handle *h) {
+    if (h->order_valid) hipEventSynchronize(h->order_ev);
 }
 static void handle_release(bmpc_handle *h) {
     if (--h->refs > 0) return;
@@ -197,7 +211,7 @@ extern "C" int bmpc_destroy(bmpc_handle *h) {
     if (!h || h->closed) return BMPC_ERR_ARG;
     {
         DevGuard dg(h->dev);
-        hipDeviceSynchronize();    // launches are asynchronous: nothing of this handle may still be running on its workspace
+        wait_for_handle(h);        // launches are asynchronous: nothing of this handle may still be running on its workspace
     }
     // captured graphs carry the addresses of the workspace and of the work queue: while one is alive the memory stays, the handle
     // only stops accepting work (bmpc_graph_launch of such a graph returns BMPC_ERR_ARG); the last bmpc_graph_destroy frees it
@@ -229,8 +243,8 @@ extern "C" int bmpc_get_bounds(const bmpc_handle *h, double *lbx, double *ubx, d
     return BMPC_OK;
 }
 
-// workspace for `waves` resident waves; growing frees the old slabs, which no launch may still be using: the device is drained
-// first, and captured graphs (which carry the old address) forbid growth -- size the first solve / capture for the largest batch
+// workspace for `waves` resident waves; growing frees the old slabs, which no launch may still be using: the handle's last launch is
+// waited for first, and captured graphs (which carry the old address) forbid growth -- size the first solve / capture for the largest batch
 static int ensure_scratch(bmpc_handle *h, int waves) {
     if (waves <= h->scr_waves) return BMPC_OK;
     DevGuard dg(h->dev);
@@ -238,7 +252,7 @@ static int ensure_scratch(bmpc_handle *h, int waves) {
         fprintf(stderr, "boundmpc_hip: a larger batch needs a larger workspace, but %d captured graph(s) hold the current one\n", h->graphs_alive);
         return BMPC_ERR_ARG;
     }
-    if (h->scratch) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(h->scratch)); h->scratch = nullptr; h->scr_waves = 0; }
+    if (h->scratch) { wait_for_handle(h); HIPCHK(hipFree(h->scratch)); h->scratch = nullptr; h->scr_waves = 0; }
     HIPCHK(hipMalloc(&h->scratch, sizeof(double) * (size_t)h->scr_stride * waves));
     h->scr_waves = waves;
     return BMPC_OK;
@@ -349,9 +363,9 @@ extern "C" int bmpc_graph_launch(bmpc_graph *gr, void *hip_stream) {
 extern "C" int bmpc_graph_destroy(bmpc_graph *gr) {
     if (!gr) return BMPC_ERR_ARG;
     bmpc_handle *h = gr->h;
-    {
-        DevGuard dg(h ? h->dev : 0);
-        hipDeviceSynchronize();        // a replay of this graph may still be in flight
+    if (h) {
+        DevGuard dg(h->dev);
+        wait_for_handle(h);            // a replay of this graph may still be in flight (bmpc_graph_launch records the handle's event behind it)
     }
     hipGraphExecDestroy(gr->exec); hipGraphDestroy(gr->graph); delete gr;
     if (h) { if (h->graphs_alive > 0) h->graphs_alive--; handle_release(h); }     // the last reference of a closed handle frees it
@@ -415,11 +429,12 @@ extern "C" int bmpc_kernel_ms(bmpc_handle *h, int back, float *ms) {
 extern "C" int bmpc_last_kernel_ms(bmpc_handle *h, float *ms) { return bmpc_kernel_ms(h, 0, ms); }
 // ---- receding-horizon streams: device-side packing / post-processing, one 64-lane wave per stream ----
 __global__ void __launch_bounds__(64) bmpc_stream_pack_kernel(int N, int S, int B, const double *path, int path_stride, double *ss, const double *rb,
-                                                             double *p, double *x0, double *dual) {
+                                                             double *p, double *x0, double *dual, const double *xlast) {
     __shared__ double sh[bmpcs::SH_LEN];
     const int b = blockIdx.x;
     bmpcs::stream_pack(N, S, path + (long long)b * path_stride, path_stride / bmpcs::PT_LEN, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
-                       p + (long long)b * (141 + 91 * S), x0 + (long long)b * 44 * N, dual ? dual + (long long)b * (57 * N + 2) : nullptr, nullptr, sh, threadIdx.x, 64);
+                       p + (long long)b * (141 + 91 * S), x0 + (long long)b * 44 * N, dual ? dual + (long long)b * (57 * N + 2) : nullptr,
+                       xlast ? xlast + (long long)b * 44 * N : nullptr, sh, threadIdx.x, 64);
 }
 __global__ void __launch_bounds__(64) bmpc_stream_post_kernel(int N, int S, int B, double h, const double *path, int path_stride, double *ss, double *rb,
                                                              const double *x, const double *g, const int *status, double *traj, int flags, double rt_tol) {
@@ -493,7 +508,8 @@ extern "C" int bmpc_stream_tick(bmpc_handle *h, int B, const double *path, int p
     { const int rc_ = ensure_scratch(h, B < h->grid ? B : h->grid); if (rc_ != BMPC_OK) return rc_; }
     hipStream_t st = (hipStream_t)hip_stream;
     if (tick_fusable(h, B)) return enqueue_tick(h, B, path, path_entries, sstate, robot, p, x0, dual_state, max_iter, x, g, iters, status, kkt, traj, flags, st, false);
-    int rc = bmpc_stream_pack(h, B, path, path_entries, sstate, robot, p, x0, dual_state, st);
+    // real-time mode: the warm start continues from the iterate of the previous tick on every launch shape (fused or not)
+    int rc = bmpc_stream_pack_rt(h, B, path, path_entries, sstate, robot, p, x0, dual_state, (flags & 2) ? x : nullptr, st);
     if (rc == BMPC_OK) rc = enqueue_solve(h, B, p, x0, dual_state, max_iter, x, g, nullptr, nullptr, nullptr, iters, status, kkt, st, h->timing != 0);
     if (rc == BMPC_OK) rc = bmpc_stream_post(h, B, path, path_entries, sstate, robot, x, g, status, traj, flags, st);
     return rc;
@@ -511,12 +527,16 @@ extern "C" int bmpc_stream_lengths(const bmpc_handle *h, int *path_entry, int *s
 }
 extern "C" int bmpc_stream_pack(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, const double *robot, double *p, double *x0,
                                 double *dual_state, void *hip_stream) {
+    return bmpc_stream_pack_rt(h, B, path, path_entries, sstate, robot, p, x0, dual_state, nullptr, hip_stream);
+}
+extern "C" int bmpc_stream_pack_rt(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, const double *robot, double *p, double *x0,
+                                   double *dual_state, const double *xlast, void *hip_stream) {
     if (!h || B < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !p || !x0))) return BMPC_ERR_ARG;
     if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // the stream kernels place one lane per stage below fixed roles at lanes 32..: horizons up to 32
     if (B == 0) return BMPC_OK;
     if (h->closed) return BMPC_ERR_ARG;
     hipLaunchKernelGGL(bmpc_stream_pack_kernel, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, path, path_entries * bmpcs::PT_LEN,
-                       sstate, robot, p, x0, dual_state);
+                       sstate, robot, p, x0, dual_state, xlast);
     HIPCHK(hipGetLastError());
     return BMPC_OK;
 }
@@ -547,7 +567,7 @@ extern "C" int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *pat
     if (rc == BMPC_OK) {
         if (tick_fusable(h, B)) rc = enqueue_tick(h, B, path, path_entries, sstate, robot, p, x0, dual_state, max_iter, x, g, iters, status, kkt, traj, flags, cs, true);
         else {
-            rc = bmpc_stream_pack(h, B, path, path_entries, sstate, robot, p, x0, dual_state, cs);
+            rc = bmpc_stream_pack_rt(h, B, path, path_entries, sstate, robot, p, x0, dual_state, (flags & 2) ? x : nullptr, cs);
             if (rc == BMPC_OK) rc = enqueue_solve(h, B, p, x0, dual_state, max_iter, x, g, nullptr, nullptr, nullptr, iters, status, kkt, cs, false, true);
             if (rc == BMPC_OK) rc = bmpc_stream_post(h, B, path, path_entries, sstate, robot, x, g, status, traj, flags, cs);
         }

@@ -174,10 +174,13 @@ class StreamBatch:
         import torch
         return ctypes.c_void_p((stream if stream is not None else torch.cuda.current_stream(self.path.device)).cuda_stream)
 
-    def pack(self, warm_dual=False, stream=None):
+    def pack(self, warm_dual=False, stream=None, continue_rejected=False):
+        """continue_rejected (real-time mode): the warm start continues from the solver's last iterate when the acceptance rule rejected
+        it (bmpc_stream_pack_rt with xlast = x), as the fused tick does; False = restart from the last accepted plan (the reference)."""
         dp = lambda t: ctypes.c_void_p(t.data_ptr())
-        _lib.check(self.solver._lib.bmpc_stream_pack(self.solver._h, self.B, dp(self.path), self.entries, dp(self.state), dp(self.robot), dp(self.p),
-                                                     dp(self.x0), dp(self.dual) if warm_dual else None, self._stream(stream)), "bmpc_stream_pack")
+        _lib.check(self.solver._lib.bmpc_stream_pack_rt(self.solver._h, self.B, dp(self.path), self.entries, dp(self.state), dp(self.robot), dp(self.p),
+                                                        dp(self.x0), dp(self.dual) if warm_dual else None, dp(self.x) if continue_rejected else None,
+                                                        self._stream(stream)), "bmpc_stream_pack_rt")
 
     def post(self, simulate=True, stream=None, accept_capped=False):
         dp = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -199,7 +202,7 @@ class StreamBatch:
                 dp(self.dual) if warm_dual else None, int(max_iter), dp(self.x), dp(self.g), dp(self.iters), dp(self.status), dp(self.kkt),
                 dp(self.traj), int(bool(simulate)) | (2 if accept_capped else 0), self._stream(stream)), "bmpc_stream_tick")
             return
-        self.pack(warm_dual, stream)
+        self.pack(warm_dual, stream, continue_rejected=accept_capped)      # the same continuation rule as the fused launch
         out = dict(x=self.x, g=self.g, iters=self.iters, status=self.status, kkt=self.kkt)
         self.solver.solve_batch(self.p, self.x0, out=out, want=("g", "iters", "status", "kkt"), stream=stream,
                                 state=self.dual if warm_dual else None, max_iter=max_iter)

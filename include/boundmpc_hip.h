@@ -22,8 +22,9 @@
  *   x0, x  [B][44*N]  stage variables z_k = [u(7) u_phi | q dq ddq | p(6) | v(6) | phi dphi ddphi] (:90-153)
  *   g      [B][43*N]  constraints in the reference's order/form (:272-349)
  *   lam_g  [B][43*N]  multipliers of g (sign: L = f + lam_g.g), lam_x [B][44*N] multipliers of lbx <= x <= ubx
- *   f, kkt [B], iters [B], status [B]  (0 converged, 1 max_iter reached, 2 stalled at a point of local infeasibility -- no progress
- *                                        of the primal infeasibility over 40 iterations --, 3 numerical failure)
+ *   f, kkt [B], iters [B], status [B]  (0 converged, 1 max_iter reached, 2 stalled at a point of local infeasibility -- the primal
+ *                                        infeasibility has not halved over `stall_window` iterations (40 for N <= 11; 20 for longer horizons,
+ *                                        where up to three barrier restarts from the stalled iterate come first) --, 3 numerical failure)
  * lbx/ubx/lbg/ubg are structural constants of the formulation (robot limits, 36 equalities
  * + 7 inequalities per stage) and do not cross the ABI per call; bmpc_get_bounds returns them.
  *
@@ -32,8 +33,8 @@
  * failure is data (status[]), as in the reference (BoundMPC.py:465-489).
  * Thread-safety: one in-flight bmpc_solve_batch per handle.
  * Memory: the handle's device workspace (one 148 KB slab per resident wave at N=10, 444 KB at N=30, 592 KB at N=40) is allocated by the first solve
- * or graph capture, for min(B, resident waves) waves, and grows when a later call brings a larger batch (the device is drained
- * first); while captured graphs of the handle exist it cannot grow -- capture for the largest batch first.
+ * or graph capture, for min(B, resident waves) waves, and grows when a later call brings a larger batch (after a host wait for
+ * the handle's own last launch; other streams and handles of the process are not stalled); while captured graphs of the handle exist it cannot grow -- capture for the largest batch first.
  */
 #ifndef BOUNDMPC_HIP_H
 #define BOUNDMPC_HIP_H
@@ -46,15 +47,16 @@ typedef struct bmpc_handle bmpc_handle;
 typedef struct {
     double tol;         /* KKT tolerance, Ipopt-style scaled error (reference: 'tol': 10e-6, BoundMPC.py:121); default 1e-8 */
     int max_iter;       /* reference: 500 (BoundMPC.py:122) */
-    double mu_init;     /* initial barrier parameter: 0.1 (Ipopt's default) for N <= 11, 0.3 for longer horizons, whose cold start is far
-                           from the solution (N=30 tight: 98 % instead of 95 % converged, 39 instead of 46 iterations); see bmpc_default_options_for */
+    double mu_init;     /* initial barrier parameter: 0.1 (Ipopt's default) for N <= 11, 3.0 for longer horizons, whose cold start is far
+                           from the solution and violates the tube rows (N=30 tight: 35 instead of 46 iterations on average); see bmpc_default_options_for */
     double mu_min_fac;  /* final barrier = tol * mu_min_fac */
-    double slack_push;  /* minimum initial slack of an inequality row (Ipopt bound_push 1e-2) */
+    double slack_push;  /* minimum initial slack of an inequality row: 1e-2 (Ipopt bound_push) for N <= 11, 0.1 for longer horizons */
     int exact_hessian;  /* 1: exact Lagrangian Hessian (reference uses CasADi's exact Hessian); 0: Gauss-Newton */
     int verbose;
     double mu_warm;     /* warm start (bmpc_solve_batch_warm): the barrier restarts at clamp(stored mu, mu_warm, mu_init); default 1e-2 (round 2: closed loops converge in 9.5 instead of 11.2 iterations with it; 1e-4 jams the iterate against moved constraints) */
     int stall_window;   /* status 2 when the primal infeasibility has not halved over this many iterations (checked every
-                           stall_window/2 iterations); 0 = never; default 40 (reference: Ipopt's restoration phase / "local infeasibility") */
+                           stall_window/2 iterations); 0 = never; default 40 for N <= 11, 20 for longer horizons (reference: Ipopt's restoration
+                           phase / "local infeasibility") */
 } bmpc_options;
 
 enum { BMPC_OK = 0, BMPC_ERR_ARG = 1, BMPC_ERR_HIP = 2, BMPC_ERR_NOGPU = 4 };
@@ -97,7 +99,9 @@ int bmpc_solve_batch_warm(bmpc_handle *h, int B, const double *p, const double *
 /* The same step captured once into a hipGraph (work-queue reset + solver kernel) and replayed per tick with hipGraphLaunch: the
  * buffers are fixed at capture time, the caller refreshes their contents (p, x0, state) between launches.  state may be NULL
  * (cold starts).  Launches of one handle (direct or replayed) share its workspace and work queue: the library orders them against each
- * other with an event whatever streams the caller uses, so they never overlap.  A graph keeps the handle's workspace and the latency
+ * other with an event whatever streams the caller uses, so they never overlap (exception: a launch on a stream the CALLER is capturing
+ * -- a graph of the caller's own around these entry points -- neither waits for nor records that event; ordering such a graph against the
+ * handle's other work is the caller's).  A graph keeps the handle's workspace and the latency
  * buffer registered at capture time (re-capture after bmpc_set_latency_buffer) and holds a reference on the handle: bmpc_destroy of
  * a handle with live graphs closes it (those graphs then refuse to launch, BMPC_ERR_ARG) and the last bmpc_graph_destroy frees it.
  * bmpc_graph_launch(g, NULL): the replay runs on a non-blocking stream of the handle, ordered by events after the work the legacy
@@ -121,7 +125,13 @@ int bmpc_graph_destroy(bmpc_graph *g);
  *                       reference: a fixed small number of solver iterations per tick, status 1 is the normal outcome): the
  *                       reference's acceptance rule BoundMPC.py:460-465 decides with the threshold of
  *                       bmpc_stream_set_rt_feasibility_tol in place of 1e-4; an iterate that fails it is not applied, the
- *                       previous plan is replayed (BoundMPC.py:468-489).
+ *                       previous plan is replayed (BoundMPC.py:468-489).  The next tick's warm start then CONTINUES FROM THE REJECTED
+ *                       ITERATE (shifted like an accepted plan; its multipliers are in the dual state anyway) instead of the last
+ *                       accepted plan -- the iterations spent on it are kept; the reference would restart from the accepted plan.
+ *                       bmpc_stream_tick / bmpc_stream_graph_create do this on every launch shape (fused or three kernels); callers of
+ *                       the separate entry points get it by packing with bmpc_stream_pack_rt(..., xlast = the solver's x buffer, ...);
+ *                       plain bmpc_stream_pack (xlast = NULL) restarts from the accepted plan as the reference does.  A numerical
+ *                       failure (status 3) is never continued from.
  * All buffers are DEVICE doubles, one row per stream, row lengths from bmpc_stream_lengths:
  *   path   [B][path_entries][path_entry]  static via-point table (built on the host once per path; layout in
  *                                          boundmpc_amd/csrc/bmpc_stream.inl, builder boundmpc_amd.stream.path_table)
@@ -135,6 +145,9 @@ int bmpc_graph_destroy(bmpc_graph *g);
 int bmpc_stream_lengths(const bmpc_handle *h, int *path_entry, int *state, int *robot, int *traj);
 int bmpc_stream_pack(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, const double *robot, double *p, double *x0,
                      double *dual_state, void *hip_stream);
+/* bmpc_stream_pack with the real-time continuation: xlast (DEVICE [B][44 N] or NULL) = the iterate the solver produced last tick */
+int bmpc_stream_pack_rt(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, const double *robot, double *p, double *x0,
+                        double *dual_state, const double *xlast, void *hip_stream);
 int bmpc_stream_post(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, const double *x, const double *g,
                      const int *status, double *traj, int flags, void *hip_stream);
 /* Threshold on the summed violation of g (beyond 1e-6 per row) below which bmpc_stream_post applies an iteration-capped iterate in

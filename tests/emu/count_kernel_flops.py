@@ -12,7 +12,9 @@ from boundmpc_amd import workload      # noqa: E402
 from oracle import c_oracle            # noqa: E402
 from tests.emu import emu              # noqa: E402
 
-out = {"convention": "add / sub / mul = 1, a*b+c = 2, division / root / transcendental = 1 (tallied in `special`); kernel text: summed over the lanes "
+import bench                            # noqa: E402  (kernel_text_hash: the count is tied to the kernel text it was taken on)
+out = {"kernel_hash": bench.kernel_text_hash(),
+       "convention": "add / sub / mul = 1, a*b+c = 2, division / root / transcendental = 1 (tallied in `special`); kernel text: summed over the lanes "
                      "of every phase (predicated phases evaluate every role in every lane and count as executed); oracle: the dense scalar restatement",
        "configs": []}
 for (N, tight, B, seed, label) in ((10, False, 64, 0, "configs[1]/[2]: N=10"), (30, True, 16, 2, "configs[3]: N=30, tight tubes")):

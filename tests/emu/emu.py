@@ -67,19 +67,21 @@ def stream_lengths(N):
     return dict(path_entry=out[0], state=out[1], robot=out[2], traj=out[3])
 
 
-def stream_pack(N, S, path, ss, rb, dual=None):
-    """path [M][48], ss (updated in place), rb -> (p, x0)"""
+def stream_pack(N, S, path, ss, rb, dual=None, xlast=None):
+    """path [M][48], ss (updated in place), rb -> (p, x0); xlast: the solver's previous iterate (real-time continuation, bmpc_stream_pack_rt)"""
     p = np.zeros(141 + 91 * S); x0 = np.zeros(44 * N)
     assert path.flags.c_contiguous and ss.flags.c_contiguous and rb.flags.c_contiguous
-    lib().bmpc_emu_stream_pack(ctypes.c_int(N), ctypes.c_int(S), _p(path), _p(ss), _p(rb), _p(p), _p(x0), _p(dual) if dual is not None else None)
+    lib().bmpc_emu_stream_pack(ctypes.c_int(N), ctypes.c_int(S), _p(path), _p(ss), _p(rb), _p(p), _p(x0), _p(dual) if dual is not None else None,
+                               _p(np.ascontiguousarray(xlast, dtype=np.float64)) if xlast is not None else None)
     return p, x0
 
 
-def stream_post(N, S, h, path, ss, rb, x, g, status, simulate=True, rt_tol=1e-4):
+def stream_post(N, S, h, path, ss, rb, x, g, status, simulate=True, rt_tol=1e-4, flags=0):
+    """flags: extra bits of the post flags (bit 1 = real-time acceptance rule)"""
     traj = np.zeros(stream_lengths(N)["traj"])
     x = np.ascontiguousarray(x, dtype=np.float64); g = np.ascontiguousarray(g, dtype=np.float64)
     lib().bmpc_emu_stream_post(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), _p(path), _p(ss), _p(rb), _p(x), _p(g), ctypes.c_int(int(status)),
-                               _p(traj), ctypes.c_int(int(simulate)), ctypes.c_double(rt_tol))
+                               _p(traj), ctypes.c_int(int(simulate) | int(flags)), ctypes.c_double(rt_tol))
     return traj
 
 

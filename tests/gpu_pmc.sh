@@ -7,6 +7,14 @@ EXTRA="$*"
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/pmc_$TAG
 mkdir -p $OUT
+# an unprofiled run of the same command first: its kernel time and configuration go into the JSON next to the counters
+timeout -k 10 300 python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --seed-sweep 0 --workers 1 $EXTRA > $OUT/bench.json 2> $OUT/bench.err || { echo "bench failed"; exit 1; }
+python3 - <<PY
+import json
+d = json.loads(open("$OUT/bench.json").read().strip().splitlines()[-1])
+c = d["config"]
+json.dump({"batch": c["global_batch"], "N": c["horizon"], "tight": "tight tubes" in c["workload"], "kernel_ms": d["roofline"]["kernel_ms"]}, open("$OUT/cfg.json", "w"))
+PY
 cd /tmp; export TMPDIR=/tmp
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
@@ -30,7 +38,24 @@ with open("$OUT/summary.txt", "w") as o:
     for k in sorted(tot):
         line = f"{k:32s} per-dispatch {tot[k]/n[k]:.6g}  (dispatches {n[k]})"
         print(line); o.write(line + "\n")
-# machine-readable copy for bench.py (profiles/pmc_current.json): per-dispatch means of every counter
-import json
-json.dump({k: tot[k] / n[k] for k in tot}, open("$OUT/summary.json", "w"), indent=1)
+# machine-readable copy for bench.py (profiles/pmc_current.json): per-dispatch means of every counter, tied to the kernel text they
+# were taken on (sha256[:16] of bmpc_wave.inl + bmpc_hip.hip = bench.kernel_text_hash) and to the configuration of the bench command
+import json, sys
+sys.path.insert(0, "$ROOT")
+import bench
+rec = {k: tot[k] / n[k] for k in tot}
+json.dump(rec, open("$OUT/summary.json", "w"), indent=1)
+cfg = json.load(open("$OUT/cfg.json")) if __import__("os").path.exists("$OUT/cfg.json") else {}
+cur = {"kernel_hash": bench.kernel_text_hash(), "batch": cfg.get("batch", 1024), "N": cfg.get("N", 10), "tight": cfg.get("tight", False)}
+if "FETCH_SIZE" in rec: cur["FETCH_SIZE_KB"] = rec["FETCH_SIZE"]
+if "WRITE_SIZE" in rec: cur["WRITE_SIZE_KB"] = rec["WRITE_SIZE"]
+for k in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+          "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU_MFMA_F64"):
+    if k in rec: cur[k] = rec[k]
+cur["kernel_ms"] = cfg.get("kernel_ms")
+cur["source"] = "tests/gpu_pmc.sh $TAG: separate rocprofv3 --pmc passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --seed-sweep 0 --workers 1 $EXTRA`; kernel_ms from an unprofiled bench run of the same call"
+cur["note"] = ("FETCH_SIZE + WRITE_SIZE (KB x 1024) per launch, separate --pmc passes; raw counter values: the kernel's 8-B-per-lane accesses are an uncalibrated "
+               "width in the guide (no x2 correction applied); this is per-wave workspace traffic between L2 and Infinity Cache/HBM, not input re-reads")
+json.dump(cur, open("$OUT/pmc_current.json", "w"), indent=1)
+print("wrote $OUT/pmc_current.json (copy to profiles/ when this is the kernel of the round):", cur["kernel_hash"])
 PY

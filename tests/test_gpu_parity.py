@@ -425,6 +425,17 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["value"] > 0 and "workload" in d["config"] and d["config"]["solved_fraction"] == 1.0
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"], k
+    # counter / flop files are tied to the kernel text by a hash: a file of another kernel text must show as stale, never as a number
+    sys.path.insert(0, root)
+    import bench
+    for name, key in (("pmc_current.json", "traffic_note"), ("flops_current.json", "flops_source")):
+        rec = json.load(open(os.path.join(root, "profiles", name)))
+        assert "kernel_hash" in rec, name
+        if rec["kernel_hash"] != bench.kernel_text_hash():
+            where = d["roofline"] if key == "traffic_note" else d["roofline_fp64"]
+            assert "stale" in where[key], (name, where[key])
+            if key == "traffic_note":
+                assert d["roofline"]["traffic"] is None
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"], k

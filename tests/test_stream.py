@@ -229,3 +229,43 @@ def test_stream_functions_other_horizons_and_windows_g12(N, S):
         np.testing.assert_allclose(td["p"], d[k + "traj_p"][i], atol=1e-11)
         assert abs(ss[bstream.SS["PHI"]] - d[k + "phi_current"][i]) < 1e-12
         _same_rotation(ss[7:10], d[k + "pr_ref"][i], 1e-11)
+
+
+def test_realtime_continuation_rule_of_stream_pack():
+    """Real-time mode (flag bit 1 of stream_post, not in the reference): an iteration-capped iterate that fails the acceptance rule is not
+    applied -- the plant replays the accepted plan -- and the NEXT warm start continues from the rejected iterate when stream_pack is given it
+    (bmpc_stream_pack_rt / the fused and the unfused tick), while plain stream_pack (xlast = NULL) restarts from the last accepted plan as the
+    reference does (BoundMPC.py:322-375,468-489).  A numerical failure (status 3) is never continued from."""
+    N = 10
+    q0 = workload.random_q0(3, seed=7)[1]
+    mpc, p0fk = workload.make_mpc(q0, solver=_Oracle())
+    T, M = bstream.path_table(mpc.ref_path)
+    ss = bstream.initial_state(mpc, N); ss[bstream.SS["NENT"]] = M
+    rb = bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([mpc.phi_max[0], 0, 0]), np.zeros(7))
+    sol = _Oracle()
+    for t in range(3):      # three accepted ticks (converged solves)
+        p, x0 = emu.stream_pack(N, 4, T, ss, rb)
+        x, g, st, _ = sol.solve(p, x0)
+        emu.stream_post(N, 4, 0.1, T, ss, rb, x, g, st, simulate=True, flags=2)
+    accepted = ss[bstream.SS["PREV"]:bstream.SS["PREV"] + 44 * N].copy()
+    # tick 3: a capped iterate (status 1) with a large constraint violation -> rejected, previous plan replayed
+    p, x0 = emu.stream_pack(N, 4, T, ss, rb)
+    x, g, st, _ = sol.solve(p, x0)
+    x_bad = x + 1e-2 * np.random.default_rng(0).standard_normal(x.shape); g_bad = g.copy(); g_bad[:36] += 1e-2
+    tr = emu.stream_post(N, 4, 0.1, T, ss, rb, x_bad, g_bad, 1, simulate=True, flags=2, rt_tol=1e-4)
+    _, fl = bstream.unpack_traj(tr, N)
+    assert fl["using_previous"] and int(ss[bstream.SS["ERRCNT"]]) == 1
+    np.testing.assert_array_equal(ss[bstream.SS["PREV"]:bstream.SS["PREV"] + 44 * N], accepted)      # the accepted plan stays the plan
+    assert ss[bstream.ss_updated(N) + 1] == 1.0
+    shift = lambda a: np.concatenate([a.reshape(N, 44)[1:], a.reshape(N, 44)[-1:]]).ravel()
+    ss_a, ss_b = ss.copy(), ss.copy()
+    _, x0_ref = emu.stream_pack(N, 4, T, ss_a, rb)                    # reference rule: from the accepted plan
+    _, x0_rt = emu.stream_pack(N, 4, T, ss_b, rb, xlast=x_bad)        # real-time rule: from the rejected iterate
+    np.testing.assert_array_equal(x0_ref, shift(accepted))
+    np.testing.assert_array_equal(x0_rt, shift(x_bad))
+    # status 3 clears the continuation word: both rules restart from the accepted plan
+    ss_c = ss.copy()
+    emu.stream_post(N, 4, 0.1, T, ss_c, rb.copy(), x_bad, g_bad, 3, simulate=True, flags=2, rt_tol=1e-4)
+    assert ss_c[bstream.ss_updated(N) + 1] == 0.0
+    _, x0_c = emu.stream_pack(N, 4, T, ss_c, rb, xlast=x_bad)
+    np.testing.assert_array_equal(x0_c, shift(accepted))
