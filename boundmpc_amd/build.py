@@ -8,7 +8,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libboundmpc_hip.so")
 SOURCES = [os.path.join(CSRC, "bmpc_hip.hip"), os.path.join(CSRC, "bmpc_wave.inl"), os.path.join(CSRC, "bmpc_stream.inl"),
-           os.path.join(HERE, "..", "include", "boundmpc_hip.h")]
+           os.path.join(HERE, "..", "include", "boundmpc_hip.h"), os.path.join(CSRC, "bmpc_team.hip"), os.path.join(CSRC, "bmpc_gpu_common.h")]
+# translation units of the library: the one-wave kernels + C ABI, and the team kernels (NW cooperating waves per problem)
+UNITS = [os.path.join(CSRC, "bmpc_hip.hip"), os.path.join(CSRC, "bmpc_team.hip")]
 
 
 def hipcc():
@@ -164,34 +166,50 @@ def lint_isa_masked_loads(asm_path, window=400):
     return hits
 
 
-def build(force=False, verbose=False, lint=True):
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in SOURCES):
-        return LIB
+def _lint_unit(src, asm, verbose):
+    # same flags, device ISA only; a hit fails the build (the compiled code would compute wrong numbers for some lanes)
+    subprocess.check_call([hipcc()] + FLAGS + ["-S", "--cuda-device-only", "-o", asm, src], cwd=CSRC, stderr=subprocess.DEVNULL)
+    bad = lint_isa(asm)
+    if bad:
+        raise RuntimeError("ISA lint: register copies ahead of an exec-mask restore (compiler defect, results would be wrong): %r" % (bad,))
+    # masked loads read after their join: fatal in the solver kernels (their text has no conditional load by construction) and
+    # anywhere when the register has no earlier definition at all; other candidates are listed with verbose=True
+    ml = lint_isa_masked_loads(asm)
+    fatal = [h for h in ml if "bmpc_solve_kernel" in (h[0] or "") or "bmpc_team_solve_kernel" in (h[0] or "") or not h[3]]
+    if verbose and ml:
+        print("ISA lint (masked loads read after the join), candidates:", ml)
+    if fatal:
+        raise RuntimeError("ISA lint: load under an exec mask whose result is read after the join without a default (results would be wrong "
+                           "for the masked-off lanes): %r" % (fatal,))
+
+
+def _compile_unit(args):
+    src, obj, asm, verbose, lint = args
     if lint:
-        # same flags, device ISA only; a hit fails the build (the compiled code would compute wrong numbers for some lanes)
-        asm_dir = os.path.join(HERE, "..", "build", "isa")
-        os.makedirs(asm_dir, exist_ok=True)
-        asm = os.path.join(asm_dir, "bmpc_hip_gfx950.s")
-        subprocess.check_call([hipcc()] + FLAGS + ["-S", "--cuda-device-only", "-o", asm, SOURCES[0]], cwd=CSRC, stderr=subprocess.DEVNULL)
-        bad = lint_isa(asm)
-        if bad:
-            raise RuntimeError("ISA lint: register copies ahead of an exec-mask restore (compiler defect, results would be wrong): %r" % (bad,))
-        # masked loads read after their join: fatal in the solver kernels (their text has no conditional load by construction) and
-        # anywhere when the register has no earlier definition at all; other candidates are listed with verbose=True
-        ml = lint_isa_masked_loads(asm)
-        fatal = [h for h in ml if "bmpc_solve_kernel" in (h[0] or "") or not h[3]]
-        if verbose and ml:
-            print("ISA lint (masked loads read after the join), candidates:", ml)
-        if fatal:
-            raise RuntimeError("ISA lint: load under an exec mask whose result is read after the join without a default (results would be wrong "
-                               "for the masked-off lanes): %r" % (fatal,))
+        _lint_unit(src, asm, verbose)
     # -amdgpu-sched-strategy=iterative-ilp: the solver runs at one wave per SIMD, so the scheduler should chase instruction-level
     # parallelism (loads hoisted ahead of their uses), not occupancy; measured 12.7 -> 10.8 ms at B=1024 (profiles/)
-    cmd = [hipcc()] + FLAGS + ["-fPIC", "-shared", "-o", LIB, SOURCES[0]]
+    cmd = [hipcc()] + FLAGS + ["-fPIC", "-c", "-o", obj, src]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)
+    return obj
+
+
+def build(force=False, verbose=False, lint=True):
+    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in SOURCES):
+        return LIB
+    from concurrent.futures import ThreadPoolExecutor
+    out_dir = os.path.join(HERE, "..", "build", "isa")
+    os.makedirs(out_dir, exist_ok=True)
+    jobs = []
+    for src in UNITS:
+        stem = os.path.splitext(os.path.basename(src))[0]
+        jobs.append((src, os.path.join(out_dir, stem + ".o"), os.path.join(out_dir, stem + "_gfx950.s"), verbose, lint))
+    with ThreadPoolExecutor(len(jobs)) as ex:      # the two units compile side by side (each: ISA for the lints, then the object)
+        objs = list(ex.map(_compile_unit, jobs))
+    subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", LIB] + objs, cwd=CSRC)
     return LIB
 
 

@@ -1,0 +1,49 @@
+// bmpc_gpu_common.h -- what the two translation units of libboundmpc_hip.so share: the device math macros the wave program
+// (bmpc_wave.inl) is written in, and the kernel argument records.  bmpc_hip.hip holds the one-wave-per-problem kernels and the C ABI,
+// bmpc_team.hip the team kernels (NW cooperating waves per problem) and their launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define BMPC_HD __host__ __device__ __forceinline__
+#define BMPC_D __device__ __forceinline__
+#define BMPC_SINCOS(x, s, c) sincos(x, s, c)
+#define BMPC_EXP(x) exp(x)
+#define BMPC_LOG(x) log(x)
+#define BMPC_SQRT(x) sqrt(x)
+#define BMPC_SIN(x) sin(x)
+#define BMPC_COS(x) cos(x)
+#define BMPC_ATAN2(y, x) atan2(y, x)
+#define BMPC_RSQRT(x) rsqrt(x)
+#define BMPC_FABS(x) fabs(x)
+#define BMPC_FMAX(a, b) fmax(a, b)
+#define BMPC_FMIN(a, b) fmin(a, b)
+#define BMPC_POW15(x) ((x) * sqrt(x))
+#define BMPC_POW(x, y) pow(x, y)
+#define LIDX 0
+#define BMPC_WAVE_RED 1
+#ifndef BMPC_NO_MFMA
+#define BMPC_MFMA 1       // Schur update of the Riccati stage on the matrix cores (v_mfma_f64_16x16x4_f64)
+#endif
+#define BMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+// kernel arguments of a solve; OPTS = the Opts type of the wave program's namespace (same layout in every instantiation)
+template <class OPTS>
+struct KArgsT {
+    int N, S, B; double h; OPTS o;
+    const double *p, *x0; double *x, *g, *lam_g, *lam_x, *f, *kkt; int *iters, *status;
+    double *state;           // optional [B][57 N + 2] dual state of a receding-horizon stream (bmpc_solve_batch_warm)
+    double *latency_us;      // optional [B]: in-kernel duration of each solve (bmpc_set_latency_buffer)
+    double *scratch; long long scr_stride; int *counter; unsigned long long *prof;
+};
+// stream arguments of a fused tick
+struct SArgs {
+    const double *path; int path_stride; double *ss, *rb, *traj; int flags; double rt_tol;
+};
+
+// ---- team kernels (bmpc_team.hip); `kargs` points at a KArgsT<...> record (the layouts are identical across instantiations) ----
+// resident workgroups per CU of the team solver kernel with `nw` waves (0: no such instantiation)
+int bmpc_team_blocks_per_cu(int nw);
+hipError_t bmpc_team_launch_solve(int nw, const void *kargs, int grid, hipStream_t st);
+hipError_t bmpc_team_launch_tick(int nw, const void *kargs, const SArgs *s, int B, hipStream_t st);
+int bmpc_team_lds_bytes(int nw);
+int bmpc_team_nmax(int nw);      // longest horizon the team kernels take (their LDS holds most of the workspace)

@@ -10,32 +10,12 @@
 
 #include "../../include/boundmpc_hip.h"
 
-#define BMPC_HD __host__ __device__ __forceinline__
-#define BMPC_D __device__ __forceinline__
-#define BMPC_SINCOS(x, s, c) sincos(x, s, c)
-#define BMPC_EXP(x) exp(x)
-#define BMPC_LOG(x) log(x)
-#define BMPC_SQRT(x) sqrt(x)
-#define BMPC_SIN(x) sin(x)
-#define BMPC_COS(x) cos(x)
-#define BMPC_ATAN2(y, x) atan2(y, x)
-#define BMPC_RSQRT(x) rsqrt(x)
-#define BMPC_FABS(x) fabs(x)
-#define BMPC_FMAX(a, b) fmax(a, b)
-#define BMPC_FMIN(a, b) fmin(a, b)
-#define BMPC_POW15(x) ((x) * sqrt(x))
-#define BMPC_POW(x, y) pow(x, y)
+#include "bmpc_gpu_common.h"
 #define LANES_BEGIN { int lane_ = threadIdx.x; asm volatile("" : "+v"(lane_)); const int lane = lane_; (void)lane;   // opaque per phase: stops LICM from hoisting per-lane address arithmetic out of the solver loops (register pressure)
 // The workgroup is ONE wave: its LDS and vector-memory instructions execute in program order, so a phase boundary needs no
 // s_barrier and no s_waitcnt drain (what __syncthreads() would emit: vmcnt(0) lgkmcnt(0), i.e. a full stall on every
 // outstanding prefetch / store).  A wavefront-scope fence keeps the COMPILER from moving memory operations across it.
 #define LANES_END } __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-#define LIDX 0
-#define BMPC_WAVE_RED 1
-#ifndef BMPC_NO_MFMA
-#define BMPC_MFMA 1       // Schur update of the Riccati stage on the matrix cores (v_mfma_f64_16x16x4_f64)
-#endif
-#define BMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 #ifdef BMPC_MARKS
 // diagnostic compile only (-S): textual markers in the ISA at the phase stamps, to count static instructions per phase
@@ -51,13 +31,10 @@
 #define BMPCS_SYNC() __syncthreads()
 #include "bmpc_stream.inl"
 
-struct KArgs {
-    int N, S, B; double h; bmpc::Opts o;
-    const double *p, *x0; double *x, *g, *lam_g, *lam_x, *f, *kkt; int *iters, *status;
-    double *state;           // optional [B][57 N + 2] dual state of a receding-horizon stream (bmpc_solve_batch_warm)
-    double *latency_us;      // optional [B]: in-kernel duration of each solve (bmpc_set_latency_buffer)
-    double *scratch; long long scr_stride; int *counter; unsigned long long *prof;
-};
+typedef KArgsT<bmpc::Opts> KArgs;
+#ifndef BMPC_TEAM_NW
+#define BMPC_TEAM_NW 4      // waves per problem of the team kernels compiled into the library (bmpc_team.hip)
+#endif
 
 #ifndef BMPC_WAVES_PER_EU
 #define BMPC_WAVES_PER_EU 1
@@ -65,7 +42,7 @@ struct KArgs {
 template <bool ZLDS>
 __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs a) {
     __shared__ double lds[bmpc::L_SIZE];
-    bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpc::make_gptr(a.scratch + (long long)blockIdx.x * a.scr_stride);
+    bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpc::make_gptr(a.scratch + (long long)blockIdx.x * a.scr_stride); W.wv = 0;
     const int np = 141 + 91 * a.S, nw = a.N * bmpc::NZ, ng = a.N * bmpc::NG;
 #ifdef BMPC_PROFILE
     if (threadIdx.x < 32) ((long long *)(lds + bmpc::L_PROF))[threadIdx.x] = 0;
@@ -105,6 +82,8 @@ struct bmpc_handle {
     double rt_viol_tol;      // acceptance threshold of stream_post in real-time mode (flag bit 1); default = the reference's 1e-4
     hipStream_t own_stream;  // graph replays requested on the legacy null stream run here, bracketed by events (bmpc_graph_launch)
     int grid; long long scr_stride; double *scratch; int scr_waves; int graphs_alive; int *counter; unsigned long long *prof;
+    int team_grid;           // resident TEAMS (workgroups of BMPC_TEAM_NW waves, bmpc_team.hip) of the device; 0: no team kernel for this handle (N > 10 or S > 4)
+    int team_mode;           // bmpc_set_team_waves: 0 automatic (teams when the batch fits into the resident teams), 1 never, BMPC_TEAM_NW whenever possible
     int timing; hipEvent_t *ev; int nev; long long n_timed;   // timing = number of launches whose {start, stop} event pairs are kept (ring)
     double *latency_us;
     double *stage_d; int *stage_i; int stage_cap;   // device staging of the host-buffer path
@@ -178,6 +157,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     if (!h) return BMPC_ERR_ARG;
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->ev = nullptr; h->nev = 0; h->n_timed = 0; h->latency_us = nullptr;
     h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->prof = nullptr; h->stage_d = nullptr; h->stage_i = nullptr; h->stage_cap = 0;
+    h->team_grid = 0; h->team_mode = 0;
     h->rt_viol_tol = 1e-4; h->dev = 0; h->refs = 1; h->closed = false; h->order_ev = nullptr; h->bridge_ev = nullptr; h->order_valid = false; h->order_stream = nullptr; h->own_stream = nullptr;
     if (opts) h->o = *opts; else bmpc_default_options_for(N, &h->o);
     int dev = 0, per_cu = 0; hipDeviceProp_t prop;
@@ -189,6 +169,8 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
         if (per_cu < 1) per_cu = 1;
         h->grid = per_cu * prop.multiProcessorCount;
         h->scr_stride = bmpc::make_scr(N).size;
+        // teams: a workgroup of BMPC_TEAM_NW waves per problem (bmpc_team.hip; iterate-in-LDS instantiation only)
+        h->team_grid = (N <= bmpc_team_nmax(BMPC_TEAM_NW) && S <= bmpc::SMAX_ZLDS) ? bmpc_team_blocks_per_cu(BMPC_TEAM_NW) * prop.multiProcessorCount : 0;
         // the per-wave workspace slabs (148 KB at N=10, 444 KB at N=30) are allocated on the first solve, for min(B, grid) waves, and grow on demand:
         // a single-problem handle (the nlpsol shim of one BoundMPC object) holds one slab, not 1024
         ok = hipMalloc(&h->counter, sizeof(int)) == hipSuccess
@@ -269,6 +251,26 @@ static int timing_slot(bmpc_handle *h, hipEvent_t **pair) {
     *pair = h->ev + 2 * (h->n_timed % h->timing);
     return BMPC_OK;
 }
+// Which kernel solves a batch of B: a team of BMPC_TEAM_NW waves per problem when the batch leaves SIMDs idle -- it fits into the resident
+// teams of the device (256 on an MI355X) -- or when the caller asked for teams; else one wave per problem.
+static bool use_team(const bmpc_handle *h, int B) {
+    if (h->team_grid <= 0 || h->team_mode == 1) return false;
+    return h->team_mode == BMPC_TEAM_NW || B <= h->team_grid;
+}
+static int launch_grid(const bmpc_handle *h, int B) { const int g = use_team(h, B) ? h->team_grid : h->grid; return B < g ? B : g; }
+extern "C" int bmpc_set_team_waves(bmpc_handle *h, int waves) {
+    if (!h || (waves != 0 && waves != 1 && waves != BMPC_TEAM_NW)) return BMPC_ERR_ARG;
+    if (waves == BMPC_TEAM_NW && h->team_grid <= 0) return BMPC_ERR_ARG;      // no team instantiation for this horizon / window
+    h->team_mode = waves;
+    return BMPC_OK;
+}
+extern "C" int bmpc_team_info(const bmpc_handle *h, int B, int *waves, int *resident_teams, int *lds_bytes) {
+    if (!h) return BMPC_ERR_ARG;
+    if (waves) *waves = use_team(h, B) ? BMPC_TEAM_NW : 1;
+    if (resident_teams) *resident_teams = h->team_grid;
+    if (lds_bytes) *lds_bytes = bmpc_team_lds_bytes(BMPC_TEAM_NW);
+    return BMPC_OK;
+}
 // fills the kernel arguments and enqueues {reset of the work-queue counter, solver kernel} on `st`
 static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g, double *lam_g,
                          double *lam_x, double *f, int *iters, int *status, double *kkt, hipStream_t st, bool timed, bool capturing = false) {
@@ -279,13 +281,14 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = lam_g; a.lam_x = lam_x; a.f = f; a.kkt = kkt; a.iters = iters; a.status = status;
     a.state = state; a.latency_us = h->latency_us;
-    const int grid = B < h->grid ? B : h->grid;
+    const int grid = launch_grid(h, B);
     if (grid > h->scr_waves) return BMPC_ERR_ARG;      // callers reserve the workspace first (never inside a stream capture)
     a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter; a.prof = h->prof;
     HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), st));
     hipEvent_t *pair = nullptr;
     if (timed) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
-    if (h->N <= 11 && h->S <= bmpc::SMAX_ZLDS) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, a);      // iterate in LDS; else in the workspace (long horizons, S > 4)
+    if (use_team(h, B)) HIPCHK(bmpc_team_launch_solve(BMPC_TEAM_NW, &a, grid, st));      // a workgroup of waves per problem (bmpc_team.hip)
+    else if (h->N <= 11 && h->S <= bmpc::SMAX_ZLDS) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, a);      // iterate in LDS; else in the workspace (long horizons, S > 4)
     else hipLaunchKernelGGL(bmpc_solve_kernel<false>, dim3(grid), dim3(64), 0, st, a);
     HIPCHK(hipGetLastError());
     if (timed) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }
@@ -297,7 +300,7 @@ extern "C" int bmpc_solve_batch(bmpc_handle *h, int B, const double *p, const do
                                 double *f, int *iters, int *status, double *kkt, void *hip_stream) {
     if (!h || B < 0 || (B > 0 && (!p || !x0 || !x))) return BMPC_ERR_ARG;
     if (B == 0) return BMPC_OK;
-    { const int rc_ = ensure_scratch(h, B < h->grid ? B : h->grid); if (rc_ != BMPC_OK) return rc_; }
+    { const int rc_ = ensure_scratch(h, launch_grid(h, B)); if (rc_ != BMPC_OK) return rc_; }
     return enqueue_solve(h, B, p, x0, nullptr, 0, x, g, lam_g, lam_x, f, iters, status, kkt, (hipStream_t)hip_stream, h->timing != 0);
 }
 
@@ -307,7 +310,7 @@ extern "C" int bmpc_solve_batch_warm(bmpc_handle *h, int B, const double *p, con
                                      double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, void *hip_stream) {
     if (!h || B < 0 || max_iter < 0 || (B > 0 && (!p || !x0 || !x || !state))) return BMPC_ERR_ARG;
     if (B == 0) return BMPC_OK;
-    { const int rc_ = ensure_scratch(h, B < h->grid ? B : h->grid); if (rc_ != BMPC_OK) return rc_; }
+    { const int rc_ = ensure_scratch(h, launch_grid(h, B)); if (rc_ != BMPC_OK) return rc_; }
     return enqueue_solve(h, B, p, x0, state, max_iter, x, g, lam_g, lam_x, f, iters, status, kkt, (hipStream_t)hip_stream, h->timing != 0);
 }
 
@@ -317,7 +320,7 @@ struct bmpc_graph { bmpc_handle *h; hipGraph_t graph; hipGraphExec_t exec; };
 extern "C" int bmpc_graph_create(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g,
                                  double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, bmpc_graph **out) {
     if (!h || !out || B < 1 || max_iter < 0 || !p || !x0 || !x) return BMPC_ERR_ARG;
-    { const int rc_ = ensure_scratch(h, B < h->grid ? B : h->grid); if (rc_ != BMPC_OK) return rc_; }
+    { const int rc_ = ensure_scratch(h, launch_grid(h, B)); if (rc_ != BMPC_OK) return rc_; }
     hipStream_t cs;
     HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     bmpc_graph *gr = new (std::nothrow) bmpc_graph();
@@ -449,9 +452,6 @@ __global__ void __launch_bounds__(64) bmpc_stream_post_kernel(int N, int S, int 
 // per tick at 1 kHz (profiles/r03_*_stream_trace.txt); here stream b is block b (B <= resident waves: no work queue, no reset node),
 // the stream functions use the reduction area of the solver's LDS, and the hand-over of p, x0 -> solver -> x, g, status goes through
 // global memory of the same wave in program order.
-struct SArgs {
-    const double *path; int path_stride; double *ss, *rb, *traj; int flags; double rt_tol;
-};
 __global__ void __launch_bounds__(64, 1) bmpc_stream_tick_kernel(KArgs a, SArgs s) {
     __shared__ double lds[bmpc::L_SIZE];
     const int b = blockIdx.x;
@@ -465,7 +465,7 @@ __global__ void __launch_bounds__(64, 1) bmpc_stream_tick_kernel(KArgs a, SArgs 
     double *dual = a.state ? a.state + (long long)b * (a.N * bmpc::NI + 2) : nullptr;
     bmpcs::stream_pack(a.N, a.S, path, s.path_stride / bmpcs::PT_LEN, ss, rb, p, x0, dual, (s.flags & 2) ? a.x + (long long)b * nw : nullptr, sh, threadIdx.x, 64);
     __syncthreads();
-    bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpc::make_gptr(a.scratch + (long long)b * a.scr_stride);
+    bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpc::make_gptr(a.scratch + (long long)b * a.scr_stride); W.wv = 0;
     bmpc::Problem pr;
     pr.p = p; pr.x0 = x0; pr.x = a.x + (long long)b * nw; pr.g = a.g + (long long)b * ng; pr.lam_g = nullptr; pr.lam_x = nullptr;
     pr.f = nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr; pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status + b; pr.state = dual;
@@ -492,20 +492,21 @@ static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entr
     const bool timed = !capturing && h->timing != 0;
     hipEvent_t *pair = nullptr;
     if (timed) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
-    hipLaunchKernelGGL(bmpc_stream_tick_kernel, dim3(B), dim3(64), 0, st, a, s);
+    if (use_team(h, B)) HIPCHK(bmpc_team_launch_tick(BMPC_TEAM_NW, &a, &s, B, st));
+    else hipLaunchKernelGGL(bmpc_stream_tick_kernel, dim3(B), dim3(64), 0, st, a, s);
     HIPCHK(hipGetLastError());
     if (timed) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }
     if (!capturing) return order_after(h, st);
     return BMPC_OK;
 }
-static bool tick_fusable(const bmpc_handle *h, int B) { return h->N <= 11 && h->S <= bmpc::SMAX_ZLDS && B <= h->grid; }
+static bool tick_fusable(const bmpc_handle *h, int B) { return h->N <= 11 && h->S <= bmpc::SMAX_ZLDS && B <= (use_team(h, B) ? h->team_grid : h->grid); }
 extern "C" int bmpc_stream_tick(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, double *p, double *x0,
                                 double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj, int flags,
                                 void *hip_stream) {
     if (!h || B < 0 || max_iter < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !p || !x0 || !x || !g || !status || !traj))) return BMPC_ERR_ARG;
     if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // the stream kernels place one lane per stage below fixed roles at lanes 32..: horizons up to 32
     if (B == 0) return BMPC_OK;
-    { const int rc_ = ensure_scratch(h, B < h->grid ? B : h->grid); if (rc_ != BMPC_OK) return rc_; }
+    { const int rc_ = ensure_scratch(h, launch_grid(h, B)); if (rc_ != BMPC_OK) return rc_; }
     hipStream_t st = (hipStream_t)hip_stream;
     if (tick_fusable(h, B)) return enqueue_tick(h, B, path, path_entries, sstate, robot, p, x0, dual_state, max_iter, x, g, iters, status, kkt, traj, flags, st, false);
     // real-time mode: the warm start continues from the iterate of the previous tick on every launch shape (fused or not)
@@ -556,7 +557,7 @@ extern "C" int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *pat
                                         int flags, bmpc_graph **out) {
     if (!h || !out || B < 1 || max_iter < 0 || path_entries < h->S + 1 || !path || !sstate || !robot || !p || !x0 || !x || !g || !status || !traj) return BMPC_ERR_ARG;
     if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // the stream kernels place one lane per stage below fixed roles at lanes 32..: horizons up to 32
-    { const int rc_ = ensure_scratch(h, B < h->grid ? B : h->grid); if (rc_ != BMPC_OK) return rc_; }
+    { const int rc_ = ensure_scratch(h, launch_grid(h, B)); if (rc_ != BMPC_OK) return rc_; }
     hipStream_t cs;
     HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     bmpc_graph *gr = new (std::nothrow) bmpc_graph();

@@ -24,7 +24,41 @@
 // forward sweeps = one lane per state component; Riccati = one lane per PAIR of integrator chains
 // (8 x 8 pairs = 64 lanes): the stage map is I_8 (x) CF, so every 4x4 block of the value-function
 // Hessian transforms independently; inequality rows = one lane per row (57 per node).
+//
+// TEAMS (BMPC_NW > 1; round 4): the same program run by a workgroup of NW cooperating waves on ONE problem, for batches that leave
+// SIMDs idle (B <= resident workgroups / NW: closed-loop streams, the single solver(...) call of the drop-in).  The waves share the
+// LDS working set and the workspace slab and execute the same wave-uniform control flow (every scalar of the driver is computed
+// redundantly by every wave from the same LDS words); what changes is who executes a phase:
+//   * WIDE_BEGIN ... WIDE_END: item-parallel passes (row passes, node gradients, stage data, trial points, outputs) run over
+//     64 NW lanes -- `wl` = wave * 64 + lane is the item lane, WS = 64 NW the stride -- and end with a workgroup barrier;
+//   * SOLO_BEGIN(w) ... SOLO_END: a region only wave w executes (the sequential sweeps: adjoint, Riccati, forward; their phases keep the
+//     wavefront-scope fences of the one-wave program), the other waves go on to the next TEAM_SYNC();
+//   * reductions over a wide pass (red_*_w) read the NW x 64 per-lane partials in a fixed order in every wave.
+// With BMPC_NW == 1 (the product kernel of large batches) every one of these reduces to the one-wave text: wl = lane, WS = 64,
+// TEAM_SYNC() = nothing, SOLO = unconditional.
 #pragma once
+
+#ifndef BMPC_NW
+#define BMPC_NW 1
+#endif
+#ifndef BMPC_NAMESPACE
+#define BMPC_NAMESPACE bmpc
+#endif
+#ifndef TEAM_SYNC
+#if BMPC_NW > 1
+#error "a team build (BMPC_NW > 1) must define TEAM_SYNC(), WIDE_BEGIN / WIDE_END and SOLO_BEGIN / SOLO_END"
+#endif
+#define TEAM_SYNC()
+#define TEAM_SYNC_LDS()
+#define WIDE_BEGIN LANES_BEGIN const int wl = lane; (void)wl;
+#define WIDE_END LANES_END
+#define SOLO_BEGIN(w) {
+#define SOLO_END }
+#define TEAM_IS(w) true
+#endif
+#ifndef BMPC_LANE_ID
+#define BMPC_LANE_ID threadIdx.x
+#endif
 
 #ifndef BMPC_PROF
 #define BMPC_PROF(W, id)
@@ -37,12 +71,14 @@
 #define BMPC_SCHED_FENCE()   // GPU build: stops the scheduler from hoisting LDS loads across this point (bounds live ranges)
 #endif
 
-namespace bmpc {
+namespace BMPC_NAMESPACE {
 
 // ----------------------------------------------------------------------------------------
 // dimensions and index maps
 // ----------------------------------------------------------------------------------------
-constexpr int NZ = 44, NG = 43, NE = 36, NS = 35, NU = 8, NW = 43, NI = 57, SMAX = 6, SMAX_ZLDS = 4, NPMAX = 141 + 91 * SMAX, NMAX = 40;
+constexpr int NZ = 44, NG = 43, NE = 36, NS = 35, NU = 8, NI = 57, SMAX = 6, SMAX_ZLDS = 4, NPMAX = 141 + 91 * SMAX, NMAX = 40;
+constexpr int NW = BMPC_NW, WS = 64 * NW;      // waves per problem (team size), lanes of a wide pass
+constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
 #define GN_MU_GATE 0.05      // Gauss-Newton fallback of the inertia correction only while mu >= GN_MU_GATE (first barrier level)
 #define GN_PROBE 3           // while the fallback keeps being needed, every GN_PROBE-th iteration tries the exact Hessian again
 #define DELTA_FIRST 1e-3     // inertia correction constants of oracle/bmpc_oracle.c
@@ -103,8 +139,11 @@ BMPC_HD inline POff make_poff_lds(int S, int lzl) {
 enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV = L_RED + 6 * 64, L_PR = L_PV + 36, L_QT = L_PR + 36,
        L_RD = L_QT + 36, L_DS = L_RD + 36, L_DSN = L_DS + 36, L_DU = L_DSN + 36, L_MV = L_DU + 8, L_AE = L_MV + 44, L_K0 = L_AE + 42,
        L_K1 = L_K0 + KREC, L_KV = L_K1 + KREC, L_XT = L_KV + KREC, L_NC = L_XT + 15 * 14, L_WY = L_NC + 160, L_WV = L_WY + 196, L_TOT = L_WV + 196,
-       L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_ZL = L_ST + 460, L_SIZE = L_ZL + 484 };
+       L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_ZL = L_ST + 460, L_SIZE1 = L_ZL + 484 };
 enum { L_KKP = L_WY };
+// per-lane partials of the wide passes: 6 slots x WS (L_REDW) and 4 x WS (L_KKPW).  One wave: the one-wave areas themselves.  Teams: own
+// areas behind the one-wave layout (a team owns a whole CU: 1 workgroup of NW waves at 512 registers each), plus the hand-over words of
+// the solo regions (forward sweep's gradient products, the Riccati sweep's verdict, the work-queue index)
 enum { L_PP = L_PM };   // [4 fields][64 pairs] partial products of P rdyn (blk_add_lane -> S0), in the area the value-function blocks used to occupy
 enum { L_DUMMY = L_FLAG + 1 };   // write-only slot: target of the stores of lanes that have nothing to store (keeps phases branch-free)
 // row descriptors of the 57 internal inequality rows (box rows: +-Z[src] - lim), built once per problem: [sgn 57 | lim 57 | src 57]
@@ -137,15 +176,55 @@ enum { NC_HPP = 0, NC_HRR = 9, NC_HPF = 18, NC_HRF = 21, NC_SC = 24 /* hff,hdd,h
 // gl - g^ (rows pos 3, v 6, phi, dphi, ddphi of Z) and a zero word (what the other rows of gl add to g^)
 enum { NCS_MU = 91, NCS_RDP = 103, NCS_ADDV = 109, NCS_ZERO = 121, NCS_DUMMY = 122, NCS_STRIDE = 128 };
 
+// Teams also keep most of the WORKSPACE in LDS (L_WSL; a team has the LDS of a whole CU, 160 KB, to itself): the row arrays of the
+// inequality rows, residuals, multipliers, gradients, defects, the kinematics and reference records and the node-cost rows -- everything
+// the wide passes exchange between phases.  With one wave per CU the 148 KB slabs of an XCD's problems do not fit its L2 (4 MB) and every
+// dependent round trip to them costs ~1.7 k cycles (Infinity Cache); measured (profiles/r04_a_*): the wide passes of a team were bound by
+// exactly those trips, not by issue.  Only the Riccati gains, the curvature prefix vectors (both consumed through the sweeps' register
+// prefetch) and, for long horizons, the iterate stay in the global slab.
+constexpr int WSL_PER_STAGE = 10 * NI + 3 * NE + NZ + 8 + NU + 36 + 42 + 12 + 2 * KREC + RREC + NCS_STRIDE;      // make_scr's LDS-resident arrays, doubles per stage
+constexpr int TEAM_NMAX = 10;      // longest horizon a team's LDS holds (the reference's experiments and BASELINE configs[1], [2], [4] run N = 10)
+#if BMPC_NW > 1
+#ifdef BMPC_EMU
+enum { WRED_STRIDE = WS };      // the emulator runs the lanes of a wide pass one after the other: per-lane slots, reduced in the GPU's order afterwards
+#else
+enum { WRED_STRIDE = NW };      // GPU: a wave reduces its 64 partials in registers (butterfly) and stores ONE word per wave and slot
+#endif
+// L_PREP: what the helper wave of the Riccati sweep hands to the sweep's wave per stage (blk_prep_lane's results: 10 block entries, 3 iota
+// increments, 1 P_ii increment per lane, plane-major), double-buffered by stage parity; L_WY2: second curvature table (the helper writes
+// stage k-1's while S0 of stage k reads its own); L_HKHP: the helper's staging of the curvature prefix vectors (the one array it needs
+// that lives in the global slab)
+enum { PREP_N = 14 };
+enum { L_REDW = L_SIZE1, L_KKPW = L_REDW + 6 * WRED_STRIDE, L_TGHD = L_KKPW + 4 * WRED_STRIDE, L_TFLAG = L_TGHD + 64, L_PREP = L_TFLAG + 8,
+       L_WY2 = L_PREP + 2 * PREP_N * 64, L_HKHP = L_WY2 + 196, L_WSL = L_HKHP + 144, L_SIZE = L_WSL + WSL_PER_STAGE * TEAM_NMAX + 16 };
+#ifndef BMPC_EMU
+static_assert(L_SIZE * 8 <= 160 * 1024, "a team's working set must fit the 160 KB of LDS of a CU");
+#endif
+#else
+enum { WRED_STRIDE = 64, L_REDW = L_RED, L_KKPW = L_KKP, L_SIZE = L_SIZE1 };
+#endif
+
 struct Opts {
     double tol; int max_iter; double mu_init; double mu_min_fac; double slack_push; int exact_hessian; int verbose; double mu_warm; int stall_window;
 };
 
 // global scratch layout (doubles) for horizon N
 struct Scr {
-    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, NU2, NCS, KHPG, size;
+    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, NU2, NCS, KHPG, size, lsize;
 };
 BMPC_HD inline Scr make_scr(int N) {
+#if BMPC_NW > 1
+    // teams: two index spaces -- `l` counts the LDS-resident arrays (offsets from L_WSL, accessor WL), `c` what stays in the global slab (accessor G)
+    Scr s; int c = 0, l = 0;
+    s.Z = c; c += N * NZ; s.ZT = c; c += N * NZ; s.DZ = c; c += N * NZ; s.KT = c; c += N * NS * NU; s.KF = c; c += N * NU; s.KHPG = c; c += 2 * N * 72;
+    s.DNU = c; c += N * NI;      // (multiplier directions: written by row pass B, read once by the update pass -- what did not fit)
+    s.T = l; l += N * NI; s.TT = l; l += N * NI; s.NUm = l; l += N * NI; s.LAM = l; l += N * NE; s.G = l; l += N * NE; s.GT = l; l += N * NE;
+    s.HIN = l; l += N * NI; s.HT = l; l += N * NI; s.DT = l; l += N * NI; s.GH = l; l += N * NZ; s.GVP = l; l += N * 8;
+    s.RJ = l; l += N * NU; s.KIN = l; l += 2 * N * KREC; s.REF = l; l += N * RREC; s.RDY = l; l += N * 36; s.AES = l; l += N * 42; s.RLV = l; l += N * 12;
+    s.SG = l; l += N * NI; s.TI = l; l += N * NI; s.SR = l; l += N * NI; s.NU2 = l; l += N * NI; s.NCS = l; l += N * NCS_STRIDE;
+    s.size = (c + 15) & ~15; s.lsize = l;
+    return s;
+#else
     Scr s; int c = 0;
     s.Z = c; c += N * NZ; s.ZT = c; c += N * NZ; s.T = c; c += N * NI; s.TT = c; c += N * NI; s.NUm = c; c += N * NI;
     s.LAM = c; c += N * NE; s.G = c; c += N * NE; s.GT = c; c += N * NE; s.HIN = c; c += N * NI; s.HT = c; c += N * NI;
@@ -154,8 +233,9 @@ BMPC_HD inline Scr make_scr(int N) {
     s.RDY = c; c += N * 36; s.AES = c; c += N * 42; s.RLV = c; c += N * 12; s.SG = c; c += N * NI; s.TI = c; c += N * NI; s.SR = c; c += N * NI; s.NU2 = c; c += N * NI;   // NU2: second multiplier buffer (the update ping-pongs)
     s.NCS = c; c += N * NCS_STRIDE;   // node-cost data of every stage (wave_stage_data_wide): see the NCS_* row layout
     s.KHPG = c; c += 2 * N * 72;      // prefix vectors of the kinematic curvature, one row per kinematics record (kin_point)
-    s.size = (c + 15) & ~15;
+    s.size = (c + 15) & ~15; s.lsize = 0;
     return s;
+#endif
 }
 
 struct Problem {           // per-problem global pointers
@@ -182,6 +262,14 @@ struct GPtr {
     BMPC_D double *ptr() const { return (double *)(b + o); }
 };
 BMPC_D inline GPtr make_gptr(double *base) { GPtr r; r.b = (char *)base; r.o = 0; return r; }
+// accessor of the workspace arrays a team keeps in LDS (make_scr): the global slab itself in the one-wave program
+#if BMPC_NW > 1
+typedef double *LPtr;
+#define BMPC_WL(W) ((W).L + L_WSL)
+#else
+typedef GPtr LPtr;
+#define BMPC_WL(W) ((W).G)
+#endif
 struct Wave {
     int N, S; double h; Opts o;
     double *L;             // LDS base (L_SIZE doubles)
@@ -192,8 +280,10 @@ struct Wave {
     int oK0, oK1, oKV, oKV1;   // LDS offsets of the four kinematics records of the current Riccati stage (the buffers rotate, see
                            // wave_backward_blk: two of the four records of stage k are records of stage k+1)
     double *Zc, *Zt, *Dz;  // iterate, trial iterate, Newton direction [N][44]: LDS-resident for N <= 11, else in the scratch slab
+    int wv;                // this wave's index in its team (0 in the one-wave program); wave-uniform
 #ifdef BMPC_EMU
     int order[64];
+    int worder[BMPC_NW];   // team emulator: order in which the waves run a wide phase
 #endif
 };
 
@@ -242,7 +332,7 @@ BMPC_D inline void bmpc_sincos(double x, double *sn, double *cs) {
 // joint axes (z,y,z,-y,z,y,z), link offsets along local z (RobotModel.py:9-16).
 // Writes the record rec[KREC]: axes, J_v columns, D = d(J dq)/dq, pos, v = J dq, dq.
 // ----------------------------------------------------------------------------------------
-template <class PR> BMPC_D inline void kin_point(const double *q, const double *dq, const PR rec, const PR hp) {
+template <class PR, class PH> BMPC_D inline void kin_point(const double *q, const double *dq, const PR rec, const PH hp) {
     const double preZ[7] = {0.0, 0.1575 + 0.2025, 0.0, 0.2375 + 0.1825, 0.0, 0.2175 + 0.1825, 0.0};
     const double toolZ = 0.081 + (0.071 + 0.145);
     double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, o[3] = {0, 0, 0}, O[7][3], a[7][3], w[7][3];
@@ -546,6 +636,7 @@ BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
             L[L_ZMAP + r] = (double)(z + (gsrc << 8) + (zero << 16) + (fr << 17) + (ir << 20));
         }
     LANES_END
+    TEAM_SYNC();      // (teams: every wave wrote the same words; nobody reads the tables or the parameter vector before all are in)
     W.ca = 2 * L[L_PAR + po.w + 5] / (W.h * W.h); W.cb = 2 * L[L_PAR + po.w + 5] / W.h;
 }
 
@@ -555,6 +646,7 @@ BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
 static_assert(64 * BMPC_RU >= 40 * 8, "the first batch of a row pass must cover the N * NU <= 320 jerk-gradient entries (KKT pass)");
 static_assert(64 * BMPC_RU >= 10 * 57, "one batch must cover the 570 multiplier rows of a ten-node pass (wave_node_grad_wide)");
 constexpr int RU = BMPC_RU;   // rows of a lane-strided pass kept in flight per lane (loads of a batch are issued before their first use)
+constexpr int RUW = cdiv_(RU, NW);   // the same for the wide passes of a team: NW x 64 lanes share the rows
 struct LaneRegs { double mc[16]; double pf[24]; double ghd; };   // ghd: the lane's share of (QP gradient) . dZ, accumulated by the forward sweep   // pf: software prefetch of the next stage's inputs (global -> registers -> LDS)   // a lane's 4x4 state block of M, kept in registers between the M and the Schur phases
 
 // ----------------------------------------------------------------------------------------
@@ -565,22 +657,47 @@ struct LaneRegs { double mc[16]; double pf[24]; double ghd; };   // ghd: the lan
 // GPU: every lane reads its own slot and the wave reduces by a butterfly of cross-lane exchanges (xor 8,16,32,1,2,4): exactly
 // the tree written out below (fp addition is commutative, so every lane ends with the same bits), without 64 LDS reads per lane
 BMPC_D inline double red_sum(const double *r) {
-    double v = r[threadIdx.x];
+    double v = r[BMPC_LANE_ID];
     v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
     return v;
 }
 BMPC_D inline double red_max(const double *r) {
-    double v = r[threadIdx.x];
+    double v = r[BMPC_LANE_ID];
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) v = BMPC_FMAX(v, __shfl_xor(v, m));
     return v;
 }
 BMPC_D inline double red_min(const double *r) {
-    double v = r[threadIdx.x];
+    double v = r[BMPC_LANE_ID];
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) v = BMPC_FMIN(v, __shfl_xor(v, m));
     return v;
 }
+// Wide passes of a team: a wave reduces the partials of its 64 lanes in registers (the one-wave tree) and leaves ONE word per wave and
+// slot in LDS; behind the barrier every wave folds the NW words in a fixed order -- every wave of the team ends with the same bits.
+BMPC_D inline double wave_sum(double v) {
+    v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    return v;
+}
+BMPC_D inline double wave_max(double v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = BMPC_FMAX(v, __shfl_xor(v, m));
+    return v;
+}
+BMPC_D inline double wave_min(double v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v = BMPC_FMIN(v, __shfl_xor(v, m));
+    return v;
+}
+BMPC_D inline double fold_sum(const double *r) { double v = r[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) v += r[w]; return v; }
+BMPC_D inline double fold_max(const double *r) { double v = r[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) v = BMPC_FMAX(v, r[w]); return v; }
+BMPC_D inline double fold_min(const double *r) { double v = r[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) v = BMPC_FMIN(v, r[w]); return v; }
 #else
 BMPC_D inline double red_sum(const double *r) {
     double a[8];
@@ -594,6 +711,34 @@ BMPC_D inline double red_max(const double *r) { double s = r[0];
 BMPC_D inline double red_min(const double *r) { double s = r[0];
 #pragma unroll
     for (int i = 1; i < 64; i++) s = BMPC_FMIN(s, r[i]); return s; }
+// wide-pass partials of a team (NW x 64 per-lane slots in the emulator): the one-wave tree per wave, then a left fold over the waves -- the
+// order of the GPU's wave_sum / fold_sum
+BMPC_D inline double red_sum_w(const double *r) { double v = red_sum(r); for (int w = 1; w < NW; w++) v += red_sum(r + 64 * w); return v; }
+BMPC_D inline double red_max_w(const double *r) { double s = r[0]; for (int i = 1; i < WS; i++) s = BMPC_FMAX(s, r[i]); return s; }
+BMPC_D inline double red_min_w(const double *r) { double s = r[0]; for (int i = 1; i < WS; i++) s = BMPC_FMIN(s, r[i]); return s; }
+#endif
+// partial of this lane into slot `slot` of a wide-pass reduction area (L_REDW / L_KKPW), and the reduced value afterwards (behind the barrier)
+#if BMPC_NW == 1
+#define WRED_PUT_SUM(area, slot, v) L[(area) + (slot) * 64 + wl] = (v)
+#define WRED_PUT_MAX(area, slot, v) L[(area) + (slot) * 64 + wl] = (v)
+#define WRED_PUT_MIN(area, slot, v) L[(area) + (slot) * 64 + wl] = (v)
+#define WRED_GET_SUM(area, slot) red_sum(L + (area) + (slot) * 64)
+#define WRED_GET_MAX(area, slot) red_max(L + (area) + (slot) * 64)
+#define WRED_GET_MIN(area, slot) red_min(L + (area) + (slot) * 64)
+#elif defined(BMPC_EMU)
+#define WRED_PUT_SUM(area, slot, v) L[(area) + (slot) * WS + wl] = (v)
+#define WRED_PUT_MAX(area, slot, v) L[(area) + (slot) * WS + wl] = (v)
+#define WRED_PUT_MIN(area, slot, v) L[(area) + (slot) * WS + wl] = (v)
+#define WRED_GET_SUM(area, slot) red_sum_w(L + (area) + (slot) * WS)
+#define WRED_GET_MAX(area, slot) red_max_w(L + (area) + (slot) * WS)
+#define WRED_GET_MIN(area, slot) red_min_w(L + (area) + (slot) * WS)
+#else
+#define WRED_PUT_SUM(area, slot, v) L[(area) + (slot) * NW + W.wv] = wave_sum(v)      // (every lane stores the wave's value to the wave's word)
+#define WRED_PUT_MAX(area, slot, v) L[(area) + (slot) * NW + W.wv] = wave_max(v)
+#define WRED_PUT_MIN(area, slot, v) L[(area) + (slot) * NW + W.wv] = wave_min(v)
+#define WRED_GET_SUM(area, slot) fold_sum(L + (area) + (slot) * NW)
+#define WRED_GET_MAX(area, slot) fold_max(L + (area) + (slot) * NW)
+#define WRED_GET_MIN(area, slot) fold_min(L + (area) + (slot) * NW)
 #endif
 
 // ========================================================================================
@@ -604,12 +749,12 @@ BMPC_D inline double red_min(const double *r) { double s = r[0];
 // pt - N): record -> KIN, curvature prefix vectors -> KHPG
 BMPC_D inline void eval_kin_lane(Wave &W, const POff &po, const Scr &sc, const double *Zs, int oG, int pt) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
-    const GPtr G = W.G; const double *PAR = W.L + L_PAR;
+    const GPtr G = W.G; const LPtr WL = BMPC_WL(W); const double *PAR = W.L + L_PAR;
     if (pt < 2 * N) {
         const int k = pt < N ? pt : pt - N;
         double q[7], dq[7];
         if (pt < N) {   // predicted point of node k+1 (jerk_trajectory_casadi.py closed form; bound_mpc_functions.py:254-260)
-            const GPtr gk = G + oG + k * NE;
+            const LPtr gk = WL + oG + k * NE;
             const double *Zn = Zs + k * NZ;
             for (int i = 0; i < 7; i++) {
                 const double q0 = ndv(PAR, po, Zs, k, ZQ + i, po.q0 + i), d0 = ndv(PAR, po, Zs, k, ZDQ + i, po.dq0 + i),
@@ -622,46 +767,26 @@ BMPC_D inline void eval_kin_lane(Wave &W, const POff &po, const Scr &sc, const d
         } else {
             for (int i = 0; i < 7; i++) { q[i] = ndv(PAR, po, Zs, k, ZQ + i, po.q0 + i); dq[i] = ndv(PAR, po, Zs, k, ZDQ + i, po.dq0 + i); }
         }
-        kin_point(q, dq, G + sc.KIN + pt * KREC, G + sc.KHPG + pt * 72);
+        kin_point(q, dq, WL + sc.KIN + pt * KREC, G + sc.KHPG + pt * 72);
     }
 }
 
-// Evaluate at Zs: kinematic records, node references, equality residuals Gd[N][36], inequality
-// values Hd[N][57]; returns the objective (wave-uniform).
-// project (trial points of the line search after a rejected first trial; oracle/bmpc_oracle.c eval_values): the lifted variables
-// pos, i-omega, v of every node are overwritten in Zs by what their defining equalities give for the trial (q, dq), so those 12
-// residual rows are exactly zero.  One lane per node: a lane writes only its own node's entries and reads its neighbours' projected
-// values from the kinematics records of phase 1 (v of the previous node; the i-omega recursion as a prefix sum from node 0), never
-// from Zs -- no cross-lane dependence inside the phase.
-// ls (trial points of the line search): the row pass also forms the trial slacks tt = t + alpha dt (-> TT) and the two sums the filter
-// needs -- theta = ||c||_1 + ||h + tt||_1 and the barrier term -mu sum log tt -- from the values it has in registers, and leaves their
-// per-lane parts in L_RED + 64 / + 128: the trial used to cost two more passes over the rows (slacks before, sums after the
-// evaluation), each a dependent round trip to the workspace.
-struct LsRows { double alpha, mu; };
-BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Zs, int oG, int oH, bool project, const LsRows *ls = nullptr) {
+// Node phase of the evaluation for ONE lane = node k (index k: node k+1): `lifted`: the twelve residual rows of the lifted variables
+// (pos, i-omega, v: these read the kinematics records) -- or, for projected trial points, the lifted variables themselves --; `refs`: the
+// path-parameter residuals, the node's reference record and its objective term (returned).  The two parts share no data except through
+// `project`, so a team runs `refs` on a second wave beside the kinematics.
+BMPC_D inline double eval_node_lane(Wave &W, const POff &po, const Scr &sc, double *Zs, int oG, bool project, int k, bool lifted, bool refs) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
-    double *L = W.L; const GPtr G = W.G;
-    const double *PAR = L + L_PAR;
-    // one lane per kinematics point: 2 N points; the points past the first 64 (N > 32 only) take a second phase
-    LANES_BEGIN
-        eval_kin_lane(W, po, sc, Zs, oG, lane);
-    LANES_END
-    if (2 * N > 64) {
-        LANES_BEGIN
-            eval_kin_lane(W, po, sc, Zs, oG, 64 + lane);
-        LANES_END
-    }
-    BMPC_PROF(W, 25);
-    LANES_BEGIN
-        double fk = 0;
-        if (lane < N) {
-            const int k = lane;
-            double *Zn = Zs + k * NZ; const GPtr kp = G + sc.KIN + k * KREC, kv = G + sc.KIN + (N + k) * KREC;
-            const GPtr gk = G + oG + k * NE, rr = G + sc.REF + k * RREC;
+    const GPtr G = W.G; const LPtr WL = BMPC_WL(W); const double *PAR = W.L + L_PAR;
+    double fk = 0;
+    {
+            double *Zn = Zs + k * NZ; const LPtr kp = WL + sc.KIN + k * KREC, kv = WL + sc.KIN + (N + k) * KREC;
+            const LPtr gk = WL + oG + k * NE, rr = WL + sc.REF + k * RREC;
+            if (lifted) {
             if (project) {
                 double iw[3] = {PAR[po.p0 + 3], PAR[po.p0 + 4], PAR[po.p0 + 5]};
                 for (int j = 0; j <= k; j++) {
-                    const GPtr kpj = G + sc.KIN + j * KREC, kvj = G + sc.KIN + (N + j) * KREC;
+                    const LPtr kpj = WL + sc.KIN + j * KREC, kvj = WL + sc.KIN + (N + j) * KREC;
                     for (int i = 0; i < 3; i++) iw[i] = iw[i] + 0.5 * h * (kvj[KV + 3 + i] + kpj[KV + 3 + i]);
                 }
                 for (int i = 0; i < 3; i++) { Zn[ZPOS + i] = kp[KPOS + i]; gk[GPOS + i] = 0.0; Zn[ZIW + i] = iw[i]; gk[GIW + i] = 0.0; }
@@ -682,6 +807,8 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
 #pragma unroll
                 for (int i = 0; i < 6; i++) gk[GV + i] = kvel[i] - Zn[ZV + i];
             }
+            }
+            if (refs) {
             const double ph = ndv(PAR, po, Zs, k, ZPHI, po.phi0), dph = ndv(PAR, po, Zs, k, ZDPHI, po.phi0 + 1),
                          ddph = ndv(PAR, po, Zs, k, ZDDPHI, po.phi0 + 2), jp0 = ndv(PAR, po, Zs, k, ZJPHI, po.jerkphi), jp1 = Zn[ZJPHI];
             gk[GPHI] = ph + h * dph + h2 / 2 * ddph + h3 / 8 * jp0 + h3 / 24 * jp1 - Zn[ZPHI];
@@ -689,13 +816,13 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
             gk[GDDPHI] = ddph + h / 2 * (jp0 + jp1) - Zn[ZDDPHI];
             node_ref(PAR, po, W.S, Zn + ZPOS, Zn + ZIW, Zn[ZPHI], rr, W.o.exact_hessian);
             // objective of node k+1 (bound_mpc_functions.py:205-246; casadi_ocp_formulation.py:227-265)
-            const double *w = PAR + po.w; const GPtr d = rr + RDP;
+            const double *w = PAR + po.w; const LPtr d = rr + RDP;
             const double sig = rr[RSIG], dde = dot3(d, rr + REP);
             double epo[3], ero[3];
             for (int c = 0; c < 3; c++) { epo[c] = sig * rr[REP + c] + (1 - sig) * dde * d[c]; ero[c] = sig * rr[RER + c] + (1 - sig) * rr[RERPAR + c]; }
             fk = w[1] * dot3(ero, ero) + w[0] * dot3(epo, epo);
             for (int c = 0; c < 6; c++) {
-                const double vp = (project && k > 0) ? G[sc.KIN + (k - 1) * KREC + KV + c] : ndv(PAR, po, Zs, k, ZV + c, po.v0 + c);
+                const double vp = (project && k > 0) ? WL[sc.KIN + (k - 1) * KREC + KV + c] : ndv(PAR, po, Zs, k, ZV + c, po.v0 + c);
                 const double rv = Zn[ZV + c] - Zn[ZDPHI] * d[c], ra = (Zn[ZV + c] - vp) / h - Zn[ZDDPHI] * d[c];
                 fk += w[2] * rv * rv + w[5] * ra * ra;
             }
@@ -705,63 +832,123 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
             }
             const double e0 = PAR[po.xphid] - Zn[ZPHI], e1 = PAR[po.xphid + 1] - Zn[ZDPHI], e2 = PAR[po.xphid + 2] - Zn[ZDDPHI];
             fk += w[6] * e0 * e0 + w[7] * e1 * e1 + w[8] * e2 * e2 + w[9] * Zn[ZJPHI] * Zn[ZJPHI];
-        }
-        L[L_RED + lane] = fk;
+            }
+    }
+    return fk;
+}
+
+// Evaluate at Zs: kinematic records, node references, equality residuals Gd[N][36], inequality
+// values Hd[N][57]; returns the objective (wave-uniform).
+// project (trial points of the line search after a rejected first trial; oracle/bmpc_oracle.c eval_values): the lifted variables
+// pos, i-omega, v of every node are overwritten in Zs by what their defining equalities give for the trial (q, dq), so those 12
+// residual rows are exactly zero.  One lane per node: a lane writes only its own node's entries and reads its neighbours' projected
+// values from the kinematics records of phase 1 (v of the previous node; the i-omega recursion as a prefix sum from node 0), never
+// from Zs -- no cross-lane dependence inside the phase.
+// ls (trial points of the line search): the row pass also forms the trial slacks tt = t + alpha dt (-> TT) and the two sums the filter
+// needs -- theta = ||c||_1 + ||h + tt||_1 and the barrier term -mu sum log tt -- from the values it has in registers, and leaves their
+// per-lane parts in L_RED + 64 / + 128: the trial used to cost two more passes over the rows (slacks before, sums after the
+// evaluation), each a dependent round trip to the workspace.
+struct LsRows { double alpha, mu; };
+BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Zs, int oG, int oH, bool project, const LsRows *ls = nullptr) {
+    const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
+    double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
+    const double *PAR = L + L_PAR;
+    // one lane per kinematics point: 2 N points; the points past the first 64 (N > 32 only) take a second phase
+    SOLO_BEGIN(0)
+    LANES_BEGIN
+        eval_kin_lane(W, po, sc, Zs, oG, lane);
     LANES_END
+    if (2 * N > 64) {
+        LANES_BEGIN
+            eval_kin_lane(W, po, sc, Zs, oG, 64 + lane);
+        LANES_END
+    }
+    SOLO_END
+    if (NW > 1 && !project) {      // team: references and objective of the nodes on wave 1, beside the kinematics
+        SOLO_BEGIN(1)
+        LANES_BEGIN
+            double fk = 0;
+            if (lane < N) fk = eval_node_lane(W, po, sc, Zs, oG, false, lane, false, true);
+            L[L_RED + lane] = fk;
+        LANES_END
+        SOLO_END
+    }
+    TEAM_SYNC();
+    BMPC_PROF(W, 25);
+    if (NW == 1 || project) {
+        // one wave (and the projected trial points of a team, which need the kinematics first): the whole node phase in one lane per node
+        SOLO_BEGIN(0)
+        LANES_BEGIN
+            double fk = 0;
+            if (lane < N) fk = eval_node_lane(W, po, sc, Zs, oG, project, lane, true, true);
+            L[L_RED + lane] = fk;
+        LANES_END
+        SOLO_END
+        TEAM_SYNC();
+    } else {
+        // team: the references / objective part of the node phase does not read the kinematics records (pos, iw, v are variables of Z):
+        // wave 1 ran it beside the kinematics of wave 0 (above); what is left are the twelve lifted residual rows per node
+        SOLO_BEGIN(0)
+        LANES_BEGIN
+            if (lane < N) eval_node_lane(W, po, sc, Zs, oG, false, lane, true, false);
+        LANES_END
+        SOLO_END
+        TEAM_SYNC();
+    }
     const double f = red_sum(L + L_RED);
     BMPC_PROF(W, 26);
-    LANES_BEGIN   // inequality values, lane-strided rows, RU rows in flight: all loads of a batch are issued before the first use
+    WIDE_BEGIN   // inequality values, lane-strided rows (wide: over the lanes of the whole team), RUW rows in flight per lane: all loads of a batch are issued before the first use
         double th = 0, br = 0;
         // wave-uniform trip counts (rows past the end are clamped duplicates): a lane-dependent loop exit makes the compiler restore the
         // exec mask behind the loop, and that is where this toolchain has placed register copies under the stale mask (build.py lint_isa)
-        const int trips_i = (N * NI + 64 * RU - 1) / (64 * RU), trips_e = (N * NE + 64 * RU - 1) / (64 * RU);
+        const int trips_i = (N * NI + WS * RUW - 1) / (WS * RUW), trips_e = (N * NE + WS * RUW - 1) / (WS * RUW);
         double the = 0;
         if (ls) {   // 1-norm of the equality residuals (written by the node phase): read ahead of this pass's stores, which its loads would
                     // otherwise have to wait for
             for (int tr_ = 0; tr_ < trips_e; tr_++) {
-                const int base = lane + tr_ * 64 * RU;
-                double gv[RU];
+                const int base = wl + tr_ * WS * RUW;
+                double gv[RUW];
 #pragma unroll
-                for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u; gv[u] = G[oG + (id0 < N * NE ? id0 : N * NE - 1)]; }
+                for (int u = 0; u < RUW; u++) { const int id0 = base + WS * u; gv[u] = WL[oG + (id0 < N * NE ? id0 : N * NE - 1)]; }
 #pragma unroll
-                for (int u = 0; u < RU; u++) the += base + 64 * u < N * NE ? BMPC_FABS(gv[u]) : 0.0;
+                for (int u = 0; u < RUW; u++) the += base + WS * u < N * NE ? BMPC_FABS(gv[u]) : 0.0;
             }
         }
         for (int tr_ = 0; tr_ < trips_i; tr_++) {
-            const int base = lane + tr_ * 64 * RU;
-            double zv[RU], rc[RU], rw[RU], sg[RU], lm[RU], tv[RU], dv[RU];
+            const int base = wl + tr_ * WS * RUW;
+            double zv[RUW], rc[RUW], rw[RUW], sg[RUW], lm[RUW], tv[RUW], dv[RUW];
 #pragma unroll
             // rows past the end are clamped to the last row: they load, compute and store exactly what its owner does (no exec-mask
             // branch anywhere in the pass)
-            for (int u = 0; u < RU; u++) {
-                const int id0 = base + 64 * u, id = id0 < N * NI ? id0 : N * NI - 1;
+            for (int u = 0; u < RUW; u++) {
+                const int id0 = base + WS * u, id = id0 < N * NI ? id0 : N * NI - 1;
                 const int k = id / NI, i = id - k * NI;
                 const int m = i >= ITUBE ? (i - ITUBE) >> 1 : 0;
                 sg[u] = L[L_ROWT + i]; lm[u] = L[L_ROWT + NI + i];
                 zv[u] = Zs[k * NZ + (int)L[L_ROWT + 2 * NI + i]];
-                const GPtr rr = G + sc.REF + k * RREC;
+                const LPtr rr = WL + sc.REF + k * RREC;
                 rc[u] = rr[RC + m]; rw[u] = rr[RWD + m];
-                if (ls) { tv[u] = G[sc.T + id]; dv[u] = G[sc.DT + id]; }      // wave-uniform condition
+                if (ls) { tv[u] = WL[sc.T + id]; dv[u] = WL[sc.DT + id]; }      // wave-uniform condition
             }
             double tprod = 1.0;
 #pragma unroll
-            for (int u = 0; u < RU; u++) {
-                const int id0 = base + 64 * u, id = id0 < N * NI ? id0 : N * NI - 1;
+            for (int u = 0; u < RUW; u++) {
+                const int id0 = base + WS * u, id = id0 < N * NI ? id0 : N * NI - 1;
                 const int i = id % NI;
                 // 0/1 factors instead of a select between the two row formulas (their operands are loads: a select becomes a branch nest)
                 const double mt = i >= ITUBE ? 1.0 : 0.0, s2 = (i >= ITUBE && ((i - ITUBE) & 1)) ? -1.0 : 1.0;
                 const double hv = mt * (s2 * rc[u] - rw[u]) + (1.0 - mt) * (sg[u] * zv[u] - lm[u]);
-                G[oH + id] = hv;
+                WL[oH + id] = hv;
                 if (ls) {
                     const double tt = tv[u] + ls->alpha * dv[u]; const bool ok_ = id0 < N * NI;
-                    G[sc.TT + id] = tt;
+                    WL[sc.TT + id] = tt;
                     th += ok_ ? BMPC_FABS(hv + tt) : 0.0; tprod *= ok_ ? tt : 1.0;
                 }
             }
             if (ls) br -= ls->mu * BMPC_LOG(tprod);      // one log per batch of RU slacks: sum of logs = log of the product (t in [1e-12, 1e2])
         }
-        if (ls) { L[L_RED + 64 + lane] = th + the; L[L_RED + 128 + lane] = br; }
-    LANES_END
+        if (ls) { WRED_PUT_SUM(L_REDW, 1, th + the); WRED_PUT_SUM(L_REDW, 2, br); }
+    WIDE_END
     return f;
 }
 
@@ -791,27 +978,29 @@ BMPC_D inline void stage_mu(Wave &W, const double *lam, const double *kp, int la
 // issued together ahead of the arithmetic: one dependent round trip per call.
 BMPC_D inline void wave_node_grad_wide(Wave &W, const POff &po, const Scr &sc, int oNU, bool use_hat, double mu) {
     const int N = W.N; const double h = W.h, hinv = 1.0 / h;
-    double *L = W.L; const GPtr G = W.G;
+    double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
     const double *PAR = L + L_PAR, *w = PAR + po.w, *Zs = W.Zc;
     const int npass = (N + 9) / 10;
     for (int pass = 0; pass < npass; pass++) {
     // the multipliers of the pass's ten nodes (570 rows: one batch) are staged through LDS with coalesced loads (the value-function block
     // area is free outside the Riccati sweep): one lane per item would otherwise issue scattered global loads of its own.  use_hat: the
     // multiplier estimate mu / t + (nu / t) r of the QP gradient instead of the stored multiplier.
-    LANES_BEGIN
+    WIDE_BEGIN
         const int first = pass * 10 * NI, last = N * NI - 1;
-        double a_[RU], b_[RU];
+        double a_[RUW], b_[RUW];
 #pragma unroll
-        for (int u = 0; u < RU; u++) {
-            const int id0 = first + lane + 64 * u, id = id0 < last ? id0 : last;
-            a_[u] = G[(use_hat ? sc.TI : oNU) + id]; b_[u] = G[sc.SR + id];
+        for (int u = 0; u < RUW; u++) {
+            const int id0 = first + wl + WS * u, id = id0 < last ? id0 : last;
+            a_[u] = WL[(use_hat ? sc.TI : oNU) + id]; b_[u] = WL[sc.SR + id];
         }
 #pragma unroll
-        for (int u = 0; u < RU; u++) { const int j0 = lane + 64 * u, j = j0 < 10 * NI ? j0 : 10 * NI - 1; const double v = use_hat ? mu * a_[u] + b_[u] : a_[u];
+        for (int u = 0; u < RUW; u++) { const int j0 = wl + WS * u, j = j0 < 10 * NI ? j0 : 10 * NI - 1; const double v = use_hat ? mu * a_[u] + b_[u] : a_[u];
                                        L[j0 < 10 * NI ? L_PB + j : L_DUMMY] = v; }
-    LANES_END
+    WIDE_END
     const double *NUV = L + L_PB - pass * 10 * NI;      // row k of the staged block: NUV + k NI for the nodes 10 pass .. 10 pass + 9
-    LANES_BEGIN
+    // (teams: the item kinds are dealt out to the waves -- wave 0: v and pos / iw rows; wave 1: path-parameter rows; box rows: trip u on
+    // wave u mod NW -- every test below is wave-uniform, and with one wave all of them are true)
+    WIDE_BEGIN
         // item maps (one integer division each per call): v / pos+iw rows 6 per node, path-parameter rows 3 per node, box rows 29 per node
         const int k6 = lane / 6, c6 = lane - 6 * k6, k3 = lane / 3, a3 = lane - 3 * k3, k29 = lane / 29, z29 = lane - 29 * k29;
         {
@@ -819,7 +1008,7 @@ BMPC_D inline void wave_node_grad_wide(Wave &W, const POff &po, const Scr &sc, i
             const int kf0 = 10 * pass + k3, kf = kf0 < N ? kf0 : N - 1;
             const bool on6 = lane < 60, on3 = lane < 30;
             // ---- loads from the workspace: reference-record entries of the items' nodes ----
-            const GPtr rv_ = G + sc.REF + kv * RREC, rn_ = G + sc.REF + kn * RREC, rf_ = G + sc.REF + kf * RREC;
+            const LPtr rv_ = WL + sc.REF + kv * RREC, rn_ = WL + sc.REF + kn * RREC, rf_ = WL + sc.REF + kf * RREC;
             const double dv = rv_[RDP + c6], dn = rn_[RDP + c6];                              // v rows: dp_d[c] of the node and of the next node
             const int cc = c6 < 3 ? c6 : c6 - 3;                                              // pos / iw rows: coordinate
             double pd[3], pdh[3], pep[3], per_[3], ppar[3], pl2[3], prr[3], pgc[5];
@@ -837,17 +1026,17 @@ BMPC_D inline void wave_node_grad_wide(Wave &W, const POff &po, const Scr &sc, i
             for (int m = 0; m < 5; m++) { fg3[m] = rf_[RGC + m * 4 + 3]; fw1[m] = rf_[RW1 + m]; }
             const double fsig = rf_[RSIG], fsig1 = rf_[RSIG1], fv2rr = rf_[RV2RR];
             // ---- v rows: tracking of v_ref = dphi dp_d and a_ref = ddphi dp_d, plus the acceleration term of node k+1 (which holds v_k) ----
-            {
+            if (NW == 1 || W.wv == 0) {
                 const double *Zn = Zs + kv * NZ, *Z1 = Zs + kn * NZ;
                 const double vk = Zn[ZV + c6], vp = kv ? Zs[(kv - 1) * NZ + ZV + c6] : PAR[po.v0 + c6];
                 const double rv = vk - Zn[ZDPHI] * dv, ra = (vk - vp) * hinv - Zn[ZDDPHI] * dv;
                 const double ra1 = (Z1[ZV + c6] - vk) * hinv - Z1[ZDDPHI] * dn;
                 const double gz = 2 * w[2] * rv + 2 * w[5] * ra * hinv;
                 const double gn = kv < N - 1 ? -2 * w[5] * ra1 * hinv : 0.0;
-                G[on6 ? sc.GH + kv * NZ + ZV + c6 : sc.GVP + 6] = gz + gn;      // lanes without an item write to a spare word
+                WL[on6 ? sc.GH + kv * NZ + ZV + c6 : sc.GVP + 6] = gz + gn;      // lanes without an item write to a spare word
             }
             // ---- pos rows (c6 < 3) and iw rows (c6 >= 3): blended tracking errors + tube rows ----
-            {
+            if (NW == 1 || W.wv == 0) {
                 const double *nuv = NUV + kv * NI;
                 const double dde = dot3(pd, pep), dd = dot3(pd, pd);
                 double epo[3], ero[3];
@@ -867,10 +1056,10 @@ BMPC_D inline void wave_node_grad_wide(Wave &W, const POff &po, const Scr &sc, i
                     if (m == 1 || m == 2) tp += dnu * pgc[m]; else ti += dnu * pgc[m];
                 }
                 const bool isp = c6 < 3;
-                G[on6 ? sc.GH + kv * NZ + (isp ? ZPOS : ZIW) + cc : sc.GVP + 6] = isp ? gpos + tp : giw + ti;
+                WL[on6 ? sc.GH + kv * NZ + (isp ? ZPOS : ZIW) + cc : sc.GVP + 6] = isp ? gpos + tp : giw + ti;
             }
             // ---- path-parameter rows phi (a3 = 0), dphi (1), ddphi (2) ----
-            {
+            if (NW == 1 || W.wv == 1 % NW) {
                 const double *Zn = Zs + kf * NZ, *nuv = NUV + kf * NI;
                 const double dde = dot3(fd, fep), dd = dot3(fd, fd);
                 double epo[3], ero[3], eperp[3], erd[3];
@@ -898,11 +1087,11 @@ BMPC_D inline void wave_node_grad_wide(Wave &W, const POff &po, const Scr &sc, i
                 }
                 gdphi += -2 * w[7] * (PAR[po.xphid + 1] - Zn[ZDPHI]) + nuv[IDPHIMAX];
                 gddphi += -2 * w[8] * (PAR[po.xphid + 2] - Zn[ZDDPHI]);
-                G[on3 ? sc.GH + kf * NZ + ZPHI + a3 : sc.GVP + 6] = a3 == 0 ? gphi : (a3 == 1 ? gdphi : gddphi);
+                WL[on3 ? sc.GH + kf * NZ + ZPHI + a3 : sc.GVP + 6] = a3 == 0 ? gphi : (a3 == 1 ? gdphi : gddphi);
             }
             // ---- box rows: jerk (8), q, dq, ddq (7 each): 2 weight (value - target) + upper - lower multiplier; two nodes per trip ----
 #pragma unroll
-            for (int u = 0; u < 5; u++) {
+            for (int u = 0; u < 5; u++) if (NW == 1 || u % NW == W.wv) {
                 const int kb0 = 10 * pass + 2 * u + k29, kb = kb0 < N ? kb0 : N - 1, z = z29;
                 const bool on = lane < 58;
                 const double *Zn = Zs + kb * NZ, *nuv = NUV + kb * NI;
@@ -913,10 +1102,10 @@ BMPC_D inline void wave_node_grad_wide(Wave &W, const POff &po, const Scr &sc, i
                 iu = (isJ || isJp) ? IJU + z : iu; il = (isJ || isJp) ? IJL + z : il;
                 const double tgt = (isQ ? 1.0 : 0.0) * PAR[po.qd + (isQ ? z - ZQ : 0)];      // clamped index + 0/1 factor: no load under a branch
                 const double v = 2 * w[wi] * (Zn[z] - tgt) + (nuv[iu] - nuv[il]);
-                G[on ? sc.GH + kb * NZ + z : sc.GVP + 6] = v;
+                WL[on ? sc.GH + kb * NZ + z : sc.GVP + 6] = v;
             }
         }
-    LANES_END
+    WIDE_END
     }
 }
 
@@ -924,9 +1113,9 @@ BMPC_D inline void wave_node_grad_wide(Wave &W, const POff &po, const Scr &sc, i
 // of node 0.  Register set PO (0 or 5) of the lane's prefetch array; LDS buffer set by stage parity.
 #define BMPC_ADJ_LOADS(j_, PO_) { double *pf = LR[LIDX].pf + (PO_); const int j0 = (j_), j = j0 >= -1 ? j0 : -1, jc = j >= 0 ? j : 0, jr = j + 1 < N ? j + 1 : N - 1; \
     const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1; \
-    pf[0] = G[sc.GH + jc * NZ + (lane < NZ ? lane : NZ - 1)]; \
-    pf[1] = G[sc.KIN + jr * KREC + lane]; pf[2] = G[sc.KIN + jr * KREC + l2]; \
-    pf[3] = G[sc.KIN + (N + jr) * KREC + lane]; pf[4] = G[sc.KIN + (N + jr) * KREC + l2]; }
+    pf[0] = WL[sc.GH + jc * NZ + (lane < NZ ? lane : NZ - 1)]; \
+    pf[1] = WL[sc.KIN + jr * KREC + lane]; pf[2] = WL[sc.KIN + jr * KREC + l2]; \
+    pf[3] = WL[sc.KIN + (N + jr) * KREC + lane]; pf[4] = WL[sc.KIN + (N + jr) * KREC + l2]; }
 #define BMPC_ADJ_COMMIT(j_, PO_) { const double *pf = LR[LIDX].pf + (PO_); const int odd_ = (N - 1 - (j_)) & 1, l2 = lane < KREC - 64 ? 64 + lane : KREC - 1; \
     const int kb = odd_ ? L_K1 : L_K0, vb = odd_ ? L_KV1 : L_KV; \
     L[L_ST + (odd_ ? ST_Z : ST_GH) + (lane < NZ ? lane : NZ - 1)] = pf[0]; \
@@ -950,7 +1139,7 @@ BMPC_D inline int adjoint_zcode(int z) {
 template <int PO>
 BMPC_D inline void adjoint_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
-    double *L = W.L; const GPtr G = W.G;
+    double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
     const int odd = (N - 1 - k) & 1;
     double *lam1 = L + L_ST + (odd ? ST_LAM0 : ST_LAM1);     // lam_{k+1} (written one step earlier)
     double *lam0 = L + L_ST + (odd ? ST_LAM1 : ST_LAM0);     // lam_k (written now)
@@ -985,14 +1174,14 @@ BMPC_D inline void adjoint_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
             {
                 const int lo_ = isJ ? L_RJP + (k & 1) * 8 + ee : (int)(lam0 - L) + ee;
                 const int gdst = isJ ? sc.GVP + k * 8 + 6 : sc.LAM + k * NE + ee;
-                L[lo_] = tot; G[gdst] = tot;
+                L[lo_] = tot; WL[gdst] = tot;
             }
         }
         {   // jerk of node k+2 enters stage k+1 (lanes 44..51; everyone else, and the last stage, write to the spare GVP slot)
             const bool on = lane >= NZ && lane < NZ + 8 && k < N - 1; const int i = on ? lane - NZ : 0;
             const double mdd = lam1[i < 7 ? GDDQ + i : GDDPHI];
             const double v = L[L_RJP + ((k + 1) & 1) * 8 + i] + (h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd);
-            G[on ? sc.RJ + (k + 1) * NU + i : sc.GVP + k * 8 + 7] = v;
+            WL[on ? sc.RJ + (k + 1) * NU + i : sc.GVP + k * 8 + 7] = v;
         }
         // inputs of the next stage into the other LDS buffer set (loaded two stages ago), then the loads for three stages ahead
         // into the registers this just freed
@@ -1005,11 +1194,12 @@ BMPC_D inline void adjoint_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
 // LAM[N][36], RJ[N][8]; GH receives d(f + nu.h)/dZ.
 BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU, bool use_hat, double mu, LaneRegs *LR) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
-    double *L = W.L; const GPtr G = W.G;
+    double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
     const double *PAR = L + L_PAR, *Zs = W.Zc;
     wave_node_grad_wide(W, po, sc, oNU, use_hat, mu);
     BMPC_PROF(W, 27);
     if (use_hat) return;   // QP gradient only
+    SOLO_BEGIN(0)          // the sweep itself is one wave's (teams: the others wait at the barrier behind it)
     // sequential sweep; lam_{k+1} lives in LDS (ping-pong ST_LAM0/ST_LAM1).  A blocking global load per stage would cost a full
     // memory round trip with nothing else in flight, and the stages are short (the round trip is longer than a stage), so the
     // inputs of a stage are loaded into registers THREE stages ahead (two register sets, the stage loop is unrolled by two) and
@@ -1037,9 +1227,11 @@ BMPC_D inline void wave_adjoint(Wave &W, const POff &po, const Scr &sc, int oNU,
         if (lane < 8) {
             const int i = lane;
             const double mdd = i < 7 ? lamz[GDDQ + i] : lamz[GDDPHI];
-            G[sc.RJ + i] = L[L_RJP + i] + (h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd);
+            WL[sc.RJ + i] = L[L_RJP + i] + (h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd);
         }
     LANES_END
+    SOLO_END
+    TEAM_SYNC();
 }
 
 // ========================================================================================
@@ -1104,8 +1296,8 @@ BMPC_D inline void kh_prefix(const double *rec, double *hp) {   // sequential ov
 
 // q~ row r (reduced-state row, r < NS) of the node cost: gl mapped through the lifting Jacobians; rows >= 14 only copy.
 // Predicated straight-line code: every lane evaluates the (q, dq)-row formula on a clamped row.
-BMPC_D inline double node_q_row(const double *L, const double *K0, int r, double h, int ex) {
-    const double *gl = L + L_NC + NC_GL, *WY = L + L_WY, *gy = L + L_ST + ST_G;   // g_y = (g_q, g_dq): rows 0..13 of g
+BMPC_D inline double node_q_row(const double *L, const double *K0, int r, double h, int ex, int oWY = L_WY) {
+    const double *gl = L + L_NC + NC_GL, *WY = L + oWY, *gy = L + L_ST + ST_G;   // g_y = (g_q, g_dq): rows 0..13 of g
     const bool heavy = r < 14; const int a = heavy ? r : 0; const bool isq = a < 7; const int ai = isq ? a : a - 7;
     const double base = gl[(int)L[L_ZMAP + r] & 255];
     double t1 = 0, t2 = 0, t3 = 0, sW = 0;
@@ -1132,21 +1324,26 @@ BMPC_D inline double node_q_row(const double *L, const double *K0, int r, double
 // zeros at the last stage; ci3 / pii / pvv = the Schur phase's iota-coupling entries and gradient entry of this lane (or zeros).
 // Predicated: every lane evaluates the joint-pair block AND the joint/phi coupling on clamped chain indices (all loads up front), the
 // pair kind only selects what is added where.  The stage's data (records oK0 / oKV1, staging area, NC, KHP, L_MU, RD) must be in LDS.
-BMPC_D inline void blk_add_lane(Wave &W, const POff &po, int k, double delta, int lane, int oK0, int oKV1, const double (&C)[4][4], const double (&ci3)[3],
-                                double pii, double pvv, double *Pb) {
+// -- first half: everything that depends on the iterate and the multipliers only (NOT on the recursion): the entries this lane adds to its
+//    block (add[16], the planes its pair kind touches), to its iota couplings (c3inc) and to P_ii (piinc), and the predicted-point curvature
+//    wpv of its joint pair (for q~).  Inputs as pointers: the one-wave program passes its LDS staging areas, the helper wave of a team the
+//    LDS-resident workspace rows of the stage (same layouts).
+struct BlkIn { const double *K0, *KV1, *KHP, *NC, *mu4 /* curvature multipliers mu_p 3 | mu_v 3 | mu_w 3 | mu_w of the next node's velocity point 3 */,
+               *dpd /* dp_d of the stage's node (6) */, *sgk /* sigma = nu / t rows of the node (57) */; };
+BMPC_D inline void blk_prep_lane(Wave &W, const POff &po, int k, double delta, int lane, const BlkIn &in, double (&add)[16], double (&c3inc)[3], double &piinc,
+                                 double (&wpv)[2][2]) {
     const int N = W.N; const double h = W.h; const int ex = W.o.exact_hessian;
     double *L = W.L;
     const double *PAR = L + L_PAR, *w = PAR + po.w;
-    const double *ST = L + L_ST;
-    const double *rr = ST + ST_REF, *sgk = ST + ST_SG;
-    double *NC = L + L_NC, *KHP = L + L_KHP;
-    const double *K0 = L + oK0, *KV1 = L + oKV1;
+    const double *sgk = in.sgk;
+    const double *NC = in.NC, *KHP = in.KHP;
+    const double *K0 = in.K0, *KV1 = in.KV1;
     const bool has_next = k < N - 1;
     const int i = lane >> 3, l = lane & 7, ci = i < l ? i : l, cl = i < l ? l : i; const bool tr = i > l;
     const bool both = cl < 7, mix = !both && ci < 7;
     const int cic = ci < 7 ? ci : 0, clc = cl < 7 ? cl : 0;
-    const double *A1 = NC + NC_A1, *A2 = NC + NC_A2, cv = NC[NC_SC + 3], *d = rr + RDP;
-    double e[2][2], wpv[2][2], vf[2], vd[2], vdd[2];
+    const double *A1 = NC + NC_A1, *A2 = NC + NC_A2, cv = NC[NC_SC + 3], *d = in.dpd;
+    double e[2][2], vf[2], vd[2], vdd[2];
     // Gv columns of the two chains: [D | J] columns (q part f = 0, dq part f = 1)
     double gi[2][6], gl_[2][6];
 #pragma unroll
@@ -1170,11 +1367,11 @@ BMPC_D inline void blk_add_lane(Wave &W, const POff &po, int k, double delta, in
             v += cv * gv;
             double wp = 0, wn = 0;
             if (ex && !(f == 1 && g == 1)) {
-                if (f == 0 && g == 0) { wp = kh_qq(K0, KHP, L + L_MU + 4, L + L_MU + 7, L + L_MU + 10, cic, clc);
-                                        if (has_next) wn = kh_qq_w(KV1, KHP + 72, L + L_MU + 13, cic, clc); }
+                if (f == 0 && g == 0) { wp = kh_qq(K0, KHP, in.mu4, in.mu4 + 3, in.mu4 + 6, cic, clc);
+                                        if (has_next) wn = kh_qq_w(KV1, KHP + 72, in.mu4 + 9, cic, clc); }
                 else { const int qi = f == 0 ? cic : clc, dj = f == 0 ? clc : cic;
-                       wp = kh_qdq(K0, L + L_MU + 7, L + L_MU + 10, qi, dj);
-                       if (has_next) wn = kh_qdq_w(KV1, L + L_MU + 13, qi, dj); }
+                       wp = kh_qdq(K0, in.mu4 + 3, in.mu4 + 6, qi, dj);
+                       if (has_next) wn = kh_qdq_w(KV1, in.mu4 + 9, qi, dj); }
             }
             wpv[f][g] = wp;
             e[f][g] = v + wp + wn;
@@ -1198,16 +1395,13 @@ BMPC_D inline void blk_add_lane(Wave &W, const POff &po, int k, double delta, in
     const int a2i = yq ? lf * 7 + lii : 0;
     const bool onII = lane >= 32 && lane < 32 + 6; const int t = onII ? lane - 32 : 0;
     const int ib = t < 3 ? 0 : (t < 5 ? 1 : 2), ic = t < 3 ? t : (t < 5 ? t - 2 : 2);
-    double c3[3];
 #pragma unroll
-    for (int b2 = 0; b2 < 3; b2++) c3[b2] = ci3[b2] + (yq ? 1.0 : 0.0) * A2[b2 * 14 + a2i] + (yphi ? 1.0 : 0.0) * NC[NC_HRF + b2];
-    const double piin = pii + NC[NC_HRR + ib * 3 + ic] + (ib == ic ? delta : 0.0);
-    // ---- the lane's value-function block: Schur result (own orientation) + the planes of Q~ its pair kind touches (static plane
-    //      indices: the block lives in registers) ----
+    for (int b2 = 0; b2 < 3; b2++) c3inc[b2] = (yq ? 1.0 : 0.0) * A2[b2 * 14 + a2i] + (yphi ? 1.0 : 0.0) * NC[NC_HRF + b2];
+    piinc = NC[NC_HRR + ib * 3 + ic] + (ib == ic ? delta : 0.0);
+    // ---- the planes of Q~ the lane's pair kind touches (static plane indices: the block lives in registers) ----
     {
         const bool dg = both && ci == cl, c77 = !both && !mix;
         const double e00 = e[0][0] + (dg ? dq0 : 0.0), e11 = e[1][1] + (dg ? dq1 : 0.0), e01 = e[0][1], e10 = dg ? e[0][1] : e[1][0];
-        double add[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) add[q] = 0.0;
         add[0] = both ? e00 : (mix ? vf[0] : p0);
@@ -1220,20 +1414,41 @@ BMPC_D inline void blk_add_lane(Wave &W, const POff &po, int k, double delta, in
         add[9] = (mix && tr) ? vdd[1] : 0.0;
         add[10] = both ? (dg ? dq2 : 0.0) : (c77 ? p2 : 0.0);
         add[15] = both ? (dg ? dq3 : 0.0) : (c77 ? p3 : 0.0);
-#pragma unroll
-        for (int f = 0; f < 4; f++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) Pb[f * 4 + g] = (tr ? C[g][f] : C[f][g]) + add[f * 4 + g];
     }
-    // ---- stores (all unconditional: a lane that has nothing to store for a role stores to the dummy word) ----
+}
+// predicted-point curvature of the joint pairs (for q~, node_q_row in S0) into the 14 x 14 table WY (an LDS offset); all stores
+// unconditional: a lane that has nothing to store for a role stores to the dummy word
+BMPC_D inline void blk_store_wy(Wave &W, int lane, int oWY, const double (&wpv)[2][2]) {
+    double *L = W.L;
+    const int i = lane >> 3, l = lane & 7, ci = i < l ? i : l, cl = i < l ? l : i;
+    const bool both = cl < 7;
+    const int cic = ci < 7 ? ci : 0, clc = cl < 7 ? cl : 0;
 #pragma unroll
     for (int f = 0; f < 2; f++)
 #pragma unroll
-        for (int g = 0; g < 2; g++) {     // predicted-point curvature of the joint pairs, for q~ (node_q_row in S0)
+        for (int g = 0; g < 2; g++) {
             const int a = f * 7 + cic, b = g * 7 + clc;
-            const int o1 = both ? L_WY + a * 14 + b : L_DUMMY, o2 = both ? L_WY + b * 14 + a : L_DUMMY;
+            const int o1 = both ? oWY + a * 14 + b : L_DUMMY, o2 = both ? oWY + b * 14 + a : L_DUMMY;
             L[o1] = wpv[f][g]; L[o2] = wpv[f][g];
         }
+}
+// -- second half: the recursion-dependent part: the lane's value-function block = Schur result (own orientation) + add, iota couplings,
+//    P_ii, gradient, and the partial products of P rdyn
+BMPC_D inline void blk_apply_lane(Wave &W, int lane, const double (&C)[4][4], const double (&ci3)[3], double pii, double pvv, const double (&add)[16],
+                                  const double (&c3inc)[3], double piinc, double *Pb) {
+    double *L = W.L;
+    const int i = lane >> 3, l = lane & 7; const bool tr = i > l;
+    const int lf = (lane & 31) >> 3, lii = lane & 7;
+    const bool onII = lane >= 32 && lane < 32 + 6; const int t = onII ? lane - 32 : 0;
+    const int ib = t < 3 ? 0 : (t < 5 ? 1 : 2), ic = t < 3 ? t : (t < 5 ? t - 2 : 2);
+    double c3[3];
+#pragma unroll
+    for (int b2 = 0; b2 < 3; b2++) c3[b2] = ci3[b2] + c3inc[b2];
+    const double piin = pii + piinc;
+#pragma unroll
+    for (int f = 0; f < 4; f++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) Pb[f * 4 + g] = (tr ? C[g][f] : C[f][g]) + add[f * 4 + g];
     L[L_PCI + pci(0, lf, lii)] = c3[0]; L[L_PCI + pci(1, lf, lii)] = c3[1]; L[L_PCI + pci(2, lf, lii)] = c3[2];   // lanes >= 32 repeat lanes 0..31
     L[onII ? L_PII + ib * 3 + ic : L_DUMMY] = piin; L[onII ? L_PII + ic * 3 + ib : L_DUMMY] = piin;
     L[L_PV + (lane < NS ? lane : 0)] = pvv;
@@ -1243,6 +1458,16 @@ BMPC_D inline void blk_add_lane(Wave &W, const POff &po, int k, double delta, in
 #pragma unroll
         for (int f = 0; f < 4; f++) L[L_PP + f * 64 + lane] = Pb[f * 4 + 0] * r0 + Pb[f * 4 + 1] * r1 + Pb[f * 4 + 2] * r2;
     }
+}
+// the whole node-cost add of one lane from the one-wave program's staging areas (records oK0 / oKV1, ST, NC, KHP, L_MU, RD in LDS)
+BMPC_D inline void blk_add_lane(Wave &W, const POff &po, int k, double delta, int lane, int oK0, int oKV1, const double (&C)[4][4], const double (&ci3)[3],
+                                double pii, double pvv, double *Pb) {
+    double *L = W.L;
+    BlkIn in; in.K0 = L + oK0; in.KV1 = L + oKV1; in.KHP = L + L_KHP; in.NC = L + L_NC; in.mu4 = L + L_MU + 4; in.dpd = L + L_ST + ST_REF + RDP; in.sgk = L + L_ST + ST_SG;
+    double add[16], c3inc[3], piinc, wpv[2][2];
+    blk_prep_lane(W, po, k, delta, lane, in, add, c3inc, piinc, wpv);
+    blk_store_wy(W, lane, L_WY, wpv);
+    blk_apply_lane(W, lane, C, ci3, pii, pvv, add, c3inc, piinc, Pb);
 }
 
 // Node-cost data of ALL Riccati stages in wide passes, once per iterate and BEFORE the backward sweep (it replaces wave_prepare_rlv and
@@ -1264,93 +1489,93 @@ BMPC_D inline void blk_add_lane(Wave &W, const POff &po, int k, double delta, in
 // the fly (t6 in S0, chain-pair entries in S1).
 BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) {
     const int N = W.N; const double h = W.h; const int ex = W.o.exact_hessian;
-    double *L = W.L; const GPtr G = W.G;
+    double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
     const double *PAR = L + L_PAR, *w = PAR + po.w;
     const int npass = (N + 9) / 10;
-    LANES_BEGIN
+    WIDE_BEGIN
         for (int pass = 0; pass < npass; pass++) {
             // ================= batch 1: lifted residuals + iota rows (R), curvature multipliers (M), chain rows of rdyn (Y), AE (E) ==========
-            constexpr int RR = 2, RM = 2, RY = 5, RE = 7;
+            constexpr int RR = cdiv_(2, NW), RM = cdiv_(2, NW), RY = cdiv_(5, NW), RE = cdiv_(7, NW);      // items in flight per lane: one batch of WS lanes covers ten stages
             double ra1[RR][7], ra2[RR][7], rg1[RR][7], rg2[RR][7], rb0[RR];
             double ml[RM][5];
             double yv[RY];
             double e1[RE], e2[RE];
 #pragma unroll
             for (int u = 0; u < RR; u++) {   // R: a residual minus two 7-term dot products of a record row with g_q, g_dq; the row kind selects bases
-                const int id0 = pass * 64 * RR + lane + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, c = id - 12 * k;
+                const int id0 = pass * WS * RR + wl + WS * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, c = id - 12 * k;
                 const int c6 = c >= 3 ? (c < 9 ? c - 3 : c - 6) : 0;                       // velocity rows 0..5; iota rows use the rotational rows 3..5
                 const int p1 = c < 3 ? KW + c * 7 : KD + c6 * 7;
                 const int p2 = c < 3 ? KA : (c < 9 ? (c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7) : KA + (c - 9) * 7);
                 const int bs = c < 3 ? GPOS + c : (c < 9 ? GV + c - 3 : GIW + c - 9);
-                const GPtr kp = G + sc.KIN + k * KREC, gk = G + sc.G + k * NE;
+                const LPtr kp = WL + sc.KIN + k * KREC, gk = WL + sc.G + k * NE;
                 rb0[u] = gk[bs];
 #pragma unroll
                 for (int i = 0; i < 7; i++) { ra1[u][i] = kp[p1 + i]; ra2[u][i] = kp[p2 + i]; rg1[u][i] = gk[GQ + i]; rg2[u][i] = gk[GDQ + i]; }
             }
 #pragma unroll
             for (int u = 0; u < RM; u++) {   // M: mu_p, mu_v, mu_w of the node and mu_w of the next node's velocity point (item = 3 g + c)
-                const int id0 = pass * 64 * RM + lane + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, ln = id - 12 * k, c = ln % 3;
+                const int id0 = pass * WS * RM + wl + WS * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, ln = id - 12 * k, c = ln % 3;
                 const int kn = k < N - 1 ? k + 1 : k;
-                const GPtr lam = G + sc.LAM + k * NE;
-                ml[u][0] = lam[GPOS + c]; ml[u][1] = lam[GV + c]; ml[u][2] = lam[GW + c]; ml[u][3] = lam[GIW + c]; ml[u][4] = G[sc.LAM + kn * NE + GIW + c];
+                const LPtr lam = WL + sc.LAM + k * NE;
+                ml[u][0] = lam[GPOS + c]; ml[u][1] = lam[GV + c]; ml[u][2] = lam[GW + c]; ml[u][3] = lam[GIW + c]; ml[u][4] = WL[sc.LAM + kn * NE + GIW + c];
             }
 #pragma unroll
             for (int u = 0; u < RY; u++) {   // Y: chain rows of rdyn = the residual row the row table names
-                const int id0 = pass * 64 * RY + lane + 64 * u, id = id0 < N * 32 ? id0 : N * 32 - 1, k = id >> 5, r = id & 31;
-                yv[u] = G[sc.G + k * NE + (((int)L[L_ZMAP + r] >> 8) & 255)];
+                const int id0 = pass * WS * RY + wl + WS * u, id = id0 < N * 32 ? id0 : N * 32 - 1, k = id >> 5, r = id & 31;
+                yv[u] = WL[sc.G + k * NE + (((int)L[L_ZMAP + r] >> 8) & 255)];
             }
 #pragma unroll
             for (int u = 0; u < RE; u++) {   // E: Ehat entries of the predicted point k-1 and of the velocity point of node k
-                const int id0 = pass * 64 * RE + lane + 64 * u, id = id0 < N * 42 ? id0 : N * 42 - 1, k = id / 42, ln = id - 42 * k, a = ln / 14, y = ln - 14 * a;
+                const int id0 = pass * WS * RE + wl + WS * u, id = id0 < N * 42 ? id0 : N * 42 - 1, k = id / 42, ln = id - 42 * k, a = ln / 14, y = ln - 14 * a;
                 const int eb = y < 7 ? KD + (3 + a) * 7 + y : KA + a * 7 + y - 7, kp = k >= 1 ? k - 1 : 0;
-                e1[u] = G[sc.KIN + kp * KREC + eb]; e2[u] = G[sc.KIN + (N + k) * KREC + eb];
+                e1[u] = WL[sc.KIN + kp * KREC + eb]; e2[u] = WL[sc.KIN + (N + k) * KREC + eb];
             }
             // ---- arithmetic and stores of batch 1 (a clamped duplicate rewrites the last item with the same value) ----
 #pragma unroll
             for (int u = 0; u < RR; u++) {
-                const int id0 = pass * 64 * RR + lane + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, c = id - 12 * k;
+                const int id0 = pass * WS * RR + wl + WS * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, c = id - 12 * k;
                 BMPC_ACC4_DECL(sa); BMPC_ACC4_DECL(sb);
 #pragma unroll
                 for (int i = 0; i < 7; i++) { BMPC_ACC4(sa, i, ra1[u][i] * rg1[u][i]); BMPC_ACC4(sb, i, ra2[u][i] * rg2[u][i]); }
                 const double s1 = BMPC_ACC4_SUM(sa), s2 = BMPC_ACC4_SUM(sb);
                 const double m2 = c < 3 ? 0.0 : 1.0, f = c < 9 ? 1.0 : 0.5 * h;
-                G[c < 9 ? sc.RLV + k * 12 + c : sc.RDY + k * 36 + SIOTA + (c - 9)] = rb0[u] - f * (s1 + m2 * s2);
+                WL[c < 9 ? sc.RLV + k * 12 + c : sc.RDY + k * 36 + SIOTA + (c - 9)] = rb0[u] - f * (s1 + m2 * s2);
             }
 #pragma unroll
             for (int u = 0; u < RM; u++) {
-                const int id0 = pass * 64 * RM + lane + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, ln = id - 12 * k, g = ln / 3;
+                const int id0 = pass * WS * RM + wl + WS * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, ln = id - 12 * k, g = ln / 3;
                 // 0/1 factors instead of selects between loaded values
                 const double m0 = g == 0 ? 1.0 : 0.0, m1 = g == 1 ? 1.0 : 0.0, m2 = g == 2 ? 1.0 : 0.0, m3 = (g == 3 && k < N - 1) ? 1.0 : 0.0;
-                G[sc.NCS + k * NCS_STRIDE + NCS_MU + ln] = m0 * ml[u][0] + m1 * ml[u][1] + m2 * (ml[u][2] + 0.5 * h * ml[u][3]) + m3 * (0.5 * h * ml[u][4]);
+                WL[sc.NCS + k * NCS_STRIDE + NCS_MU + ln] = m0 * ml[u][0] + m1 * ml[u][1] + m2 * (ml[u][2] + 0.5 * h * ml[u][3]) + m3 * (0.5 * h * ml[u][4]);
             }
 #pragma unroll
             for (int u = 0; u < RY; u++) {
-                const int id0 = pass * 64 * RY + lane + 64 * u, id = id0 < N * 32 ? id0 : N * 32 - 1, k = id >> 5, r = id & 31;
+                const int id0 = pass * WS * RY + wl + WS * u, id = id0 < N * 32 ? id0 : N * 32 - 1, k = id >> 5, r = id & 31;
                 const bool zero = (((int)L[L_ZMAP + r] >> 16) & 1) != 0;                    // jerk states carry no defect
-                G[sc.RDY + k * 36 + r] = zero ? 0.0 : yv[u];
+                WL[sc.RDY + k * 36 + r] = zero ? 0.0 : yv[u];
             }
 #pragma unroll
             for (int u = 0; u < RE; u++) {
-                const int id0 = pass * 64 * RE + lane + 64 * u, id = id0 < N * 42 ? id0 : N * 42 - 1;
+                const int id0 = pass * WS * RE + wl + WS * u, id = id0 < N * 42 ? id0 : N * 42 - 1;
                 const double v = 0.5 * h * (e1[u] + e2[u]);
-                G[sc.AES + id] = id >= 42 ? v : 0.0;                                          // stage 0 has no iota coupling
+                WL[sc.AES + id] = id >= 42 ? v : 0.0;                                          // stage 0 has no iota coupling
             }
         }
         for (int pass = 0; pass < npass; pass++) {
             // ================= batch 2: Hpp, Hrr (C, 9 entries per stage); Hp,phi, Hr,phi, H phi,phi, scalar curvatures, dp_d (D, 3 items per stage) =====
-            constexpr int RC = 2;
+            constexpr int RC = cdiv_(2, NW);
             double h0[RC], h1[RC], ss[RC][5], ga[RC][5], gb[RC][5];
 #pragma unroll
             for (int u = 0; u < RC; u++) {
-                const int id0 = pass * 64 * RC + lane + 64 * u, id = id0 < N * 9 ? id0 : N * 9 - 1, k = id / 9, ln = id - 9 * k, a = ln / 3, b = ln - 3 * a;
-                const GPtr rr = G + sc.REF + k * RREC, sgk = G + sc.SG + k * NI;
+                const int id0 = pass * WS * RC + wl + WS * u, id = id0 < N * 9 ? id0 : N * 9 - 1, k = id / 9, ln = id - 9 * k, a = ln / 3, b = ln - 3 * a;
+                const LPtr rr = WL + sc.REF + k * RREC, sgk = WL + sc.SG + k * NI;
                 h0[u] = rr[RHPPG + ln]; h1[u] = rr[RHRRG + ln];
 #pragma unroll
                 for (int m = 0; m < 5; m++) { ss[u][m] = sgk[ITUBE + 2 * m] + sgk[ITUBE + 2 * m + 1]; ga[u][m] = rr[RGC + m * 4 + a]; gb[u][m] = rr[RGC + m * 4 + b]; }
             }
-            const int idd0 = pass * 64 + lane, idd = idd0 < N * 3 ? idd0 : N * 3 - 1, kd = idd / 3, ad = idd - 3 * kd;
+            const int idd0 = pass * WS + wl, idd = idd0 < N * 3 ? idd0 : N * 3 - 1, kd = idd / 3, ad = idd - 3 * kd;
             double su[5], sl[5], g3[5], w1[5], gd[5], nu_u[5], nu_l[5], c2[5], w2[5];
-            const GPtr rrd = G + sc.REF + kd * RREC, sgd = G + sc.SG + kd * NI, nud = G + sc.NUm + kd * NI;
+            const LPtr rrd = WL + sc.REF + kd * RREC, sgd = WL + sc.SG + kd * NI, nud = WL + sc.NUm + kd * NI;
             const double hp0 = rrd[RHPFG + ad], hr0 = rrd[RHRFG + ad], dpdp = rrd[RDPDP], hffg = rrd[RHFFG];
             const double s_phi0 = sgd[IPHI0], s_phimax = sgd[IPHIMAX], s_dphimax = sgd[IDPHIMAX];
             const double dp_a = rrd[RDP + ad], dp_b = rrd[RDP + 3 + ad];
@@ -1362,14 +1587,14 @@ BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) 
             // ---- arithmetic and stores of batch 2 ----
 #pragma unroll
             for (int u = 0; u < RC; u++) {
-                const int id0 = pass * 64 * RC + lane + 64 * u, id = id0 < N * 9 ? id0 : N * 9 - 1, k = id / 9, ln = id - 9 * k;
+                const int id0 = pass * WS * RC + wl + WS * u, id = id0 < N * 9 ? id0 : N * 9 - 1, k = id / 9, ln = id - 9 * k;
                 double hp = h0[u], hr = h1[u];
 #pragma unroll
                 for (int m = 0; m < 5; m++) {
                     const double gg = ss[u][m] * ga[u][m] * gb[u][m];
                     if (m == 1 || m == 2) hp += gg; else hr += gg;
                 }
-                G[sc.NCS + k * NCS_STRIDE + NC_HPP + ln] = hp; G[sc.NCS + k * NCS_STRIDE + NC_HRR + ln] = hr;
+                WL[sc.NCS + k * NCS_STRIDE + NC_HPP + ln] = hp; WL[sc.NCS + k * NCS_STRIDE + NC_HRR + ln] = hr;
             }
             {
                 double hp = hp0, hr = hr0;
@@ -1383,7 +1608,7 @@ BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) 
                     hff += su[m] * gpu_ * gpu_ + sl[m] * gpl_ * gpl_;
                     hff += exm * (nu_u[m] * (c2[m] - w2[m]) + nu_l[m] * (-c2[m] - w2[m]));
                 }
-                const GPtr row = G + sc.NCS + kd * NCS_STRIDE;
+                const LPtr row = WL + sc.NCS + kd * NCS_STRIDE;
                 row[NC_HPF + ad] = hp; row[NC_HRF + ad] = hr;
                 // the four scalars: every item of the stage has them, item a writes scalar a; the fourth, the zero word and dp_d ride along
                 const double sc1 = 2 * w[2] * dpdp + 2 * w[7] + s_dphimax, sc2 = 2 * w[5] * dpdp + 2 * w[8];
@@ -1393,43 +1618,43 @@ BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) 
                 row[NCS_RDP + ad] = dp_a; row[NCS_RDP + 3 + ad] = dp_b;
             }
         }
-    LANES_END
+    WIDE_END
     // ---- second phase: what needs the small blocks and the lifted residuals of the first ----
-    LANES_BEGIN
+    WIDE_BEGIN
         for (int pass = 0; pass < npass; pass++) {
             // ================= batch 3: A1 = Hpp Jp (21), A2 = (h/2) Hrr Ehat (42): one 3-term product per entry =================
-            constexpr int RA = 10;
+            constexpr int RA = cdiv_(10, NW);
             double cf[RA][3], kc[RA][3];
 #pragma unroll
             for (int u = 0; u < RA; u++) {
-                const int id0 = pass * 64 * RA + lane + 64 * u, id = id0 < N * 63 ? id0 : N * 63 - 1, k = id / 63, e = id - 63 * k;
+                const int id0 = pass * WS * RA + wl + WS * u, id = id0 < N * 63 ? id0 : N * 63 - 1, k = id / 63, e = id - 63 * k;
                 const bool isA1 = e < 21; const int e2 = isA1 ? 0 : e - 21;
                 const int c = isA1 ? e / 7 : e2 / 14, i = isA1 ? e - 7 * c : 0, y = isA1 ? 0 : e2 - 14 * c;
                 const int cb = isA1 ? NC_HPP + c * 3 : NC_HRR + c * 3, kb = isA1 ? KW + i : (y < 7 ? KD + 21 + y : KA + y - 7);
-                const GPtr row = G + sc.NCS + k * NCS_STRIDE, K0 = G + sc.KIN + k * KREC;
+                const LPtr row = WL + sc.NCS + k * NCS_STRIDE, K0 = WL + sc.KIN + k * KREC;
 #pragma unroll
                 for (int b2 = 0; b2 < 3; b2++) { cf[u][b2] = row[cb + b2]; kc[u][b2] = K0[kb + b2 * 7]; }
             }
 #pragma unroll
             for (int u = 0; u < RA; u++) {
-                const int id0 = pass * 64 * RA + lane + 64 * u, id = id0 < N * 63 ? id0 : N * 63 - 1, k = id / 63, e = id - 63 * k;
+                const int id0 = pass * WS * RA + wl + WS * u, id = id0 < N * 63 ? id0 : N * 63 - 1, k = id / 63, e = id - 63 * k;
                 double sacc = 0;
 #pragma unroll
                 for (int b2 = 0; b2 < 3; b2++) sacc += cf[u][b2] * kc[u][b2];
-                G[sc.NCS + k * NCS_STRIDE + NC_A1 + e] = e < 21 ? sacc : 0.5 * h * sacc;
+                WL[sc.NCS + k * NCS_STRIDE + NC_A1 + e] = e < 21 ? sacc : 0.5 * h * sacc;
             }
         }
         for (int pass = 0; pass < npass; pass++) {
             // ================= batch 4: the 12 rows of gl = g^ + H r + cross terms that differ from g^ (pos 3, v 6, phi, dphi, ddphi) =================
-            constexpr int RV = 2;
+            constexpr int RV = cdiv_(2, NW);
             double nc3[RV][3], rl3[RV][3], rv0[RV], rvm[RV], rvp[RV], cvv[RV], dd[RV][6], r6[RV][6], m6[RV][6];
 #pragma unroll
             for (int u = 0; u < RV; u++) {
-                const int id0 = pass * 64 * RV + lane + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, t = id - 12 * k;
+                const int id0 = pass * WS * RV + wl + WS * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, t = id - 12 * k;
                 const bool isPos = t < 3, isV = t >= 3 && t < 9;
                 const int c = isV ? t - 3 : 0, pa = isPos ? NC_HPP + t * 3 : NC_HPF;            // 3-vector that multiplies r_pos
                 const int kp = k >= 1 ? k - 1 : 0, kn = k < N - 1 ? k + 1 : k;
-                const GPtr row = G + sc.NCS + k * NCS_STRIDE, rl = G + sc.RLV + k * 12, rm = G + sc.RLV + kp * 12, rp = G + sc.RLV + kn * 12;
+                const LPtr row = WL + sc.NCS + k * NCS_STRIDE, rl = WL + sc.RLV + k * 12, rm = WL + sc.RLV + kp * 12, rp = WL + sc.RLV + kn * 12;
 #pragma unroll
                 for (int b2 = 0; b2 < 3; b2++) { nc3[u][b2] = row[pa + b2]; rl3[u][b2] = rl[b2]; }
                 rv0[u] = rl[3 + c]; rvm[u] = rm[3 + c]; rvp[u] = rp[3 + c]; cvv[u] = row[NC_SC + 3];
@@ -1438,7 +1663,7 @@ BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) 
             }
 #pragma unroll
             for (int u = 0; u < RV; u++) {
-                const int id0 = pass * 64 * RV + lane + 64 * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, t = id - 12 * k;
+                const int id0 = pass * WS * RV + wl + WS * u, id = id0 < N * 12 ? id0 : N * 12 - 1, k = id / 12, t = id - 12 * k;
                 const bool isPos = t < 3, isV = t >= 3 && t < 9, isPhi = t == 9, isD = t == 10, isDD = t == 11;
                 double sA = 0, s1 = 0, s2 = 0;
 #pragma unroll
@@ -1449,10 +1674,10 @@ BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) 
                 const double tV = cvv[u] * rv0[u] - W.ca * vm - W.ca * vp, tD = -2 * w[2] * s1, tDD = -W.cb * s1 + (k >= 1 ? W.cb * s2 : 0.0);
                 double addv = 0.0;
                 addv = isDD ? tDD : addv; addv = isD ? tD : addv; addv = isV ? tV : addv; addv = (isPos || isPhi) ? sA : addv;
-                G[sc.NCS + k * NCS_STRIDE + NCS_ADDV + t] = addv;
+                WL[sc.NCS + k * NCS_STRIDE + NCS_ADDV + t] = addv;
             }
         }
-    LANES_END
+    WIDE_END
 }
 
 // Gv[c6][y] of a kinematics record: d(v)/d(q,dq) = [D | J]
@@ -1467,7 +1692,7 @@ BMPC_D inline double gv_at(const double *rec, int c6, int y) {
 // a neighbour node that does not exist is replaced by the nearest one -- its data is masked by the consumers), and the commit
 // stores to the same clamped slots (identical values), so neither has a single exec-mask branch.
 BMPC_D inline void backward_loads_lane(Wave &W, const Scr &sc, int k, double *pf, int lane, bool full) {
-    const int N = W.N; const GPtr G = W.G;
+    const int N = W.N; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
     const int kn = k < N - 1 ? k + 1 : k, kp = k >= 1 ? k - 1 : 0;
     const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1;
     const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1;
@@ -1475,24 +1700,24 @@ BMPC_D inline void backward_loads_lane(Wave &W, const Scr &sc, int k, double *pf
     // of the four kinematics records of a stage (node k, velocity point of node k+1, node k-1, velocity point of node k) the
     // first two are the last two of the previous stage (k+1): they stay in LDS, only the first stage of a sweep loads all four
     if (full) {
-        pf[0] = G[sc.KIN + k * KREC + lane]; pf[1] = G[sc.KIN + k * KREC + l2];
-        pf[2] = G[sc.KIN + (N + kn) * KREC + lane]; pf[3] = G[sc.KIN + (N + kn) * KREC + l2];
+        pf[0] = WL[sc.KIN + k * KREC + lane]; pf[1] = WL[sc.KIN + k * KREC + l2];
+        pf[2] = WL[sc.KIN + (N + kn) * KREC + lane]; pf[3] = WL[sc.KIN + (N + kn) * KREC + l2];
     }
-    pf[4] = G[sc.KIN + kp * KREC + lane]; pf[5] = G[sc.KIN + kp * KREC + l2];
-    pf[6] = G[sc.KIN + (N + k) * KREC + lane]; pf[7] = G[sc.KIN + (N + k) * KREC + l2];
+    pf[4] = WL[sc.KIN + kp * KREC + lane]; pf[5] = WL[sc.KIN + kp * KREC + l2];
+    pf[6] = WL[sc.KIN + (N + k) * KREC + lane]; pf[7] = WL[sc.KIN + (N + k) * KREC + l2];
     // node-cost data of the stage (wave_stage_data_wide): NCS row (two slots), defects, iota couplings; gl = g^ + its non-trivial entries
-    pf[8] = G[sc.NCS + k * NCS_STRIDE + lane]; pf[9] = G[sc.NCS + k * NCS_STRIDE + 64 + lane];
-    pf[10] = G[sc.RDY + k * 36 + l35]; pf[11] = G[sc.GH + k * NZ + lz];
+    pf[8] = WL[sc.NCS + k * NCS_STRIDE + lane]; pf[9] = WL[sc.NCS + k * NCS_STRIDE + 64 + lane];
+    pf[10] = WL[sc.RDY + k * 36 + l35]; pf[11] = WL[sc.GH + k * NZ + lz];
     {   // rows pos (29..31), v (35..40), phi, dphi, ddphi (41..43) of Z have a non-trivial entry, the others add the zero word
         const int t = lz >= ZV ? lz - ZV + 3 : lz - ZPOS; const bool sp = lz >= ZV || (lz >= ZPOS && lz < ZIW);
-        pf[13] = G[sc.NCS + k * NCS_STRIDE + (sp ? NCS_ADDV + t : NCS_ZERO)];
+        pf[13] = WL[sc.NCS + k * NCS_STRIDE + (sp ? NCS_ADDV + t : NCS_ZERO)];
     }
-    pf[12] = G[sc.SG + k * NI + li]; pf[14] = G[sc.G + k * NE + le];
+    pf[12] = WL[sc.SG + k * NI + li]; pf[14] = WL[sc.G + k * NE + le];
     // prefix vectors of the two curvature records (predicted point k, velocity point of node k+1): 2 x 72 doubles in three slots
     pf[15] = G[sc.KHPG + k * 72 + lane];
     pf[16] = G[lane < 8 ? sc.KHPG + k * 72 + 64 + lane : sc.KHPG + (N + kn) * 72 + lane - 8];
     pf[17] = G[sc.KHPG + (N + kn) * 72 + 56 + (lane < 16 ? lane : 15)];
-    pf[20] = G[sc.AES + k * 42 + l42];
+    pf[20] = WL[sc.AES + k * 42 + l42];
 }
 // record buffers of stage k: (K0, K1) and (KV1, KV) swap roles from stage to stage
 BMPC_D inline void backward_buffers(int N, int k, int &oK0, int &oK1, int &oKV, int &oKV1) {
@@ -1527,10 +1752,56 @@ BMPC_D inline void backward_commit_lane(Wave &W, int k, const double *pf, int la
 // ----------------------------------------------------------------------------------------
 // Riccati backward sweep, block form.  Returns false (wave-uniform) if a stage's 8x8 jerk block is not positive definite.
 // ----------------------------------------------------------------------------------------
+#if BMPC_NW > 1
+// Helper wave of a team's Riccati sweep: the recursion-independent half of the node-cost block add of stage j (blk_prep_lane), computed
+// from the LDS-resident workspace rows of the stage while the sweep's wave works on stage j+1; results to L_PREP[j & 1] (plane-major) and the
+// curvature table of parity j.
+BMPC_D inline void team_blk_prep(Wave &W, const POff &po, const Scr &sc, int j, double delta) {
+    const int N = W.N;
+    double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
+    const int jn = j < N - 1 ? j + 1 : j;
+    LANES_BEGIN      // prefix vectors of the two curvature records (predicted point j, velocity point of node j+1) from the global slab
+        const double a_ = G[sc.KHPG + j * 72 + lane];
+        const double b_ = G[lane < 8 ? sc.KHPG + j * 72 + 64 + lane : sc.KHPG + (N + jn) * 72 + lane - 8];
+        const double c_ = G[sc.KHPG + (N + jn) * 72 + 56 + (lane < 16 ? lane : 15)];
+        L[L_HKHP + lane] = a_; L[L_HKHP + 64 + lane] = b_; L[L_HKHP + 128 + (lane < 16 ? lane : 15)] = c_;
+    LANES_END
+    LANES_BEGIN
+        const double *row = WL + sc.NCS + j * NCS_STRIDE;
+        BlkIn in; in.K0 = WL + sc.KIN + j * KREC; in.KV1 = WL + sc.KIN + (N + jn) * KREC; in.KHP = L + L_HKHP; in.NC = row; in.mu4 = row + NCS_MU;
+        in.dpd = row + NCS_RDP; in.sgk = WL + sc.SG + j * NI;
+        double add[16], c3inc[3], piinc, wpv[2][2];
+        blk_prep_lane(W, po, j, delta, lane, in, add, c3inc, piinc, wpv);
+        blk_store_wy(W, lane, (j & 1) ? L_WY2 : L_WY, wpv);
+        double *o = L + L_PREP + (j & 1) * PREP_N * 64 + lane;
+        o[0] = add[0]; o[64] = add[1]; o[128] = add[2]; o[192] = add[4]; o[256] = add[5]; o[320] = add[6]; o[384] = add[8]; o[448] = add[9];
+        o[512] = add[10]; o[576] = add[15]; o[640] = c3inc[0]; o[704] = c3inc[1]; o[768] = c3inc[2]; o[832] = piinc;
+    LANES_END
+}
+// the sweep's wave picks the helper's results of stage j up and finishes the block add
+BMPC_D inline void team_blk_apply(Wave &W, int j, int lane, const double (&C)[4][4], const double (&ci3)[3], double pii, double pvv, double *Pb) {
+    const double *o = W.L + L_PREP + (j & 1) * PREP_N * 64 + lane;
+    double add[16], c3inc[3];
+#pragma unroll
+    for (int q = 0; q < 16; q++) add[q] = 0.0;
+    add[0] = o[0]; add[1] = o[64]; add[2] = o[128]; add[4] = o[192]; add[5] = o[256]; add[6] = o[320]; add[8] = o[384]; add[9] = o[448];
+    add[10] = o[512]; add[15] = o[576]; c3inc[0] = o[640]; c3inc[1] = o[704]; c3inc[2] = o[768];
+    blk_apply_lane(W, lane, C, ci3, pii, pvv, add, c3inc, o[832], Pb);
+}
+#endif
+
 BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, double mu, double delta, LaneRegs *LR) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
-    double *L = W.L; const GPtr G = W.G;
+    double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
     const double *PAR = L + L_PAR, *w = PAR + po.w;
+    // Teams: every wave of the team runs this function (same control flow, one barrier per stage); the recursion is wave 0's (SOLO(0)), wave 1
+    // prepares the node-cost block of the NEXT stage of the sweep beside it (SOLO(1): team_blk_prep), the other waves only keep the barriers.
+#if BMPC_NW > 1
+    SOLO_BEGIN(1 % NW)
+    team_blk_prep(W, po, sc, N - 1, delta);
+    SOLO_END
+#endif
+    SOLO_BEGIN(0)
     LANES_BEGIN
         for (int id = lane; id < 96 + 12; id += 64) L[L_PCI + id] = 0.0;
         if (lane < 36) L[L_PV + lane] = 0.0;
@@ -1540,12 +1811,31 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
         backward_commit_lane(W, N - 1, LR[LIDX].pf, lane, true);
         backward_loads_lane(W, sc, N >= 2 ? N - 2 : 0, LR[LIDX].pf, lane, false);
     LANES_END
+    SOLO_END
     backward_buffers(N, N - 1, W.oK0, W.oK1, W.oKV, W.oKV1);
+    TEAM_SYNC_LDS();      // (the helper's block data of the last stage is in LDS)
+    SOLO_BEGIN(0)
     LANES_BEGIN   // value function of the last node = its node cost: the block add on a zero block
         const double Z4[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, Z3[3] = {0, 0, 0};
+#if BMPC_NW > 1
+        team_blk_apply(W, N - 1, lane, Z4, Z3, 0.0, 0.0, LR[LIDX].mc);
+#else
         blk_add_lane(W, po, N - 1, delta, lane, W.oK0, W.oKV1, Z4, Z3, 0.0, 0.0, LR[LIDX].mc);
+#endif
     LANES_END
+    SOLO_END
     for (int k = N - 1; k >= 0; k--) {
+#if BMPC_NW > 1
+        if (k >= 1) {
+            SOLO_BEGIN(1 % NW)
+            team_blk_prep(W, po, sc, k - 1, delta);      // beside the recursion's stage k; handed over at the barrier below
+            SOLO_END
+        }
+        const int oWYk = (k & 1) ? L_WY2 : L_WY, oFLAGk = L_FLAG + 2 + (k & 1);
+#else
+        constexpr int oWYk = L_WY, oFLAGk = L_FLAG;
+#endif
+        SOLO_BEGIN(0)
         BMPC_PROF(W, 6);
         backward_buffers(N, k, W.oK0, W.oK1, W.oKV, W.oKV1);
         BMPC_PROF(W, 24);
@@ -1566,7 +1856,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 for (int l = 0; l < 8; l++) BMPC_ACC4(pa, l, L[L_PP + f * 64 + i * 8 + l]);        // partial products of the eight pairs of chain i (blk_add_lane)
 #pragma unroll
                 for (int a = 0; a < 3; a++) BMPC_ACC4(pa, a, L[L_PCI + pci(a, f, i)] * L[L_RD + SIOTA + a]);
-                const double qr = node_q_row(L, L + W.oK0, r, h, W.o.exact_hessian);          // q~ of node k+1 joins the value-function gradient here
+                const double qr = node_q_row(L, L + W.oK0, r, h, W.o.exact_hessian, oWYk);          // q~ of node k+1 joins the value-function gradient here
                 L[L_PR + r] = (L[L_PV + r] + qr) + BMPC_ACC4_SUM(pa);      // off-lanes repeat row 0 (same value): no conditional store
             }
             {   // iota rows of PR
@@ -1766,7 +2056,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 }
             }
             BMPC_PROF(W, 20);
-            L[L_FLAG] = pd ? 1.0 : 0.0;            // identical in every lane
+            L[oFLAGk] = pd ? 1.0 : 0.0;            // identical in every lane
             {   // gains: one column per lane (lanes >= 36 repeat column 0: identical values, duplicate stores; when the block is not
                 // positive definite the values are discarded with the whole sweep)
                 const int c = lane < 36 ? lane : 0; double kc[NU];
@@ -1793,8 +2083,14 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
             }
         LANES_END
         BMPC_PROF(W, 23);
-        if (L[L_FLAG] == 0.0) return false;
+        SOLO_END
+        // Team: the stage's one barrier.  Behind it the verdict of the 8x8 factorisation and the helper's half of the node-cost add of stage
+        // k-1 (L_PREP, the curvature table) are in LDS.  Only LDS words cross here, so the barrier does not drain the vector-memory
+        // counter: the sweep's register prefetch of stage k-2 stays in flight (TEAM_SYNC_LDS).
+        TEAM_SYNC_LDS();
+        if (L[oFLAGk] == 0.0) return false;            // (teams: every wave reads the same word, written two stages apart per parity)
         // ---- S3: Schur complement, block lanes write the value function of node k ----
+        SOLO_BEGIN(0)
         if (k >= 1) {
             LANES_BEGIN
                 const int i = lane >> 3, l = lane & 7, ci = i < l ? i : l, cl = i < l ? l : i; const bool tr = i > l;
@@ -1873,13 +2169,18 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 BMPC_PROF(W, 17);
                 // ---- node cost of stage k-1 added to the block just formed (registers), iota couplings, gradient, partial products: no
                 //      store of the chain blocks any more ----
+#if BMPC_NW > 1
+                team_blk_apply(W, k - 1, lane, C, ci3, pii, pvv, LR[LIDX].mc);      // (the recursion-independent half came from the helper wave)
+#else
                 {
                     int q0_, q1_, q2_, q3_; backward_buffers(N, k - 1, q0_, q1_, q2_, q3_);
                     blk_add_lane(W, po, k - 1, delta, lane, q0_, q3_, C, ci3, pii, pvv, LR[LIDX].mc);
                 }
+#endif
                 BMPC_PROF(W, 30);
             LANES_END
         }
+        SOLO_END
         BMPC_PROF(W, 13);
     }
     return true;
@@ -1892,12 +2193,12 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 #define BMPC_FWD_LOADS(j_, PO_) { double *pf = LR[LIDX].pf + (PO_); const int j = (j_) < N ? (j_) : N - 1; \
     _Pragma("unroll") for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; pf[u] = G[sc.KT + j * NS * NU + (id < NS * NU ? id : NS * NU - 1)]; } \
     pf[5] = G[sc.KF + j * NU + (lane < NU ? lane : NU - 1)]; \
-    pf[6] = G[sc.RDY + j * 36 + (lane < 36 ? lane : 35)]; \
-    pf[7] = G[sc.AES + j * 42 + (lane < 42 ? lane : 41)]; \
-    pf[8] = G[sc.RLV + j * 12 + (lane < 12 ? lane : 11)]; \
-    pf[9] = G[sc.KIN + j * KREC + lane]; pf[10] = G[sc.KIN + j * KREC + (lane < KREC - 64 ? 64 + lane : KREC - 1)]; \
+    pf[6] = WL[sc.RDY + j * 36 + (lane < 36 ? lane : 35)]; \
+    pf[7] = WL[sc.AES + j * 42 + (lane < 42 ? lane : 41)]; \
+    pf[8] = WL[sc.RLV + j * 12 + (lane < 12 ? lane : 11)]; \
+    pf[9] = WL[sc.KIN + j * KREC + lane]; pf[10] = WL[sc.KIN + j * KREC + (lane < KREC - 64 ? 64 + lane : KREC - 1)]; \
     { const int t_ = lane < NZ ? lane : 0, r_ = t_ < NS ? t_ : 0; int z_ = (int)L[L_ZMAP + r_] & 255; z_ = t_ >= NS ? (t_ < NS + 3 ? ZPOS + t_ - NS : ZV + t_ - NS - 3) : z_; \
-      pf[11] = G[sc.GH + j * NZ + z_]; } }   /* the QP-gradient entry of the component of dZ this lane will write (forward_stage) */
+      pf[11] = WL[sc.GH + j * NZ + z_]; } }   /* the QP-gradient entry of the component of dZ this lane will write (forward_stage) */
 #define BMPC_FWD_COMMIT(j_, PO_) { const double *pf = LR[LIDX].pf + (PO_); const int odd_ = (j_) & 1; double *sb_ = L + (odd_ ? L_GS : L_ST), *kb_ = L + (odd_ ? L_K1 : L_K0); \
     _Pragma("unroll") for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; sb_[ST_KT + (id < NS * NU ? id : NS * NU - 1)] = pf[u]; } \
     sb_[ST_KF + (lane < NU ? lane : NU - 1)] = pf[5]; \
@@ -1909,7 +2210,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 template <int PO>
 BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
     const int N = W.N; const double h = W.h;
-    double *L = W.L; const GPtr G = W.G;
+    double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
     const double *sb = L + ((k & 1) ? L_GS : L_ST), *K0 = L + ((k & 1) ? L_K1 : L_K0);
     LANES_BEGIN   // du = kff + K ds: partial sums on all 64 lanes (control u = lane & 7, every 8th state b), reduced by the consumers
         {
@@ -1972,7 +2273,7 @@ BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
 }
 BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
     const int N = W.N;
-    double *L = W.L; const GPtr G = W.G;
+    double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
     static_assert(ST_GHF + 64 <= 288 + 64 + 288 && ST_GHF + 64 <= 460, "forward staging buffers must fit into L_ST and into the idle GS/R8/KS area");
     LANES_BEGIN
         if (lane < 36) L[L_DS + lane] = 0.0;
@@ -1987,6 +2288,20 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
     int k = 0;
     for (; k + 1 < N; k += 2) { forward_stage<12>(W, sc, LR, k); forward_stage<0>(W, sc, LR, k + 1); }
     if (k < N) forward_stage<12>(W, sc, LR, k);
+#if BMPC_NW > 1
+    LANES_BEGIN      // teams: the lanes' shares of (QP gradient) . dZ leave the sweep's wave through LDS (row pass B runs on every wave)
+        L[L_TGHD + lane] = LR[LIDX].ghd;
+    LANES_END
+#endif
+}
+
+// The Riccati sweep: one wave's in the one-wave program; in a team wave 0 runs the recursion, wave 1 the recursion-independent half of every
+// stage's node-cost add beside it, and all waves hear the verdict (positive definite or not) through an LDS word behind the stage's barrier.
+BMPC_D inline bool team_backward(Wave &W, const POff &po, const Scr &sc, double mu, double delta, LaneRegs *LR) {
+    // (every wave of a team runs the sweep function: wave 0 the recursion, wave 1 the helper's half, all of them its barriers and verdict)
+    const bool ok_ = wave_backward_blk(W, po, sc, mu, delta, LR);
+    TEAM_SYNC();
+    return ok_;
 }
 
 // ----------------------------------------------------------------------------------------
@@ -1997,7 +2312,7 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
 template <bool ZLDS>
 BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     const int N = W.N, S = W.S;
-    double *L = W.L; const GPtr G = W.G;
+    double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
     const POff po = make_poff_lds(S, L_ZL);      // LDS-relative (S > 4: the tail of p sits in the free iterate area, ZLDS is false then)
     Scr sc = make_scr(N);
     const Opts &o = W.o;
@@ -2011,10 +2326,10 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     constexpr bool zlds = ZLDS;
     const bool longh = !ZLDS && N > 11;      // long-horizon rules of the algorithm (oracle/bmpc_oracle.c): the instantiation without the LDS iterate also serves S > 4 at short horizons
     if (ZLDS) { W.Zc = L + L_ZL; W.Zt = L + L_PB; W.Dz = L + L_PB + 512; } else { W.Zc = (G + sc.Z).ptr(); W.Zt = (G + sc.ZT).ptr(); W.Dz = (G + sc.DZ).ptr(); }
-    LANES_BEGIN
-        for (int id = lane; id < np; id += 64) L[L_PAR + (ZLDS ? id : lds_index_of_p(S, id, L_ZL))] = pr.p[id];
-        for (int id = lane; id < nw; id += 64) W.Zc[id] = pr.x0[id];
-    LANES_END
+    WIDE_BEGIN
+        for (int id = wl; id < np; id += WS) L[L_PAR + (ZLDS ? id : lds_index_of_p(S, id, L_ZL))] = pr.p[id];
+        for (int id = wl; id < nw; id += WS) W.Zc[id] = pr.x0[id];
+    WIDE_END
     wave_init_tables(W, po);
     const double *PAR = L + L_PAR;
     // warm start (oracle/bmpc_oracle.c solve_one): barrier restarts at clamp(stored mu, mu_warm, mu_init); the stored
@@ -2032,29 +2347,29 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     // Row pass "A0": slacks and multipliers from the inequality values -- at the start of the solve (warm: slack bounded from below by
     // the stored multiplier) and again at every barrier restart of a stalled long-horizon solve (re-centred on a high barrier level).
 #define BMPC_ROWS_INIT(WARM_, PUSH_) \
-        LANES_BEGIN \
+        WIDE_BEGIN \
             double ep = 0, cmax = -1e300, cmin = 1e300, sn = 0; \
-            for (int tr_ = 0; tr_ < (ni + 64 * RU - 1) / (64 * RU); tr_++) { const int base = lane + tr_ * 64 * RU;      /* wave-uniform trip count */ \
-                double hv[RU], tv[RU]; \
+            for (int tr_ = 0; tr_ < (ni + WS * RUW - 1) / (WS * RUW); tr_++) { const int base = wl + tr_ * WS * RUW;      /* wave-uniform trip count */ \
+                double hv[RUW], tv[RUW]; \
 _Pragma("unroll") \
-                for (int u = 0; u < RU; u++) { \
-                    const int id = base + 64 * u; hv[u] = id < ni ? G[sc.HIN + id] : -1.0; \
+                for (int u = 0; u < RUW; u++) { \
+                    const int id = base + WS * u; hv[u] = id < ni ? WL[sc.HIN + id] : -1.0; \
                     const double ns = ((WARM_) && id < ni) ? pr.state[id] : 0.0; \
                     tv[u] = ns > 0.0 ? BMPC_FMIN(mu / ns, (PUSH_)) : (PUSH_); \
                 } \
 _Pragma("unroll") \
-                for (int u = 0; u < RU; u++) { \
-                    const int id = base + 64 * u; \
+                for (int u = 0; u < RUW; u++) { \
+                    const int id = base + WS * u; \
                     if (id < ni) { \
                         const double t = (-hv[u] > tv[u]) ? -hv[u] : tv[u], ti = 1.0 / t, nu = mu * ti, r = hv[u] + t; \
-                        G[sc.T + id] = t; G[sc.NUm + id] = nu; G[sc.SG + id] = nu * ti; G[sc.TI + id] = ti; G[sc.SR + id] = nu * ti * r; \
+                        WL[sc.T + id] = t; WL[sc.NUm + id] = nu; WL[sc.SG + id] = nu * ti; WL[sc.TI + id] = ti; WL[sc.SR + id] = nu * ti * r; \
                         const double v = BMPC_FABS(r), c = nu * t; \
                         ep = v > ep ? v : ep; cmax = c > cmax ? c : cmax; cmin = c < cmin ? c : cmin; sn += nu; \
                     } \
                 } \
             } \
-            L[L_KKP + lane] = ep; L[L_KKP + 64 + lane] = cmax; L[L_KKP + 128 + lane] = cmin; L[L_KKP + 192 + lane] = sn; \
-        LANES_END
+            WRED_PUT_MAX(L_KKPW, 0, ep); WRED_PUT_MAX(L_KKPW, 1, cmax); WRED_PUT_MIN(L_KKPW, 2, cmin); WRED_PUT_SUM(L_KKPW, 3, sn); \
+        WIDE_END
     BMPC_ROWS_INIT(warm, o.slack_push)
     int n_restart = 0, it_restart = 0;
     int it = 0, status = 1; double E0 = 0, ep_old = 0, ep_mid = 0;
@@ -2063,26 +2378,36 @@ _Pragma("unroll") \
         wave_adjoint(W, po, sc, sc.NUm, false, 0.0, LRs);
         BMPC_PROF(W, 1);
         // ---- KKT error (Ipopt-style scaling), deterministic reductions; the inequality part comes from row pass A ----
-        LANES_BEGIN
-            double ed = 0, ep = L[L_KKP + lane], sl = 0, g1 = 0;
+        WIDE_BEGIN
+#if BMPC_NW > 1
+            double ed = 0, ep = 0, sl = 0, g1 = 0;      // (the row pass's share of the primal infeasibility joins behind the barrier)
+#else
+            double ed = 0, ep = L[L_KKPW + wl], sl = 0, g1 = 0;
+#endif
             // the jerk-gradient entries ride in the first batch of the residual rows (one round trip to the workspace for the whole pass;
             // clamped duplicates do not change a maximum)
             const int nrj = N * NU;
-            for (int tr_ = 0; tr_ < (ne + 64 * RU - 1) / (64 * RU); tr_++) { const int base = lane + tr_ * 64 * RU;      /* wave-uniform trip count */
-                double gv[RU], lv[RU], rj[RU];
+            for (int tr_ = 0; tr_ < (ne + WS * RUW - 1) / (WS * RUW); tr_++) { const int base = wl + tr_ * WS * RUW;      /* wave-uniform trip count */
+                double gv[RUW], lv[RUW], rj[RUW];
 #pragma unroll
-                for (int u = 0; u < RU; u++) { const int id0 = base + 64 * u, id = id0 < ne ? id0 : ne - 1; gv[u] = G[sc.G + id]; lv[u] = G[sc.LAM + id];
-                                               rj[u] = G[sc.RJ + (id0 < nrj ? id0 : nrj - 1)]; }
+                for (int u = 0; u < RUW; u++) { const int id0 = base + WS * u, id = id0 < ne ? id0 : ne - 1; gv[u] = WL[sc.G + id]; lv[u] = WL[sc.LAM + id];
+                                               rj[u] = WL[sc.RJ + (id0 < nrj ? id0 : nrj - 1)]; }
 #pragma unroll
-                for (int u = 0; u < RU; u++) { const double v = BMPC_FABS(rj[u]); ed = v > ed ? v : ed; }
+                for (int u = 0; u < RUW; u++) { const double v = BMPC_FABS(rj[u]); ed = v > ed ? v : ed; }
 #pragma unroll
-                for (int u = 0; u < RU; u++) { const bool ok_ = base + 64 * u < ne; const double v = ok_ ? BMPC_FABS(gv[u]) : 0.0; ep = v > ep ? v : ep; g1 += v; sl += ok_ ? BMPC_FABS(lv[u]) : 0.0; }
+                for (int u = 0; u < RUW; u++) { const bool ok_ = base + WS * u < ne; const double v = ok_ ? BMPC_FABS(gv[u]) : 0.0; ep = v > ep ? v : ep; g1 += v; sl += ok_ ? BMPC_FABS(lv[u]) : 0.0; }
             }
-            L[L_RED + lane] = ed; L[L_RED + 64 + lane] = ep; L[L_RED + 128 + lane] = sl; L[L_RED + 192 + lane] = g1;
-        LANES_END
-        const double theta_eq = red_sum(L + L_RED + 192);      // ||c||_1 of the current iterate, for the filter's theta (row pass B)
-        const double ed = red_max(L + L_RED), ep = red_max(L + L_RED + 64), cmax = red_max(L + L_KKP + 64), cmin = red_min(L + L_KKP + 128),
-                     sl = red_sum(L + L_RED + 128), sn = red_sum(L + L_KKP + 192);
+            WRED_PUT_MAX(L_REDW, 0, ed); WRED_PUT_MAX(L_REDW, 1, ep); WRED_PUT_SUM(L_REDW, 2, sl); WRED_PUT_SUM(L_REDW, 3, g1);
+        WIDE_END
+        const double theta_eq = WRED_GET_SUM(L_REDW, 3);      // ||c||_1 of the current iterate, for the filter's theta (row pass B)
+#if BMPC_NW > 1
+        const double ep = BMPC_FMAX(WRED_GET_MAX(L_REDW, 1), WRED_GET_MAX(L_KKPW, 0));
+#else
+        const double ep = WRED_GET_MAX(L_REDW, 1);
+#endif
+        const double ed = WRED_GET_MAX(L_REDW, 0), cmax = WRED_GET_MAX(L_KKPW, 1), cmin = WRED_GET_MIN(L_KKPW, 2),
+                     sl = WRED_GET_SUM(L_REDW, 2), sn = WRED_GET_SUM(L_KKPW, 3);
+        TEAM_SYNC();      // (teams: every wave has read the partials before a barrier restart below, or the next pass, rewrites them)
         const double sd = BMPC_FMAX(100.0, (sl + sn) / (N * (NE + NI))) / 100.0, scl = BMPC_FMAX(100.0, sn / (N * NI)) / 100.0;
         E0 = BMPC_FMAX(BMPC_FMAX(ed / sd, ep), BMPC_FMAX(cmax, -cmin) / scl);
 #ifdef BMPC_EMU
@@ -2139,12 +2464,12 @@ _Pragma("unroll") \
             wave_stage_data_wide(W, po, sc);
         }
         for (int tries = 0; tries < 40; tries++) {
-            if (wave_backward_blk(W, po, sc, mu, delta, LRs)) { ok = true; break; }
+            if (team_backward(W, po, sc, mu, delta, LRs)) { ok = true; break; }
             if (gn_allowed && !used_gn) {
                 used_gn = true; W.o.exact_hessian = 0;
                 wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);
                 wave_stage_data_wide(W, po, sc);
-                if (wave_backward_blk(W, po, sc, mu, 0.0, LRs)) { ok = true; delta = 0.0; break; }
+                if (team_backward(W, po, sc, mu, 0.0, LRs)) { ok = true; delta = 0.0; break; }
             }
             if (delta == 0.0) delta = delta_last > 0 ? BMPC_FMAX(1e-20, delta_last / 3.0) : DELTA_FIRST;
             else delta *= (delta_last > 0 ? 8.0 : DELTA_UP_FIRST);
@@ -2156,49 +2481,52 @@ _Pragma("unroll") \
         if (delta > 0) delta_last = delta;
         delta_prev = delta;
         BMPC_PROF(W, 6);
+        SOLO_BEGIN(0)
         wave_forward(W, sc, LRs);
+        SOLO_END
+        TEAM_SYNC();
         BMPC_PROF(W, 7);
         // ---- row pass "B": slack / multiplier directions, fraction to the boundary, merit ingredients ----
         const double tau = BMPC_FMAX(0.99, 1.0 - mu);
-        LANES_BEGIN
+        WIDE_BEGIN
             double ap = 1.0, adl = 1.0, dbar = 0, nhd = 0, th = 0, bar = 0, pn_ = 1.0, pd_ = 0.0, dn_ = 1.0, dd_ = 0.0;
-            for (int tr_ = 0; tr_ < (ni + 64 * RU - 1) / (64 * RU); tr_++) { const int base = lane + tr_ * 64 * RU;      /* wave-uniform trip count */
-                double tv[RU], nv[RU], hv[RU], sg[RU], tiv[RU], sr[RU], hd[RU], tprod = 1.0;
+            for (int tr_ = 0; tr_ < (ni + WS * RUW - 1) / (WS * RUW); tr_++) { const int base = wl + tr_ * WS * RUW;      /* wave-uniform trip count */
+                double tv[RUW], nv[RUW], hv[RUW], sg[RUW], tiv[RUW], sr[RUW], hd[RUW], tprod = 1.0;
 #pragma unroll
-                for (int u = 0; u < RU; u++) {   // rows past the end are clamped to the last row (branch-free); their contributions are masked below
-                    const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1;
-                    tv[u] = G[sc.T + id]; nv[u] = G[sc.NUm + id]; hv[u] = G[sc.HIN + id];
-                    sg[u] = G[sc.SG + id]; tiv[u] = G[sc.TI + id]; sr[u] = G[sc.SR + id];
+                for (int u = 0; u < RUW; u++) {   // rows past the end are clamped to the last row (branch-free); their contributions are masked below
+                    const int id0 = base + WS * u, id = id0 < ni ? id0 : ni - 1;
+                    tv[u] = WL[sc.T + id]; nv[u] = WL[sc.NUm + id]; hv[u] = WL[sc.HIN + id];
+                    sg[u] = WL[sc.SG + id]; tiv[u] = WL[sc.TI + id]; sr[u] = WL[sc.SR + id];
                 }
                 {   // hd = grad h_i . dZ with the loads of the whole batch in front (see ineq_dir for the row formulas)
-                    double c0[RU], c1[RU], c2[RU], c3[RU], w1[RU], d0[RU], d1[RU], d2[RU], dph[RU];
+                    double c0[RUW], c1[RUW], c2[RUW], c3[RUW], w1[RUW], d0[RUW], d1[RUW], d2[RUW], dph[RUW];
 #pragma unroll
-                    for (int u = 0; u < RU; u++) {
-                        const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1;
+                    for (int u = 0; u < RUW; u++) {
+                        const int id0 = base + WS * u, id = id0 < ni ? id0 : ni - 1;
                         const int k = id / NI, i = id - k * NI;
                         // box rows and tube rows run the same instructions: clamped indices, unconditional loads, 0/1 factors (a select
                         // between loaded values would put the loads under an exec-mask branch)
                         const bool tube = i >= ITUBE; const int m = tube ? (i - ITUBE) >> 1 : 0, ti = tube ? 1 : 0; const double mt = tube ? 1.0 : 0.0;
                         const double sgn = L[L_ROWT + i]; const int src = (int)L[L_ROWT + 2 * NI + i];
-                        const GPtr rr = G + sc.REF + k * RREC; const double *dz = W.Dz + k * NZ;
+                        const LPtr rr = WL + sc.REF + k * RREC; const double *dz = W.Dz + k * NZ;
                         const int vo = src + ti * (tube_voff(m) - src);
                         c0[u] = mt * rr[RGC + m * 4 + 0] + (1.0 - mt) * sgn; c1[u] = mt * rr[RGC + m * 4 + 1]; c2[u] = mt * rr[RGC + m * 4 + 2];
                         c3[u] = mt * rr[RGC + m * 4 + 3]; w1[u] = mt * rr[RW1 + m];
                         d0[u] = dz[vo]; d1[u] = dz[vo + ti]; d2[u] = dz[vo + 2 * ti]; dph[u] = dz[ZPHI];
                     }
 #pragma unroll
-                    for (int u = 0; u < RU; u++) {
-                        const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1; const int i = id % NI;
+                    for (int u = 0; u < RUW; u++) {
+                        const int id0 = base + WS * u, id = id0 < ni ? id0 : ni - 1; const int i = id % NI;
                         const double sv = c0[u] * d0[u] + c1[u] * d1[u] + c2[u] * d2[u] + c3[u] * dph[u];
                         hd[u] = ((i >= ITUBE && ((i - ITUBE) & 1)) ? -1.0 : 1.0) * sv - w1[u] * dph[u];
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < RU; u++) {
-                    const int id0 = base + 64 * u; const bool ok_ = id0 < ni; const int id = ok_ ? id0 : ni - 1;
+                for (int u = 0; u < RUW; u++) {
+                    const int id0 = base + WS * u; const bool ok_ = id0 < ni; const int id = ok_ ? id0 : ni - 1;
                     const double t = tv[u], nu = nv[u], r = hv[u] + t, mti = mu * tiv[u], nuh = mti + sr[u];
                     const double dt = -r - hd[u], dnu = mti - nu - sg[u] * dt;
-                    G[sc.DT + id] = dt; G[sc.DNU + id] = dnu;          // a clamped row rewrites the last row with the same values
+                    WL[sc.DT + id] = dt; G[sc.DNU + id] = dnu;          // a clamped row rewrites the last row with the same values
                     // fraction to the boundary: the smallest ratio t/|dt| (nu/|dnu|) is tracked by cross-multiplication, one
                     // division per lane at the end instead of two per row
                     const bool c1 = ok_ && dt < 0 && t * pd_ < pn_ * -dt, c2 = ok_ && dnu < 0 && nu * dd_ < dn_ * -dnu;
@@ -2212,15 +2540,20 @@ _Pragma("unroll") \
             BMPC_PROF(W, 28);
             // (QP gradient) . dZ was summed by the forward sweep (one entry per lane and stage), the 1-norm of the equality residuals by
             // the KKT pass at the top of the iteration: no further trip to the workspace here
+            #if BMPC_NW > 1
+            const double ghd = W.wv == 0 ? L[L_TGHD + lane] : 0.0;
+#else
             const double ghd = LRs[LIDX].ghd;
-            th += lane == 0 ? theta_eq : 0.0;
+#endif
+            th += wl == 0 ? theta_eq : 0.0;
             BMPC_PROF(W, 29);
-            L[L_RED + lane] = ap; L[L_RED + 64 + lane] = adl; L[L_RED + 128 + lane] = dbar; L[L_RED + 192 + lane] = ghd - nhd;
-            L[L_RED + 256 + lane] = th; L[L_RED + 320 + lane] = bar;
-        LANES_END
-        const double ap = red_min(L + L_RED), dbar = red_sum(L + L_RED + 128), gfd = red_sum(L + L_RED + 192),
-                     theta = red_sum(L + L_RED + 256), bar = red_sum(L + L_RED + 320);
-        ad = red_min(L + L_RED + 64);
+            WRED_PUT_MIN(L_REDW, 0, ap); WRED_PUT_MIN(L_REDW, 1, adl); WRED_PUT_SUM(L_REDW, 2, dbar); WRED_PUT_SUM(L_REDW, 3, ghd - nhd);
+            WRED_PUT_SUM(L_REDW, 4, th); WRED_PUT_SUM(L_REDW, 5, bar);
+        WIDE_END
+        const double ap = WRED_GET_MIN(L_REDW, 0), dbar = WRED_GET_SUM(L_REDW, 2), gfd = WRED_GET_SUM(L_REDW, 3),
+                     theta = WRED_GET_SUM(L_REDW, 4), bar = WRED_GET_SUM(L_REDW, 5);
+        ad = WRED_GET_MIN(L_REDW, 1);
+        TEAM_SYNC();
         BMPC_PROF(W, 8);
         // ---- filter line search (Waechter & Biegler 2006, Ipopt constants) on theta and phi = f - mu sum log t ----
         const double dphi = gfd + dbar, phi0 = fval + bar;
@@ -2228,15 +2561,15 @@ _Pragma("unroll") \
         if (theta_min < 0) { theta_min = 1e-4 * BMPC_FMAX(1.0, theta); theta_max = 1e4 * BMPC_FMAX(1.0, theta); }
         double alpha = ap, ft = 0; bool accepted = false, armijo_step = false;
         for (int ls = 0; ls < 14; ls++) {
-            LANES_BEGIN
+            WIDE_BEGIN
                 // wave-uniform trip count, clamped index (the lanes past the end rewrite the last entry with the same value)
-                for (int t_ = 0; t_ < (nw + 63) / 64; t_++) { const int id0 = lane + 64 * t_, id = id0 < nw ? id0 : nw - 1; W.Zt[id] = W.Zc[id] + alpha * W.Dz[id]; }
-            LANES_END
+                for (int t_ = 0; t_ < (nw + WS - 1) / WS; t_++) { const int id0 = wl + WS * t_, id = id0 < nw ? id0 : nw - 1; W.Zt[id] = W.Zc[id] + alpha * W.Dz[id]; }
+            WIDE_END
             BMPC_PROF(W, 9);
             const LsRows lsr = {alpha, mu};
             ft = wave_eval(W, po, sc, W.Zt, sc.GT, sc.HT, ls > 0, &lsr);      // also: trial slacks -> TT, theta and barrier sums -> L_RED
             BMPC_PROF(W, 0);
-            const double tht = red_sum(L + L_RED + 64), phit = ft + red_sum(L + L_RED + 128);
+            const double tht = WRED_GET_SUM(L_REDW, 1), phit = ft + WRED_GET_SUM(L_REDW, 2);
             bool okk = (phit - phit == 0.0) && tht <= theta_max;
             for (int j = 0; j < nfilt && okk; j++) if (!(tht < L[L_FILT + 2 * j] || phit < L[L_FILT + 2 * j + 1])) okk = false;
             armijo_step = false;
@@ -2254,71 +2587,71 @@ _Pragma("unroll") \
 #endif
         if (!accepted) nfilt = 0;          // smallest step taken, filter reset
         else if (!armijo_step && nfilt < 32) {
-            LANES_BEGIN
+            LANES_BEGIN      // (teams: every wave writes the same two words)
                 if (lane == 0) { L[L_FILT + 2 * nfilt] = (1 - 1e-5) * theta; L[L_FILT + 2 * nfilt + 1] = phi0 - 1e-8 * theta; }
             LANES_END
             nfilt++;
         }
         // accept the last trial: iterate (LDS copy or slab swap), slab swaps for t / g / h; then row pass "A" with the multiplier update
         if (zlds) {
-            LANES_BEGIN
-                for (int t_ = 0; t_ < (nw + 63) / 64; t_++) { const int id0 = lane + 64 * t_, id = id0 < nw ? id0 : nw - 1; W.Zc[id] = W.Zt[id]; }
-            LANES_END
+            WIDE_BEGIN
+                for (int t_ = 0; t_ < (nw + WS - 1) / WS; t_++) { const int id0 = wl + WS * t_, id = id0 < nw ? id0 : nw - 1; W.Zc[id] = W.Zt[id]; }
+            WIDE_END
         } else { double *t_ = W.Zc; W.Zc = W.Zt; W.Zt = t_; }
         { int t_; t_ = sc.T; sc.T = sc.TT; sc.TT = t_; t_ = sc.G; sc.G = sc.GT; sc.GT = t_; t_ = sc.HIN; sc.HIN = sc.HT; sc.HT = t_; }
         fval = ft;
-        LANES_BEGIN
+        WIDE_BEGIN
             double ep = 0, cmax = -1e300, cmin = 1e300, sn = 0;
-            for (int tr_ = 0; tr_ < (ni + 64 * RU - 1) / (64 * RU); tr_++) { const int base = lane + tr_ * 64 * RU;      /* wave-uniform trip count */
-                double tv[RU], nv[RU], dv[RU], hv[RU];
+            for (int tr_ = 0; tr_ < (ni + WS * RUW - 1) / (WS * RUW); tr_++) { const int base = wl + tr_ * WS * RUW;      /* wave-uniform trip count */
+                double tv[RUW], nv[RUW], dv[RUW], hv[RUW];
 #pragma unroll
-                for (int u = 0; u < RU; u++) {   // loads on clamped rows (branch-free)
-                    const int id0 = base + 64 * u, id = id0 < ni ? id0 : ni - 1;
-                    tv[u] = G[sc.T + id]; nv[u] = G[sc.NUm + id]; dv[u] = G[sc.DNU + id]; hv[u] = G[sc.HIN + id];
+                for (int u = 0; u < RUW; u++) {   // loads on clamped rows (branch-free)
+                    const int id0 = base + WS * u, id = id0 < ni ? id0 : ni - 1;
+                    tv[u] = WL[sc.T + id]; nv[u] = WL[sc.NUm + id]; dv[u] = G[sc.DNU + id]; hv[u] = WL[sc.HIN + id];
                 }
 #pragma unroll
-                for (int u = 0; u < RU; u++) {
-                    const int id = base + 64 * u; const bool ok_ = id < ni;
+                for (int u = 0; u < RUW; u++) {
+                    const int id = base + WS * u; const bool ok_ = id < ni;
                     const double t = tv[u], ti = 1.0 / t; double nu = nv[u] + ad * dv[u];
                     const double lo = mu * ti * 1e-10, hi = 1e10 * mu * ti;
                     nu = nu < lo ? lo : (nu > hi ? hi : nu);
                     const double r = hv[u] + t, sgm = nu * ti;
                     // the new multipliers go to the OTHER buffer (ping-pong), so a clamped duplicate of the last row may store too
-                    { const int ic = ok_ ? id : ni - 1; G[sc.NU2 + ic] = nu; G[sc.SG + ic] = sgm; G[sc.TI + ic] = ti; G[sc.SR + ic] = sgm * r; }
+                    { const int ic = ok_ ? id : ni - 1; WL[sc.NU2 + ic] = nu; WL[sc.SG + ic] = sgm; WL[sc.TI + ic] = ti; WL[sc.SR + ic] = sgm * r; }
                     const double v = ok_ ? BMPC_FABS(r) : 0.0, c = nu * t;
                     ep = v > ep ? v : ep; cmax = (ok_ && c > cmax) ? c : cmax; cmin = (ok_ && c < cmin) ? c : cmin; sn += ok_ ? nu : 0.0;
                 }
             }
-            L[L_KKP + lane] = ep; L[L_KKP + 64 + lane] = cmax; L[L_KKP + 128 + lane] = cmin; L[L_KKP + 192 + lane] = sn;
-        LANES_END
+            WRED_PUT_MAX(L_KKPW, 0, ep); WRED_PUT_MAX(L_KKPW, 1, cmax); WRED_PUT_MIN(L_KKPW, 2, cmin); WRED_PUT_SUM(L_KKPW, 3, sn);
+        WIDE_END
         { const int t_ = sc.NUm; sc.NUm = sc.NU2; sc.NU2 = t_; }
     }
     // ---- outputs in the reference's conventions (casadi nlpsol: x, g, lam_g, lam_x, f) ----
-    LANES_BEGIN
-        if (pr.x) for (int id = lane; id < nw; id += 64) pr.x[id] = W.Zc[id];
-        for (int id = lane; id < N * NG; id += 64) {
+    WIDE_BEGIN
+        if (pr.x) for (int id = wl; id < nw; id += WS) pr.x[id] = W.Zc[id];
+        for (int id = wl; id < N * NG; id += WS) {
             const int k = id / NG, i = id - k * NG;
-            const double *Zn = W.Zc + k * NZ; const GPtr rr = G + sc.REF + k * RREC, nu = G + sc.NUm + k * NI;
+            const double *Zn = W.Zc + k * NZ; const LPtr rr = WL + sc.REF + k * RREC, nu = WL + sc.NUm + k * NI;
             double gv, lv;
-            if (i < NE) { gv = G[sc.G + k * NE + i]; lv = G[sc.LAM + k * NE + i]; }
+            if (i < NE) { gv = WL[sc.G + k * NE + i]; lv = WL[sc.LAM + k * NE + i]; }
             else if (i == 36) { gv = Zn[ZPHI] - PAR[po.phimax]; lv = nu[IPHIMAX]; }
             else if (i == 37) { gv = Zn[ZDPHI] - PAR[po.dphimax]; lv = nu[IDPHIMAX]; }
             else { const int m = i - 38; const double c = rr[RC + m], wd = rr[RWD + m]; gv = c * c - wd * wd; lv = wd > 0 ? (nu[ITUBE + 2 * m] + nu[ITUBE + 2 * m + 1]) / (2 * wd) : 0.0; }
             if (pr.g) pr.g[id] = gv;
             if (pr.lam_g) pr.lam_g[id] = lv;
         }
-        if (pr.lam_x) for (int id = lane; id < nw; id += 64) {
-            const int k = id / NZ, z = id - k * NZ; const GPtr nu = G + sc.NUm + k * NI; double v = 0;
+        if (pr.lam_x) for (int id = wl; id < nw; id += WS) {
+            const int k = id / NZ, z = id - k * NZ; const LPtr nu = WL + sc.NUm + k * NI; double v = 0;
             if (z < 8) v = nu[IJU + z] - nu[IJL + z]; else if (z < ZDQ) v = nu[IQU + z - ZQ] - nu[IQL + z - ZQ];
             else if (z < ZDDQ) v = nu[IDQU + z - ZDQ] - nu[IDQL + z - ZDQ]; else if (z == ZPHI) v = -nu[IPHI0];
             pr.lam_x[id] = v;
         }
-        if (pr.state) for (int id = lane; id < ni; id += 64) pr.state[id] = G[sc.NUm + id];
-        if (lane == 0) {
+        if (pr.state) for (int id = wl; id < ni; id += WS) pr.state[id] = WL[sc.NUm + id];
+        if (wl == 0) {
             if (pr.f) *pr.f = fval; if (pr.iters) *pr.iters = it; if (pr.status) *pr.status = status; if (pr.kkt) *pr.kkt = E0;
             if (pr.state) { pr.state[ni] = mu; pr.state[ni + 1] = (double)it; }
         }
-    LANES_END
+    WIDE_END
 }
 
-}  // namespace bmpc
+}  // namespace BMPC_NAMESPACE

@@ -70,6 +70,17 @@ class BatchedOCPSolver:
         self._lib.bmpc_launch_info(self._h, ctypes.byref(g), ctypes.byref(l), ctypes.byref(s))
         return dict(grid=g.value, lds_bytes=l.value, scratch_bytes=s.value)
 
+    def set_team_waves(self, waves=0):
+        """Waves per problem: 0 (default) automatic -- a batch that fits into the resident teams of the device (256 on an MI355X) is solved by
+        workgroups of 4 cooperating waves, a larger one by one wave per problem; 1 never teams; 4 teams whenever the kernel exists
+        (N <= 11, S <= 4).  Re-capture graphs after changing it."""
+        _lib.check(self._lib.bmpc_set_team_waves(self._h, int(waves)), "bmpc_set_team_waves")
+
+    def team_info(self, B):
+        w, r, l = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(self._lib.bmpc_team_info(self._h, int(B), ctypes.byref(w), ctypes.byref(r), ctypes.byref(l)), "bmpc_team_info")
+        return dict(waves=w.value, resident_teams=r.value, lds_bytes=l.value)
+
     def set_rt_feasibility_tol(self, tol):
         """Threshold of the reference's acceptance rule (summed violation of g, BoundMPC.py:462-465) that stream ticks in real-time mode
         apply to an iteration-capped iterate (default 1e-4, the reference's).  Set it before the tick graph is captured."""

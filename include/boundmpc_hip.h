@@ -180,6 +180,16 @@ int bmpc_last_kernel_ms(bmpc_handle *h, float *ms);
  * (wall-clock counter read when a wavefront takes the problem from the queue and when it has written the outputs); NULL = off. */
 int bmpc_set_latency_buffer(bmpc_handle *h, double *latency_us);
 
+/* Teams: for horizons N <= 10 and S <= 4 the library also holds kernels that put a WORKGROUP OF 4 COOPERATING WAVES on one problem (the
+ * item-parallel passes of an iteration run over 256 lanes, the recursions on one wave): about 1.3x faster per iteration, but only a quarter
+ * as many problems are resident (256 on an MI355X: a team keeps most of its workspace in the 160 KB of LDS of the CU it owns).  They serve the batches that leave SIMDs idle anyway: closed-loop streams
+ * (BASELINE configs[4]: 256) and the single solver(...) call of the drop-in (BoundMPC.py:446-453).  bmpc_set_team_waves(h, 0) (default): a
+ * batch is solved by teams when it fits into the resident teams, else by one wave per problem; (h, 1): never; (h, 4): whenever the
+ * instantiation exists.  Results agree with the one-wave kernels up to the order of a few sums (same iterates unless a filter decision
+ * sits on a rounding error).  bmpc_team_info: waves per problem a batch of B would get, resident teams, LDS bytes of a team. */
+int bmpc_set_team_waves(bmpc_handle *h, int waves);
+int bmpc_team_info(const bmpc_handle *h, int B, int *waves, int *resident_teams, int *lds_bytes);
+
 /* launch geometry actually used: resident workgroups (one wave each), LDS bytes per workgroup, scratch bytes per workgroup */
 int bmpc_launch_info(const bmpc_handle *h, int *grid, int *lds_bytes, long long *scratch_bytes);
 

@@ -60,6 +60,39 @@ def solve(p, x0, N, S, h, opts=None, lane_order=0, nthreads=0, state=None):
     return out
 
 
+# ---- team variant of the wave program (tests/emu/bmpc_emu_team.cpp: NW cooperating waves per problem) ----
+_TLIBS = {}
+
+
+def team_lib(nw=4):
+    if nw not in _TLIBS:
+        path = os.path.join(_HERE, f"libbmpc_emu_team{nw}.so")
+        src = [os.path.join(_HERE, "bmpc_emu_team.cpp"), _SRC[1]]
+        if not os.path.exists(path) or any(os.path.getmtime(path) < os.path.getmtime(s) for s in src):
+            subprocess.check_call(["g++", "-O2", "-fopenmp", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-Wno-enum-compare",
+                                   f"-DBMPC_NW={nw}", "-o", path, src[0]])
+        _TLIBS[nw] = ctypes.CDLL(path)
+        assert _TLIBS[nw].bmpc_emu_team_waves() == nw
+    return _TLIBS[nw]
+
+
+def solve_team(p, x0, N, S, h, nw=4, opts=None, lane_order=0, wave_order=0, nthreads=0, state=None):
+    """The team program (nw waves per problem) on the CPU: wide phases run wave after wave in `wave_order` (0 forward, 1 reverse,
+    2 scrambled), lanes in `lane_order`."""
+    p = np.ascontiguousarray(np.atleast_2d(p), dtype=np.float64)
+    x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
+    B = p.shape[0]
+    out = dict(x=np.zeros((B, N * 44)), g=np.zeros((B, N * 43)), lam_g=np.zeros((B, N * 43)), lam_x=np.zeros((B, N * 44)),
+               f=np.zeros(B), iters=np.zeros(B, dtype=np.int32), status=np.zeros(B, dtype=np.int32), kkt=np.zeros(B))
+    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20) if N > 11 else default_opts())
+    rc = team_lib(nw).bmpc_emu_team_solve(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(B), _p(p), _p(x0),
+                                          _p(state) if state is not None else None, _p(out["x"]), _p(out["g"]), _p(out["lam_g"]), _p(out["lam_x"]),
+                                          _p(out["f"]), _p(out["iters"]), _p(out["status"]), _p(out["kkt"]), ctypes.c_int(lane_order),
+                                          ctypes.c_int(wave_order), ctypes.c_int(nthreads))
+    assert rc == 0
+    return out
+
+
 # ---- CPU build of the stream functions (boundmpc_amd/csrc/bmpc_stream.inl) ----
 def stream_lengths(N):
     out = (ctypes.c_int * 4)()

@@ -10,9 +10,15 @@ from boundmpc_amd import workload, _lib
 csrc = os.path.join(ROOT, "boundmpc_amd", "csrc")
 prof_lib = os.path.join(ROOT, "gpurun_out", "libboundmpc_hip_prof.so")
 os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-DBMPC_PROFILE"] + os.environ.get("BMPC_PROF_DEFS", "").split() + ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
-                       "-Wno-unused-variable", "-Wno-unused-value", "-Wno-duplicate-decl-specifier", "-o", prof_lib,
-                       os.path.join(csrc, "bmpc_hip.hip")])
+flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-DBMPC_PROFILE"] + os.environ.get("BMPC_PROF_DEFS", "").split() + \
+        ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-duplicate-decl-specifier"]
+objs = []
+procs = []
+for unit in ("bmpc_hip", "bmpc_team"):      # the two translation units of the library, side by side
+    objs.append(os.path.join(ROOT, "gpurun_out", unit + "_prof.o"))
+    procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + ["-c", "-o", objs[-1], os.path.join(csrc, unit + ".hip")]))
+assert all(pr.wait() == 0 for pr in procs)
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", prof_lib] + objs)
 lib = ctypes.CDLL(prof_lib)
 vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
 lib.bmpc_create.argtypes = [ci, ci, cd, vp, ctypes.POINTER(vp)]
@@ -20,10 +26,13 @@ lib.bmpc_solve_batch.argtypes = [vp, ci] + [vp] * 11
 lib.bmpc_get_profile.argtypes = [vp, vp]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-TIGHT = len(sys.argv) > 3 and sys.argv[3] == "tight"
+TIGHT = "tight" in sys.argv[3:]
+TEAM = 4 if "team" in sys.argv[3:] else (1 if "one" in sys.argv[3:] else 0)      # waves per problem: team kernels / one wave / the library's choice
 P, X, _ = workload.make_batch(B, seed=0, N=N, tight=TIGHT)
 h = vp()
 assert lib.bmpc_create(N, 4, 0.1, None, ctypes.byref(h)) == 0
+lib.bmpc_set_team_waves.argtypes = [vp, ci]
+assert lib.bmpc_set_team_waves(h, TEAM) == 0
 p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
 x = torch.empty_like(x0); it = torch.empty(B, dtype=torch.int32, device="cuda")
 prof = np.zeros(32, dtype=np.uint64)
@@ -34,6 +43,6 @@ for rep in range(2):
     lib.bmpc_get_profile(h, vp(prof.ctypes.data))
 names = ["eval", "adjoint", "kkt+mu", "qp-gradient", "prepare-rlv", "bwd:node(after p5..)", "bwd:stage-in", "forward", "step-dirs", "ls-trial", "nu-update", "(merged into nc:p1)", "st:S1 M-blocks", "st:S3d p1 of next stage", "st:S3a mfma + C", "load", "wide: rlv+iota loop", "st:S3b small roles", "nc:p2+p3 A1/A2/mu/gl", "st:S2a commit + prefetch", "st:S2b cholesky", "st:S0 q~/PR/U/PE", "st:S0b Mci/m", "st:S2 chol+gains", "bwd:staging burst", "eval:kinematics (2N lanes)", "eval:node refs+objective (N lanes)", "adjoint:node gradients (N lanes)", "step-dirs: row loop", "step-dirs: grad.dz + theta loops", "st:S3c stores", "wide: rdy rows + AE loops"]
 tot = float(prof.sum()); its = float(it.sum().item())
-print(f"B={B} N={N}{' tight' if TIGHT else ''} wall {dt*1e3:.1f} ms, total iterations {its:.0f}, cycles/iteration (lane-0 stamps, profile build) {tot/its:.0f}")
+print(f"B={B} N={N}{' tight' if TIGHT else ''} waves/problem {TEAM or 'auto'} (team kernels: stamps of lane 0 of wave 0) wall {dt*1e3:.1f} ms, total iterations {its:.0f}, cycles/iteration (lane-0 stamps, profile build) {tot/its:.0f}")
 for n, c in zip(names, prof):
     if c: print(f"  {n:28s} {100.0*float(c)/tot:5.1f} %   {float(c)/its:9.0f} cycles/iter")

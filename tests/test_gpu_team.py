@@ -1,0 +1,124 @@
+"""Team kernels (a workgroup of 4 cooperating waves per problem, boundmpc_amd/csrc/bmpc_team.hip) on the GPU: against the CPU oracle, against
+the one-wave kernels, bitwise determinism, the automatic choice by batch size, the warm entry and the fused closed-loop tick."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _solvers(N=10, **kw):
+    from boundmpc_amd import BatchedOCPSolver
+    one, team = BatchedOCPSolver(N, 4, 0.1, **kw), BatchedOCPSolver(N, 4, 0.1, **kw)
+    one.set_team_waves(1); team.set_team_waves(4)
+    return one, team
+
+
+@pytest.mark.parametrize("B", [1, 37, 256])
+def test_team_kernel_matches_oracle_and_one_wave_kernel(B):
+    import torch
+    from boundmpc_amd import workload
+    from oracle import c_oracle
+    P, X, _ = workload.make_batch(1024, seed=0, rows=(0, B))
+    p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
+    one, team = _solvers()
+    try:
+        assert team.team_info(B)["waves"] == 4 and one.team_info(B)["waves"] == 1
+        want = ("g", "lam_g", "lam_x", "f", "iters", "status", "kkt")
+        o1 = {k: v.cpu().numpy() for k, v in one.solve_batch(p, x0, out={}, want=want).items()}
+        o4 = {k: v.cpu().numpy() for k, v in team.solve_batch(p, x0, out={}, want=want).items()}
+        o4b = {k: v.cpu().numpy() for k, v in team.solve_batch(p, x0, out={}, want=want).items()}
+    finally:
+        one.close(); team.close()
+    ref = c_oracle.solve(P, X, 10, 4, 0.1, nthreads=16)
+    assert (o4["status"] == ref["status"]).all() and (o4["status"] == 0).all()
+    assert np.abs(o4["iters"] - ref["iters"]).max() <= 2
+    d = (o4["x"] - ref["x"]).reshape(B, 10, 44)[:, :, 8:15]
+    assert np.sqrt((d ** 2).mean(axis=(1, 2))).max() < 1e-6 and np.sqrt((d ** 2).mean()) < 1e-7      # rad, per problem and over the batch
+    assert o4["kkt"].max() <= 1e-8
+    # a team changes the order of a few sums that only feed accept / reject decisions: same iterates as the one-wave kernel
+    assert np.array_equal(o4["iters"], o1["iters"])
+    for k in ("x", "g", "lam_g", "lam_x", "f"):
+        np.testing.assert_allclose(o4[k], o1[k], rtol=1e-9, atol=1e-9, err_msg=k)
+        assert np.array_equal(o4[k], o4b[k]), k      # bitwise deterministic from launch to launch
+
+
+def test_team_choice_is_automatic_by_batch_size():
+    from boundmpc_amd import BatchedOCPSolver
+    s = BatchedOCPSolver(10, 4, 0.1)
+    s11, s30 = BatchedOCPSolver(11, 4, 0.1), BatchedOCPSolver(30, 4, 0.1)
+    try:
+        r = s.team_info(1)["resident_teams"]
+        assert r >= 64 and s.team_info(1)["lds_bytes"] <= 160 * 1024
+        assert s.team_info(1)["waves"] == 4 and s.team_info(r)["waves"] == 4 and s.team_info(r + 1)["waves"] == 1 and s.team_info(1024)["waves"] == 1
+        # horizons beyond a team's LDS: one wave per problem whatever the batch; asking for teams there is an error
+        assert s11.team_info(1)["waves"] == 1 and s30.team_info(1)["waves"] == 1
+        with pytest.raises(Exception):
+            s30.set_team_waves(4)
+    finally:
+        s.close(); s11.close(); s30.close()
+
+
+def test_team_kernel_warm_entry_iteration_cap_and_other_horizons():
+    import torch
+    from boundmpc_amd import workload
+    one, team = _solvers()
+    try:
+        P, X, _ = workload.make_batch(64, seed=4)
+        p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
+        sa, sb = one.new_state(64), team.new_state(64)
+        for rep, cap in enumerate((3, 0, 0)):      # capped cold start (status 1), then warm solves from the stored duals
+            a = one.solve_batch(p, x0, out={}, want=("iters", "status"), state=sa, max_iter=cap)
+            b = team.solve_batch(p, x0, out={}, want=("iters", "status"), state=sb, max_iter=cap)
+            assert torch.equal(a["iters"], b["iters"]) and torch.equal(a["status"], b["status"])
+            assert float((a["x"] - b["x"]).abs().max()) < 1e-9 and float((sa - sb).abs().max()) < 1e-6
+            if cap:
+                assert int(b["status"].max()) == 1 and int(b["iters"].max()) == cap
+    finally:
+        one.close(); team.close()
+    for N in (3, 7):
+        o, t = _solvers(N)
+        try:
+            P, X, _ = workload.make_batch(48, seed=5, N=N)
+            p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
+            a, b = o.solve_batch(p, x0, out={}, want=("iters", "status")), t.solve_batch(p, x0, out={}, want=("iters", "status"))
+            assert int(b["status"].max()) == 0 and torch.equal(a["iters"], b["iters"]) and float((a["x"] - b["x"]).abs().max()) < 1e-9
+        finally:
+            o.close(); t.close()
+
+
+def test_team_tick_equals_one_wave_tick_in_closed_loop():
+    """The fused closed-loop tick {pack, solve, post} by teams (wave 0 packs and post-processes, the team solves) against the one-wave tick
+    over 12 ticks of 16 streams: same plant trajectories."""
+    import torch
+    from boundmpc_amd import workload
+    from boundmpc_amd import stream as bstream
+    q0s = workload.random_q0(16, seed=3)
+    outs = []
+    for waves in (1, 4):
+        from boundmpc_amd import BatchedOCPSolver
+        s = BatchedOCPSolver(10, 4, 0.1)
+        s.set_team_waves(waves)
+        mpcs, recs = [], []
+        for q0 in q0s:
+            m, p0fk = workload.make_mpc(q0)
+            mpcs.append(m)
+            recs.append(bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([m.phi_max[0], 0, 0]), np.zeros(7)))
+        sb = bstream.StreamBatch(s, mpcs)
+        sb.set_robot(np.stack(recs))
+        try:
+            for t in range(12):
+                sb.tick(warm_dual=True, simulate=True)
+            torch.cuda.synchronize()
+            outs.append((sb.robot.cpu().numpy().copy(), sb.iters.cpu().numpy().copy(), sb.status.cpu().numpy().copy(), sb.traj.cpu().numpy().copy()))
+        finally:
+            sb.close(); s.close()
+    (r1, i1, s1, t1), (r4, i4, s4, t4) = outs
+    assert (s4 == 0).all() and np.array_equal(s1, s4)
+    np.testing.assert_allclose(r4, r1, atol=1e-7)
+    np.testing.assert_allclose(t4, t1, atol=1e-6)
