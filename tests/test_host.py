@@ -309,3 +309,55 @@ def test_pack_and_postprocess_other_horizons_and_windows_g12(N, S):
         assert abs(mpc.phi_current[0] - d[k + "phi_current"][i]) < 1e-13 and mpc.ref_path.sector == d[k + "sector"][i]
         np.testing.assert_allclose(mpc.pr_ref, d[k + "pr_ref"][i], atol=1e-12)
         np.testing.assert_allclose(mpc.iw_ref, d[k + "iw_ref"][i], atol=1e-12)
+
+
+# ---- the node's control loop without ROS (boundmpc_amd/node_loop.py vs bound_mpc_node.py:48-83,292-372) ----
+@pytest.mark.parametrize("which", [1, 2])
+def test_node_loop_retraces_the_reference_closed_loop_g7(which):
+    """NodeLoop (reset + step: forward kinematics, mpc.step, fails / switch bookkeeping, kinematic plant step, new jerk) driven by a solver
+    that replays the solutions recorded in fixture G7 -- the closed loop the REFERENCE's own BoundMPC.step() ran tick by tick with the same
+    node-side integration (tests/golden/make_golden.py) -- must hand the solver the recorded (p, x0) and arrive at the recorded plant state
+    on every tick."""
+    from boundmpc_amd.node_loop import NodeLoop
+    G = os.path.join(os.path.dirname(__file__), "golden")
+    d6 = np.load(os.path.join(G, f"g6_pack_exp{which}_tick0.npz")); d7 = np.load(os.path.join(G, f"g7_closedloop_exp{which}.npz"))
+    mk = lambda k: [np.array(v) for v in d6[k]]
+
+    class Replay:
+        def __init__(self):
+            self.t = 0
+
+        def generate_dependencies(self, *a, **k):
+            pass
+
+        def __call__(self, x0=None, lbx=None, ubx=None, lbg=None, ubg=None, p=None):
+            t = self.t
+            np.testing.assert_allclose(np.asarray(p, dtype=float)[mask], d7["p"][t][mask], atol=1e-9, rtol=1e-9, err_msg=f"p at tick {t}")      # (mask: rows the reference leaves undefined)
+            np.testing.assert_allclose(np.asarray(x0, dtype=float), d7["x0"][t], atol=1e-9, err_msg=f"x0 at tick {t}")
+            from oracle import nlp
+            _, g = nlp.nlp_eval(d7["x"][t], d7["p"][t], 10, 4, 0.1)
+            self.t += 1
+            self._st = dict(iter_count=int(d7["iters"][t]), success=bool(d7["status"][t] == 0), return_status="replayed")
+            return dict(x=d7["x"][t], g=g, lam_g=np.zeros_like(g), lam_x=np.zeros(440), f=0.0)
+
+        def stats(self):
+            return self._st
+
+    published = []
+    mask = d6["p_defined_mask"]
+    q0 = d7["q"][0]
+    loop = NodeLoop(mk("p_via"), mk("r_via"), [mk("p_lower"), mk("p_upper")], [mk("r_lower"), mk("r_upper")], mk("bp1_in"), mk("br1_in"), list(d6["s_in"]),
+                    list(d6["e_p_min_in"]), list(d6["e_r_min_in"]), list(d6["e_p_max_in"]), list(d6["e_r_max_in"]), p0=d6["p0fk"].copy(), q0=q0,
+                    params=workload.Params(weights=d6["weights_f64"], real_time=True), solver=Replay(), publish=published.append)
+    T = len(d7["q"])
+    for t in range(T - 1):
+        for k, v in (("q", loop.q), ("dq", loop.dq), ("ddq", loop.ddq), ("jerk", loop.jerk), ("v", loop.v)):
+            np.testing.assert_allclose(v, d7[k][t], atol=1e-9, err_msg=f"{k} before tick {t}")
+        out = loop.step()
+        assert out is not None
+        np.testing.assert_allclose(out[0]["q"], d7["traj_q"][t][:, :out[0]["q"].shape[1]], atol=1e-9)
+        assert loop.mpc.error_count == int(d7["error_count"][t]) and abs(loop.mpc.phi_current[0] - d7["phi_current"][t]) < 1e-10
+    assert len(published) == T - 1 and published[-1]["iterations"] == int(d7["iters"][T - 2]) and len(published[-1]["fails"]) == T - 1
+    assert published[-1]["stamp"] == pytest.approx((T - 1) * 0.1) and published[-1]["q"].shape[0] == 7
+    # the switch bookkeeping saw every window shift of the path (sector of the fixture)
+    assert len(loop.t_switch) == int(d7["sector"][T - 2])
