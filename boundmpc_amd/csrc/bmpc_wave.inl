@@ -954,10 +954,9 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
 
 // mu_q, mu_dq of stage kk (node kk -> kk+1) from lam_kk and the predicted-point record, into L_MU[0..15]
 // (lanes 0..7; chain 7 = path parameter)
-BMPC_D inline void stage_mu(Wave &W, const double *lam, const double *kp, int lane) {
-    double *L = W.L; const double h = W.h;
-    // branch-free: lanes >= 8 repeat chain 0 (identical values, duplicate stores); chain 7 (path parameter) selects its own pair
-    const int ch = lane < 8 ? lane : 0, i = ch < 7 ? ch : 0;
+// (value form: chain ch of 0..7, 7 = path parameter; branch-free on a clamped joint index)
+BMPC_D inline void stage_mu_vals(const double *lam, const double *kp, double h, int ch, double &muq, double &mudq) {
+    const int i = ch < 7 ? ch : 0;
     double s = lam[GQ + i], s2 = lam[GDQ + i];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
@@ -966,7 +965,14 @@ BMPC_D inline void stage_mu(Wave &W, const double *lam, const double *kp, int la
         s2 += kp[KW + c * 7 + i] * mv + kp[KA + c * 7 + i] * mw;
     }
     const double lp = lam[GPHI], ld = lam[GDPHI];
-    L[L_MU + ch] = ch < 7 ? s : lp; L[L_MU + 8 + ch] = ch < 7 ? s2 : ld;
+    muq = ch < 7 ? s : lp; mudq = ch < 7 ? s2 : ld;
+}
+BMPC_D inline void stage_mu(Wave &W, const double *lam, const double *kp, int lane) {
+    double *L = W.L;
+    // branch-free: lanes >= 8 repeat chain 0 (identical values, duplicate stores); chain 7 (path parameter) selects its own pair
+    const int ch = lane < 8 ? lane : 0;
+    double muq, mudq; stage_mu_vals(lam, kp, W.h, ch, muq, mudq);
+    L[L_MU + ch] = muq; L[L_MU + 8 + ch] = mudq;
 }
 
 // d(f + nu.h)/dZ of every node -> GH [N][44] (the reference's objective_function / error_function, casadi_ocp_formulation.py:227-265,
@@ -1135,7 +1141,7 @@ BMPC_D inline int adjoint_zcode(int z) {
     return fc | (i << 2) | ((has ? 1 : 0) << 5) | (((i < 7 && fc <= 1) ? 1 : 0) << 6) | ((isIw ? 1 : 0) << 7) | (cw << 8) | ((isJ ? 1 : 0) << 10)
          | (ee << 11) | (mdd << 17) | (eb << 23);
 }
-// one stage of the sequential adjoint sweep (two phases); PO = register set that holds the inputs of stage k-1
+// one stage of the sequential adjoint sweep (one phase); PO = register set that holds the inputs of stage k-1
 template <int PO>
 BMPC_D inline void adjoint_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
@@ -1144,13 +1150,12 @@ BMPC_D inline void adjoint_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
     double *lam1 = L + L_ST + (odd ? ST_LAM0 : ST_LAM1);     // lam_{k+1} (written one step earlier)
     double *lam0 = L + L_ST + (odd ? ST_LAM1 : ST_LAM0);     // lam_k (written now)
     const double *k0 = L + (odd ? L_K1 : L_K0), *kvb = L + (odd ? L_KV1 : L_KV), *ghb = L + L_ST + (odd ? ST_Z : ST_GH);
-    if (k < N - 1) {
-        LANES_BEGIN
-            stage_mu(W, lam1, k0, lane);
-        LANES_END
-    }
     LANES_BEGIN   // one lane per component of Z; its kind comes from the component table (adjoint_ztab), decoded with shifts: integer
                   // indices and 0/1 factors, no exec-mask branch
+        // mu_q, mu_dq of the lane's own chain, in the lane (round 4): until round 3 eight lanes computed them in a phase of their own and
+        // every lane read them back from LDS -- a whole phase boundary (store, fence, load latency) per stage of a sweep whose stages are
+        // shorter than a round trip.  Lanes 0..43: the chain of their component; lanes 44..51 (the jerk role below): chain lane - 44.
+        double muq, mudq;
         {
             const bool on = lane < NZ; const int z = on ? lane : 0;
             const double *kv = kvb;
@@ -1159,7 +1164,8 @@ BMPC_D inline void adjoint_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
             const double mh = ((code >> 5) & 1) ? 1.0 : 0.0, me = ((code >> 6) & 1) ? 1.0 : 0.0, mi = ((code >> 7) & 1) ? 1.0 : 0.0;
             const bool isJ = ((code >> 10) & 1) != 0, nxt = k < N - 1;
             const double mdd = lam1[(code >> 17) & 63];
-            const double chainv = L[L_CFT + fc] * L[L_MU + i] + L[L_CFT + 5 + fc] * L[L_MU + 8 + i] + L[L_CFT + 10 + fc] * mdd;
+            stage_mu_vals(lam1, k0, h, on ? i : ((lane - NZ) & 7), muq, mudq);
+            const double chainv = L[L_CFT + fc] * muq + L[L_CFT + 5 + fc] * mudq + L[L_CFT + 10 + fc] * mdd;
             const int eb = (code >> 23) & 127;                                  // Ehat column of (q_i) or (dq_i): rows at stride 7
             double e = 0;
 #pragma unroll
@@ -1170,9 +1176,10 @@ BMPC_D inline void adjoint_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
             // Stores without branches: one LDS store and one global store per lane, the row kind selects the ADDRESS.
             // jerk rows: the residual of node k still lacks the term of the NEXT sweep step (stage k-1 -> k); it is parked in LDS
             // and completed there (a global read-modify-write would wait for this store to land and come back); their global
-            // store goes to a spare slot of the node's GVP row.  Off-lanes repeat row 0 (a jerk row) with identical values.
+            // store goes to a spare slot of the node's GVP row.  Off-lanes evaluate row 0 (a jerk row) with the multipliers of ANOTHER
+            // chain (theirs of the jerk role below): their LDS store goes to the dummy word, their global store to the spare slot anyway.
             {
-                const int lo_ = isJ ? L_RJP + (k & 1) * 8 + ee : (int)(lam0 - L) + ee;
+                const int lo_ = on ? (isJ ? L_RJP + (k & 1) * 8 + ee : (int)(lam0 - L) + ee) : L_DUMMY;
                 const int gdst = isJ ? sc.GVP + k * 8 + 6 : sc.LAM + k * NE + ee;
                 L[lo_] = tot; WL[gdst] = tot;
             }
@@ -1180,7 +1187,7 @@ BMPC_D inline void adjoint_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
         {   // jerk of node k+2 enters stage k+1 (lanes 44..51; everyone else, and the last stage, write to the spare GVP slot)
             const bool on = lane >= NZ && lane < NZ + 8 && k < N - 1; const int i = on ? lane - NZ : 0;
             const double mdd = lam1[i < 7 ? GDDQ + i : GDDPHI];
-            const double v = L[L_RJP + ((k + 1) & 1) * 8 + i] + (h3 / 24 * L[L_MU + i] + h2 / 6 * L[L_MU + 8 + i] + h / 2 * mdd);
+            const double v = L[L_RJP + ((k + 1) & 1) * 8 + i] + (h3 / 24 * muq + h2 / 6 * mudq + h / 2 * mdd);      // (lanes 44..51 hold their own chain's pair)
             WL[on ? sc.RJ + (k + 1) * NU + i : sc.GVP + k * 8 + 7] = v;
         }
         // inputs of the next stage into the other LDS buffer set (loaded two stages ago), then the loads for three stages ahead
@@ -2206,26 +2213,58 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
     sb_[ST_AES + (lane < 42 ? lane : 41)] = pf[7]; \
     sb_[ST_RLVF + (lane < 12 ? lane : 11)] = pf[8]; \
     kb_[lane] = pf[9]; kb_[lane < KREC - 64 ? 64 + lane : KREC - 1] = pf[10]; sb_[ST_GHF + lane] = pf[11]; }
-// one stage of the forward sweep (three phases); PO = register set that holds the inputs of stage k+1
+// dZ rows of stage k from the stage's next reduced state dn (LDS): lanes 0..34 scatter the reduced state through the row map (iota rows add
+// their lifting term), lanes 35..43 evaluate the lifted rows (pos 3, v 6); contiguous lane ranges = shallow selects, no branch nest.
+// sb / K0: the staging buffer and the kinematics record of stage k.
+BMPC_D inline void forward_dz_lane(Wave &W, LaneRegs *LR, int k, int lane, const double *dn, const double *sb, const double *K0) {
+    double *L = W.L; const double h = W.h;
+    const bool on = lane < NZ; const int t = on ? lane : 0;
+    const double *rlv = sb + ST_RLVF;
+    const bool isIw = t >= SIOTA && t < NS, isPos = t >= NS && t < NS + 3, isV = t >= NS + 3;
+    const int c = isIw ? t - SIOTA : (isPos ? t - NS : (isV ? t - NS - 3 : 0));              // c6 for the v rows
+    const int r = t < NS ? t : 0;
+    // flat chains of selects on integers and 0/1 factors on values: no exec-mask branch in the phase
+    int z = (int)L[L_ZMAP + r] & 255; z = isPos ? ZPOS + c : z; z = isV ? ZV + c : z;
+    int p1 = KD + c * 7; p1 = isIw ? KD + (3 + c) * 7 : p1; p1 = isPos ? KW + c * 7 : p1;
+    int p2 = c < 3 ? KW + c * 7 : KA + (c - 3) * 7; p2 = isIw ? KA + c * 7 : p2;
+    BMPC_ACC4_DECL(za);
+#pragma unroll
+    for (int i = 0; i < 7; i++) { BMPC_ACC4(za, i, K0[p1 + i] * dn[SQ + i]); }
+    BMPC_ACC4_DECL(zb);
+#pragma unroll
+    for (int i = 0; i < 7; i++) { BMPC_ACC4(zb, i, K0[p2 + i] * dn[SDQ + i]); }
+    const double s1 = BMPC_ACC4_SUM(za), s2 = BMPC_ACC4_SUM(zb);
+    const double ml = (isPos || isV) ? 1.0 : 0.0, addv = ml * rlv[isPos ? c : 3 + c] + (1.0 - ml) * dn[r];
+    double fa = 0.0; fa = isV ? 1.0 : fa; fa = isIw ? 0.5 * h : fa; fa = isPos ? 1.0 : fa;
+    const double v = addv + fa * (s1 + ((isIw || isV) ? 1.0 : 0.0) * s2);
+    W.Dz[k * NZ + z] = v;
+    LR[LIDX].ghd += on ? sb[ST_GHF + lane] * v : 0.0;      // (QP gradient) . dZ for the line search, summed where dZ is made
+}
+// one stage of the forward sweep (two phases since round 4: the reduced state ping-pongs between L_DS and L_DSN by stage parity instead of
+// being copied back in a phase of its own, and the dZ rows of stage k-1 -- which need that stage's complete next state -- ride in the
+// first phase of stage k, beside the partial sums of du: the two share no data); PO = register set that holds the inputs of stage k+1
 template <int PO>
 BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
     const int N = W.N; const double h = W.h;
     double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
     const double *sb = L + ((k & 1) ? L_GS : L_ST), *K0 = L + ((k & 1) ? L_K1 : L_K0);
+    const double *sbp = L + ((k & 1) ? L_ST : L_GS), *K0p = L + ((k & 1) ? L_K0 : L_K1);      // stage k-1's (their buffers are rewritten at the END of stage k)
+    const double *ds = L + ((k & 1) ? L_DSN : L_DS); double *dsn = L + ((k & 1) ? L_DS : L_DSN);
     LANES_BEGIN   // du = kff + K ds: partial sums on all 64 lanes (control u = lane & 7, every 8th state b), reduced by the consumers
         {
             const int u = lane & 7, part = lane >> 3; double acc = 0.0;
 #pragma unroll
-            for (int j = 0; j < 5; j++) { const int b0 = part + 8 * j, b = b0 < NS ? b0 : NS - 1; const double pr_ = sb[ST_KT + u * NS + b] * L[L_DS + b]; acc += b0 < NS ? pr_ : 0.0; }
+            for (int j = 0; j < 5; j++) { const int b0 = part + 8 * j, b = b0 < NS ? b0 : NS - 1; const double pr_ = sb[ST_KT + u * NS + b] * ds[b]; acc += b0 < NS ? pr_ : 0.0; }
             L[L_RED + part * 8 + u] = acc;
         }
+        if (k >= 1) forward_dz_lane(W, LR, k - 1, lane, ds, sbp, K0p);      // wave-uniform condition; ds = the next state of stage k-1
     LANES_END
     LANES_BEGIN   // next reduced state, predicated: chain rows and iota rows evaluated by every lane on clamped indices
         {
             const bool on = lane < NS; const int r = on ? lane : 0;
             const bool chain = r < SIOTA;
             const int code = (int)L[L_ZMAP + r], f = (code >> 17) & 7, i = chain ? (code >> 20) & 7 : 7, a = chain ? 0 : r - SIOTA;
-            const double *ds = L + L_DS, *dp_ = L + L_RED + i;   // fixed-order tree over the 8 partial sums of du
+            const double *dp_ = L + L_RED + i;   // fixed-order tree over the 8 partial sums of du
             const double du_i = sb[ST_KF + i] + (((dp_[0] + dp_[8]) + (dp_[16] + dp_[24])) + ((dp_[32] + dp_[40]) + (dp_[48] + dp_[56])));
             double vc = 0;
 #pragma unroll
@@ -2236,35 +2275,8 @@ BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
             for (int y = 0; y < 14; y++) BMPC_ACC4(ia, y, sb[ST_AES + a * 14 + y] * ds[y]);
             const double mc_ = chain ? 1.0 : 0.0;            // 0/1 factors, not a select between loaded values (that would be a branch)
             const double v = sb[ST_RDY + r] + (mc_ * vc + (1.0 - mc_) * (ds[r] + BMPC_ACC4_SUM(ia)));
-            L[L_DSN + r] = v;
+            dsn[r] = v;            // (off-lanes repeat row 0 with the same value)
         }
-    LANES_END
-    LANES_BEGIN   // dZ of the stage: lanes 0..34 scatter the reduced state through the row map (iota rows add their lifting term),
-                  // lanes 35..43 evaluate the lifted rows (pos 3, v 6); contiguous lane ranges = shallow selects, no branch nest
-        {
-            const bool on = lane < NZ; const int t = on ? lane : 0;
-            const double *dn = L + L_DSN, *rlv = sb + ST_RLVF;
-            const bool isIw = t >= SIOTA && t < NS, isPos = t >= NS && t < NS + 3, isV = t >= NS + 3;
-            const int c = isIw ? t - SIOTA : (isPos ? t - NS : (isV ? t - NS - 3 : 0));              // c6 for the v rows
-            const int r = t < NS ? t : 0;
-            // flat chains of selects on integers and 0/1 factors on values: no exec-mask branch in the phase
-            int z = (int)L[L_ZMAP + r] & 255; z = isPos ? ZPOS + c : z; z = isV ? ZV + c : z;
-            int p1 = KD + c * 7; p1 = isIw ? KD + (3 + c) * 7 : p1; p1 = isPos ? KW + c * 7 : p1;
-            int p2 = c < 3 ? KW + c * 7 : KA + (c - 3) * 7; p2 = isIw ? KA + c * 7 : p2;
-            BMPC_ACC4_DECL(za);
-#pragma unroll
-            for (int i = 0; i < 7; i++) { BMPC_ACC4(za, i, K0[p1 + i] * dn[SQ + i]); }
-            BMPC_ACC4_DECL(zb);
-#pragma unroll
-            for (int i = 0; i < 7; i++) { BMPC_ACC4(zb, i, K0[p2 + i] * dn[SDQ + i]); }
-            const double s1 = BMPC_ACC4_SUM(za), s2 = BMPC_ACC4_SUM(zb);
-            const double ml = (isPos || isV) ? 1.0 : 0.0, addv = ml * rlv[isPos ? c : 3 + c] + (1.0 - ml) * dn[r];
-            double fa = 0.0; fa = isV ? 1.0 : fa; fa = isIw ? 0.5 * h : fa; fa = isPos ? 1.0 : fa;
-            const double v = addv + fa * (s1 + ((isIw || isV) ? 1.0 : 0.0) * s2);
-            W.Dz[k * NZ + z] = v;
-            LR[LIDX].ghd += on ? sb[ST_GHF + lane] * v : 0.0;      // (QP gradient) . dZ for the line search, summed where dZ is made
-        }
-        { const int r = lane < 36 ? lane : 35; const double v = L[L_DSN + (r < NS ? r : 0)]; L[L_DS + r] = r < NS ? v : 0.0; }
         // inputs of stage k+1 into the other LDS buffer set (loaded two stages ago), then the loads of stage k+3 (clamped to the
         // last stage) into the registers this just freed
         BMPC_FWD_COMMIT(k + 1, PO)
@@ -2288,6 +2300,9 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
     int k = 0;
     for (; k + 1 < N; k += 2) { forward_stage<12>(W, sc, LR, k); forward_stage<0>(W, sc, LR, k + 1); }
     if (k < N) forward_stage<12>(W, sc, LR, k);
+    LANES_BEGIN      // dZ rows of the last stage
+        forward_dz_lane(W, LR, N - 1, lane, L + ((N & 1) ? L_DSN : L_DS), L + (((N - 1) & 1) ? L_GS : L_ST), L + (((N - 1) & 1) ? L_K1 : L_K0));
+    LANES_END
 #if BMPC_NW > 1
     LANES_BEGIN      // teams: the lanes' shares of (QP gradient) . dZ leave the sweep's wave through LDS (row pass B runs on every wave)
         L[L_TGHD + lane] = LR[LIDX].ghd;

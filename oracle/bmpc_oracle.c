@@ -945,7 +945,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
                  * with boundary-limited steps; with the stall test off 93 % of them do converge (after 130 iterations at the median):
                  * they are feasible, the iterate is jammed.  From a re-centred iterate 94 % of them converge within ~50 further
                  * iterations.  (What Ipopt's restoration phase is for; the kernel's N <= 11 instantiation does not carry the path.) */
-                if (N <= GN_MIN_HORIZON || n_restart >= STALL_RESTARTS) { status = 2; break; }
+                if ((N <= GN_MIN_HORIZON && !getenv("BMPC_ORACLE_RESTART_ALL")) || n_restart >= STALL_RESTARTS) { status = 2; break; }
                 n_restart++; it_restart = it;
                 mu = STALL_RESTART_MU;
                 for (int i = 0; i < N * NI; i++) { W->t[i] = fmax(-W->hin[i], STALL_RESTART_PUSH); W->nu[i] = mu / W->t[i]; }

@@ -6,7 +6,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.path.insert(0, ROOT)
     import time, numpy as np, torch
     from boundmpc_amd import BatchedOCPSolver, workload
-    for B in (1024, 8192):
+    for B in [int(b) for b in os.environ.get("BMPC_AB_BATCHES", "256,1024,8192").split(",")]:
         P, X, _ = workload.make_batch(B, seed=0)
         s = BatchedOCPSolver(10, 4, 0.1)
         p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
