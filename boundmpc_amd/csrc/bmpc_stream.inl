@@ -419,7 +419,8 @@ BMPC_HD inline void stream_pack(int N, int S, const double *path, int cap, doubl
 // normal outcome.  The reference's acceptance rule (BoundMPC.py:460-465: solver success OR summed violation of g beyond 1e-6 below
 // 1e-4) still decides -- with the threshold rt_tol in place of 1e-4 (bmpc_stream_set_rt_feasibility_tol; default 1e-4, the
 // reference's).  A capped iterate that fails it is NOT applied: the previous plan is replayed from its error count, as the reference
-// does after a failed solve (:468-489).  (Round 2 accepted every capped iterate unconditionally; closed loops then ran away.)
+// does after a failed solve (:468-489).  (Round 2 accepted every capped iterate unconditionally; closed loops then ran away.)  Since
+// round 4 the violation also counts the plan's variable bounds (below): no accepted plan leaves the joint limits by more than rt_tol in sum.
 BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int cap, double *ss, double *rb, const double *x, const double *g, int status,
                                 double *traj, int flags, double rt_tol, double *sh, int lane, int nl) {
     // ---- phase 0: feasibility rule :460-465 (strided partial sums, fixed-order total) ----
@@ -429,6 +430,20 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
             const double v = g[id]; const int i = id % 43;
             if (i < 36 && v < -1e-6) part -= v;
             if (v > 1e-6) part += v;
+        }
+        // Real-time mode (flag bit 1) also counts the violation of the VARIABLE bounds lbx <= x <= ubx of the plan (jerks +-35, joint
+        // positions and velocities RobotModel.py:20-43, phi >= 0).  The reference's rule looks at g only: an Ipopt iterate satisfies the
+        // variable bounds by construction, an iteration-capped iterate of this solver (bounds as slack rows) need not -- round 3's
+        // capped closed loops left the joint limits on plans that passed the g rule (profiles/r03_rt_safety_modes.log).
+        if (flags & 2) {
+            const double qd[7] = {165, 115, 165, 115, 165, 115, 170}, dqd[7] = {85, 85, 100, 75, 130, 135, 135};
+            for (int id = lane; id < 44 * N; id += nl) {
+                const int i = id % 44; const double v = x[id];
+                double lim = -1.0;
+                if (i < 8) lim = 35.0; else if (i < 15) lim = qd[i - 8] * (3.14159265358979323846 / 180.0); else if (i < 22) lim = dqd[i - 15] * (3.14159265358979323846 / 180.0);
+                if (lim > 0.0 && (v > lim + 1e-6 || v < -lim - 1e-6)) part += (v > 0 ? v : -v) - lim;
+                if (i == 41 && v < -1e-6) part -= v;
+            }
         }
         sh[SH_RED + lane] = part;
     }

@@ -124,7 +124,9 @@ int bmpc_graph_destroy(bmpc_graph *g);
  *                       (util_functions.py:152-161, bound_mpc_node.py:292-372); bit 1 (real-time iteration, not in the
  *                       reference: a fixed small number of solver iterations per tick, status 1 is the normal outcome): the
  *                       reference's acceptance rule BoundMPC.py:460-465 decides with the threshold of
- *                       bmpc_stream_set_rt_feasibility_tol in place of 1e-4; an iterate that fails it is not applied, the
+ *                       bmpc_stream_set_rt_feasibility_tol in place of 1e-4, and with the violation of the variable bounds lbx <= x <= ubx
+ *                       of the plan (jerk, joint position and velocity limits; an iteration-capped iterate need not satisfy them)
+ *                       added to the violation of g; an iterate that fails it is not applied, the
  *                       previous plan is replayed (BoundMPC.py:468-489).  The next tick's warm start then CONTINUES FROM THE REJECTED
  *                       ITERATE (shifted like an accepted plan; its multipliers are in the dual state anyway) instead of the last
  *                       accepted plan -- the iterations spent on it are kept; the reference would restart from the accepted plan.

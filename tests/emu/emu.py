@@ -8,7 +8,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libbmpc_emu.so")
-_SRC = [os.path.join(_HERE, "bmpc_emu.cpp"), os.path.join(_HERE, "..", "..", "boundmpc_amd", "csrc", "bmpc_wave.inl")]
+_SRC = [os.path.join(_HERE, "bmpc_emu.cpp"), os.path.join(_HERE, "..", "..", "boundmpc_amd", "csrc", "bmpc_wave.inl"),
+        os.path.join(_HERE, "..", "..", "boundmpc_amd", "csrc", "bmpc_stream.inl")]
 
 
 class Opts(ctypes.Structure):

@@ -269,3 +269,30 @@ def test_realtime_continuation_rule_of_stream_pack():
     assert ss_c[bstream.ss_updated(N) + 1] == 0.0
     _, x0_c = emu.stream_pack(N, 4, T, ss_c, rb, xlast=x_bad)
     np.testing.assert_array_equal(x0_c, shift(accepted))
+
+
+def test_realtime_acceptance_counts_the_variable_bounds():
+    """Real-time mode: a capped iterate whose g passes the rule but whose plan leaves a joint limit is NOT applied (the reference's rule looks at
+    g only -- Ipopt iterates satisfy the variable bounds by construction; an iteration-capped interior-point iterate of this solver need not)."""
+    N = 10
+    q0 = workload.random_q0(3, seed=7)[1]
+    mpc, p0fk = workload.make_mpc(q0)
+    T, M = bstream.path_table(mpc.ref_path)
+    ss = bstream.initial_state(mpc, N); ss[bstream.SS["NENT"]] = M
+    rb = bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([mpc.phi_max[0], 0, 0]), np.zeros(7))
+    sol = _Oracle()
+    p, x0 = emu.stream_pack(N, 4, T, ss, rb)
+    x, g, st, _ = sol.solve(p, x0)
+    emu.stream_post(N, 4, 0.1, T, ss, rb, x, g, st, simulate=True, flags=2)
+    p, x0 = emu.stream_pack(N, 4, T, ss, rb)
+    x, g, st, _ = sol.solve(p, x0)
+    qlim = np.array(RobotModel().q_lim_upper)
+    for bad_col, amount, applied in ((8 + 1, 1e-2, False), (8 + 1, 1e-9, True), (0, 1.0, False)):      # q_2 of stage 3 beyond its limit; within 1e-6; a jerk beyond 35
+        xb = x.reshape(N, 44).copy()
+        xb[3, bad_col] = (qlim[bad_col - 8] if bad_col >= 8 else 35.0) + amount
+        tr = emu.stream_post(N, 4, 0.1, T, ss.copy(), rb.copy(), xb.ravel(), g, 1, simulate=True, flags=2, rt_tol=1e-4)
+        _, fl = bstream.unpack_traj(tr, N)
+        assert fl["success"] == applied, (bad_col, amount, fl)
+        # the reference's own rule (flags bit 1 off) does not look at x: the same iterate passes on its g
+        tr = emu.stream_post(N, 4, 0.1, T, ss.copy(), rb.copy(), xb.ravel(), g, 1, simulate=True, flags=0)
+        assert bstream.unpack_traj(tr, N)[1]["success"]
