@@ -39,6 +39,8 @@ def main():
     ap.add_argument("--rt-feas-tol", type=float, default=1e-2,
                     help="threshold of the reference's acceptance rule (summed violation of g, BoundMPC.py:462-465: 1e-4) that decides whether an "
                          "iteration-capped iterate is applied in the real-time modes; an iterate that fails it is not applied, the previous plan is replayed")
+    ap.add_argument("--rt-bound-margin", type=float, default=2e-3, help="joint limits tightened inside the solver of the time-budgeted modes (rad, rad/s)")
+    ap.add_argument("--only", default="", help="comma-separated substrings: run only the modes whose name contains one of them (the converged loop always runs: it is the reference of the deviations)")
     ap.add_argument("--unsafe-too", action="store_true", help="also run the real-time modes with every capped iterate applied (the round-2 behaviour), for comparison")
     args = ap.parse_args()
     import torch
@@ -71,6 +73,13 @@ def main():
     for cap in (6, 5, 4, 3):
         rtgn[cap] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=cap, mu_warm=args.rt_mu_warm, exact_hessian=False)
         rtgn[cap].set_timing(True)
+    # time-budgeted real-time modes (round 4): no fixed iteration count -- the fused tick starts no further iteration once the budget (from
+    # kernel entry) is used up; loose tolerance, dual state carried
+    rtb = {}
+    for us in (600, 700, 800):
+        for gn in (False, True):
+            rtb[(us, gn)] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=30, mu_warm=args.rt_mu_warm, exact_hessian=not gn, bound_margin=args.rt_bound_margin)
+            rtb[(us, gn)].set_timing(True)
     evaluate = BatchedOCPSolver(10, 4, 0.1, max_iter=0)       # f, g at a given point (no iteration)
     reference = BatchedOCPSolver(10, 4, 0.1, tol=args.tol, max_iter=args.max_iter)    # every tick's problem solved to tolerance, untimed
     res, ref_q = [], None
@@ -80,7 +89,8 @@ def main():
         + [(f"rtgn-tol{args.rt_tol:g}-cap{c}-feas{FT:g}", rtgn[c], 0, True, FT) for c in (6, 5, 4, 3)] \
         + [(f"rtgn-tol{args.rt_tol:g}-cap4-feas1e-4(reference rule)", rtgn[4], 0, True, 1e-4)] \
         + [(f"rt-tol{args.rt_tol:g}-cap{c}-feas{FT:g}", rt[c], 0, False, FT) for c in (8, 6)] \
-        + [("rti-3-feas%g" % FT, solver, 3, True, FT)]
+        + [("rti-3-feas%g" % FT, solver, 3, True, FT)] \
+        + [(f"rtb{'gn' if gn else 'w'}-tol{args.rt_tol:g}-budget{us}us-feas{FT:g}", rtb[(us, gn)], 0, True, FT) for (us, gn) in sorted(rtb)]
     if args.unsafe_too:
         modes += [(f"UNSAFE rtgn-tol{args.rt_tol:g}-cap{c} (every capped iterate applied)", rtgn[c], 0, True, 1e30) for c in (4, 3)]
     from boundmpc_amd.robot_model import RobotModel
@@ -89,7 +99,12 @@ def main():
     # without a host synchronisation in between ended in a GPU memory fault on ROCm 7.2 (80 ticks into the warm mode, reproducibly); the
     # same sequence with direct launches instead of the graph, or on any explicit stream, is clean.
     torch.cuda.set_stream(torch.cuda.Stream())
+    only = [k for k in args.only.split(",") if k]
+    budget_of = {id(rtb[k]): k[0] for k in rtb}
     for mode, slv, cap, warm, feas in modes:
+        if only and mode != "converged" and not any(k in mode for k in only):
+            continue
+        budget = budget_of.get(id(slv), 0)
         capped = feas is not None
         if capped:
             slv.set_rt_feasibility_tol(feas)          # read when the tick graph is captured
@@ -102,9 +117,13 @@ def main():
                 print("trace", mode, t, file=sys.stderr, flush=True)
             # the first tick of every stream is its cold start from rest: solved to tolerance in all modes (not timed)
             if t == 0:
+                if budget:
+                    slv.set_time_budget_us(0)
                 sb.tick(max_iter=100, warm_dual=True, simulate=True)
                 if not warm:
                     sb.dual.zero_()
+                if budget:
+                    slv.set_time_budget_us(budget)      # read when the tick graph is captured (next tick)
             else:
                 ev0.record()
                 sb.tick_graph(max_iter=cap, warm_dual=warm, simulate=True, accept_capped=capped)
@@ -144,7 +163,7 @@ def main():
                     "ticks_per_s": float(1e3 / wall.mean()), "solves_per_s": float(B * 1e3 / wall.mean()), "mean_iters": float(its.mean()),
                     "applied_tick_fraction": float(np.mean(ok[1:])), "streams_with_a_plan_at_the_end": float(alive[-1]), "streams_with_a_plan_min_over_ticks": float(np.min(alive)),
                     "acceptance_threshold_g_viol": feas, "g_viol_of_the_solver_iterates": {"median": float(np.median(np.concatenate(gviol))), "p90": float(np.percentile(np.concatenate(gviol), 90)), "p99": float(np.percentile(np.concatenate(gviol), 99))},
-                    "joint_limit_violations_of_the_plant_state": int((np.abs(Q) > qlim + 1e-9).sum()),
+                    "joint_limit_violations_of_the_plant_state": int((np.abs(Q) > qlim + 1e-9).sum()), "largest_joint_limit_excess_rad": float(max((np.abs(Q) - qlim).max(), 0.0)),
                     "rms_joint_dev_vs_converged_loop_rad": float(np.sqrt(np.mean(dev ** 2))),
                     "median_stream_rms_dev_rad": float(np.median(per_stream)), "streams_within_1e-2_rad_rms": float((per_stream <= 1e-2).mean()),
                     "max_joint_dev_rad": float(np.abs(dev).max()), "mean_phi_after_last_tick": float(phi.mean())})

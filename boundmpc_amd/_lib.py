@@ -12,13 +12,14 @@ SYMBOLS = ["bmpc_default_options", "bmpc_default_options_for", "bmpc_error_strin
            "bmpc_num_params", "bmpc_get_bounds", "bmpc_solve_batch", "bmpc_solve_batch_host", "bmpc_set_timing",
            "bmpc_last_kernel_ms", "bmpc_kernel_ms", "bmpc_launch_info", "bmpc_state_len", "bmpc_solve_batch_warm", "bmpc_graph_create",
            "bmpc_graph_launch", "bmpc_graph_destroy", "bmpc_stream_lengths", "bmpc_stream_pack", "bmpc_stream_pack_rt", "bmpc_stream_post",
-           "bmpc_stream_graph_create", "bmpc_set_latency_buffer", "bmpc_stream_set_rt_feasibility_tol", "bmpc_stream_tick", "bmpc_set_team_waves", "bmpc_team_info"]
+           "bmpc_stream_graph_create", "bmpc_set_latency_buffer", "bmpc_stream_set_rt_feasibility_tol", "bmpc_stream_tick", "bmpc_set_team_waves", "bmpc_team_info", "bmpc_stream_set_time_budget"]
 
 
 class Options(ctypes.Structure):
     _fields_ = [("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("mu_init", ctypes.c_double),
                 ("mu_min_fac", ctypes.c_double), ("slack_push", ctypes.c_double),
-                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double), ("stall_window", ctypes.c_int)]
+                ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double), ("stall_window", ctypes.c_int),
+                ("bound_margin", ctypes.c_double)]
 
 
 class BoundMPCHipError(RuntimeError):
@@ -65,6 +66,7 @@ def load():
     lib.bmpc_stream_tick.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp]
     lib.bmpc_stream_graph_create.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, ctypes.POINTER(vp)]
     lib.bmpc_set_latency_buffer.argtypes = [vp, vp]
+    lib.bmpc_stream_set_time_budget.argtypes = [vp, cd]
     lib.bmpc_set_team_waves.argtypes = [vp, ci]
     lib.bmpc_team_info.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     lib.bmpc_set_timing.argtypes = [vp, ci]

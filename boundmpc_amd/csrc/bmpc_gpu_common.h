@@ -25,6 +25,7 @@
 #define BMPC_MFMA 1       // Schur update of the Riccati stage on the matrix cores (v_mfma_f64_16x16x4_f64)
 #endif
 #define BMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define BMPC_NOW() ((long long)wall_clock64())      // constant 100 MHz counter
 
 // kernel arguments of a solve; OPTS = the Opts type of the wave program's namespace (same layout in every instantiation)
 template <class OPTS>
@@ -34,6 +35,7 @@ struct KArgsT {
     double *state;           // optional [B][57 N + 2] dual state of a receding-horizon stream (bmpc_solve_batch_warm)
     double *latency_us;      // optional [B]: in-kernel duration of each solve (bmpc_set_latency_buffer)
     double *scratch; long long scr_stride; int *counter; unsigned long long *prof;
+    long long budget_ticks;  // fused closed-loop tick only: time budget of a tick in counts of the 100 MHz wall clock, from kernel entry (0 = none)
 };
 // stream arguments of a fused tick
 struct SArgs {

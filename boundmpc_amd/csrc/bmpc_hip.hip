@@ -43,6 +43,7 @@ template <bool ZLDS>
 __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs a) {
     __shared__ double lds[bmpc::L_SIZE];
     bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpc::make_gptr(a.scratch + (long long)blockIdx.x * a.scr_stride); W.wv = 0;
+    W.deadline = 0;
     const int np = 141 + 91 * a.S, nw = a.N * bmpc::NZ, ng = a.N * bmpc::NG;
 #ifdef BMPC_PROFILE
     if (threadIdx.x < 32) ((long long *)(lds + bmpc::L_PROF))[threadIdx.x] = 0;
@@ -80,6 +81,7 @@ struct bmpc_handle {
     // caller uses: every launch records order_ev, a launch on another stream waits for it first
     hipEvent_t order_ev, bridge_ev; bool order_valid; hipStream_t order_stream;
     double rt_viol_tol;      // acceptance threshold of stream_post in real-time mode (flag bit 1); default = the reference's 1e-4
+    double rt_budget_us;     // time budget of a fused tick (bmpc_stream_set_time_budget); 0 = none
     hipStream_t own_stream;  // graph replays requested on the legacy null stream run here, bracketed by events (bmpc_graph_launch)
     int grid; long long scr_stride; double *scratch; int scr_waves; int graphs_alive; int *counter; unsigned long long *prof;
     int team_grid;           // resident TEAMS (workgroups of BMPC_TEAM_NW waves, bmpc_team.hip) of the device; 0: no team kernel for this handle (N > 10 or S > 4)
@@ -134,7 +136,7 @@ static void handle_release(bmpc_handle *h) {
 
 extern "C" int bmpc_default_options(bmpc_options *o) {
     if (!o) return BMPC_ERR_ARG;
-    o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0; o->mu_warm = 1e-2; o->stall_window = 40;
+    o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0; o->mu_warm = 1e-2; o->stall_window = 40; o->bound_margin = 0.0;
     return BMPC_OK;
 }
 extern "C" int bmpc_default_options_for(int N, bmpc_options *o) {
@@ -150,7 +152,7 @@ extern "C" const char *bmpc_error_string(int c) {
 }
 extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bmpc_handle **out) {
     if (!out || N < 1 || N > bmpc::NMAX || S < 2 || S > bmpc::SMAX || !(dt > 0)) return BMPC_ERR_ARG;
-    if (opts && (!(opts->tol > 0) || opts->max_iter < 0 || opts->stall_window < 0 || (opts->stall_window & 1) || !(opts->mu_init > 0) || !(opts->slack_push > 0))) return BMPC_ERR_ARG;
+    if (opts && (!(opts->tol > 0) || opts->max_iter < 0 || opts->stall_window < 0 || (opts->stall_window & 1) || !(opts->mu_init > 0) || !(opts->slack_push > 0) || !(opts->bound_margin >= 0) || opts->bound_margin > 0.5)) return BMPC_ERR_ARG;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BMPC_ERR_NOGPU;
     bmpc_handle *h = new (std::nothrow) bmpc_handle();
@@ -158,7 +160,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->ev = nullptr; h->nev = 0; h->n_timed = 0; h->latency_us = nullptr;
     h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->prof = nullptr; h->stage_d = nullptr; h->stage_i = nullptr; h->stage_cap = 0;
     h->team_grid = 0; h->team_mode = 0;
-    h->rt_viol_tol = 1e-4; h->dev = 0; h->refs = 1; h->closed = false; h->order_ev = nullptr; h->bridge_ev = nullptr; h->order_valid = false; h->order_stream = nullptr; h->own_stream = nullptr;
+    h->rt_viol_tol = 1e-4; h->rt_budget_us = 0.0; h->dev = 0; h->refs = 1; h->closed = false; h->order_ev = nullptr; h->bridge_ev = nullptr; h->order_valid = false; h->order_stream = nullptr; h->own_stream = nullptr;
     if (opts) h->o = *opts; else bmpc_default_options_for(N, &h->o);
     int dev = 0, per_cu = 0; hipDeviceProp_t prop;
     bool ok = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess;
@@ -278,9 +280,9 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     if (!capturing) { const int rc_ = order_before(h, st); if (rc_ != BMPC_OK) return rc_; }
     KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
     a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
-    a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window;
+    a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window; a.o.bound_margin = h->o.bound_margin;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = lam_g; a.lam_x = lam_x; a.f = f; a.kkt = kkt; a.iters = iters; a.status = status;
-    a.state = state; a.latency_us = h->latency_us;
+    a.state = state; a.latency_us = h->latency_us; a.budget_ticks = 0;
     const int grid = launch_grid(h, B);
     if (grid > h->scr_waves) return BMPC_ERR_ARG;      // callers reserve the workspace first (never inside a stream capture)
     a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter; a.prof = h->prof;
@@ -454,6 +456,7 @@ __global__ void __launch_bounds__(64) bmpc_stream_post_kernel(int N, int S, int 
 // global memory of the same wave in program order.
 __global__ void __launch_bounds__(64, 1) bmpc_stream_tick_kernel(KArgs a, SArgs s) {
     __shared__ double lds[bmpc::L_SIZE];
+    const long long tk0_ = a.budget_ticks ? BMPC_NOW() : 0;
     const int b = blockIdx.x;
     if (b >= a.B) return;
     const int np = 141 + 91 * a.S, nw = a.N * bmpc::NZ, ng = a.N * bmpc::NG;
@@ -463,6 +466,13 @@ __global__ void __launch_bounds__(64, 1) bmpc_stream_tick_kernel(KArgs a, SArgs 
     double *ss = s.ss + (long long)b * bmpcs::ss_len(a.N), *rb = s.rb + (long long)b * bmpcs::RB_LEN;
     double *p = const_cast<double *>(a.p) + (long long)b * np, *x0 = const_cast<double *>(a.x0) + (long long)b * nw;
     double *dual = a.state ? a.state + (long long)b * (a.N * bmpc::NI + 2) : nullptr;
+    // A stream that has lost its plan (N consecutive ticks without an accepted solution: BoundMPC.step() returns five Nones there and the
+    // reference node stops, BoundMPC.py:498-506, bound_mpc_node.py:318) is not ticked any further: its problems are the ones nobody could
+    // solve (tests/golden/g13_hard_ticks.npz), each would run to the stall test or the iteration cap, and a tick lasts as long as its slowest stream.
+    if (ss[bmpcs::SS_ERRCNT] >= (double)a.N) {
+        if (threadIdx.x == 0) { a.status[b] = 3; if (a.iters) a.iters[b] = 0; if (a.kkt) a.kkt[b] = 0.0; }
+        return;
+    }
     bmpcs::stream_pack(a.N, a.S, path, s.path_stride / bmpcs::PT_LEN, ss, rb, p, x0, dual, (s.flags & 2) ? a.x + (long long)b * nw : nullptr, sh, threadIdx.x, 64);
     __syncthreads();
     bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpc::make_gptr(a.scratch + (long long)b * a.scr_stride); W.wv = 0;
@@ -470,7 +480,8 @@ __global__ void __launch_bounds__(64, 1) bmpc_stream_tick_kernel(KArgs a, SArgs 
     pr.p = p; pr.x0 = x0; pr.x = a.x + (long long)b * nw; pr.g = a.g + (long long)b * ng; pr.lam_g = nullptr; pr.lam_x = nullptr;
     pr.f = nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr; pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status + b; pr.state = dual;
     const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
-    bmpc::wave_solve<true>(W, pr);
+    W.deadline = a.budget_ticks ? tk0_ + a.budget_ticks : 0;
+    bmpc::wave_solve<true, true>(W, pr);
     __syncthreads();
     if (a.latency_us && threadIdx.x == 0) a.latency_us[b] = (double)((long long)wall_clock64() - t0_) * 0.01;
     bmpcs::stream_post(a.N, a.S, a.h, path, s.path_stride / bmpcs::PT_LEN, ss, rb, pr.x, pr.g, a.status[b], s.traj + (long long)b * bmpcs::tr_len(a.N), s.flags, s.rt_tol,
@@ -483,9 +494,9 @@ static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entr
     if (!capturing) { const int rc_ = order_before(h, st); if (rc_ != BMPC_OK) return rc_; }
     KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
     a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
-    a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window;
+    a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window; a.o.bound_margin = h->o.bound_margin;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = nullptr; a.lam_x = nullptr; a.f = nullptr; a.kkt = kkt; a.iters = iters; a.status = status;
-    a.state = dual_state; a.latency_us = h->latency_us;
+    a.state = dual_state; a.latency_us = h->latency_us; a.budget_ticks = (long long)(h->rt_budget_us * 100.0);
     if (B > h->scr_waves) return BMPC_ERR_ARG;
     a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter; a.prof = h->prof;
     SArgs s; s.path = path; s.path_stride = path_entries * bmpcs::PT_LEN; s.ss = sstate; s.rb = robot; s.traj = traj; s.flags = flags; s.rt_tol = h->rt_viol_tol;
@@ -519,6 +530,11 @@ extern "C" int bmpc_stream_tick(bmpc_handle *h, int B, const double *path, int p
 extern "C" int bmpc_stream_set_rt_feasibility_tol(bmpc_handle *h, double tol) {
     if (!h || !(tol > 0)) return BMPC_ERR_ARG;
     h->rt_viol_tol = tol;      // read at launch / capture time: re-capture a tick graph after changing it
+    return BMPC_OK;
+}
+extern "C" int bmpc_stream_set_time_budget(bmpc_handle *h, double microseconds) {
+    if (!h || !(microseconds >= 0.0) || microseconds > 1e7) return BMPC_ERR_ARG;
+    h->rt_budget_us = microseconds;      // read at launch / capture time: re-capture a tick graph after changing it
     return BMPC_OK;
 }
 extern "C" int bmpc_stream_lengths(const bmpc_handle *h, int *path_entry, int *state, int *robot, int *traj) {

@@ -420,7 +420,7 @@ BMPC_HD inline void stream_pack(int N, int S, const double *path, int cap, doubl
 // 1e-4) still decides -- with the threshold rt_tol in place of 1e-4 (bmpc_stream_set_rt_feasibility_tol; default 1e-4, the
 // reference's).  A capped iterate that fails it is NOT applied: the previous plan is replayed from its error count, as the reference
 // does after a failed solve (:468-489).  (Round 2 accepted every capped iterate unconditionally; closed loops then ran away.)  Since
-// round 4 the violation also counts the plan's variable bounds (below): no accepted plan leaves the joint limits by more than rt_tol in sum.
+// round 4 a plan with any variable outside its bounds (below) is not accepted either (for thresholds below 1): no accepted plan leaves the joint limits.
 BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int cap, double *ss, double *rb, const double *x, const double *g, int status,
                                 double *traj, int flags, double rt_tol, double *sh, int lane, int nl) {
     // ---- phase 0: feasibility rule :460-465 (strided partial sums, fixed-order total) ----
@@ -441,8 +441,21 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
                 const int i = id % 44; const double v = x[id];
                 double lim = -1.0;
                 if (i < 8) lim = 35.0; else if (i < 15) lim = qd[i - 8] * (3.14159265358979323846 / 180.0); else if (i < 22) lim = dqd[i - 15] * (3.14159265358979323846 / 180.0);
-                if (lim > 0.0 && (v > lim + 1e-6 || v < -lim - 1e-6)) part += (v > 0 ? v : -v) - lim;
-                if (i == 41 && v < -1e-6) part -= v;
+                // strict: a plan with ANY entry outside its bounds counts as grossly infeasible (+1e6: recognisable in the reported violation)
+                if (lim > 0.0 && (v > lim || v < -lim)) part += 1e6;
+                if (i == 41 && v < 0.0) part += 1e6;
+            }
+            // ... and the trajectory the plant would actually follow: the joint chains re-integrated from the measured state with the plan's
+            // jerks (phase 1 below does the same for the return data).  A plan may satisfy its own bounds and still be off its dynamics rows
+            // by up to the threshold: the re-integrated q, dq then leave the limits by that much (round 4, measured: 1e-5 ... 1e-4 rad).
+            for (int j = lane; j < 7; j += nl) {
+                double a = rb[RB_Q + j], da = rb[RB_DQ + j], dda = rb[RB_DDQ + j], up = rb[RB_JERK + j];
+                const double ql = qd[j] * (3.14159265358979323846 / 180.0), dql = dqd[j] * (3.14159265358979323846 / 180.0);
+                for (int i = 0; i < N; i++) {
+                    const double u = x[i * 44 + j];
+                    chain_step(a, da, dda, up, u, h); up = u;
+                    if (a > ql || a < -ql || da > dql || da < -dql) part += 1e6;
+                }
             }
         }
         sh[SH_RED + lane] = part;
@@ -451,7 +464,9 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
     if (lane == 0) {
         double viol = 0.0;
         for (int l = 0; l < nl; l++) viol += sh[SH_RED + l];
-        const bool success = status == 0 || viol < ((flags & 2) ? rt_tol : 1e-4);
+        // (real-time mode: a bound violation of the plan or of the trajectory the plant would follow shows as >= 1e6 in viol and also vetoes an
+        // iterate the solver calls converged -- at the loose tolerance of the real-time modes "converged" leaves bound rows open by up to that)
+        const bool success = (flags & 2) ? ((status == 0 && viol < 1e6) || viol < rt_tol) : (status == 0 || viol < 1e-4);
         int ec = (int)ss[SS_ERRCNT], using_prev = 0, use_prev_plan = 0;
         if (!success) {
             ec += 1; using_prev = 1;

@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_solve_kernel(KArgsT
     __shared__ double lds[bmpct::L_SIZE];
     bmpct::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpct::make_gptr(a.scratch + (long long)blockIdx.x * a.scr_stride);
     W.wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    W.deadline = 0;
     const int np = 141 + 91 * a.S, nw = a.N * bmpct::NZ, ng = a.N * bmpct::NG;
 #ifdef BMPC_PROFILE
     if (threadIdx.x < 32) ((long long *)(lds + bmpct::L_PROF))[threadIdx.x] = 0;
@@ -83,6 +84,7 @@ __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_solve_kernel(KArgsT
 // one closed-loop tick of a stream in ONE launch by a team: wave 0 packs, the team solves, wave 0 post-processes (stream b = block b)
 __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_tick_kernel(KArgsTeam a, SArgs s) {
     __shared__ double lds[bmpct::L_SIZE];
+    const long long tk0_ = a.budget_ticks ? BMPC_NOW() : 0;
     const int b = blockIdx.x;
     if (b >= a.B) return;
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -93,6 +95,13 @@ __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_tick_kernel(KArgsTe
     double *ss = s.ss + (long long)b * bmpcs::ss_len(a.N), *rb = s.rb + (long long)b * bmpcs::RB_LEN;
     double *p = const_cast<double *>(a.p) + (long long)b * np, *x0 = const_cast<double *>(a.x0) + (long long)b * nw;
     double *dual = a.state ? a.state + (long long)b * (a.N * bmpct::NI + 2) : nullptr;
+    // A stream that has lost its plan (N consecutive ticks without an accepted solution: BoundMPC.step() returns five Nones there and the
+    // reference node stops, BoundMPC.py:498-506, bound_mpc_node.py:318) is not ticked any further: its problems are the ones nobody could
+    // solve (tests/golden/g13_hard_ticks.npz), each would run to the stall test or the iteration cap, and a tick lasts as long as its slowest stream.
+    if (ss[bmpcs::SS_ERRCNT] >= (double)a.N) {
+        if (threadIdx.x == 0) { a.status[b] = 3; if (a.iters) a.iters[b] = 0; if (a.kkt) a.kkt[b] = 0.0; }
+        return;
+    }
     if (wv == 0) bmpcs::stream_pack(a.N, a.S, path, s.path_stride / bmpcs::PT_LEN, ss, rb, p, x0, dual, (s.flags & 2) ? a.x + (long long)b * nw : nullptr, sh, threadIdx.x, 64);
     __syncthreads();
     bmpct::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpct::make_gptr(a.scratch + (long long)b * a.scr_stride); W.wv = wv;
@@ -100,7 +109,8 @@ __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_tick_kernel(KArgsTe
     pr.p = p; pr.x0 = x0; pr.x = a.x + (long long)b * nw; pr.g = a.g + (long long)b * ng; pr.lam_g = nullptr; pr.lam_x = nullptr;
     pr.f = nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr; pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status + b; pr.state = dual;
     const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
-    bmpct::wave_solve<true>(W, pr);
+    W.deadline = a.budget_ticks ? tk0_ + a.budget_ticks : 0;
+    bmpct::wave_solve<true, true>(W, pr);
     __syncthreads();
     if (a.latency_us && threadIdx.x == 0) a.latency_us[b] = (double)((long long)wall_clock64() - t0_) * 0.01;
     if (wv == 0) bmpcs::stream_post(a.N, a.S, a.h, path, s.path_stride / bmpcs::PT_LEN, ss, rb, pr.x, pr.g, a.status[b], s.traj + (long long)b * bmpcs::tr_len(a.N), s.flags, s.rt_tol,

@@ -206,6 +206,8 @@ enum { WRED_STRIDE = 64, L_REDW = L_RED, L_KKPW = L_KKP, L_SIZE = L_SIZE1 };
 
 struct Opts {
     double tol; int max_iter; double mu_init; double mu_min_fac; double slack_push; int exact_hessian; int verbose; double mu_warm; int stall_window;
+    double bound_margin;      // joint position / velocity limits tightened by this much inside the solver (real-time modes: a plan solved to a loose
+                              // tolerance then still respects the true limits); 0 = the reference's limits
 };
 
 // global scratch layout (doubles) for horizon N
@@ -281,6 +283,8 @@ struct Wave {
                            // wave_backward_blk: two of the four records of stage k are records of stage k+1)
     double *Zc, *Zt, *Dz;  // iterate, trial iterate, Newton direction [N][44]: LDS-resident for N <= 11, else in the scratch slab
     int wv;                // this wave's index in its team (0 in the one-wave program); wave-uniform
+    long long deadline;    // real-time instantiation (wave_solve<., true>: the fused closed-loop tick) only: wall-clock count (BMPC_NOW) after
+                           // which no further iteration is started; 0 = none
 #ifdef BMPC_EMU
     int order[64];
     int worder[BMPC_NW];   // team emulator: order in which the waves run a wide phase
@@ -618,6 +622,7 @@ BMPC_D inline void wave_init_tables(Wave &W, const POff &po) {
     LANES_BEGIN
         if (lane < NI) {
             int src; double sgn, lim; ineq_box_row(L + L_PAR, po, lane, src, sgn, lim);
+            if (lane >= IQU && lane < IPHI0) lim -= W.o.bound_margin;      // joint position and velocity rows
             L[L_ROWT + lane] = sgn; L[L_ROWT + NI + lane] = lim; L[L_ROWT + 2 * NI + lane] = (double)src;
         }
     LANES_END
@@ -2324,7 +2329,13 @@ BMPC_D inline bool team_backward(Wave &W, const POff &po, const Scr &sc, double 
 // ----------------------------------------------------------------------------------------
 // ZLDS: the iterate / trial iterate / direction live in LDS (horizons N <= 11); a compile-time switch so that the compiler
 // knows the address space of every access (a run-time select would degrade them to FLAT instructions).
-template <bool ZLDS>
+// RT: real-time instantiation (closed-loop ticks): the iteration loop also ends -- status 1, like the iteration cap -- once the wall clock
+// has passed W.deadline (bmpc_stream_set_time_budget): every stream gets the iterations that fit the tick instead of the same fixed number,
+// and the tick is bounded whatever a stream's Riccati retries or line-search trials cost.  Not part of the batch solver kernels.
+#ifndef BMPC_NOW
+#define BMPC_NOW() 0LL
+#endif
+template <bool ZLDS, bool RT = false>
 BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     const int N = W.N, S = W.S;
     double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
@@ -2430,6 +2441,19 @@ _Pragma("unroll") \
 #endif
         if (E0 <= o.tol) { status = 0; break; }
         if (it == o.max_iter) break;
+        if (RT && W.deadline) {      // real-time tick: out of time (teams: one lane reads the clock, every wave hears the verdict behind a barrier)
+#if BMPC_NW > 1
+            LANES_BEGIN
+                if (lane == 0 && W.wv == 0) L[L_TFLAG + 4] = BMPC_NOW() > W.deadline ? 1.0 : 0.0;
+            LANES_END
+            TEAM_SYNC_LDS();
+            const bool late_ = L[L_TFLAG + 4] != 0.0;
+            TEAM_SYNC_LDS();
+            if (late_) break;
+#else
+            if (BMPC_NOW() > W.deadline) break;
+#endif
+        }
         // stalled primal feasibility -> status 2, numerical breakdown -> status 3 (oracle/bmpc_oracle.c solve_one)
         if (it == 0) ep_old = ep_mid = 1e300;
         else if (o.stall_window > 0 && it % (o.stall_window / 2) == 0) {

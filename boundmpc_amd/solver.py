@@ -14,7 +14,7 @@ NZ, NG = 44, 43
 
 
 class BatchedOCPSolver:
-    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=None, slack_push=None, exact_hessian=True, mu_warm=1e-2, stall_window=None):
+    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=None, slack_push=None, exact_hessian=True, mu_warm=1e-2, stall_window=None, bound_margin=0.0):
         self._lib = _lib.load()
         o = _lib.Options()
         self._lib.bmpc_default_options_for(int(N), ctypes.byref(o))      # mu_init 0.1 / slack_push 1e-2 for N <= 11, 3.0 / 0.1 for longer horizons
@@ -24,6 +24,7 @@ class BatchedOCPSolver:
             slack_push = o.slack_push
         o.tol, o.max_iter, o.mu_init, o.slack_push, o.exact_hessian = tol, int(max_iter), mu_init, slack_push, int(exact_hessian)
         o.mu_warm = mu_warm
+        o.bound_margin = float(bound_margin)      # joint limits tightened inside the solver (real-time modes; 0 = the reference's limits)
         if stall_window is not None:
             o.stall_window = int(stall_window)      # default: 40 for N <= 11, 20 for longer horizons (bmpc_default_options_for)
         self._h = ctypes.c_void_p()
@@ -85,6 +86,11 @@ class BatchedOCPSolver:
         """Threshold of the reference's acceptance rule (summed violation of g, BoundMPC.py:462-465) that stream ticks in real-time mode
         apply to an iteration-capped iterate (default 1e-4, the reference's).  Set it before the tick graph is captured."""
         _lib.check(self._lib.bmpc_stream_set_rt_feasibility_tol(self._h, float(tol)), "bmpc_stream_set_rt_feasibility_tol")
+
+    def set_time_budget_us(self, microseconds):
+        """Time budget of a fused closed-loop tick (0 = none): no further solver iteration is started once it is used up
+        (bmpc_stream_set_time_budget).  Set it before the tick graph is captured."""
+        _lib.check(self._lib.bmpc_stream_set_time_budget(self._h, float(microseconds)), "bmpc_stream_set_time_budget")
 
     def set_timing(self, keep=1):
         """HIP events around the solver kernel on its launch stream; the pairs of the last `keep` launches are kept (0/False = off)."""

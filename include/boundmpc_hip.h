@@ -57,6 +57,9 @@ typedef struct {
     int stall_window;   /* status 2 when the primal infeasibility has not halved over this many iterations (checked every
                            stall_window/2 iterations); 0 = never; default 40 for N <= 11, 20 for longer horizons (reference: Ipopt's restoration
                            phase / "local infeasibility") */
+    double bound_margin;/* joint position / velocity limits tightened by this much (rad, rad/s) INSIDE the solver; default 0 = the reference's limits
+                           (RobotModel.py:20-39).  For real-time closed loops solved to a loose tolerance or an iteration / time budget: a plan whose
+                           bound rows are met to 1e-3 only then still respects the true limits the acceptance rule checks.  (appended in round 4) */
 } bmpc_options;
 
 enum { BMPC_OK = 0, BMPC_ERR_ARG = 1, BMPC_ERR_HIP = 2, BMPC_ERR_NOGPU = 4 };
@@ -155,10 +158,18 @@ int bmpc_stream_post(bmpc_handle *h, int B, const double *path, int path_entries
 /* Threshold on the summed violation of g (beyond 1e-6 per row) below which bmpc_stream_post applies an iteration-capped iterate in
  * real-time mode (flags bit 1).  Default 1e-4 = the reference's rule (BoundMPC.py:462-465).  Read when a post is launched or captured. */
 int bmpc_stream_set_rt_feasibility_tol(bmpc_handle *h, double tol);
+/* Time budget of a FUSED tick (bmpc_stream_tick / bmpc_stream_graph_create when they fuse), in microseconds from kernel entry; 0 (default) = none.
+ * With a budget the solver of a tick starts no further iteration once the budget is used up (status 1, like the iteration cap): every stream
+ * gets the iterations that fit -- a stream whose Riccati sweep repeats or whose line search takes extra trials gets fewer -- and the tick is
+ * bounded by budget + one iteration + the post-processing.  The iteration count of a stream then depends on the clock: results of such ticks
+ * are not reproducible bit for bit.  Use with flags bit 1 (the acceptance rule decides what is applied).  Read at launch / capture time. */
+int bmpc_stream_set_time_budget(bmpc_handle *h, double microseconds);
 /* One whole tick {pack, warm-started solve with max_iter (0 = options), post} of B streams.  For N <= 11 and B within the resident
  * waves of the device (bmpc_launch_info: grid) it is ONE kernel launch: the wave that owns a stream packs its problem, solves it and
  * post-processes the result (no work queue, no launch boundary between the steps); otherwise the three kernels are enqueued.
- * Arguments as bmpc_stream_pack / bmpc_solve_batch_warm / bmpc_stream_post. */
+ * Arguments as bmpc_stream_pack / bmpc_solve_batch_warm / bmpc_stream_post.  In the fused launch a stream that has lost its plan (error count
+ * >= N: BoundMPC.step() returns five Nones there, BoundMPC.py:498-506) is skipped (status 3, 0 iterations): re-plan it (StreamBatch.update)
+ * or restart it. */
 int bmpc_stream_tick(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, double *p, double *x0,
                      double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj, int flags,
                      void *hip_stream);
