@@ -547,6 +547,25 @@ def test_closed_loop_ticks_against_independent_scipy_solutions(solver):
     assert np.abs(out["f"] - d["f"]).max() < 1e-7
 
 
+def test_benchmark_batches_against_independent_slsqp_solutions():
+    """HIP kernels against the independent SLSQP solutions of samples of the benchmark batches (fixture g8_scipy_batch: configs[1] seed 0 cold
+    starts; tight N = 20 / N = 30 from a start near the oracle's solution) -- tests/test_oracle_golden.py holds the criteria."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver
+    from tests.test_oracle_golden import check_against_slsqp_batch
+
+    def solve(P, X0, N):
+        s = BatchedOCPSolver(N, 4, 0.1)
+        try:
+            s.set_team_waves(1)      # the kernel of the benchmark batches (one wave per problem); teams are compared with it in tests/test_gpu_team.py
+            o = s.solve_batch(torch.tensor(P, device="cuda"), torch.tensor(X0, device="cuda"), out={}, want=("f", "status"))
+            return {k: v.cpu().numpy() for k, v in o.items()}
+        finally:
+            s.close()
+    rep = check_against_slsqp_batch(solve, "HIP kernel")
+    assert rep["c1"]["same_minimiser"] >= 60
+
+
 def test_kkt_certificate_with_the_references_own_derivatives(solver):
     """HIP solutions of recorded closed-loop ticks (cold start, segment switch, end of path, experiment 2's tight tube) are KKT points of
     the REFERENCE's NLP: stationarity with the gradient / Jacobian obtained by a complex step through the reference's own builder
