@@ -88,7 +88,7 @@ struct bmpc_handle {
     int team_mode;           // bmpc_set_team_waves: 0 automatic (teams when the batch fits into the resident teams), 1 never, BMPC_TEAM_NW whenever possible
     int timing; hipEvent_t *ev; int nev; long long n_timed;   // timing = number of launches whose {start, stop} event pairs are kept (ring)
     double *latency_us;
-    double *stage_d; int *stage_i; int stage_cap;   // device staging of the host-buffer path
+    double *stage_d, *stage_h; int stage_cap;   // device and pinned host staging of the host-buffer path (bmpc_solve_batch_host)
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "boundmpc_hip: %s failed: %s\n", #x, hipGetErrorString(e_)); return BMPC_ERR_HIP; } } while (0)
@@ -130,7 +130,7 @@ static void handle_release(bmpc_handle *h) {
     if (h->order_ev) hipEventDestroy(h->order_ev);
     if (h->bridge_ev) hipEventDestroy(h->bridge_ev);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
-    hipFree(h->scratch); hipFree(h->counter); hipFree(h->prof); hipFree(h->stage_d); hipFree(h->stage_i);
+    hipFree(h->scratch); hipFree(h->counter); hipFree(h->prof); hipFree(h->stage_d); if (h->stage_h) hipHostFree(h->stage_h);
     delete h;
 }
 
@@ -158,7 +158,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     bmpc_handle *h = new (std::nothrow) bmpc_handle();
     if (!h) return BMPC_ERR_ARG;
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->ev = nullptr; h->nev = 0; h->n_timed = 0; h->latency_us = nullptr;
-    h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->prof = nullptr; h->stage_d = nullptr; h->stage_i = nullptr; h->stage_cap = 0;
+    h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->prof = nullptr; h->stage_d = nullptr; h->stage_h = nullptr; h->stage_cap = 0;
     h->team_grid = 0; h->team_mode = 0;
     h->rt_viol_tol = 1e-4; h->rt_budget_us = 0.0; h->dev = 0; h->refs = 1; h->closed = false; h->order_ev = nullptr; h->bridge_ev = nullptr; h->order_valid = false; h->order_stream = nullptr; h->own_stream = nullptr;
     if (opts) h->o = *opts; else bmpc_default_options_for(N, &h->o);
@@ -377,17 +377,20 @@ extern "C" int bmpc_graph_destroy(bmpc_graph *gr) {
     return BMPC_OK;
 }
 
-// host-buffer path: device staging buffers are owned by the handle and grow on demand (no hipMalloc per call: the single-problem
-// solver(...) call of the drop-in shim runs every tick)
+// host-buffer path: device and pinned host staging buffers are owned by the handle and grow on demand (no hipMalloc per call: the
+// single-problem solver(...) call of the drop-in shim runs every tick).  One staging record holds everything that crosses PCIe for a
+// call, inputs first: [p | x0 | x | lam_x | g | lam_g | f | kkt] doubles, then [iters | status] ints -- so a call is ONE host-to-device
+// copy of the inputs, the launch, ONE device-to-host copy of the outputs and one stream synchronisation (until round 3: two blocking
+// copies in, a device synchronisation and eight blocking copies out, ~190 us around a 1.1 ms single-problem launch).
 static int host_stage_reserve(bmpc_handle *h, int B) {
     if (B <= h->stage_cap) return BMPC_OK;
     const size_t np = 141 + 91 * h->S, nw = (size_t)h->N * 44, ng = (size_t)h->N * 43;
-    const size_t nd = (size_t)B * (np + 3 * nw + 2 * ng + 2), ni = (size_t)B * 2;
+    const size_t bytes = ((size_t)B * (np + 3 * nw + 2 * ng + 2)) * sizeof(double) + (size_t)B * 2 * sizeof(int);
     if (h->stage_d) { hipFree(h->stage_d); h->stage_d = nullptr; }
-    if (h->stage_i) { hipFree(h->stage_i); h->stage_i = nullptr; }
+    if (h->stage_h) { hipHostFree(h->stage_h); h->stage_h = nullptr; }
     h->stage_cap = 0;
-    if (hipMalloc(&h->stage_d, nd * sizeof(double)) != hipSuccess || hipMalloc(&h->stage_i, ni * sizeof(int)) != hipSuccess) {
-        hipFree(h->stage_d); hipFree(h->stage_i); h->stage_d = nullptr; h->stage_i = nullptr;
+    if (hipMalloc(&h->stage_d, bytes) != hipSuccess || hipHostMalloc(&h->stage_h, bytes, hipHostMallocDefault) != hipSuccess) {
+        hipFree(h->stage_d); if (h->stage_h) hipHostFree(h->stage_h); h->stage_d = nullptr; h->stage_h = nullptr;
         return BMPC_ERR_HIP;
     }
     h->stage_cap = B;
@@ -400,20 +403,27 @@ extern "C" int bmpc_solve_batch_host(bmpc_handle *h, int B, const double *p, con
     int rc = host_stage_reserve(h, B);
     if (rc != BMPC_OK) return rc;
     const size_t np = 141 + 91 * h->S, nw = (size_t)h->N * 44, ng = (size_t)h->N * 43, b = (size_t)B;
+    const size_t n_in = b * (np + nw), n_out = b * (2 * nw + 2 * ng + 2);
     double *dp = h->stage_d, *dx0 = dp + b * np, *dx = dx0 + b * nw, *dlx = dx + b * nw, *dg = dlx + b * nw, *dlg = dg + b * ng, *df = dlg + b * ng, *dk = df + b;
-    int *dit = h->stage_i, *dst = dit + b;
+    int *dit = (int *)(dk + b), *dst = dit + b;
+    double *hp = h->stage_h, *hx0 = hp + b * np, *hx = hx0 + b * nw, *hlx = hx + b * nw, *hg = hlx + b * nw, *hlg = hg + b * ng, *hf = hlg + b * ng, *hk = hf + b;
+    const int *hit = (const int *)(hk + b), *hst = hit + b;
 #define TRY(x) do { if (rc == BMPC_OK && (x) != hipSuccess) rc = BMPC_ERR_HIP; } while (0)
-    TRY(hipMemcpy(dp, p, b * np * 8, hipMemcpyHostToDevice)); TRY(hipMemcpy(dx0, x0, b * nw * 8, hipMemcpyHostToDevice));
+    memcpy(hp, p, b * np * sizeof(double)); memcpy(hx0, x0, b * nw * sizeof(double));
+    TRY(hipMemcpyAsync(dp, hp, n_in * sizeof(double), hipMemcpyHostToDevice, nullptr));
     if (rc == BMPC_OK) rc = bmpc_solve_batch(h, B, dp, dx0, dx, dg, dlg, dlx, df, dit, dst, dk, nullptr);
-    TRY(hipDeviceSynchronize());
-    TRY(hipMemcpy(x, dx, b * nw * 8, hipMemcpyDeviceToHost));
-    if (g) TRY(hipMemcpy(g, dg, b * ng * 8, hipMemcpyDeviceToHost));
-    if (lam_g) TRY(hipMemcpy(lam_g, dlg, b * ng * 8, hipMemcpyDeviceToHost));
-    if (lam_x) TRY(hipMemcpy(lam_x, dlx, b * nw * 8, hipMemcpyDeviceToHost));
-    if (f) TRY(hipMemcpy(f, df, b * 8, hipMemcpyDeviceToHost));
-    if (kkt) TRY(hipMemcpy(kkt, dk, b * 8, hipMemcpyDeviceToHost));
-    if (iters) TRY(hipMemcpy(iters, dit, b * 4, hipMemcpyDeviceToHost));
-    if (status) TRY(hipMemcpy(status, dst, b * 4, hipMemcpyDeviceToHost));
+    TRY(hipMemcpyAsync(hx, dx, n_out * sizeof(double) + b * 2 * sizeof(int), hipMemcpyDeviceToHost, nullptr));
+    TRY(hipStreamSynchronize(nullptr));
+    if (rc == BMPC_OK) {
+        memcpy(x, hx, b * nw * sizeof(double));
+        if (g) memcpy(g, hg, b * ng * sizeof(double));
+        if (lam_g) memcpy(lam_g, hlg, b * ng * sizeof(double));
+        if (lam_x) memcpy(lam_x, hlx, b * nw * sizeof(double));
+        if (f) memcpy(f, hf, b * sizeof(double));
+        if (kkt) memcpy(kkt, hk, b * sizeof(double));
+        if (iters) memcpy(iters, hit, b * sizeof(int));
+        if (status) memcpy(status, hst, b * sizeof(int));
+    }
 #undef TRY
     return rc;
 }

@@ -22,3 +22,14 @@ tg, tc, tgi = np.array(tg) * 1e3, np.array(tc) * 1e3, np.array(tgi) * 1e3
 print(f"kernel time of the one-problem launch (HIP events): p50 {np.percentile(tk,50):.2f} ms p99 {np.percentile(tk,99):.2f} ms")
 print(f"single-problem call over {len(tg)} recorded ticks (mean {np.mean(it):.1f} iterations): GPU shim back-to-back p50 {np.percentile(tg,50):.2f} ms p99 {np.percentile(tg,99):.2f} ms; "
       f"after ~10 ms of device idle p50 {np.percentile(tgi,50):.2f} ms p99 {np.percentile(tgi,99):.2f} ms; CPU oracle (1 thread) p50 {np.percentile(tc,50):.2f} ms p99 {np.percentile(tc,99):.2f} ms")
+
+# the same calls at the REFERENCE's own convergence tolerance (ipopt 'tol': 10e-6, BoundMPC.py:121) -- the drop-in's default is 1e-8
+s5 = BatchedOCPSolver(10, 4, 0.1, tol=1e-5); shim5 = NlpSolverShim(s5); s5.set_timing(True)
+for warm in range(3):
+    shim5(x0=d["x0"][0], p=d["p"][0])
+t5, it5, k5 = [], [], []
+for t in ticks:
+    t0 = time.perf_counter(); shim5(x0=d["x0"][t], p=d["p"][t]); t5.append(time.perf_counter() - t0); it5.append(shim5.stats()["iter_count"]); k5.append(s5.last_kernel_ms())
+t5 = np.array(t5) * 1e3
+print(f"at the reference's tolerance 1e-5 (mean {np.mean(it5):.1f} iterations): call p50 {np.percentile(t5,50):.2f} ms p99 {np.percentile(t5,99):.2f} ms, kernel p50 {np.percentile(k5,50):.2f} ms; "
+      f"waves per problem: {s.team_info(1)['waves']}")

@@ -444,7 +444,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert rf["flops_per_iteration"] > 1e6 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and "riccati (factorise + forward)" in rf["flops_per_iteration_by_phase"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["gpu_vs_cpu_sample_joint_rms_rad"] < 1e-6
     # `achieved` is priced with the kernel's own operation count; the dense oracle's count (several times larger) is reported beside it
-    assert 1e6 < rf["flops_per_iteration"] < rf["oracle_dense_flops_per_iteration"] and rf["frac"] < rf["oracle_dense_frac"] and "flops_source" in rf
+    assert "flops_source" in rf
+    if "stale" not in rf["flops_source"]:      # (a count of another kernel text is never used: the oracle's count stands in, and says so)
+        assert 1e6 < rf["flops_per_iteration"] < rf["oracle_dense_flops_per_iteration"] and rf["frac"] < rf["oracle_dense_frac"]
     # informational leg at the reference's Ipopt tolerance: fewer iterations, same problems solved, close to the 1e-8 solutions
     rt = d["at_reference_tolerance"]
     assert rt["tol"] == 1e-5 and rt["solved_fraction"] == 1.0 and rt["mean_iters"] < d["config"]["mean_iters"] and rt["joint_rms_vs_tol_1e-8_rad"] < 1e-3
