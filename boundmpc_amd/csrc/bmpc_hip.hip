@@ -458,12 +458,13 @@ __global__ void __launch_bounds__(64) bmpc_stream_post_kernel(int N, int S, int 
     bmpcs::stream_post(N, S, h, path + (long long)b * path_stride, path_stride / bmpcs::PT_LEN, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
                        x + (long long)b * 44 * N, g + (long long)b * 43 * N, status[b], traj + (long long)b * bmpcs::tr_len(N), flags, rt_tol, sh, threadIdx.x, 64);
 }
-// ---- one closed-loop tick of a stream in ONE launch: {pack, solve, post} by the wave that owns the stream (N <= 11) ----
+// ---- one closed-loop tick of a stream in ONE launch: {pack, solve, post} by the wave that owns the stream (both instantiations of the solver) ----
 // The three steps of a tick are each "one wave per stream" and strictly sequential per stream, so they need no grid-wide boundary
 // between them: as three kernels + the work-queue reset they cost three launch ramps, three drains and ~130 us of launch overhead
 // per tick at 1 kHz (profiles/r03_*_stream_trace.txt); here stream b is block b (B <= resident waves: no work queue, no reset node),
 // the stream functions use the reduction area of the solver's LDS, and the hand-over of p, x0 -> solver -> x, g, status goes through
 // global memory of the same wave in program order.
+template <bool ZLDS>
 __global__ void __launch_bounds__(64, 1) bmpc_stream_tick_kernel(KArgs a, SArgs s) {
     __shared__ double lds[bmpc::L_SIZE];
     const long long tk0_ = a.budget_ticks ? BMPC_NOW() : 0;
@@ -491,7 +492,7 @@ __global__ void __launch_bounds__(64, 1) bmpc_stream_tick_kernel(KArgs a, SArgs 
     pr.f = nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr; pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status + b; pr.state = dual;
     const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
     W.deadline = a.budget_ticks ? tk0_ + a.budget_ticks : 0;
-    bmpc::wave_solve<true, true>(W, pr);
+    bmpc::wave_solve<ZLDS, true>(W, pr);
     __syncthreads();
     if (a.latency_us && threadIdx.x == 0) a.latency_us[b] = (double)((long long)wall_clock64() - t0_) * 0.01;
     bmpcs::stream_post(a.N, a.S, a.h, path, s.path_stride / bmpcs::PT_LEN, ss, rb, pr.x, pr.g, a.status[b], s.traj + (long long)b * bmpcs::tr_len(a.N), s.flags, s.rt_tol,
@@ -514,18 +515,19 @@ static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entr
     hipEvent_t *pair = nullptr;
     if (timed) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
     if (use_team(h, B)) HIPCHK(bmpc_team_launch_tick(BMPC_TEAM_NW, &a, &s, B, st));
-    else hipLaunchKernelGGL(bmpc_stream_tick_kernel, dim3(B), dim3(64), 0, st, a, s);
+    else if (h->N <= 11 && h->S <= bmpc::SMAX_ZLDS) hipLaunchKernelGGL(bmpc_stream_tick_kernel<true>, dim3(B), dim3(64), 0, st, a, s);
+    else hipLaunchKernelGGL(bmpc_stream_tick_kernel<false>, dim3(B), dim3(64), 0, st, a, s);      // long horizons, 5 or 6 path segments: iterate in the workspace
     HIPCHK(hipGetLastError());
     if (timed) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }
     if (!capturing) return order_after(h, st);
     return BMPC_OK;
 }
-static bool tick_fusable(const bmpc_handle *h, int B) { return h->N <= 11 && h->S <= bmpc::SMAX_ZLDS && B <= (use_team(h, B) ? h->team_grid : h->grid); }
+static bool tick_fusable(const bmpc_handle *h, int B) { return B <= (use_team(h, B) ? h->team_grid : h->grid); }      // stream b = workgroup b: every stream needs a resident workgroup
 extern "C" int bmpc_stream_tick(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, double *p, double *x0,
                                 double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj, int flags,
                                 void *hip_stream) {
     if (!h || B < 0 || max_iter < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !p || !x0 || !x || !g || !status || !traj))) return BMPC_ERR_ARG;
-    if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // the stream kernels place one lane per stage below fixed roles at lanes 32..: horizons up to 32
+    if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // (the solver's own limit)
     if (B == 0) return BMPC_OK;
     { const int rc_ = ensure_scratch(h, launch_grid(h, B)); if (rc_ != BMPC_OK) return rc_; }
     hipStream_t st = (hipStream_t)hip_stream;
@@ -559,7 +561,7 @@ extern "C" int bmpc_stream_pack(bmpc_handle *h, int B, const double *path, int p
 extern "C" int bmpc_stream_pack_rt(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, const double *robot, double *p, double *x0,
                                    double *dual_state, const double *xlast, void *hip_stream) {
     if (!h || B < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !p || !x0))) return BMPC_ERR_ARG;
-    if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // the stream kernels place one lane per stage below fixed roles at lanes 32..: horizons up to 32
+    if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // (the solver's own limit)
     if (B == 0) return BMPC_OK;
     if (h->closed) return BMPC_ERR_ARG;
     hipLaunchKernelGGL(bmpc_stream_pack_kernel, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, path, path_entries * bmpcs::PT_LEN,
@@ -570,7 +572,7 @@ extern "C" int bmpc_stream_pack_rt(bmpc_handle *h, int B, const double *path, in
 extern "C" int bmpc_stream_post(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, const double *x, const double *g,
                                 const int *status, double *traj, int flags, void *hip_stream) {
     if (!h || B < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !x || !g || !status || !traj))) return BMPC_ERR_ARG;
-    if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // the stream kernels place one lane per stage below fixed roles at lanes 32..: horizons up to 32
+    if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // (the solver's own limit)
     if (B == 0) return BMPC_OK;
     hipLaunchKernelGGL(bmpc_stream_post_kernel, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, h->h, path,
                        path_entries * bmpcs::PT_LEN, sstate, robot, x, g, status, traj, flags, h->rt_viol_tol);
@@ -582,7 +584,7 @@ extern "C" int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *pat
                                         double *dual_state, int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj,
                                         int flags, bmpc_graph **out) {
     if (!h || !out || B < 1 || max_iter < 0 || path_entries < h->S + 1 || !path || !sstate || !robot || !p || !x0 || !x || !g || !status || !traj) return BMPC_ERR_ARG;
-    if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // the stream kernels place one lane per stage below fixed roles at lanes 32..: horizons up to 32
+    if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // (the solver's own limit)
     { const int rc_ = ensure_scratch(h, launch_grid(h, B)); if (rc_ != BMPC_OK) return rc_; }
     hipStream_t cs;
     HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));

@@ -23,7 +23,7 @@
 #pragma once
 
 namespace bmpcs {
-constexpr int STREAM_NMAX = 32;      // one lane per stage below the fixed roles at lanes 32.. (stream_post)
+constexpr int STREAM_NMAX = 40;      // the solver's longest horizon (stream_post: one role per stage, then the fixed roles behind them)
 
 // path table entry (one per via-point slot), doubles
 enum { PT_P = 0, PT_IW = 3, PT_DPN = 6, PT_DR = 9, PT_RRV = 12, PT_PLO = 15, PT_PUP = 17, PT_RLO = 19, PT_RUP = 21, PT_BP1 = 23, PT_BP2 = 26,
@@ -508,15 +508,16 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
         traj[TRN - 4] = ec < N ? (double)n : 0.0; traj[TRN - 3] = (double)using_prev; traj[TRN - 2] = success ? 1.0 : 0.0; traj[TRN - 1] = sh[SH_FLAG + 4];
     }
     if (ec >= N) return;                                          // step() returns None :504-506 (uniform over the lanes)
-    // ---- phase 2: roles 0..n-1: Cartesian trajectory of one stage :568-587; role 32: rotation reference and path-parameter
-    //      state :594-611; role 33: the node's kinematic plant step (util_functions.py:152-161) ----
-    // Roles 34..34+ec-1 (only while a previous plan is replayed): the leading, already executed columns of that plan, of which
+    // ---- phase 2: roles 0..n-1: Cartesian trajectory of one stage :568-587; role RF: rotation reference and path-parameter
+    //      state :594-611; role RF+1: the node's kinematic plant step (util_functions.py:152-161); RF = max(N, 32) ----
+    // Roles RF+2..RF+2+ec-1 (only while a previous plan is replayed): the leading, already executed columns of that plan, of which
     // only the Cartesian derivatives for a later re-planning are kept.
     double *pc = ss + ss_pc(N);
-    for (int role = lane; role < 34 + ec; role += nl) {
-        if (role < n || role >= 34) {
-            const bool lead = role >= 34;
-            const int i = lead ? 0 : role, col = lead ? role - 34 : ec + role;        // trajectory index / column of the plan
+    const int RF = N > 32 ? N : 32;
+    for (int role = lane; role < RF + 2 + ec; role += nl) {
+        if (role < n || role >= RF + 2) {
+            const bool lead = role >= RF + 2;
+            const int i = lead ? 0 : role, col = lead ? role - (RF + 2) : ec + role;        // trajectory index / column of the plan
             double q[7], dq[7], ddq[7], u[7];
             for (int j = 0; j < 7; j++) {
                 if (lead) { q[j] = w[col * 44 + 8 + j]; dq[j] = w[col * 44 + 15 + j]; ddq[j] = w[col * 44 + 22 + j]; }
@@ -540,7 +541,7 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
                 pc[(3 + c) * N + col] = w[col * 44 + 35 + c];
                 pc[(6 + c) * N + col] = a; pc[(9 + c) * N + col] = jk;
             }
-        } else if (role == 32) {
+        } else if (role == RF) {
             int sector = (int)ss[SS_SECTOR];
             sector = sector > cap - 2 ? cap - 2 : sector; sector = sector < 0 ? 0 : sector;       // clamped to the table (see stream_pack)
             const double *e0 = path + sector * PT_LEN, *e1 = path + (sector + 1) * PT_LEN;
@@ -555,7 +556,7 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
             }
             for (int c = 0; c < 3; c++) ss[SS_PRREF + c] = prn[c];
             ss[SS_PHI] = phi0; ss[SS_DPHI] = Tdphi[0]; ss[SS_DDPHI] = Tddphi[0]; ss[SS_DDDPHI] = Tjphi[0];
-        } else if (role == 33 && (flags & 1)) {
+        } else if (role == RF + 1 && (flags & 1)) {
             // integrate with [jerk_current, first planned jerk], then FK
             double qs[7], dqs[7], ddqs[7];
             for (int j = 0; j < 7; j++) { qs[j] = rb[RB_Q + j]; dqs[j] = rb[RB_DQ + j]; ddqs[j] = rb[RB_DDQ + j]; chain_step(qs[j], dqs[j], ddqs[j], rb[RB_JERK + j], Tj[j * N], h); }

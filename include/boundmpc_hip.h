@@ -68,9 +68,8 @@ int bmpc_default_options(bmpc_options *o);                 /* the N <= 11 defaul
 int bmpc_default_options_for(int N, bmpc_options *o);      /* defaults for horizon N; what bmpc_create(…, NULL, …) uses */
 const char *bmpc_error_string(int code);
 
-/* N horizon (1..40; the closed-loop stream entry points bmpc_stream_* accept N <= 32 and return BMPC_ERR_ARG above), S path segments in
- * the window (2..6; with 5 or 6 the iterate lives in the workspace instead of LDS at every horizon, as it does for N > 11, and stream ticks are
- * not fused into one launch), dt sampling time */
+/* N horizon (1..40, also for the closed-loop stream entry points bmpc_stream_*), S path segments in the window (2..6; with 5 or 6 the iterate
+ * lives in the workspace instead of LDS at every horizon, as it does for N > 11), dt sampling time */
 int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bmpc_handle **out);
 int bmpc_destroy(bmpc_handle *h);
 
@@ -164,8 +163,8 @@ int bmpc_stream_set_rt_feasibility_tol(bmpc_handle *h, double tol);
  * bounded by budget + one iteration + the post-processing.  The iteration count of a stream then depends on the clock: results of such ticks
  * are not reproducible bit for bit.  Use with flags bit 1 (the acceptance rule decides what is applied).  Read at launch / capture time. */
 int bmpc_stream_set_time_budget(bmpc_handle *h, double microseconds);
-/* One whole tick {pack, warm-started solve with max_iter (0 = options), post} of B streams.  For N <= 11 and B within the resident
- * waves of the device (bmpc_launch_info: grid) it is ONE kernel launch: the wave that owns a stream packs its problem, solves it and
+/* One whole tick {pack, warm-started solve with max_iter (0 = options), post} of B streams.  For B within the resident workgroups of the device
+ * (bmpc_launch_info: grid; teams: bmpc_team_info) it is ONE kernel launch, whatever N and S: the wave that owns a stream packs its problem, solves it and
  * post-processes the result (no work queue, no launch boundary between the steps); otherwise the three kernels are enqueued.
  * Arguments as bmpc_stream_pack / bmpc_solve_batch_warm / bmpc_stream_post.  In the fused launch a stream that has lost its plan (error count
  * >= N: BoundMPC.step() returns five Nones there, BoundMPC.py:498-506) is skipped (status 3, 0 iterations): re-plan it (StreamBatch.update)

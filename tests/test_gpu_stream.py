@@ -380,3 +380,34 @@ def test_solver_close_destroys_its_graphs_first():
     s.close()
     assert g._g is None
     g.close()
+
+
+@pytest.mark.gpu
+def test_streams_at_36_stages_fused_tick_matches_the_three_kernel_tick():
+    """Closed-loop streams beyond 32 stages (round 4): the fused tick of the long-horizon instantiation (pack + solve + post in one launch,
+    iterate in the workspace) against the three separate launches, 6 streams x 5 ticks at N = 36 -- same plants, plans and statuses; and the
+    CPU build of the stream functions around the oracle retraces stream 0 (tests/test_stream.py pins that build against the host mirror)."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, stream as bstream, workload
+    N = 36
+    q0s = workload.random_q0(6, seed=11)
+    runs = []
+    for fused in (True, False):
+        s = BatchedOCPSolver(N, 4, 0.1)
+        mpcs, recs = [], []
+        for q0 in q0s:
+            m, p0fk = workload.make_mpc(q0, N=N)
+            mpcs.append(m)
+            recs.append(bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([m.phi_max[0], 0, 0]), np.zeros(7)))
+        sb = bstream.StreamBatch(s, mpcs)
+        sb.set_robot(np.stack(recs))
+        for t in range(5):
+            sb.tick(simulate=True, fused=fused)
+        torch.cuda.synchronize()
+        runs.append((sb.robot.cpu().numpy().copy(), sb.traj.cpu().numpy().copy(), sb.status.cpu().numpy().copy(), sb.x.cpu().numpy().copy()))
+        sb.close(); s.close()
+    (r1, t1, s1, x1), (r2, t2, s2, x2) = runs
+    assert (s1 == 0).all() and np.array_equal(s1, s2)
+    np.testing.assert_allclose(r1, r2, atol=1e-9); np.testing.assert_allclose(t1, t2, atol=1e-8); np.testing.assert_allclose(x1, x2, atol=1e-8)
+    td, fl = bstream.unpack_traj(t1[0], N)
+    assert fl["success"] and fl["n_valid"] == N and td["q"].shape == (7, N)

@@ -296,3 +296,43 @@ def test_realtime_acceptance_counts_the_variable_bounds():
         # the reference's own rule (flags bit 1 off) does not look at x: the same iterate passes on its g
         tr = emu.stream_post(N, 4, 0.1, T, ss.copy(), rb.copy(), xb.ravel(), g, 1, simulate=True, flags=0)
         assert bstream.unpack_traj(tr, N)[1]["success"]
+
+
+def test_stream_functions_at_the_longest_horizons_match_the_host_mirror():
+    """stream_pack / stream_post beyond 32 stages (round 4: the role map of stream_post follows the horizon): closed loop of the device
+    functions against the host mirror (which fixture G12 pins against the reference for other (n, nr_segs)) at N = 36, with one forced failure."""
+    N = 36
+    q0 = workload.random_q0(3, seed=11)[0]
+
+    class Orc(_Oracle):
+        def solve(self, p, x0):
+            r = c_oracle.solve(p, x0, N, 4, 0.1, nthreads=4)
+            x, g, st = r["x"][0], r["g"][0].copy(), int(r["status"][0])
+            if self.calls in self.fail_at:
+                g[:] = 1.0; st = 3
+            self.calls += 1
+            return x, g, st, int(r["iters"][0])
+    fails = (2,)
+    mpc, p0fk = workload.make_mpc(q0, N=N, solver=Orc(fails))
+    ref, _ = workload.make_mpc(q0, N=N, solver=Orc())
+    T, M = bstream.path_table(ref.ref_path)
+    ss = bstream.initial_state(ref, N); ss[bstream.SS["NENT"]] = M
+    rm = RobotModel()
+    q, dq, ddq, jerk, v = q0.copy(), np.zeros(7), np.zeros(7), np.zeros(7), np.zeros(6)
+    x_phi_d = np.array([mpc.phi_max[0], 0, 0])
+    rb = bstream.robot_record(q, dq, ddq, p0fk, v, x_phi_d, jerk)
+    sol = Orc(fails)
+    for t in range(4):
+        p_lie = rm.forward_kinematics(q, dq)[0]
+        traj, _, _, _, _ = mpc.step(q, dq, ddq, p_lie, v, x_phi_d, jerk)
+        p, x0 = emu.stream_pack(N, 4, T, ss, rb)
+        x, g, st, _ = sol.solve(p, x0)
+        tr = emu.stream_post(N, 4, 0.1, T, ss, rb, x, g, st, simulate=True)
+        td, fl = bstream.unpack_traj(tr, N)
+        assert int(ss[bstream.SS["ERRCNT"]]) == mpc.error_count and fl["using_previous"] == (t in fails) and fl["n_valid"] == N - mpc.error_count
+        for k in ("q", "dq", "p", "v", "phi", "dphi"):
+            np.testing.assert_allclose(td[k], traj[k], atol=5e-5, err_msg=f"tick {t} {k}")      # two closed loops of 36-stage solves (tol 1e-8 each)
+        jm = np.concatenate((jerk[:, None], traj["dddq"][:, :2]), axis=1)
+        q, dq, ddq, p_lie, v = integrate_joint(rm, jm, q, dq, ddq, mpc.dt)[:5]
+        jerk = traj["dddq"][:, 0].copy()
+        np.testing.assert_allclose(rb[:7], q, atol=1e-6)
