@@ -1711,24 +1711,37 @@ BMPC_D inline void backward_loads_lane(Wave &W, const Scr &sc, int k, double *pf
     const int l35 = lane < NS ? lane : NS - 1, l42 = lane < 42 ? lane : 41;
     // of the four kinematics records of a stage (node k, velocity point of node k+1, node k-1, velocity point of node k) the
     // first two are the last two of the previous stage (k+1): they stay in LDS, only the first stage of a sweep loads all four
+    // (teams, BMPC_NW > 1: what only the node-cost add reads -- the velocity-point record of the next node, the small Hessian blocks, the
+    // barrier ratios, the curvature prefix vectors -- is the helper wave's business (team_blk_prep reads it from the LDS-resident rows): the
+    // sweep's wave neither loads nor stages it)
     if (full) {
         pf[0] = WL[sc.KIN + k * KREC + lane]; pf[1] = WL[sc.KIN + k * KREC + l2];
+#if BMPC_NW == 1
         pf[2] = WL[sc.KIN + (N + kn) * KREC + lane]; pf[3] = WL[sc.KIN + (N + kn) * KREC + l2];
+#endif
     }
     pf[4] = WL[sc.KIN + kp * KREC + lane]; pf[5] = WL[sc.KIN + kp * KREC + l2];
-    pf[6] = WL[sc.KIN + (N + k) * KREC + lane]; pf[7] = WL[sc.KIN + (N + k) * KREC + l2];
+#if BMPC_NW == 1
+    pf[6] = WL[sc.KIN + (N + k) * KREC + lane]; pf[7] = WL[sc.KIN + (N + k) * KREC + l2];      // (velocity point of node k: next stage's KV1, read by the node-cost add only)
+#endif
     // node-cost data of the stage (wave_stage_data_wide): NCS row (two slots), defects, iota couplings; gl = g^ + its non-trivial entries
-    pf[8] = WL[sc.NCS + k * NCS_STRIDE + lane]; pf[9] = WL[sc.NCS + k * NCS_STRIDE + 64 + lane];
+#if BMPC_NW == 1
+    pf[8] = WL[sc.NCS + k * NCS_STRIDE + lane];
+#endif
+    pf[9] = WL[sc.NCS + k * NCS_STRIDE + 64 + lane];
     pf[10] = WL[sc.RDY + k * 36 + l35]; pf[11] = WL[sc.GH + k * NZ + lz];
     {   // rows pos (29..31), v (35..40), phi, dphi, ddphi (41..43) of Z have a non-trivial entry, the others add the zero word
         const int t = lz >= ZV ? lz - ZV + 3 : lz - ZPOS; const bool sp = lz >= ZV || (lz >= ZPOS && lz < ZIW);
         pf[13] = WL[sc.NCS + k * NCS_STRIDE + (sp ? NCS_ADDV + t : NCS_ZERO)];
     }
-    pf[12] = WL[sc.SG + k * NI + li]; pf[14] = WL[sc.G + k * NE + le];
+    pf[14] = WL[sc.G + k * NE + le];
+#if BMPC_NW == 1
+    pf[12] = WL[sc.SG + k * NI + li];
     // prefix vectors of the two curvature records (predicted point k, velocity point of node k+1): 2 x 72 doubles in three slots
     pf[15] = G[sc.KHPG + k * 72 + lane];
     pf[16] = G[lane < 8 ? sc.KHPG + k * 72 + 64 + lane : sc.KHPG + (N + kn) * 72 + lane - 8];
     pf[17] = G[sc.KHPG + (N + kn) * 72 + 56 + (lane < 16 ? lane : 15)];
+#endif
     pf[20] = WL[sc.AES + k * 42 + l42];
 }
 // record buffers of stage k: (K0, K1) and (KV1, KV) swap roles from stage to stage
@@ -1742,10 +1755,18 @@ BMPC_D inline void backward_commit_lane(Wave &W, int k, const double *pf, int la
     const int l2 = lane < KREC - 64 ? 64 + lane : KREC - 1;
     const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1;
     const int l35 = lane < NS ? lane : NS - 1, l42 = lane < 42 ? lane : 41;
+#if BMPC_NW == 1
     if (first) { L[oK0 + lane] = pf[0]; L[oKV1 + lane] = pf[2]; L[oK0 + l2] = pf[1]; L[oKV1 + l2] = pf[3]; }
-    L[oK1 + lane] = pf[4]; L[oKV + lane] = pf[6];
-    L[oK1 + l2] = pf[5]; L[oKV + l2] = pf[7];
+#else
+    if (first) { L[oK0 + lane] = pf[0]; L[oK0 + l2] = pf[1]; }
+#endif
+    L[oK1 + lane] = pf[4]; L[oK1 + l2] = pf[5];
+#if BMPC_NW == 1
+    L[oKV + lane] = pf[6]; L[oKV + l2] = pf[7];
+#endif
+#if BMPC_NW == 1
     L[L_NC + lane] = pf[8];
+#endif
     {   // second slot of the NCS row: the rest of the L_NC mirror, the curvature multipliers, dp_d (flat chain of selects on the address)
         const int idx = 64 + lane;
         int dst = L_DUMMY;
@@ -1756,8 +1777,11 @@ BMPC_D inline void backward_commit_lane(Wave &W, int k, const double *pf, int la
     }
     L[L_RD + l35] = pf[10];
     L[L_NC + NC_GL + lz] = pf[11] + pf[13];
-    L[L_ST + ST_SG + li] = pf[12]; L[L_ST + ST_G + le] = pf[14];
+    L[L_ST + ST_G + le] = pf[14];
+#if BMPC_NW == 1
+    L[L_ST + ST_SG + li] = pf[12];
     L[L_KHP + lane] = pf[15]; L[L_KHP + 64 + lane] = pf[16]; L[L_KHP + 128 + (lane < 16 ? lane : 15)] = pf[17];
+#endif
     L[L_AE + l42] = pf[20];
 }
 
