@@ -24,3 +24,11 @@ cd $R
 find gpurun_out/prof_$TAG -name '*kernel_stats.csv' -exec cat {} \;
 timeout -k 10 300 python tests/gpu_profile_phases.py > gpurun_out/phases_$TAG.log 2>&1 || true
 tail -40 gpurun_out/phases_$TAG.log
+# teams (round 4): the batch sizes that leave SIMDs idle -- one wave per problem against a team of four, phase stamps of both at B = 256,
+# the drop-in's single call
+timeout -k 10 300 python tests/gpu_profile_phases.py 256 10 one > gpurun_out/phases_${TAG}_B256_one_wave.log 2>&1 || true
+timeout -k 10 300 python tests/gpu_profile_phases.py 256 10 team > gpurun_out/phases_${TAG}_B256_team.log 2>&1 || true
+timeout -k 10 300 python tests/gpu_team.py 1 16 64 256 > gpurun_out/team_${TAG}.log 2>&1 || true
+tail -12 gpurun_out/team_${TAG}.log
+timeout -k 10 300 python tests/gpu_single_latency.py > gpurun_out/single_call_latency_${TAG}.txt 2>&1 || true
+tail -4 gpurun_out/single_call_latency_${TAG}.txt

@@ -584,8 +584,8 @@ def test_kkt_certificate_with_the_references_own_derivatives(solver):
         assert (out["lam_g"][0].reshape(10, 43)[:, 36:] >= 0).all()
 
 def test_horizon_limits_of_the_handle():
-    """bmpc_create accepts N = 1..40 (BoundMPC.py:35 makes the horizon a parameter); the stream entry points, whose kernels place one lane
-    per stage below fixed roles, refuse N > 32 instead of computing something else."""
+    """bmpc_create accepts N = 1..40 (BoundMPC.py:35 makes the horizon a parameter), and so do the stream entry points since round 4 (their
+    closed loops at N = 36: tests/test_gpu_stream.py); malformed calls are refused before anything is launched."""
     import torch
     from boundmpc_amd import BatchedOCPSolver, BoundMPCHipError
     with pytest.raises(BoundMPCHipError):
@@ -600,8 +600,12 @@ def test_horizon_limits_of_the_handle():
         assert int((o["status"] == 0).sum()) == 8
         import ctypes
         buf = torch.zeros(64, dtype=torch.float64, device="cuda"); vp = ctypes.c_void_p(buf.data_ptr())
-        rc = s._lib.bmpc_stream_pack(s._h, 1, vp, 5, vp, vp, vp, vp, None, None)      # refused before anything is launched
+        rc = s._lib.bmpc_stream_pack(s._h, 1, vp, 4, vp, vp, vp, vp, None, None)      # a path table shorter than the window (S + 1 entries): refused before anything is launched
         assert rc == 1, rc      # BMPC_ERR_ARG
+        rc = s._lib.bmpc_stream_pack(s._h, 1, None, 5, vp, vp, vp, vp, None, None)    # missing buffer: refused
+        assert rc == 1, rc
+        lens = [ctypes.c_int() for _ in range(4)]
+        assert s._lib.bmpc_stream_lengths(s._h, *[ctypes.byref(v) for v in lens]) == 0 and lens[1].value == 32 + 56 * 40 + 2
     finally:
         s.close()
 
