@@ -399,7 +399,10 @@ def check_against_slsqp_batch(solve, label):
         lower = ok & feas & (fs < fo - 1e-6)
         report[gname] = dict(n=len(P), converged=int(ok.sum()), same_minimiser=int(same.sum()), slsqp_lower=int(lower.sum()),
                              rms_median=float(np.median(rms[same])) if same.any() else None, rms_max=float(rms[same].max()) if same.any() else None)
-        assert rms[same].max() < 5e-6, (label, gname, rms[same].max())
+        # cold starts (SLSQP ran its 1000 iterations): 5e-6 rad; starts in the basin (SLSQP stops after ~25 iterations of a 880 / 1320-variable
+        # dense QP sequence when its line search cannot improve, exit 8: its own accuracy there is ~1e-5 rad): the north-star tolerance 1e-4
+        near = int(d[f"{gname}_def"][4]) == 1
+        assert rms[same].max() < (1e-4 if near else 5e-6), (label, gname, rms[same].max())
         assert same.sum() >= 0.9 * ok.sum(), (label, gname, report[gname])
         if int(d[f"{gname}_def"][4]) == 0:      # cold starts: the solver itself must have converged on every problem of the sample
             assert ok.all(), (label, gname)
