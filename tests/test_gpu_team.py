@@ -126,3 +126,24 @@ def test_team_tick_equals_one_wave_tick_in_closed_loop():
     assert (s4 == 0).all() and np.array_equal(s1, s4)
     np.testing.assert_allclose(r4, r1, atol=1e-7)
     np.testing.assert_allclose(t4, t1, atol=1e-6)
+
+
+def test_team_work_queue_with_more_problems_than_resident_teams():
+    """Teams forced on a batch larger than the resident teams (bmpc_set_team_waves(h, 4)): the teams pull problems from the work queue like the
+    one-wave kernel's waves do; same solutions as one wave per problem, bitwise deterministic (which team solves which problem does not matter)."""
+    import torch
+    from boundmpc_amd import workload
+    B = 700
+    P, X, _ = workload.make_batch(B, seed=12)
+    p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
+    one, team = _solvers()
+    try:
+        assert team.team_info(B)["waves"] == 4 and team.team_info(B)["resident_teams"] < B
+        a = one.solve_batch(p, x0, out={}, want=("iters", "status"))
+        b = team.solve_batch(p, x0, out={}, want=("iters", "status"))
+        c = team.solve_batch(p, x0, out={}, want=("iters", "status"))
+        torch.cuda.synchronize()
+        assert int(b["status"].max()) == 0 and torch.equal(a["iters"], b["iters"]) and float((a["x"] - b["x"]).abs().max()) < 1e-9
+        assert torch.equal(b["x"], c["x"])
+    finally:
+        one.close(); team.close()
