@@ -59,6 +59,9 @@
 #ifndef BMPC_LANE_ID
 #define BMPC_LANE_ID threadIdx.x
 #endif
+#ifndef LIDXW
+#define LIDXW LIDX      // index of a lane's register set inside a wide phase (the emulator of a team: the item lane)
+#endif
 
 #ifndef BMPC_PROF
 #define BMPC_PROF(W, id)
@@ -195,7 +198,8 @@ enum { WRED_STRIDE = NW };      // GPU: a wave reduces its 64 partials in regist
 // stage k-1's while S0 of stage k reads its own); L_HKHP: the helper's staging of the curvature prefix vectors (the one array it needs
 // that lives in the global slab)
 enum { PREP_N = 14 };
-enum { L_REDW = L_SIZE1, L_KKPW = L_REDW + 6 * WRED_STRIDE, L_TGHD = L_KKPW + 4 * WRED_STRIDE, L_TFLAG = L_TGHD + 64, L_PREP = L_TFLAG + 8,
+// L_DSA: the forward sweep's reduced states of all stages (36 per stage), from which a wide pass forms the dZ rows behind the sweep
+enum { L_REDW = L_SIZE1, L_KKPW = L_REDW + 6 * WRED_STRIDE, L_DSA = L_KKPW + 4 * WRED_STRIDE, L_TFLAG = L_DSA + 36 * TEAM_NMAX, L_PREP = L_TFLAG + 8,
        L_WY2 = L_PREP + 2 * PREP_N * 64, L_HKHP = L_WY2 + 196, L_WSL = L_HKHP + 144, L_SIZE = L_WSL + WSL_PER_STAGE * TEAM_NMAX + 16 };
 #ifndef BMPC_EMU
 static_assert(L_SIZE * 8 <= 160 * 1024, "a team's working set must fit the 160 KB of LDS of a CU");
@@ -2226,29 +2230,42 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 // kinematics record) are loaded into registers three stages ahead (two register sets, the stage loop is unrolled by two) and
 // committed to LDS one stage ahead, double-buffered by stage parity (staging area: L_ST / the idle gain area L_GS; record:
 // L_K0 / L_K1); the commit burst and the next loads ride at the end of a stage's last phase: three phases per stage.
+// (what only the dZ rows read: lifted residuals, the kinematics record, the QP-gradient entry of the component of dZ the lane writes; a team
+// forms the dZ rows of all stages in a wide pass behind the sweep -- wave_dz_wide -- from the LDS-resident rows and does not stage them)
+#if BMPC_NW == 1
+#define BMPC_FWD_LOADS_DZ(j) \
+    pf[8] = WL[sc.RLV + j * 12 + (lane < 12 ? lane : 11)]; \
+    pf[9] = WL[sc.KIN + j * KREC + lane]; pf[10] = WL[sc.KIN + j * KREC + (lane < KREC - 64 ? 64 + lane : KREC - 1)]; \
+    { const int t_ = lane < NZ ? lane : 0, r_ = t_ < NS ? t_ : 0; int z_ = (int)L[L_ZMAP + r_] & 255; z_ = t_ >= NS ? (t_ < NS + 3 ? ZPOS + t_ - NS : ZV + t_ - NS - 3) : z_; \
+      pf[11] = WL[sc.GH + j * NZ + z_]; }
+#define BMPC_FWD_COMMIT_DZ() \
+    sb_[ST_RLVF + (lane < 12 ? lane : 11)] = pf[8]; \
+    kb_[lane] = pf[9]; kb_[lane < KREC - 64 ? 64 + lane : KREC - 1] = pf[10]; sb_[ST_GHF + lane] = pf[11];
+#else
+#define BMPC_FWD_LOADS_DZ(j)
+#define BMPC_FWD_COMMIT_DZ()
+#endif
 #define BMPC_FWD_LOADS(j_, PO_) { double *pf = LR[LIDX].pf + (PO_); const int j = (j_) < N ? (j_) : N - 1; \
     _Pragma("unroll") for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; pf[u] = G[sc.KT + j * NS * NU + (id < NS * NU ? id : NS * NU - 1)]; } \
     pf[5] = G[sc.KF + j * NU + (lane < NU ? lane : NU - 1)]; \
     pf[6] = WL[sc.RDY + j * 36 + (lane < 36 ? lane : 35)]; \
     pf[7] = WL[sc.AES + j * 42 + (lane < 42 ? lane : 41)]; \
-    pf[8] = WL[sc.RLV + j * 12 + (lane < 12 ? lane : 11)]; \
-    pf[9] = WL[sc.KIN + j * KREC + lane]; pf[10] = WL[sc.KIN + j * KREC + (lane < KREC - 64 ? 64 + lane : KREC - 1)]; \
-    { const int t_ = lane < NZ ? lane : 0, r_ = t_ < NS ? t_ : 0; int z_ = (int)L[L_ZMAP + r_] & 255; z_ = t_ >= NS ? (t_ < NS + 3 ? ZPOS + t_ - NS : ZV + t_ - NS - 3) : z_; \
-      pf[11] = WL[sc.GH + j * NZ + z_]; } }   /* the QP-gradient entry of the component of dZ this lane will write (forward_stage) */
+    BMPC_FWD_LOADS_DZ(j) }
 #define BMPC_FWD_COMMIT(j_, PO_) { const double *pf = LR[LIDX].pf + (PO_); const int odd_ = (j_) & 1; double *sb_ = L + (odd_ ? L_GS : L_ST), *kb_ = L + (odd_ ? L_K1 : L_K0); \
     _Pragma("unroll") for (int u = 0; u < 5; u++) { const int id = lane + 64 * u; sb_[ST_KT + (id < NS * NU ? id : NS * NU - 1)] = pf[u]; } \
     sb_[ST_KF + (lane < NU ? lane : NU - 1)] = pf[5]; \
     sb_[ST_RDY + (lane < 36 ? lane : 35)] = pf[6]; \
     sb_[ST_AES + (lane < 42 ? lane : 41)] = pf[7]; \
-    sb_[ST_RLVF + (lane < 12 ? lane : 11)] = pf[8]; \
-    kb_[lane] = pf[9]; kb_[lane < KREC - 64 ? 64 + lane : KREC - 1] = pf[10]; sb_[ST_GHF + lane] = pf[11]; }
+    BMPC_FWD_COMMIT_DZ() }
 // dZ rows of stage k from the stage's next reduced state dn (LDS): lanes 0..34 scatter the reduced state through the row map (iota rows add
 // their lifting term), lanes 35..43 evaluate the lifted rows (pos 3, v 6); contiguous lane ranges = shallow selects, no branch nest.
 // sb / K0: the staging buffer and the kinematics record of stage k.
-BMPC_D inline void forward_dz_lane(Wave &W, LaneRegs *LR, int k, int lane, const double *dn, const double *sb, const double *K0) {
+// rlv: the stage's lifted residuals (12), gh: QP-gradient row of the stage indexed by the component of Z (one-wave: null -- the lane's entry was
+// staged at sb[ST_GHF + lane]); item lane t = 0..43; returns the lane's share of (QP gradient) . dZ.
+template <class PK>
+BMPC_D inline double forward_dz_item(Wave &W, int k, int t0, const double *dn, const double *rlv, const PK K0, const double *ghrow, const double *ghf) {
     double *L = W.L; const double h = W.h;
-    const bool on = lane < NZ; const int t = on ? lane : 0;
-    const double *rlv = sb + ST_RLVF;
+    const bool on = t0 < NZ; const int t = on ? t0 : 0;
     const bool isIw = t >= SIOTA && t < NS, isPos = t >= NS && t < NS + 3, isV = t >= NS + 3;
     const int c = isIw ? t - SIOTA : (isPos ? t - NS : (isV ? t - NS - 3 : 0));              // c6 for the v rows
     const int r = t < NS ? t : 0;
@@ -2267,7 +2284,11 @@ BMPC_D inline void forward_dz_lane(Wave &W, LaneRegs *LR, int k, int lane, const
     double fa = 0.0; fa = isV ? 1.0 : fa; fa = isIw ? 0.5 * h : fa; fa = isPos ? 1.0 : fa;
     const double v = addv + fa * (s1 + ((isIw || isV) ? 1.0 : 0.0) * s2);
     W.Dz[k * NZ + z] = v;
-    LR[LIDX].ghd += on ? sb[ST_GHF + lane] * v : 0.0;      // (QP gradient) . dZ for the line search, summed where dZ is made
+    const double ghe = ghrow ? ghrow[z] : ghf[t0];
+    return on ? ghe * v : 0.0;      // (QP gradient) . dZ for the line search, summed where dZ is made
+}
+BMPC_D inline void forward_dz_lane(Wave &W, LaneRegs *LR, int k, int lane, const double *dn, const double *sb, const double *K0) {
+    LR[LIDX].ghd += forward_dz_item(W, k, lane, dn, sb + ST_RLVF, K0, (const double *)nullptr, sb + ST_GHF);
 }
 // one stage of the forward sweep (two phases since round 4: the reduced state ping-pongs between L_DS and L_DSN by stage parity instead of
 // being copied back in a phase of its own, and the dZ rows of stage k-1 -- which need that stage's complete next state -- ride in the
@@ -2286,7 +2307,9 @@ BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
             for (int j = 0; j < 5; j++) { const int b0 = part + 8 * j, b = b0 < NS ? b0 : NS - 1; const double pr_ = sb[ST_KT + u * NS + b] * ds[b]; acc += b0 < NS ? pr_ : 0.0; }
             L[L_RED + part * 8 + u] = acc;
         }
+#if BMPC_NW == 1
         if (k >= 1) forward_dz_lane(W, LR, k - 1, lane, ds, sbp, K0p);      // wave-uniform condition; ds = the next state of stage k-1
+#endif
     LANES_END
     LANES_BEGIN   // next reduced state, predicated: chain rows and iota rows evaluated by every lane on clamped indices
         {
@@ -2305,6 +2328,9 @@ BMPC_D inline void forward_stage(Wave &W, const Scr &sc, LaneRegs *LR, int k) {
             const double mc_ = chain ? 1.0 : 0.0;            // 0/1 factors, not a select between loaded values (that would be a branch)
             const double v = sb[ST_RDY + r] + (mc_ * vc + (1.0 - mc_) * (ds[r] + BMPC_ACC4_SUM(ia)));
             dsn[r] = v;            // (off-lanes repeat row 0 with the same value)
+#if BMPC_NW > 1
+            L[L_DSA + k * 36 + r] = v;      // teams: kept for the wide dZ pass behind the sweep (wave_dz_wide)
+#endif
         }
         // inputs of stage k+1 into the other LDS buffer set (loaded two stages ago), then the loads of stage k+3 (clamped to the
         // last stage) into the registers this just freed
@@ -2329,15 +2355,31 @@ BMPC_D inline void wave_forward(Wave &W, const Scr &sc, LaneRegs *LR) {
     int k = 0;
     for (; k + 1 < N; k += 2) { forward_stage<12>(W, sc, LR, k); forward_stage<0>(W, sc, LR, k + 1); }
     if (k < N) forward_stage<12>(W, sc, LR, k);
+#if BMPC_NW == 1
     LANES_BEGIN      // dZ rows of the last stage
         forward_dz_lane(W, LR, N - 1, lane, L + ((N & 1) ? L_DSN : L_DS), L + (((N - 1) & 1) ? L_GS : L_ST), L + (((N - 1) & 1) ? L_K1 : L_K0));
     LANES_END
-#if BMPC_NW > 1
-    LANES_BEGIN      // teams: the lanes' shares of (QP gradient) . dZ leave the sweep's wave through LDS (row pass B runs on every wave)
-        L[L_TGHD + lane] = LR[LIDX].ghd;
-    LANES_END
 #endif
 }
+#if BMPC_NW > 1
+// Teams: the dZ rows of ALL stages in one wide pass behind the forward sweep (items (stage, component): 44 N over 64 NW lanes), from the
+// reduced states the sweep left in L_DSA and the LDS-resident workspace rows (kinematics records, lifted residuals, QP gradient).  In the
+// one-wave program these rows ride in the sweep (a phase of 44 lanes per stage); here the sweep's wave does the recursion only.  Every lane
+// keeps its share of (QP gradient) . dZ in a register for row pass B (same lane there).
+BMPC_D inline void wave_dz_wide(Wave &W, const Scr &sc, LaneRegs *LR) {
+    const int N = W.N;
+    double *L = W.L; const LPtr WL = BMPC_WL(W);
+    WIDE_BEGIN
+        double ghd = 0.0;
+        for (int t_ = 0; t_ < (N * NZ + WS - 1) / WS; t_++) {      // wave-uniform trip count, clamped item (duplicate store of the same value)
+            const int id0 = wl + WS * t_, id = id0 < N * NZ ? id0 : N * NZ - 1, k = id / NZ, t = id - k * NZ;
+            const double g_ = forward_dz_item(W, k, t, L + L_DSA + k * 36, WL + sc.RLV + k * 12, WL + sc.KIN + k * KREC, WL + sc.GH + k * NZ, (const double *)nullptr);
+            ghd += id0 < N * NZ ? g_ : 0.0;
+        }
+        LR[LIDXW].ghd = ghd;
+    WIDE_END
+}
+#endif
 
 // The Riccati sweep: one wave's in the one-wave program; in a team wave 0 runs the recursion, wave 1 the recursion-independent half of every
 // stage's node-cost add beside it, and all waves hear the verdict (positive definite or not) through an LDS word behind the stage's barrier.
@@ -2368,7 +2410,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     const Opts &o = W.o;
     const int np = po.size, nw = N * NZ, ni = N * NI, ne = N * NE;
 #ifdef BMPC_EMU
-    LaneRegs LRs[64];
+    LaneRegs LRs[WS];      // (emulator: one register set per lane of the team)
 #else
     LaneRegs LRs[1];
 #endif
@@ -2548,6 +2590,9 @@ _Pragma("unroll") \
         wave_forward(W, sc, LRs);
         SOLO_END
         TEAM_SYNC();
+#if BMPC_NW > 1
+        wave_dz_wide(W, sc, LRs);
+#endif
         BMPC_PROF(W, 7);
         // ---- row pass "B": slack / multiplier directions, fraction to the boundary, merit ingredients ----
         const double tau = BMPC_FMAX(0.99, 1.0 - mu);
@@ -2603,11 +2648,7 @@ _Pragma("unroll") \
             BMPC_PROF(W, 28);
             // (QP gradient) . dZ was summed by the forward sweep (one entry per lane and stage), the 1-norm of the equality residuals by
             // the KKT pass at the top of the iteration: no further trip to the workspace here
-            #if BMPC_NW > 1
-            const double ghd = W.wv == 0 ? L[L_TGHD + lane] : 0.0;
-#else
-            const double ghd = LRs[LIDX].ghd;
-#endif
+                        const double ghd = LRs[LIDXW].ghd;      // (teams: the lane's own share from wave_dz_wide; same item lane)
             th += wl == 0 ? theta_eq : 0.0;
             BMPC_PROF(W, 29);
             WRED_PUT_MIN(L_REDW, 0, ap); WRED_PUT_MIN(L_REDW, 1, adl); WRED_PUT_SUM(L_REDW, 2, dbar); WRED_PUT_SUM(L_REDW, 3, ghd - nhd);

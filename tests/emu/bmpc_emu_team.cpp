@@ -38,6 +38,7 @@
 #define LANES_BEGIN for (int li_ = 0; li_ < 64; ++li_) { const int lane = W.order[li_]; (void)lane;
 #define LANES_END }
 #define LIDX lane
+#define LIDXW wl
 #define TEAM_SYNC()
 #define TEAM_SYNC_LDS()
 #define WIDE_BEGIN for (int wi_ = 0; wi_ < BMPC_NW; ++wi_) { W.wv = W.worder[wi_]; LANES_BEGIN const int wl = W.wv * 64 + lane; (void)wl;
