@@ -200,7 +200,7 @@ enum { WRED_STRIDE = NW };      // GPU: a wave reduces its 64 partials in regist
 enum { PREP_N = 14 };
 // L_DSA: the forward sweep's reduced states of all stages (36 per stage), from which a wide pass forms the dZ rows behind the sweep
 enum { L_REDW = L_SIZE1, L_KKPW = L_REDW + 6 * WRED_STRIDE, L_DSA = L_KKPW + 4 * WRED_STRIDE, L_TFLAG = L_DSA + 36 * TEAM_NMAX, L_PREP = L_TFLAG + 8,
-       L_WY2 = L_PREP + 2 * PREP_N * 64, L_HKHP = L_WY2 + 196, L_WSL = L_HKHP + 144, L_SIZE = L_WSL + WSL_PER_STAGE * TEAM_NMAX + 16 };
+       L_WY2 = L_PREP + 2 * PREP_N * 64, L_HKHP = L_WY2 + 196, L_QRB = L_KV1 /* 2 x 40: q~ rows + t6 per stage parity */, L_HGL = L_KV /* 44: the helper's gl */, L_WSL = L_HKHP + 144, L_SIZE = L_WSL + WSL_PER_STAGE * TEAM_NMAX + 16 };
 #ifndef BMPC_EMU
 static_assert(L_SIZE * 8 <= 160 * 1024, "a team's working set must fit the 160 KB of LDS of a CU");
 #endif
@@ -1312,8 +1312,8 @@ BMPC_D inline void kh_prefix(const double *rec, double *hp) {   // sequential ov
 
 // q~ row r (reduced-state row, r < NS) of the node cost: gl mapped through the lifting Jacobians; rows >= 14 only copy.
 // Predicated straight-line code: every lane evaluates the (q, dq)-row formula on a clamped row.
-BMPC_D inline double node_q_row(const double *L, const double *K0, int r, double h, int ex, int oWY = L_WY) {
-    const double *gl = L + L_NC + NC_GL, *WY = L + oWY, *gy = L + L_ST + ST_G;   // g_y = (g_q, g_dq): rows 0..13 of g
+// (inputs as pointers: gl = the node's Z-space gradient (44), WY = curvature table (14 x 14), gy = (g_q, g_dq): rows 0..13 of g, K0 = record)
+BMPC_D inline double node_q_row_p(const double *L, const double *gl, const double *WY, const double *gy, const double *K0, int r, double h, int ex) {
     const bool heavy = r < 14; const int a = heavy ? r : 0; const bool isq = a < 7; const int ai = isq ? a : a - 7;
     const double base = gl[(int)L[L_ZMAP + r] & 255];
     double t1 = 0, t2 = 0, t3 = 0, sW = 0;
@@ -1329,6 +1329,17 @@ BMPC_D inline double node_q_row(const double *L, const double *K0, int r, double
         for (int b2 = 0; b2 < 14; b2++) sW += WY[a * 14 + b2] * gy[b2];
     }
     return base + (heavy ? (isq ? t1 : 0.0) + 0.5 * h * t2 + t3 - sW : 0.0);
+}
+BMPC_D inline double node_q_row(const double *L, const double *K0, int r, double h, int ex, int oWY = L_WY) {      // from the one-wave sweep's staging areas
+    return node_q_row_p(L, L + L_NC + NC_GL, L + oWY, L + L_ST + ST_G, K0, r, h, ex);
+}
+// t6 = C rdyn (6): the rdyn side of X^T rdyn = Gv(K1)^T (C rdyn); K0 = the stage's record, rd = its defect vector, dpn = dp_d of its node
+BMPC_D inline double stage_t6(Wave &W, const double *K0, const double *rd, const double *dpn, int c6) {
+    const int jo = c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7;
+    BMPC_ACC4_DECL(ta);
+#pragma unroll
+    for (int r = 0; r < 7; r++) { BMPC_ACC4(ta, r, K0[KD + c6 * 7 + r] * rd[r]); BMPC_ACC4(ta, r + 1, K0[jo + r] * rd[7 + r]); }
+    return -W.ca * BMPC_ACC4_SUM(ta) + W.cb * dpn[c6] * rd[SDDPHI];
 }
 
 // Node cost in block form, for ONE lane = one chain pair (i, l): the lane's 4x4 block of Q~ of node k+1 (index k) is added to the block
@@ -1738,8 +1749,8 @@ BMPC_D inline void backward_loads_lane(Wave &W, const Scr &sc, int k, double *pf
         const int t = lz >= ZV ? lz - ZV + 3 : lz - ZPOS; const bool sp = lz >= ZV || (lz >= ZPOS && lz < ZIW);
         pf[13] = WL[sc.NCS + k * NCS_STRIDE + (sp ? NCS_ADDV + t : NCS_ZERO)];
     }
-    pf[14] = WL[sc.G + k * NE + le];
 #if BMPC_NW == 1
+    pf[14] = WL[sc.G + k * NE + le];
     pf[12] = WL[sc.SG + k * NI + li];
     // prefix vectors of the two curvature records (predicted point k, velocity point of node k+1): 2 x 72 doubles in three slots
     pf[15] = G[sc.KHPG + k * 72 + lane];
@@ -1781,8 +1792,8 @@ BMPC_D inline void backward_commit_lane(Wave &W, int k, const double *pf, int la
     }
     L[L_RD + l35] = pf[10];
     L[L_NC + NC_GL + lz] = pf[11] + pf[13];
-    L[L_ST + ST_G + le] = pf[14];
 #if BMPC_NW == 1
+    L[L_ST + ST_G + le] = pf[14];
     L[L_ST + ST_SG + li] = pf[12];
     L[L_KHP + lane] = pf[15]; L[L_KHP + 64 + lane] = pf[16]; L[L_KHP + 128 + (lane < 16 ? lane : 15)] = pf[17];
 #endif
@@ -1816,6 +1827,26 @@ BMPC_D inline void team_blk_prep(Wave &W, const POff &po, const Scr &sc, int j, 
         double *o = L + L_PREP + (j & 1) * PREP_N * 64 + lane;
         o[0] = add[0]; o[64] = add[1]; o[128] = add[2]; o[192] = add[4]; o[256] = add[5]; o[320] = add[6]; o[384] = add[8]; o[448] = add[9];
         o[512] = add[10]; o[576] = add[15]; o[640] = c3inc[0]; o[704] = c3inc[1]; o[768] = c3inc[2]; o[832] = piinc;
+        // gl of the stage = QP-gradient row + the non-trivial entries of gl - g^ (what backward_commit_lane forms for the one-wave sweep), into the
+        // helper's own staging (L_HGL: the velocity-point record buffer the sweep's wave of a team no longer uses)
+        {
+            const int lz = lane < NZ ? lane : NZ - 1;
+            const int t = lz >= ZV ? lz - ZV + 3 : lz - ZPOS; const bool sp = lz >= ZV || (lz >= ZPOS && lz < ZIW);
+            L[L_HGL + lz] = WL[sc.GH + j * NZ + lz] + row[sp ? NCS_ADDV + t : NCS_ZERO];
+        }
+    LANES_END
+    LANES_BEGIN      // q~ rows (32 chain rows) and t6 of the stage: recursion-independent too (they need the curvature table this wave just wrote)
+        const double *row = WL + sc.NCS + j * NCS_STRIDE, *K0 = WL + sc.KIN + j * KREC;
+        {
+            const int r = lane < 32 ? lane : 0;
+            const double qr = node_q_row_p(L, L + L_HGL, L + ((j & 1) ? L_WY2 : L_WY), WL + sc.G + j * NE, K0, r, W.h, W.o.exact_hessian);
+            L[lane < 32 ? L_QRB + (j & 1) * 40 + r : L_DUMMY] = qr;
+        }
+        {
+            const bool on = lane >= 48 && lane < 54; const int c6 = on ? lane - 48 : 0;
+            const double v = stage_t6(W, K0, WL + sc.RDY + j * 36, row + NCS_RDP, c6);
+            L[on ? L_QRB + (j & 1) * 40 + 32 + c6 : L_DUMMY] = v;
+        }
     LANES_END
 }
 // the sweep's wave picks the helper's results of stage j up and finishes the block add
@@ -1871,9 +1902,9 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
             team_blk_prep(W, po, sc, k - 1, delta);      // beside the recursion's stage k; handed over at the barrier below
             SOLO_END
         }
-        const int oWYk = (k & 1) ? L_WY2 : L_WY, oFLAGk = L_FLAG + 2 + (k & 1);
+        const int oWYk = (k & 1) ? L_WY2 : L_WY, oFLAGk = L_FLAG + 2 + (k & 1), oQRk = L_QRB + (k & 1) * 40, oT6k = oQRk + 32;
 #else
-        constexpr int oWYk = L_WY, oFLAGk = L_FLAG;
+        constexpr int oWYk = L_WY, oFLAGk = L_FLAG, oT6k = L_T6;
 #endif
         SOLO_BEGIN(0)
         BMPC_PROF(W, 6);
@@ -1896,7 +1927,11 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 for (int l = 0; l < 8; l++) BMPC_ACC4(pa, l, L[L_PP + f * 64 + i * 8 + l]);        // partial products of the eight pairs of chain i (blk_add_lane)
 #pragma unroll
                 for (int a = 0; a < 3; a++) BMPC_ACC4(pa, a, L[L_PCI + pci(a, f, i)] * L[L_RD + SIOTA + a]);
+#if BMPC_NW > 1
+                const double qr = L[oQRk + r];          // q~ of node k+1, from the helper wave (team_blk_prep)
+#else
                 const double qr = node_q_row(L, L + W.oK0, r, h, W.o.exact_hessian, oWYk);          // q~ of node k+1 joins the value-function gradient here
+#endif
                 L[L_PR + r] = (L[L_PV + r] + qr) + BMPC_ACC4_SUM(pa);      // off-lanes repeat row 0 (same value): no conditional store
             }
             {   // iota rows of PR
@@ -1928,14 +1963,11 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 L[L_PE + ln] = sacc;
             }
             {   // t6 = C rdyn: the rdyn side of X^T rdyn = Gv(K1)^T (C rdyn)
+#if BMPC_NW == 1
                 const bool on = k >= 1 && lane >= 48 && lane < 54; const int c6 = on ? lane - 48 : 0;
-                const double *K0 = L + W.oK0, *dpn = L + L_ST + ST_REF + RDP;
-                const int jo = c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7;
-                BMPC_ACC4_DECL(ta);
-#pragma unroll
-                for (int r = 0; r < 7; r++) { BMPC_ACC4(ta, r, K0[KD + c6 * 7 + r] * L[L_RD + r]); BMPC_ACC4(ta, r + 1, K0[jo + r] * L[L_RD + 7 + r]); }
-                const double v = -W.ca * BMPC_ACC4_SUM(ta) + W.cb * dpn[c6] * L[L_RD + SDDPHI];
+                const double v = stage_t6(W, L + W.oK0, L + L_RD, L + L_ST + ST_REF + RDP, c6);
                 L[on ? L_T6 + c6 : L_DUMMY] = v;
+#endif      // (teams: the helper wave delivered t6 with the q~ rows, team_blk_prep)
             }
         LANES_END
         BMPC_PROF(W, 21);
@@ -1961,7 +1993,7 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 {
                     const double *K1 = L + W.oK1;
 #pragma unroll
-                    for (int c6 = 0; c6 < 6; c6++) sx += K1[(fp == 0 ? KD + c6 * 7 : (c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7)) + ic] * L[L_T6 + c6];
+                    for (int c6 = 0; c6 < 6; c6++) sx += K1[(fp == 0 ? KD + c6 * 7 : (c6 < 3 ? KW + c6 * 7 : KA + (c6 - 3) * 7)) + ic] * L[oT6k + c6];
                 }
                 v += (yq ? 1.0 : 0.0) * ve + ((yq && k >= 1) ? 1.0 : 0.0) * sx;
                 {   // unconditional stores, the row kind selects the address (lanes without a row write to the dummy word)
