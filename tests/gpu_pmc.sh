@@ -53,7 +53,7 @@ for k in ("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INS
           "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_VALU_MFMA_F64"):
     if k in rec: cur[k] = rec[k]
 cur["kernel_ms"] = cfg.get("kernel_ms")
-cur["source"] = "tests/gpu_pmc.sh $TAG: separate rocprofv3 --pmc passes of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --seed-sweep 0 --workers 1 $EXTRA`; kernel_ms from an unprofiled bench run of the same call"
+cur["source"] = "tests/gpu_pmc.sh $TAG: separate rocprofv3 --pmc passes of python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --seed-sweep 0 --workers 1 $EXTRA; kernel_ms from an unprofiled bench run of the same call"
 cur["note"] = ("FETCH_SIZE + WRITE_SIZE (KB x 1024) per launch, separate --pmc passes; raw counter values: the kernel's 8-B-per-lane accesses are an uncalibrated "
                "width in the guide (no x2 correction applied); this is per-wave workspace traffic between L2 and Infinity Cache/HBM, not input re-reads")
 json.dump(cur, open("$OUT/pmc_current.json", "w"), indent=1)

@@ -24,4 +24,21 @@ for (N, tight, B, seeds) in CASES:
               f"joint RMS {np.sqrt((d ** 2).mean()):.2e}, worst problem {per.max():.2e}, problems > 1e-6: {int((per > 1e-6).sum())}", flush=True)
         worst = max(worst, float(np.sqrt((d ** 2).mean())))
     s.close()
-print("worst batch RMS", worst)
+# teams (round 4): batches that fit the resident teams, N <= 10, loose and tight tubes, against the oracle problem by problem
+tworst = 0.0
+for (N, tight, B, seeds) in (((10, False, 256, tuple(range(20, 36))), (10, True, 256, (36, 37, 38, 39)), (7, True, 256, (40, 41)), (4, False, 200, (42,)), (10, False, 1, (43, 44, 45))) if BIG
+                             else ((10, False, 256, (20, 21)), (10, True, 128, (36,)), (6, True, 100, (40,)))):
+    s = BatchedOCPSolver(N, 4, 0.1); s.set_team_waves(4)
+    for seed in seeds:
+        P, X, _ = workload.make_batch(max(B, 2), seed=seed, N=N, tight=tight); P, X = P[:B], X[:B]
+        o = s.solve_batch(torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda"))
+        ref = c_oracle.solve(P, X, N, 4, 0.1, nthreads=16)
+        st, it, x = o["status"].cpu().numpy(), o["iters"].cpu().numpy(), o["x"].cpu().numpy()
+        ok = (st == 0) & (ref["status"] == 0)
+        d = (x[ok] - ref["x"][ok]).reshape(-1, N, 44)[:, :, 8:15]
+        per = np.sqrt((d ** 2).mean(axis=(1, 2)))
+        print(f"TEAM N={N} tight={tight} B={B} seed={seed}: status equal {int((st == ref['status']).sum())}/{B}, |iters diff| max {int(np.abs(it - ref['iters']).max())}, "
+              f"joint RMS {np.sqrt((d ** 2).mean()):.2e}, worst problem {per.max():.2e}, problems > 1e-6: {int((per > 1e-6).sum())}", flush=True)
+        tworst = max(tworst, float(np.sqrt((d ** 2).mean())))
+    s.close()
+print("worst batch RMS", worst, "teams", tworst)
