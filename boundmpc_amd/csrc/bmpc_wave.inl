@@ -164,7 +164,7 @@ static_assert(8 + 3 * 57 <= 15 * 14, "row table must fit into the retired XT are
 //   PCI [3][4][8]  P[(f,i)][iota_a] ;  PII [3][3] ;  GS [8][36] jerk rows of M (col 35 = m_j) ; R8 [8][8] ; KS [8][36] gains (col 35 = kff)
 //   MCI [3][5][8]  C^T P_c,iota, then M_c,iota in place ;  PE [3][14] = P_ii E ;  KHP [2][72] prefix vectors of the kinematic curvature
 enum { L_PB = L_PM, L_PCI = L_PB + 1024, L_PII = L_PCI + 96, L_GS = L_PII + 12, L_R8 = L_GS + 288, L_KS = L_R8 + 64, L_MCI = L_KS + 288,
-       L_PE = L_MCI + 120, L_BLK_END = L_PE + 42, L_KHP = L_WV /* 144 of the 196 */ };
+       L_PE = L_MCI + 120, L_BLK_END = L_PE + 42, L_KHP = L_WV /* 152 of the 196 */ };
 static_assert(10 * 57 <= (int)L_PV - (int)L_PB, "multiplier staging of the adjoint (ten nodes per pass) must fit into the block area");
 static_assert((int)L_BLK_END <= (int)L_PV, "block Riccati storage must fit into the retired PM/SR/RED region");
 // staging area inside L_ST: per-stage inputs of the sequential sweeps, loaded from the scratch slab in ONE burst per stage
@@ -177,6 +177,13 @@ enum { NC_HPP = 0, NC_HRR = 9, NC_HPF = 18, NC_HRF = 21, NC_SC = 24 /* hff,hdd,h
 // row of the NCS workspace array (one per stage): [0, 91) mirrors the LDS node-cost area L_NC (small blocks 28 | A1 21 | A2 42),
 // then the curvature multipliers (12 -> L_MU + 4), dp_d of the stage's node (6 -> ST_REF + RDP), the 12 non-trivial entries of
 // gl - g^ (rows pos 3, v 6, phi, dphi, ddphi of Z) and a zero word (what the other rows of gl add to g^)
+// Per-joint vectors of the kinematic curvature of a stage (round 4): with them an entry of sum lambda . d2F/dq_i dq_l is three dot products
+// (kh_qq) instead of five double cross products.  Row layout [vector 0..6][coordinate 0..2][joint 0..6] like the kinematics record:
+//   X = mu_p x a + (mu_v x W) x a - (mu_v x a) x W,  n = mu_v x a,  o = mu_w x a   (roles of the FIRST index i)
+//   Y = a x V + W x w,  g = a x Wgt                                                  (roles of the SECOND index l)
+//   g' = a' x Wgt', o' = mu_w' x a'                                                  (velocity point of the next node: only its angular rows)
+// (a, w: axes and J_v columns of the record; W = Wlt, V = Vge, Wgt: the prefix vectors kin_point leaves in KHPG)
+enum { KHV_X = 0, KHV_N = 21, KHV_O = 42, KHV_Y = 63, KHV_G = 84, KHV_G1 = 105, KHV_O1 = 126, KHV_LEN = 147, KHV_STRIDE = 152 };
 enum { NCS_MU = 91, NCS_RDP = 103, NCS_ADDV = 109, NCS_ZERO = 121, NCS_DUMMY = 122, NCS_STRIDE = 128 };
 
 // Teams also keep most of the WORKSPACE in LDS (L_WSL; a team has the LDS of a whole CU, 160 KB, to itself): the row arrays of the
@@ -200,7 +207,7 @@ enum { WRED_STRIDE = NW };      // GPU: a wave reduces its 64 partials in regist
 enum { PREP_N = 14 };
 // L_DSA: the forward sweep's reduced states of all stages (36 per stage), from which a wide pass forms the dZ rows behind the sweep
 enum { L_REDW = L_SIZE1, L_KKPW = L_REDW + 6 * WRED_STRIDE, L_DSA = L_KKPW + 4 * WRED_STRIDE, L_TFLAG = L_DSA + 36 * TEAM_NMAX, L_PREP = L_TFLAG + 8,
-       L_WY2 = L_PREP + 2 * PREP_N * 64, L_HKHP = L_WY2 + 196, L_QRB = L_KV1 /* 2 x 40: q~ rows + t6 per stage parity */, L_HGL = L_KV /* 44: the helper's gl */, L_WSL = L_HKHP + 144, L_SIZE = L_WSL + WSL_PER_STAGE * TEAM_NMAX + 16 };
+       L_WY2 = L_PREP + 2 * PREP_N * 64, L_HKHP = L_WY2 + 196, L_QRB = L_KV1 /* 2 x 40: q~ rows + t6 per stage parity */, L_HGL = L_KV /* 44: the helper's gl */, L_WSL = L_HKHP + KHV_STRIDE, L_SIZE = L_WSL + WSL_PER_STAGE * TEAM_NMAX + 16 };
 #ifndef BMPC_EMU
 static_assert(L_SIZE * 8 <= 160 * 1024, "a team's working set must fit the 160 KB of LDS of a CU");
 #endif
@@ -216,13 +223,13 @@ struct Opts {
 
 // global scratch layout (doubles) for horizon N
 struct Scr {
-    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, NU2, NCS, KHPG, size, lsize;
+    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, NU2, NCS, KHPG, KHV, size, lsize;
 };
 BMPC_HD inline Scr make_scr(int N) {
 #if BMPC_NW > 1
     // teams: two index spaces -- `l` counts the LDS-resident arrays (offsets from L_WSL, accessor WL), `c` what stays in the global slab (accessor G)
     Scr s; int c = 0, l = 0;
-    s.Z = c; c += N * NZ; s.ZT = c; c += N * NZ; s.DZ = c; c += N * NZ; s.KT = c; c += N * NS * NU; s.KF = c; c += N * NU; s.KHPG = c; c += 2 * N * 72;
+    s.Z = c; c += N * NZ; s.ZT = c; c += N * NZ; s.DZ = c; c += N * NZ; s.KT = c; c += N * NS * NU; s.KF = c; c += N * NU; s.KHPG = c; c += 2 * N * 72; s.KHV = c; c += N * KHV_STRIDE;
     s.DNU = c; c += N * NI;      // (multiplier directions: written by row pass B, read once by the update pass -- what did not fit)
     s.T = l; l += N * NI; s.TT = l; l += N * NI; s.NUm = l; l += N * NI; s.LAM = l; l += N * NE; s.G = l; l += N * NE; s.GT = l; l += N * NE;
     s.HIN = l; l += N * NI; s.HT = l; l += N * NI; s.DT = l; l += N * NI; s.GH = l; l += N * NZ; s.GVP = l; l += N * 8;
@@ -239,6 +246,7 @@ BMPC_HD inline Scr make_scr(int N) {
     s.RDY = c; c += N * 36; s.AES = c; c += N * 42; s.RLV = c; c += N * 12; s.SG = c; c += N * NI; s.TI = c; c += N * NI; s.SR = c; c += N * NI; s.NU2 = c; c += N * NI;   // NU2: second multiplier buffer (the update ping-pongs)
     s.NCS = c; c += N * NCS_STRIDE;   // node-cost data of every stage (wave_stage_data_wide): see the NCS_* row layout
     s.KHPG = c; c += 2 * N * 72;      // prefix vectors of the kinematic curvature, one row per kinematics record (kin_point)
+    s.KHV = c; c += N * KHV_STRIDE;   // per-joint vectors of the kinematic curvature, one row per stage (wave_stage_data_wide)
     s.size = (c + 15) & ~15; s.lsize = 0;
     return s;
 #endif
@@ -1261,43 +1269,36 @@ BMPC_D inline int pbi(int f, int g, int i, int l) { return (f * 4 + g) * 64 + i 
 BMPC_D inline int pci(int a, int f, int i) { return a * 32 + f * 8 + i; }
 BMPC_D inline int mci(int a, int f, int i) { return a * 40 + f * 8 + i; }                      // f = 0..4
 
-// curvature entries from a kinematics record + its prefix vectors hp = [Wlt 8x3 | Vge 7x3 | Wgt 7x3]
-BMPC_D inline double kh_qq(const double *rec, const double *hp, const double *mu_p, const double *mu_v, const double *mu_w, int i, int l) {
-    double ai[3], al[3], wl[3], t[3], t2[3], u[3], Wil[3];
-    ldA(rec, i, ai); ldA(rec, l, al); ldW(rec, l, wl);
-    const double *Wi = hp + 3 * i, *Wl = hp + 3 * l, *Vl = hp + 24 + 3 * l, *Gl = hp + 45 + 3 * l;
-    cross3(ai, wl, t); double val = dot3(mu_p, t);
-    cross3(Wi, t, u); val += dot3(mu_v, u);
-    cross3(al, Vl, t2); cross3(ai, t2, u); val += dot3(mu_v, u);
-    for (int c = 0; c < 3; c++) Wil[c] = Wl[c] - Wi[c];
-    cross3(Wil, wl, t2); cross3(ai, t2, u); val += dot3(mu_v, u);
-    cross3(al, Gl, t2); cross3(ai, t2, u); val += dot3(mu_w, u);
+// Curvature entries sum lambda . d2F / dy_a dy_b of the kinematic maps of a stage, from the stage's record and its table of per-joint vectors
+// (KHV_*, formed once per iterate by wave_stage_data_wide): with x . (y x z) = z . (x x y) every double cross product of the direct
+// differentiation turns into a dot product of one vector of joint i with one of joint l.  i <= l.
+BMPC_D inline double kh_qq(const double *rec, const double *khv, int i, int l) {
+    double val = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) val += rec[KW + c * 7 + l] * khv[KHV_X + c * 7 + i] + khv[KHV_Y + c * 7 + l] * khv[KHV_N + c * 7 + i] + khv[KHV_G + c * 7 + l] * khv[KHV_O + c * 7 + i];
     return val;
 }
-BMPC_D inline double kh_qdq(const double *rec, const double *mu_v, const double *mu_w, int i, int j) {   // d2/(dq_i d dq_j)
+BMPC_D inline double kh_qdq(const double *rec, const double *khv, int i, int j) {   // d2/(dq_i d dq_j)
     const int lo = i <= j ? i : j, hi = i <= j ? j : i;
-    double alo[3], whi[3], t[3]; ldA(rec, lo, alo); ldW(rec, hi, whi);
-    cross3(alo, whi, t); double val = dot3(mu_v, t);
-    // the i < j term is evaluated by every lane and masked by a 0/1 factor: a conditional with loads inside becomes an exec-mask
-    // branch, and `c ? x : 0.0` lets the compiler skip the work under a branch as well
-    { double aj[3]; ldA(rec, j, aj); cross3(alo, aj, t); val += (i < j ? 1.0 : 0.0) * dot3(mu_w, t); }
+    double v1 = 0, v2 = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { v1 += rec[KW + c * 7 + hi] * khv[KHV_N + c * 7 + lo]; v2 += rec[KA + c * 7 + j] * khv[KHV_O + c * 7 + lo]; }
+    return v1 + (i < j ? 1.0 : 0.0) * v2;      // 0/1 factor, not a branch around loads
+}
+// the same with only the angular-velocity multiplier of the velocity point of the NEXT node (its position and linear-velocity rows belong to
+// that node's own cost); at the last stage that multiplier is zero and so is o'
+BMPC_D inline double kh_qq_w(const double *khv, int i, int l) {
+    double val = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) val += khv[KHV_G1 + c * 7 + l] * khv[KHV_O1 + c * 7 + i];
     return val;
 }
-// the same entries with only an angular-velocity multiplier (mu_p = mu_v = 0): what the velocity point of the NEXT node
-// contributes (its position and linear-velocity rows belong to that node's own cost).  Written out because 0 * x cannot be
-// folded away under IEEE rules: the general forms would do all the work and multiply it by zero.
-BMPC_D inline double kh_qq_w(const double *rec, const double *hp, const double *mu_w, int i, int l) {
-    double ai[3], al[3], t2[3], u[3];
-    ldA(rec, i, ai); ldA(rec, l, al);
-    const double *Gl = hp + 45 + 3 * l;
-    cross3(al, Gl, t2); cross3(ai, t2, u);
-    return dot3(mu_w, u);
-}
-BMPC_D inline double kh_qdq_w(const double *rec, const double *mu_w, int i, int j) {
+BMPC_D inline double kh_qdq_w(const double *rec1, const double *khv, int i, int j) {
     const int lo = i <= j ? i : j;
-    double alo[3], aj[3], t[3]; ldA(rec, lo, alo); ldA(rec, j, aj);
-    cross3(alo, aj, t);
-    return (i < j ? 1.0 : 0.0) * dot3(mu_w, t);
+    double v2 = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) v2 += rec1[KA + c * 7 + j] * khv[KHV_O1 + c * 7 + lo];
+    return (i < j ? 1.0 : 0.0) * v2;
 }
 BMPC_D inline void kh_prefix(const double *rec, double *hp) {   // sequential over the 7 joints (one lane)
     double wl[3] = {0, 0, 0};
@@ -1355,7 +1356,7 @@ BMPC_D inline double stage_t6(Wave &W, const double *K0, const double *rd, const
 //    block (add[16], the planes its pair kind touches), to its iota couplings (c3inc) and to P_ii (piinc), and the predicted-point curvature
 //    wpv of its joint pair (for q~).  Inputs as pointers: the one-wave program passes its LDS staging areas, the helper wave of a team the
 //    LDS-resident workspace rows of the stage (same layouts).
-struct BlkIn { const double *K0, *KV1, *KHP, *NC, *mu4 /* curvature multipliers mu_p 3 | mu_v 3 | mu_w 3 | mu_w of the next node's velocity point 3 */,
+struct BlkIn { const double *K0, *KV1, *KHV /* per-joint curvature vectors of the stage (KHV_*) */, *NC, *mu4 /* curvature multipliers mu_p 3 | mu_v 3 | mu_w 3 | mu_w of the next node's velocity point 3 */,
                *dpd /* dp_d of the stage's node (6) */, *sgk /* sigma = nu / t rows of the node (57) */; };
 BMPC_D inline void blk_prep_lane(Wave &W, const POff &po, int k, double delta, int lane, const BlkIn &in, double (&add)[16], double (&c3inc)[3], double &piinc,
                                  double (&wpv)[2][2]) {
@@ -1363,7 +1364,7 @@ BMPC_D inline void blk_prep_lane(Wave &W, const POff &po, int k, double delta, i
     double *L = W.L;
     const double *PAR = L + L_PAR, *w = PAR + po.w;
     const double *sgk = in.sgk;
-    const double *NC = in.NC, *KHP = in.KHP;
+    const double *NC = in.NC, *KHV = in.KHV;
     const double *K0 = in.K0, *KV1 = in.KV1;
     const bool has_next = k < N - 1;
     const int i = lane >> 3, l = lane & 7, ci = i < l ? i : l, cl = i < l ? l : i; const bool tr = i > l;
@@ -1394,11 +1395,11 @@ BMPC_D inline void blk_prep_lane(Wave &W, const POff &po, int k, double delta, i
             v += cv * gv;
             double wp = 0, wn = 0;
             if (ex && !(f == 1 && g == 1)) {
-                if (f == 0 && g == 0) { wp = kh_qq(K0, KHP, in.mu4, in.mu4 + 3, in.mu4 + 6, cic, clc);
-                                        if (has_next) wn = kh_qq_w(KV1, KHP + 72, in.mu4 + 9, cic, clc); }
+                if (f == 0 && g == 0) { wp = kh_qq(K0, KHV, cic, clc);
+                                        if (has_next) wn = kh_qq_w(KHV, cic, clc); }
                 else { const int qi = f == 0 ? cic : clc, dj = f == 0 ? clc : cic;
-                       wp = kh_qdq(K0, in.mu4 + 3, in.mu4 + 6, qi, dj);
-                       if (has_next) wn = kh_qdq_w(KV1, in.mu4 + 9, qi, dj); }
+                       wp = kh_qdq(K0, KHV, qi, dj);
+                       if (has_next) wn = kh_qdq_w(KV1, KHV, qi, dj); }
             }
             wpv[f][g] = wp;
             e[f][g] = v + wp + wn;
@@ -1490,7 +1491,7 @@ BMPC_D inline void blk_apply_lane(Wave &W, int lane, const double (&C)[4][4], co
 BMPC_D inline void blk_add_lane(Wave &W, const POff &po, int k, double delta, int lane, int oK0, int oKV1, const double (&C)[4][4], const double (&ci3)[3],
                                 double pii, double pvv, double *Pb) {
     double *L = W.L;
-    BlkIn in; in.K0 = L + oK0; in.KV1 = L + oKV1; in.KHP = L + L_KHP; in.NC = L + L_NC; in.mu4 = L + L_MU + 4; in.dpd = L + L_ST + ST_REF + RDP; in.sgk = L + L_ST + ST_SG;
+    BlkIn in; in.K0 = L + oK0; in.KV1 = L + oKV1; in.KHV = L + L_KHP; in.NC = L + L_NC; in.mu4 = L + L_MU + 4; in.dpd = L + L_ST + ST_REF + RDP; in.sgk = L + L_ST + ST_SG;
     double add[16], c3inc[3], piinc, wpv[2][2];
     blk_prep_lane(W, po, k, delta, lane, in, add, c3inc, piinc, wpv);
     blk_store_wy(W, lane, L_WY, wpv);
@@ -1672,6 +1673,39 @@ BMPC_D inline void wave_stage_data_wide(Wave &W, const POff &po, const Scr &sc) 
             }
         }
         for (int pass = 0; pass < npass; pass++) {
+            // ================= batch 5: per-joint vectors of the kinematic curvature (items (stage, joint); KHV_* row layout) =================
+            // needs the curvature multipliers of batch M (first phase) and the prefix vectors kin_point left in KHPG
+            constexpr int RJ_ = cdiv_(2, NW);
+            double ja[RJ_][3], jw[RJ_][3], jW[RJ_][3], jV[RJ_][3], jG[RJ_][3], ja1[RJ_][3], jG1[RJ_][3], jmu[RJ_][12];
+#pragma unroll
+            for (int u = 0; u < RJ_; u++) {
+                const int id0 = pass * WS * RJ_ + wl + WS * u, id = id0 < N * 7 ? id0 : N * 7 - 1, k = id / 7, j = id - 7 * k, kn = k < N - 1 ? k + 1 : k;
+                const LPtr rec = WL + sc.KIN + k * KREC, rec1 = WL + sc.KIN + (N + kn) * KREC, row = WL + sc.NCS + k * NCS_STRIDE;
+                const GPtr hp = G + sc.KHPG + k * 72, hp1 = G + sc.KHPG + (N + kn) * 72;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    ja[u][c] = rec[KA + c * 7 + j]; jw[u][c] = rec[KW + c * 7 + j]; jW[u][c] = hp[3 * j + c]; jV[u][c] = hp[24 + 3 * j + c]; jG[u][c] = hp[45 + 3 * j + c];
+                    ja1[u][c] = rec1[KA + c * 7 + j]; jG1[u][c] = hp1[45 + 3 * j + c];
+                }
+#pragma unroll
+                for (int m = 0; m < 12; m++) jmu[u][m] = row[NCS_MU + m];
+            }
+#pragma unroll
+            for (int u = 0; u < RJ_; u++) {
+                const int id0 = pass * WS * RJ_ + wl + WS * u, id = id0 < N * 7 ? id0 : N * 7 - 1, k = id / 7, j = id - 7 * k;
+                const double *mu_p = jmu[u], *mu_v = jmu[u] + 3, *mu_w = jmu[u] + 6, *mu_w1 = jmu[u] + 9;
+                double m_[3], n_[3], o_[3], c_[3], p_[3], z_[3], s_[3], u_[3], g_[3], g1_[3], o1_[3];
+                cross3(mu_p, ja[u], m_); cross3(mu_v, ja[u], n_); cross3(mu_w, ja[u], o_); cross3(mu_v, jW[u], c_); cross3(c_, ja[u], p_); cross3(n_, jW[u], z_);
+                cross3(ja[u], jV[u], s_); cross3(jW[u], jw[u], u_); cross3(ja[u], jG[u], g_); cross3(ja1[u], jG1[u], g1_); cross3(mu_w1, ja1[u], o1_);
+                const GPtr kv = G + sc.KHV + k * KHV_STRIDE;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    kv[KHV_X + c * 7 + j] = (m_[c] + p_[c]) - z_[c]; kv[KHV_N + c * 7 + j] = n_[c]; kv[KHV_O + c * 7 + j] = o_[c];
+                    kv[KHV_Y + c * 7 + j] = s_[c] + u_[c]; kv[KHV_G + c * 7 + j] = g_[c]; kv[KHV_G1 + c * 7 + j] = g1_[c]; kv[KHV_O1 + c * 7 + j] = o1_[c];
+                }
+            }
+        }
+        for (int pass = 0; pass < npass; pass++) {
             // ================= batch 4: the 12 rows of gl = g^ + H r + cross terms that differ from g^ (pos 3, v 6, phi, dphi, ddphi) =================
             constexpr int RV = cdiv_(2, NW);
             double nc3[RV][3], rl3[RV][3], rv0[RV], rvm[RV], rvp[RV], cvv[RV], dd[RV][6], r6[RV][6], m6[RV][6];
@@ -1752,10 +1786,8 @@ BMPC_D inline void backward_loads_lane(Wave &W, const Scr &sc, int k, double *pf
 #if BMPC_NW == 1
     pf[14] = WL[sc.G + k * NE + le];
     pf[12] = WL[sc.SG + k * NI + li];
-    // prefix vectors of the two curvature records (predicted point k, velocity point of node k+1): 2 x 72 doubles in three slots
-    pf[15] = G[sc.KHPG + k * 72 + lane];
-    pf[16] = G[lane < 8 ? sc.KHPG + k * 72 + 64 + lane : sc.KHPG + (N + kn) * 72 + lane - 8];
-    pf[17] = G[sc.KHPG + (N + kn) * 72 + 56 + (lane < 16 ? lane : 15)];
+    // per-joint curvature vectors of the stage (147 doubles in three slots)
+    pf[15] = G[sc.KHV + k * KHV_STRIDE + lane]; pf[16] = G[sc.KHV + k * KHV_STRIDE + 64 + lane]; pf[17] = G[sc.KHV + k * KHV_STRIDE + 128 + (lane < 24 ? lane : 23)];
 #endif
     pf[20] = WL[sc.AES + k * 42 + l42];
 }
@@ -1795,7 +1827,7 @@ BMPC_D inline void backward_commit_lane(Wave &W, int k, const double *pf, int la
 #if BMPC_NW == 1
     L[L_ST + ST_G + le] = pf[14];
     L[L_ST + ST_SG + li] = pf[12];
-    L[L_KHP + lane] = pf[15]; L[L_KHP + 64 + lane] = pf[16]; L[L_KHP + 128 + (lane < 16 ? lane : 15)] = pf[17];
+    L[L_KHP + lane] = pf[15]; L[L_KHP + 64 + lane] = pf[16]; L[L_KHP + 128 + (lane < 24 ? lane : 23)] = pf[17];
 #endif
     L[L_AE + l42] = pf[20];
 }
@@ -1811,15 +1843,13 @@ BMPC_D inline void team_blk_prep(Wave &W, const POff &po, const Scr &sc, int j, 
     const int N = W.N;
     double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
     const int jn = j < N - 1 ? j + 1 : j;
-    LANES_BEGIN      // prefix vectors of the two curvature records (predicted point j, velocity point of node j+1) from the global slab
-        const double a_ = G[sc.KHPG + j * 72 + lane];
-        const double b_ = G[lane < 8 ? sc.KHPG + j * 72 + 64 + lane : sc.KHPG + (N + jn) * 72 + lane - 8];
-        const double c_ = G[sc.KHPG + (N + jn) * 72 + 56 + (lane < 16 ? lane : 15)];
-        L[L_HKHP + lane] = a_; L[L_HKHP + 64 + lane] = b_; L[L_HKHP + 128 + (lane < 16 ? lane : 15)] = c_;
+    LANES_BEGIN      // per-joint curvature vectors of the stage from the global slab
+        const double a_ = G[sc.KHV + j * KHV_STRIDE + lane], b_ = G[sc.KHV + j * KHV_STRIDE + 64 + lane], c_ = G[sc.KHV + j * KHV_STRIDE + 128 + (lane < 24 ? lane : 23)];
+        L[L_HKHP + lane] = a_; L[L_HKHP + 64 + lane] = b_; L[L_HKHP + 128 + (lane < 24 ? lane : 23)] = c_;
     LANES_END
     LANES_BEGIN
         const double *row = WL + sc.NCS + j * NCS_STRIDE;
-        BlkIn in; in.K0 = WL + sc.KIN + j * KREC; in.KV1 = WL + sc.KIN + (N + jn) * KREC; in.KHP = L + L_HKHP; in.NC = row; in.mu4 = row + NCS_MU;
+        BlkIn in; in.K0 = WL + sc.KIN + j * KREC; in.KV1 = WL + sc.KIN + (N + jn) * KREC; in.KHV = L + L_HKHP; in.NC = row; in.mu4 = row + NCS_MU;
         in.dpd = row + NCS_RDP; in.sgk = WL + sc.SG + j * NI;
         double add[16], c3inc[3], piinc, wpv[2][2];
         blk_prep_lane(W, po, j, delta, lane, in, add, c3inc, piinc, wpv);
