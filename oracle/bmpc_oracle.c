@@ -64,7 +64,7 @@ enum { IJU = 0, IJL = 8, IQU = 16, IQL = 23, IDQU = 30, IDQL = 37, IPHI0 = 44, I
 static const double Q_LIM_DEG[7] = {165, 115, 165, 115, 165, 115, 170};
 static const double DQ_LIM_DEG[7] = {85, 85, 100, 75, 130, 135, 135};
 #define U_LIM 35.0
-#define GN_MU_GATE 0.05
+#define GN_MU_GATE 0.0 /* Gauss-Newton fallback at every barrier level (round 4; was 0.05 = first level only): tight N = 30 batch, 2048 problems: mean 35.3 -> 32.7 iterations, failed sweeps 6.2 -> 4.1 per problem, p99 108 -> 78, 99.71 -> 99.80 % converged */
 #define GN_MIN_HORIZON 11 /* long horizons only (the kernel's N <= 11 instantiation does not carry the path) */
 #define DELTA_FIRST 1e-3   /* first regularisation tried by a solve, escalated by DELTA_UP_FIRST until the factorisation succeeds */
 #define DELTA_UP_FIRST 10.0
@@ -973,7 +973,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
          *  - far from the solution (first barrier level, long horizons) an indefinite exact Hessian is mostly the kinematic
          *    curvature weighted with meaningless multipliers: the Gauss-Newton Hessian (positive semidefinite by construction) is
          *    tried once before regularising, and while that fallback keeps being needed the following iterations start from it
-         *    directly (every GN_PROBE-th tries the exact Hessian again).  Never below GN_MU_GATE, only for N > GN_MIN_HORIZON. */
+         *    directly (every GN_PROBE-th tries the exact Hessian again).  Only for N > GN_MIN_HORIZON (and mu >= GN_MU_GATE, which is 0 since round 4). */
         double delta = 0.0; int ok = 0, used_gn = 0;
         if (delta_prev > 0.0) { delta = delta_prev / 3.0; if (delta < DELTA_KEEP_MIN) delta = 0.0; }
         const int gn_allowed = N > GN_MIN_HORIZON && C->o.exact_hessian && mu >= GN_MU_GATE;

@@ -11,7 +11,7 @@ import argparse, collections, os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KERNELS = {"true": "_Z17bmpc_solve_kernelILb1EEv5KArgs:", "false": "_Z17bmpc_solve_kernelILb0EEv5KArgs:", "tick": "_Z23bmpc_stream_tick_kernel5KArgs5SArgs:"}
+KERNELS = {"true": "_Z17bmpc_solve_kernelILb1EE", "false": "_Z17bmpc_solve_kernelILb0EE", "tick": "_Z23bmpc_stream_tick_kernelILb1EE"}      # prefixes of the mangled names
 
 
 def listing(path):
