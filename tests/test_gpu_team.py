@@ -80,7 +80,10 @@ def test_team_kernel_warm_entry_iteration_cap_and_other_horizons():
             # decision on a rounding error may send a warm solve through another trial point: solutions agree to the solve tolerance)
             assert torch.equal(b["x"], c["x"]) and torch.equal(sb, sc) and torch.equal(b["iters"], c["iters"])
             assert torch.equal(a["status"], b["status"]) and int((a["iters"] - b["iters"]).abs().max()) <= 1
-            assert float((a["x"] - b["x"]).abs().max()) < 1e-6
+            # two solutions to the same KKT tolerance (1e-8, scaled) may differ by tol / curvature in a direction: the joint positions carry
+            # weight w_q = 0.01 and bound rows (2 tol / (2 w_q) = 1e-6 rad), the jerks only w_j = 1e-4 (2 tol / (2 w_j) = 1e-4)
+            dx = (a["x"] - b["x"]).reshape(64, 10, 44)
+            assert float(dx[:, :, 8:15].abs().max()) < 1e-6 and float(dx.abs().max()) < 1e-4
             if cap:
                 assert int(b["status"].max()) == 1 and int(b["iters"].max()) == cap
     finally:
