@@ -168,9 +168,14 @@ def main():
                     "median_stream_rms_dev_rad": float(np.median(per_stream)), "streams_within_1e-2_rad_rms": float((per_stream <= 1e-2).mean()),
                     "max_joint_dev_rad": float(np.abs(dev).max()), "mean_phi_after_last_tick": float(phi.mean())})
         sb.close()
+    # the 1 kHz target, as the round-3 verdict states it: a safeguarded mode whose tick is p50 <= 1.0 ms / p99 <= 1.3 ms, >= 75 % of the streams hold a
+    # plan after the last tick, no plant sample outside the joint limits -- computed from this run's modes, not asserted
+    met = [r["mode"] for r in res if r["tick_ms_p50"] <= 1.0 and r["tick_ms_p99"] <= 1.3 and r["streams_with_a_plan_at_the_end"] >= 0.75
+           and r["joint_limit_violations_of_the_plant_state"] == 0]
+    verdict = ("met by " + ", ".join(met)) if met else "not met by any mode of this run"
     print(json.dumps({"metric": "closed-loop tick latency, 256 streams, whole tick in one hipGraph (BASELINE configs[4])", "batch": B, "ticks": T - 1,
                       "tol": args.tol, "mu_warm": args.mu_warm, "budget_ms": 1.0,
-                      "verdict_on_the_1_kHz_target": "see DESIGN.md 5b: met only by modes whose closed loops do not track the converged loops over the whole path; not met",
+                      "verdict_on_the_1_kHz_target": verdict + " (criteria: tick p50 <= 1.0 ms, p99 <= 1.3 ms, >= 75 % of the streams with a plan after the last tick, no plant sample outside the joint limits)",
                       "workload": "256 closed loops, random q0 (seed 3), own experiment1-pattern path, N=10, h=0.1 s; pack+solve+post+plant on device",
                       "results": res}))
 
