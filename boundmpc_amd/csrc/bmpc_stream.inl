@@ -242,6 +242,64 @@ BMPC_HD inline void forward_kinematics(const double *q, const double *dq, Fk &F)
     }
 }
 
+// Pose, Cartesian velocity / acceleration and the linear jerk rows of a planned motion in ONE pass over the chain (round 4): what the
+// post-processing needs of forward_kinematics + jacobian_lin_ddot,
+//   v = J dq,  a = J ddq + dJ dq  (6 rows),  jk = J u + dJ ddq + ddJ dq  (3 linear rows),
+// accumulated joint by joint from the same chain quantities (notation of jacobian_lin_ddot): v_lin, a_lin are the totals of its two suffix
+// sums, v_ang, a_ang the totals of its two prefix sums.  No Jacobian array is formed: the two functions together kept ~280 doubles live
+// (J, dJ, ddJ and nine 7x3 work arrays: 600-750 B of scratch per lane in the post / fused-tick kernels), this one 84 (axes, lever arms and
+// the two prefix sums per joint).  dJ_v of forward_kinematics and dw_j here are the same vector by the Jacobi identity.
+struct FkMotion { double p[6], v[6], a[6], jk[3]; };
+BMPC_HD inline void fk_motion(const double *q, const double *dq, const double *ddq, const double *u, FkMotion &M) {
+    const int ax[7] = {2, 1, 2, -1, 2, 1, 2};
+    const double pre[7] = {0.0, 0.1575 + 0.2025, 0.0, 0.2375 + 0.1825, 0.0, 0.2175 + 0.1825, 0.0};
+    const double tool = 0.081 + (0.071 + 0.145);
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, o[3] = {0, 0, 0}, A[7][3], r[7][3];
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        for (int c = 0; c < 3; c++) { o[c] += R[c * 3 + 2] * pre[j]; r[j][c] = o[c]; }
+        double cs, sn; BMPC_NAMESPACE::bmpc_sincos(q[j], &sn, &cs);      // joint angles are bounded: the wave program's two-constant reduction (bmpc_wave.inl) instead of the library's full-range one
+        if (ax[j] == 2) {
+            for (int c = 0; c < 3; c++) { A[j][c] = R[c * 3 + 2]; const double c0 = R[c * 3], c1 = R[c * 3 + 1]; R[c * 3] = cs * c0 + sn * c1; R[c * 3 + 1] = -sn * c0 + cs * c1; }
+        } else {
+            const double sg = (double)ax[j]; sn *= sg;
+            for (int c = 0; c < 3; c++) { A[j][c] = sg * R[c * 3 + 1]; const double c0 = R[c * 3], c2 = R[c * 3 + 2]; R[c * 3] = cs * c0 - sn * c2; R[c * 3 + 2] = sn * c0 + cs * c2; }
+        }
+    }
+    for (int c = 0; c < 3; c++) M.p[c] = o[c] + R[c * 3 + 2] * tool;
+    mat_to_rotvec(R, M.p + 3);
+    // forward: omega_j = sum_{i<j} dq_i a_i,  omega_j' = sum_{i<j} (ddq_i a_i + dq_i a_i'),  a_i' = omega_i x a_i
+    double om[7][3], dom[7][3];
+    {
+        double acc[3] = {0, 0, 0}, dacc[3] = {0, 0, 0}, da[3];
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            for (int c = 0; c < 3; c++) { om[j][c] = acc[c]; dom[j][c] = dacc[c]; r[j][c] = M.p[c] - r[j][c]; }
+            cross3s(acc, A[j], da);
+            for (int c = 0; c < 3; c++) { acc[c] += dq[j] * A[j][c]; dacc[c] += ddq[j] * A[j][c] + dq[j] * da[c]; }
+        }
+        for (int c = 0; c < 3; c++) { M.v[3 + c] = acc[c]; M.a[3 + c] = dacc[c]; }
+    }
+    // backward: suffix sums of dq_i w_i and of ddq_i w_i + dq_i w_i'; w_j', w_j'' as in jacobian_lin_ddot
+    double suf[3] = {0, 0, 0}, suf2[3] = {0, 0, 0}, jk[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 6; j >= 0; j--) {
+        double w[3], da[3], dr[3], dw[3], dda[3], ddr[3], t[3], u1[3], u2[3], u3[3];
+        cross3s(A[j], r[j], w);
+        for (int c = 0; c < 3; c++) suf[c] += dq[j] * w[c];
+        cross3s(om[j], A[j], da);
+        cross3s(om[j], r[j], t); for (int c = 0; c < 3; c++) dr[c] = t[c] + suf[c];
+        cross3s(da, r[j], u1); cross3s(A[j], dr, u2);
+        for (int c = 0; c < 3; c++) dw[c] = u1[c] + u2[c];
+        for (int c = 0; c < 3; c++) suf2[c] += ddq[j] * w[c] + dq[j] * dw[c];
+        cross3s(dom[j], A[j], u1); cross3s(om[j], da, u2); for (int c = 0; c < 3; c++) dda[c] = u1[c] + u2[c];
+        cross3s(dom[j], r[j], u1); cross3s(om[j], dr, u2); for (int c = 0; c < 3; c++) ddr[c] = u1[c] + u2[c] + suf2[c];
+        cross3s(dda, r[j], u1); cross3s(da, dr, u2); cross3s(A[j], ddr, u3);
+        for (int c = 0; c < 3; c++) jk[c] += u[j] * w[c] + ddq[j] * dw[c] + dq[j] * (u1[c] + 2.0 * u2[c] + u3[c]);
+    }
+    for (int c = 0; c < 3; c++) { M.v[c] = suf[c]; M.a[c] = suf2[c]; M.jk[c] = jk[c]; }
+}
+
 // quartic a4..a0 on [0, L] with f(0)=e0, f(L)=e1, f(L/2)=emax, f'(0)=s, f'(L)=-s  (mpc_utils_casadi.py:130-137 at phi0 = 0)
 BMPC_HD inline void bound_params(double L, double e0, double e1, double s, double emax, double *a4, double *a3, double *a2, double *a1, double *a0) {
     const double r1 = e1 - e0 - s * L, r2 = emax - e0 - s * L / 2, r3 = -2 * s * L;
@@ -524,22 +582,14 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
                 else { q[j] = Tq[j * N + i]; dq[j] = Tdq[j * N + i]; ddq[j] = Tddq[j * N + i]; }
                 u[j] = w[col * 44 + j];
             }
-            Fk F; forward_kinematics(q, dq, F);
-            if (!lead) for (int c = 0; c < 6; c++) {
-                double v = 0, a = 0;
-                for (int j = 0; j < 7; j++) { v += F.J[c * 7 + j] * dq[j]; a += F.J[c * 7 + j] * ddq[j] + F.dJ[c * 7 + j] * dq[j]; }
-                Tp[c * N + i] = F.p[c]; Tv[c * N + i] = v; Ta[c * N + i] = a;
-            }
+            FkMotion M; fk_motion(q, dq, ddq, u, M);
+            if (!lead) for (int c = 0; c < 6; c++) { Tp[c * N + i] = M.p[c]; Tv[c * N + i] = M.v[c]; Ta[c * N + i] = M.a[c]; }
             // previous-plan arrays of BoundMPC.py:557-566 (linear rows): position of the re-integrated plan (the plan's own entry for
             // a leading column), the SOLVER's velocity variables, J ddq + dJ dq, J u + dJ ddq + ddJ dq
-            double ddJ[21];
-            jacobian_lin_ddot(q, dq, ddq, ddJ);
             for (int c = 0; c < 3; c++) {
-                double a = 0, jk = 0;
-                for (int j = 0; j < 7; j++) { a += F.J[c * 7 + j] * ddq[j] + F.dJ[c * 7 + j] * dq[j]; jk += F.J[c * 7 + j] * u[j] + F.dJ[c * 7 + j] * ddq[j] + ddJ[c * 7 + j] * dq[j]; }
-                pc[c * N + col] = lead ? w[col * 44 + 29 + c] : F.p[c];
+                pc[c * N + col] = lead ? w[col * 44 + 29 + c] : M.p[c];
                 pc[(3 + c) * N + col] = w[col * 44 + 35 + c];
-                pc[(6 + c) * N + col] = a; pc[(9 + c) * N + col] = jk;
+                pc[(6 + c) * N + col] = M.a[c]; pc[(9 + c) * N + col] = M.jk[c];
             }
         } else if (role == RF) {
             int sector = (int)ss[SS_SECTOR];
@@ -560,9 +610,11 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
             // integrate with [jerk_current, first planned jerk], then FK
             double qs[7], dqs[7], ddqs[7];
             for (int j = 0; j < 7; j++) { qs[j] = rb[RB_Q + j]; dqs[j] = rb[RB_DQ + j]; ddqs[j] = rb[RB_DDQ + j]; chain_step(qs[j], dqs[j], ddqs[j], rb[RB_JERK + j], Tj[j * N], h); }
-            Fk F; forward_kinematics(qs, dqs, F);
-            for (int j = 0; j < 7; j++) { rb[RB_Q + j] = qs[j]; rb[RB_DQ + j] = dqs[j]; rb[RB_DDQ + j] = ddqs[j]; rb[RB_JERK + j] = Tj[j * N]; }
-            for (int c = 0; c < 6; c++) { double v = 0; for (int j = 0; j < 7; j++) v += F.J[c * 7 + j] * dqs[j]; rb[RB_P + c] = F.p[c]; rb[RB_V + c] = v; }
+            double u0[7];
+            for (int j = 0; j < 7; j++) u0[j] = Tj[j * N];
+            FkMotion M; fk_motion(qs, dqs, ddqs, u0, M);      // (pose and v = J dq are what is kept)
+            for (int j = 0; j < 7; j++) { rb[RB_Q + j] = qs[j]; rb[RB_DQ + j] = dqs[j]; rb[RB_DDQ + j] = ddqs[j]; rb[RB_JERK + j] = u0[j]; }
+            for (int c = 0; c < 6; c++) { rb[RB_P + c] = M.p[c]; rb[RB_V + c] = M.v[c]; }
         }
     }
 }
