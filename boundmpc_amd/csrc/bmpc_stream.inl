@@ -23,6 +23,11 @@
 #pragma once
 
 namespace bmpcs {
+// sine / cosine of a BOUNDED angle (joint angles, rotation angles <= 2 pi, half angles): the wave program's two-constant Cody-Waite reduction
+// (bmpc_wave.inl bmpc_sincos: < 1 ulp, checked against libm over [-50, 50]) instead of the library's full-range functions, whose
+// Payne-Hanek path (v_trig_preop_f64, a private work array) was inlined at every call site of the pack / post kernels
+BMPC_HD inline double sin_b(double x) { double s_, c_; BMPC_NAMESPACE::bmpc_sincos(x, &s_, &c_); return s_; }
+BMPC_HD inline double cos_b(double x) { double s_, c_; BMPC_NAMESPACE::bmpc_sincos(x, &s_, &c_); return c_; }
 constexpr int STREAM_NMAX = 40;      // the solver's longest horizon (stream_post: one role per stage, then the fixed roles behind them)
 
 // path table entry (one per via-point slot), doubles
@@ -62,8 +67,8 @@ BMPC_HD inline void rotvec_to_quat(const double *v, double *q) {
     const double ang = norm3(v);
     double sc;
     if (ang <= 1e-3) { const double a2 = ang * ang; sc = 0.5 - a2 / 48 + a2 * a2 / 3840; }
-    else sc = BMPC_SIN(ang / 2) / ang;
-    q[0] = sc * v[0]; q[1] = sc * v[1]; q[2] = sc * v[2]; q[3] = BMPC_COS(ang / 2);
+    else sc = sin_b(ang / 2) / ang;
+    q[0] = sc * v[0]; q[1] = sc * v[1]; q[2] = sc * v[2]; q[3] = cos_b(ang / 2);
 }
 BMPC_HD inline void quat_to_mat(const double *q, double *M) {
     const double x = q[0], y = q[1], z = q[2], w = q[3];
@@ -98,7 +103,7 @@ BMPC_HD inline void quat_to_rotvec(const double *qin, double *v) {
     const double ang = 2 * BMPC_ATAN2(norm3(q), q[3]);
     double sc;
     if (ang <= 1e-3) { const double a2 = ang * ang; sc = 2 + a2 / 12 + 7 * a2 * a2 / 2880; }
-    else sc = ang / BMPC_SIN(ang / 2);
+    else sc = ang / sin_b(ang / 2);
     v[0] = sc * q[0]; v[1] = sc * q[1]; v[2] = sc * q[2];
 }
 BMPC_HD inline void mat_to_rotvec(const double *M, double *v) { double q[4]; mat_to_quat(M, q); quat_to_rotvec(q, v); }
@@ -115,7 +120,7 @@ BMPC_HD inline void jac_so3_inv(const double *a, double sign, double *J) {
     const double th = norm3(a) + 1e-6;
     const double K[9] = {0, -a[2], a[1], a[2], 0, -a[0], -a[1], a[0], 0};
     double K2[9]; mat3_mul(K, K, K2);
-    const double c = 1 / (th * th) - (1 + BMPC_COS(th)) / (2 * th * BMPC_SIN(th));
+    const double c = 1 / (th * th) - (1 + cos_b(th)) / (2 * th * sin_b(th));
     for (int i = 0; i < 9; i++) J[i] = (i % 4 == 0 ? 1.0 : 0.0) + sign * 0.5 * K[i] + c * K2[i];
 }
 BMPC_HD inline void mat3_vec(const double *A, const double *x, double *y) {
@@ -134,7 +139,7 @@ BMPC_HD inline void integrate_rotation_reference(const double *pr_ref, const dou
         const double k[3] = {om[0] / n, om[1] / n, om[2] / n};
         const double K[9] = {0, -k[2], k[1], k[2], 0, -k[0], -k[1], k[0], 0};
         double K2[9]; mat3_mul(K, K, K2);
-        const double ang = (phi1 - phi0) * n, s = BMPC_SIN(ang), c1 = 1 - BMPC_COS(ang);
+        const double ang = (phi1 - phi0) * n, s = sin_b(ang), c1 = 1 - cos_b(ang);
         double E[9];
         for (int i = 0; i < 9; i++) E[i] = (i % 4 == 0 ? 1.0 : 0.0) + s * K[i] + c1 * K2[i];
         mat3_mul(E, R0, R0);
@@ -165,7 +170,7 @@ BMPC_HD inline void jacobian_lin_ddot(const double *q, const double *dq, const d
 #pragma unroll
     for (int j = 0; j < 7; j++) {
         for (int c = 0; c < 3; c++) { o[c] += R[c * 3 + 2] * pre[j]; O[j][c] = o[c]; }
-        double cs = BMPC_COS(q[j]), sn = BMPC_SIN(q[j]);
+        double cs = cos_b(q[j]), sn = sin_b(q[j]);
         if (ax[j] == 2) {
             for (int c = 0; c < 3; c++) { A[j][c] = R[c * 3 + 2]; const double c0 = R[c * 3], c1 = R[c * 3 + 1]; R[c * 3] = cs * c0 + sn * c1; R[c * 3 + 1] = -sn * c0 + cs * c1; }
         } else {
@@ -211,7 +216,7 @@ BMPC_HD inline void forward_kinematics(const double *q, const double *dq, Fk &F)
 #pragma unroll
     for (int j = 0; j < 7; j++) {
         for (int c = 0; c < 3; c++) { o[c] += R[c * 3 + 2] * pre[j]; O[j][c] = o[c]; }
-        double cs = BMPC_COS(q[j]), sn = BMPC_SIN(q[j]);
+        double cs = cos_b(q[j]), sn = sin_b(q[j]);
         if (ax[j] == 2) {
             for (int c = 0; c < 3; c++) { A[j][c] = R[c * 3 + 2]; const double c0 = R[c * 3], c1 = R[c * 3 + 1]; R[c * 3] = cs * c0 + sn * c1; R[c * 3 + 1] = -sn * c0 + cs * c1; }
         } else {
