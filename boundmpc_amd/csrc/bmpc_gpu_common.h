@@ -26,6 +26,7 @@
 #endif
 #define BMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define BMPC_NOW() ((long long)wall_clock64())      // constant 100 MHz counter
+#define BMPCS_OPAQUE(x) asm volatile("" : "+v"(x))      // stream functions: keeps a loaded value out of the optimiser's reach (no re-sinking of the load under a branch)
 
 // kernel arguments of a solve; OPTS = the Opts type of the wave program's namespace (same layout in every instantiation)
 template <class OPTS>

@@ -22,6 +22,9 @@
 // The same text is compiled by g++ for the CPU tests (tests/emu).
 #pragma once
 
+#ifndef BMPCS_OPAQUE
+#define BMPCS_OPAQUE(x)      // GPU builds: asm volatile("" : "+v"(x)) (bmpc_gpu_common.h); host builds of the same text: nothing
+#endif
 namespace bmpcs {
 // sine / cosine of a BOUNDED angle (joint angles, rotation angles <= 2 pi, half angles): the wave program's two-constant Cody-Waite reduction
 // (bmpc_wave.inl bmpc_sincos: < 1 ulp, checked against libm over [-50, 50]) instead of the library's full-range functions, whose
@@ -592,7 +595,10 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
             // previous-plan arrays of BoundMPC.py:557-566 (linear rows): position of the re-integrated plan (the plan's own entry for
             // a leading column), the SOLVER's velocity variables, J ddq + dJ dq, J u + dJ ddq + ddJ dq
             for (int c = 0; c < 3; c++) {
-                pc[c * N + col] = lead ? w[col * 44 + 29 + c] : M.p[c];
+                // unconditional load (col is a valid column in both roles), then a select; the value is made opaque so that the compiler does not sink
+                // the load back under the exec mask of the `lead` lanes (a masked load whose result is read behind the join is what build.py's lint flags)
+                double wpos = w[col * 44 + 29 + c]; BMPCS_OPAQUE(wpos);
+                pc[c * N + col] = lead ? wpos : M.p[c];
                 pc[(3 + c) * N + col] = w[col * 44 + 35 + c];
                 pc[(6 + c) * N + col] = M.a[c]; pc[(9 + c) * N + col] = M.jk[c];
             }
