@@ -51,6 +51,12 @@ extern "C" void bmpc_emu_stream_post(int N, int S, double h, const double *path,
 }
 
 extern "C" void bmpc_emu_jacobian_lin_ddot(const double *q, const double *dq, const double *ddq, double *out) { bmpcs::jacobian_lin_ddot(q, dq, ddq, out); }
+// fk_motion: out = [p 6 | v 6 | a 6 | jk 3]
+extern "C" void bmpc_emu_fk_motion(const double *q, const double *dq, const double *ddq, const double *u, double *out) {
+    bmpcs::FkMotion M; bmpcs::fk_motion(q, dq, ddq, u, M);
+    for (int c = 0; c < 6; c++) { out[c] = M.p[c]; out[6 + c] = M.v[c]; out[12 + c] = M.a[c]; }
+    for (int c = 0; c < 3; c++) out[18 + c] = M.jk[c];
+}
 
 extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, int B, const double *p, const double *x0, double *state, double *x, double *g,
                               double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, int lane_order, int nthreads) {

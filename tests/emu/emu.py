@@ -128,6 +128,14 @@ def jacobian_lin_ddot(q, dq, ddq):
     return out
 
 
+def fk_motion(q, dq, ddq, u):
+    """Pose, v = J dq, a = J ddq + dJ dq and the linear rows of J u + dJ ddq + ddJ dq in one pass over the chain (csrc/bmpc_stream.inl fk_motion)."""
+    a = [np.ascontiguousarray(v, dtype=np.float64) for v in (q, dq, ddq, u)]
+    out = np.zeros(21)
+    lib().bmpc_emu_fk_motion(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), _p(out))
+    return out[:6], out[6:12], out[12:18], out[18:21]
+
+
 # ---- flop-counting build of the same kernel text (tests/emu/bmpc_emu_flops.cpp) ----
 _FLIB = os.path.join(_HERE, "libbmpc_emu_flops.so")
 _fl = None

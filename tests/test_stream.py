@@ -162,6 +162,24 @@ def test_second_time_derivative_of_the_jacobian_g1():
         np.testing.assert_allclose(emu.jacobian_lin_ddot(d["q"][i], d["dq"][i], d["ddq"][i]), d["ddjacobian_fk"][i][:3], atol=2e-14)
 
 
+def test_fk_motion_against_the_references_kinematics_g1():
+    """fk_motion (csrc/bmpc_stream.inl: the post-processing's one-pass pose / velocity / acceleration / jerk) against the reference's own
+    kinematics on the 256 random states of fixture G1: pose = fk, v = J dq, a = J ddq + dJ dq with the Maple-generated jacobian_fk /
+    djacobian_fk values, and the linear jerk rows J u + dJ ddq + ddJ dq with its ddjacobian_fk (RobotModel.py:254-1053)."""
+    d = np.load(os.path.join(G, "g1_kinematics.npz"))
+    rng = np.random.default_rng(0)
+    for i in range(len(d["q"])):
+        q, dq, ddq = d["q"][i], d["dq"][i], d["ddq"][i]
+        u = rng.uniform(-5, 5, 7)
+        p, v, a, jk = emu.fk_motion(q, dq, ddq, u)
+        J, dJ, ddJ = d["jacobian_fk"][i], d["djacobian_fk"][i], d["ddjacobian_fk"][i]
+        np.testing.assert_allclose(p[:3], d["fk_pos"][i], atol=1e-14)
+        np.testing.assert_allclose(p, d["fk"][i], atol=1e-13)      # pose [position | rotation vector] of RobotModel.forward_kinematics
+        np.testing.assert_allclose(v, J @ dq, atol=1e-13)
+        np.testing.assert_allclose(a, J @ ddq + dJ @ dq, atol=1e-12)
+        np.testing.assert_allclose(jk, (J @ u + dJ @ ddq + ddJ @ dq)[:3], atol=1e-11)
+
+
 def test_stream_replanning_matches_reference_update_g11():
     """Re-planning on the stream functions: the recorded experiment-1 loop up to the tick of the update, `apply_update` (the state part
     of BoundMPC.update), then the ticks after it -- whose warm start goes through the re-projection branch with the Cartesian
