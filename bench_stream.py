@@ -41,6 +41,11 @@ def main():
                          "iteration-capped iterate is applied in the real-time modes; an iterate that fails it is not applied, the previous plan is replayed")
     ap.add_argument("--rt-bound-margin", type=float, default=2e-3, help="joint limits tightened inside the solver of the time-budgeted modes (rad, rad/s)")
     ap.add_argument("--only", default="", help="comma-separated substrings: run only the modes whose name contains one of them (the converged loop always runs: it is the reference of the deviations)")
+    ap.add_argument("--stall-window", type=int, default=16,
+                    help="stall window of the converged / warm loops (0: the handle's default, 40 for N <= 11).  A stream that is losing its plan (locally infeasible "
+                         "ticks, DESIGN.md 3) runs every solve to this test, and a tick lasts as long as its slowest stream: with 40 the converged loops take "
+                         "p50 7.1 / p99 11.8 ms per tick, with 16 3.0 / 7.1 ms -- the same 92.6 %% of the streams keep their plan, the same ticks are applied "
+                         "(12: 2.7 / 5.4 ms, but two more streams lose their plan); healthy warm-started ticks converge in ~10-12 iterations")
     ap.add_argument("--unsafe-too", action="store_true", help="also run the real-time modes with every capped iterate applied (the round-2 behaviour), for comparison")
     args = ap.parse_args()
     import torch
@@ -53,7 +58,7 @@ def main():
         mpcs.append(m)
         recs.append(bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([m.phi_max[0], 0.0, 0.0]), np.zeros(7)))
     recs = np.stack(recs)
-    solver = BatchedOCPSolver(10, 4, 0.1, tol=args.tol, mu_warm=args.mu_warm, max_iter=args.max_iter)
+    solver = BatchedOCPSolver(10, 4, 0.1, tol=args.tol, mu_warm=args.mu_warm, max_iter=args.max_iter, stall_window=args.stall_window or None)
     solver.set_timing(True)
     # real-time modes: loose tolerance + hard iteration cap per tick, COLD duals (the barrier restarts centred every tick: carrying a
     # small mu jams the iterate against the constraints that change with the shifted horizon)
