@@ -54,11 +54,37 @@ def experiment1_path(p0fk, e_p_min=0.01, e_r_min=15 * np.pi / 180, e_p_max=0.5, 
                 s=[0.0] * n, e_p_min=[e_p_min] * n, e_r_min=[e_r_min] * n, e_p_max=[e_p_max] * n, e_r_max=[e_r_max] * n)
 
 
-def make_mpc(q0, N=10, S=4, dt=0.1, tight=False, solver=None, weights=None):
+Q0_EXP2 = np.array([0.0, 0.0, 0.0, -np.pi / 1.8, 0.0, np.pi / 2 - np.pi / 1.8, 0.0])
+
+
+def experiment2_path(p0fk):
+    """Via points / rotations / limits of experiment2 (nodes/experiment2_runner.py:20-127 of the reference; defaults of
+    path_utils.get_default_path :4-39): five via points with per-segment ASYMMETRIC tube limits (segment 1: position +-[0.01, 1.0],
+    rotation +-0.11; segments 3, 4: +-0.1) and mixed basis vectors -- the secondary parity target of SURVEY 8(d), config 1b."""
+    p0 = p0fk[:3]
+    r0 = R.from_rotvec(p0fk[3:])
+    r1 = R.from_euler('XYZ', [np.pi / 2, 0, 0]) * r0
+    r2 = R.from_euler('XYZ', [0, 0, -np.pi / 3]) * r1
+    turn = R.from_euler('XYZ', [np.pi / 2, 0, 0]) * R.from_euler('XYZ', [0, 0, -np.pi / 2]) * r1
+    r3 = R.from_euler('XYZ', [0, 0, np.pi / 2.01]) * turn
+    r4 = R.from_euler('XYZ', [0, 0, np.pi / 2]) * turn
+    p_via = [p0, p0 + np.array([-0.2, -0.0, 0.1]), p0 + np.array([-0.6, -0.6, 0.1]), p0 + np.array([-0.8, -0.5, -0.2]), p0 + np.array([-0.8, -0.5, -0.5])]
+    r_via = [r.as_matrix() for r in (r0, r1, r2, r3, r4)]
+    arr = lambda rows: [np.array(v) for v in rows]
+    p_up = [[1.0, 1.0], [0.01, 1.0], [1.0, 1.0], [0.1, 0.1], [0.1, 0.1]]
+    r_up = [[1.0, 1.0], [0.11, 0.11], [1.0, 1.0], [0.1, 0.1], [0.1, 0.1]]
+    n = 5
+    return dict(pos_points=p_via, rot_points=r_via, pos_lim=[arr([[-a, -b] for a, b in p_up]), arr(p_up)], rot_lim=[arr([[-a, -b] for a, b in r_up]), arr(r_up)],
+                bp1=arr([[0., 0., 1.], [0., 0., 1.], [0., 0., 1.], [0., 1., 0.], [0., 1., 0.]]),
+                br1=arr([[0., 0., 1.], [0., 1., 0.], [0., 0., 1.], [0., 1., 0.], [0., 1., 0.]]),
+                s=[0.0] * n, e_p_min=[0.01] * n, e_r_min=[15 * np.pi / 180] * n, e_p_max=[0.20] * n, e_r_max=[45 * np.pi / 180] * n)
+
+
+def make_mpc(q0, N=10, S=4, dt=0.1, tight=False, solver=None, weights=None, experiment=1):
     rm = RobotModel()
     p0fk = rm.fk(q0)
     kw = dict(e_p_min=0.002, e_p_max=0.05, e_r_min=3 * np.pi / 180, e_r_max=10 * np.pi / 180) if tight else {}
-    path = experiment1_path(p0fk, **kw)
+    path = experiment1_path(p0fk, **kw) if experiment == 1 else experiment2_path(p0fk)      # (tight tubes: the synthetic batches of experiment 1 only)
     mpc = BoundMPC(p0=p0fk.copy(), params=Params(n=N, dt=dt, nr_segs=S, weights=weights),
                    solver=solver if solver is not None else _NoSolver(), **path)
     return mpc, p0fk

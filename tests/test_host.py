@@ -191,6 +191,28 @@ def test_workload_generator_reproducible_and_exp1():
     np.testing.assert_allclose(p[d6["p_defined_mask"]], d6["p_f64"][d6["p_defined_mask"]], atol=1e-13)
 
 
+def test_experiment2_setup_and_first_tick_against_the_reference_g6():
+    """workload.experiment2_path / Q0_EXP2 (the product-side restatement of nodes/experiment2_runner.py) against the inputs the reference's
+    own runner constants produced (recorded in fixture G6 next to its parameter vector), and the cold first tick packed from them against
+    the reference's p and x0."""
+    d6 = np.load(os.path.join(G, "g6_pack_exp2_tick0.npz"))
+    np.testing.assert_allclose(workload.Q0_EXP2, d6["q0"], atol=1e-15)
+    p0fk = RobotModel().fk(workload.Q0_EXP2)
+    np.testing.assert_allclose(p0fk, d6["p0fk"], atol=1e-13)
+    path = workload.experiment2_path(d6["p0fk"])
+    for key, ref in (("pos_points", d6["p_via"]), ("rot_points", d6["r_via"]), ("bp1", d6["bp1_in"]), ("br1", d6["br1_in"]), ("s", d6["s_in"]),
+                     ("e_p_min", d6["e_p_min_in"]), ("e_r_min", d6["e_r_min_in"]), ("e_p_max", d6["e_p_max_in"]), ("e_r_max", d6["e_r_max_in"])):
+        np.testing.assert_allclose(np.array(path[key]), ref, atol=1e-14, err_msg=key)
+    np.testing.assert_allclose(np.array(path["pos_lim"][0]), d6["p_lower"], atol=0); np.testing.assert_allclose(np.array(path["pos_lim"][1]), d6["p_upper"], atol=0)
+    np.testing.assert_allclose(np.array(path["rot_lim"][0]), d6["r_lower"], atol=0); np.testing.assert_allclose(np.array(path["rot_lim"][1]), d6["r_upper"], atol=0)
+    mpc, p0 = workload.make_mpc(workload.Q0_EXP2, experiment=2)
+    x_phi_d = np.array([mpc.phi_max[0], 0.0, 0.0])
+    w0, params, _ = mpc.pack(workload.Q0_EXP2, np.zeros(7), np.zeros(7), p0, np.zeros(6), x_phi_d, np.zeros(7))
+    m = d6["p_defined_mask"]
+    np.testing.assert_allclose(np.array(params)[m], d6["p_f64"][m], atol=1e-12)
+    np.testing.assert_allclose(np.array(w0), d6["x0_f64"], atol=1e-13)
+
+
 class _StubOk:
     """nlpsol-shaped stub answering with a given x and success flag (a failure carries a grossly infeasible g)."""
 
