@@ -64,6 +64,7 @@ def main():
     ap.add_argument("--procs", type=int, default=6)
     ap.add_argument("--max-iter", type=int, default=100)
     ap.add_argument("--slsqp", type=int, default=24, help="hard ticks handed to SLSQP (0 = none)")
+    ap.add_argument("--first-only", action="store_true", help="hand only the FIRST failing tick of every stream to SLSQP (what follows is a warm start from an outdated plan)")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "g13_hard_ticks.npz"))
     a = ap.parse_args()
     q0s = workload.random_q0(256, seed=3)[:a.streams]
@@ -83,7 +84,7 @@ def main():
         print(f"  stream {r['b']:3d} tick {r['t']:3d}: status {r['status']} iters {r['iters']:3d} kkt {r['kkt']:.1e} g_viol {r['g_viol']:.1e} phi {r['phi']:.3f}/{r['phi_max']:.3f} errcnt {r['errcnt']}")
     # SLSQP gets the FIRST failing tick of every stream (what follows a failure is a warm start from an outdated plan), then the slow ones
     first = [r for r in hard if r["errcnt"] == 1]
-    pick = (first + slow + [r for r in hard if r["errcnt"] == 2])[:a.slsqp] if a.slsqp else []
+    pick = ((first if a.first_only else first + slow + [r for r in hard if r["errcnt"] == 2])[:a.slsqp]) if a.slsqp else []
     out = {}
     if pick:
         with mp.get_context("fork").Pool(a.procs) as pool:

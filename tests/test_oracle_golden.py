@@ -434,3 +434,28 @@ def test_hard_closed_loop_ticks_g13():
     # no failing tick on which SLSQP CONVERGED to a feasible minimiser (exit 0): where it reached feasibility it stopped in its line search (exit 8)
     assert not (failed & slsqp_feasible & (d["slsqp_exit"] == 0)).any()
     assert (failed & ~slsqp_feasible).sum() >= 4      # SLSQP cannot make these feasible either
+
+
+def test_first_failures_of_all_256_closed_loops_g13b():
+    """Fixture g13b (tests/cpu_closed_loop.py --streams 256 --first-only): EVERY first failing tick of the 256 closed loops of BASELINE configs[4]
+    over 130 ticks (38 ticks on 31 streams; 19 streams go on to lose their plan), with SLSQP's end point from the same start.
+    * SLSQP ends infeasible on 28 of them, and the oracle with the stall test OFF and Ipopt's iteration limit (500) converges on NONE of those:
+      locally infeasible problems for both algorithms (14 of the 19 lost streams start their fatal run on such a tick);
+    * SLSQP reaches a feasible point on 10, and there the oracle -- which reported a stall after 60-100 iterations -- DOES converge when it is
+      given the iterations (8 of the 10, in 63-340 iterations), to SLSQP's objective where SLSQP's point is a minimiser: feasible, but an order
+      of magnitude slower than a healthy tick (the plan has to leave the tube centre by a lot: f up to 6x the previous tick's).
+    The stall test trades those for time: a batched tick lasts as long as its slowest stream."""
+    d = np.load(os.path.join(G, "g13b_first_failures_256_streams.npz"))
+    assert len(d["stream"]) == 38 and len(set(d["stream"].tolist())) == 31
+    out = c_oracle.solve(d["p"], d["x0"], 10, 4, 0.1, opts=c_oracle.default_opts(max_iter=100), nthreads=4)
+    assert np.array_equal(out["status"], d["oracle_status"]) and (d["oracle_status"] != 0).all()
+    feas = (d["slsqp_eq"] < 1e-8) & (d["slsqp_ineq"] < 1e-8) & (d["slsqp_bounds"] < 1e-8)
+    assert feas.sum() == 10 and (d["slsqp_exit"][feas] == 0).sum() == 1
+    patient = c_oracle.default_opts(max_iter=500, stall_window=0)
+    a = c_oracle.solve(d["p"][feas], d["x0"][feas], 10, 4, 0.1, opts=patient, nthreads=4)
+    conv = a["status"] == 0
+    assert conv.sum() >= 8 and a["iters"][conv].min() >= 60
+    rel = (a["f"][conv] - d["slsqp_f"][feas][conv]) / d["slsqp_f"][feas][conv]
+    assert (rel < 1e-6).sum() >= 7 and rel.max() < 5e-3      # same objective as SLSQP's point on seven; SLSQP lower by 4e-3 on one (another minimiser)
+    b = c_oracle.solve(d["p"][~feas], d["x0"][~feas], 10, 4, 0.1, opts=patient, nthreads=4)
+    assert (b["status"] != 0).all()
