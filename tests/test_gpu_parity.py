@@ -632,3 +632,28 @@ def test_five_and_six_path_segments_against_the_oracle(N, S):
     assert (per > 1e-6).sum() <= (1 if N > 11 else 0), float(per.max())
     assert np.sqrt((d[per <= 1e-6] ** 2).mean()) < 1e-7
     assert (np.abs(it - ref["iters"]) <= 2).mean() >= 0.97
+
+
+@pytest.mark.gpu
+def test_first_failures_of_the_closed_loops_g13b_on_the_gpu():
+    """Fixture g13b: every first failing tick of the 256 closed loops of configs[4] (38 problems: 28 infeasible for SLSQP, 10 feasible but slow).
+    The kernels (one wave per problem and teams) fail on all of them at the handle's defaults, as the oracle does; a patient handle
+    (stall test off, Ipopt's 500 iterations) converges on none of the 28 and on the 8 of the 10 on which the oracle converges, to its objective."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver
+    from oracle import c_oracle
+    d = np.load(os.path.join(G, "g13b_first_failures_256_streams.npz"))
+    p, x0 = torch.tensor(d["p"], device="cuda"), torch.tensor(d["x0"], device="cuda")
+    feas = (d["slsqp_eq"] < 1e-8) & (d["slsqp_ineq"] < 1e-8) & (d["slsqp_bounds"] < 1e-8)
+    for waves in (1, 4):
+        s = BatchedOCPSolver(10, 4, 0.1, max_iter=100); s.set_team_waves(waves)
+        o = s.solve_batch(p, x0); st = o["status"].cpu().numpy()
+        assert (st != 0).all() and (st == d["oracle_status"]).mean() >= 0.9      # (a stalled solve may end as status 2 in one and 3 in the other)
+        s.close()
+        sp = BatchedOCPSolver(10, 4, 0.1, max_iter=500, stall_window=0); sp.set_team_waves(waves)
+        o = sp.solve_batch(p, x0); st = o["status"].cpu().numpy(); f = o["f"].cpu().numpy()
+        ref = c_oracle.solve(d["p"], d["x0"], 10, 4, 0.1, opts=c_oracle.default_opts(max_iter=500, stall_window=0), nthreads=8)
+        assert (st[~feas] != 0).all() and (ref["status"][~feas] != 0).all()
+        both = (st == 0) & (ref["status"] == 0)
+        assert both[feas].sum() >= 7 and np.abs(f[both] - ref["f"][both]).max() < 1e-6 * np.abs(ref["f"][both]).max()
+        sp.close()
