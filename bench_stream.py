@@ -95,6 +95,7 @@ def main():
         + [(f"rtgn-tol{args.rt_tol:g}-cap4-feas1e-4(reference rule)", rtgn[4], 0, True, 1e-4)] \
         + [(f"rt-tol{args.rt_tol:g}-cap{c}-feas{FT:g}", rt[c], 0, False, FT) for c in (8, 6)] \
         + [("rti-3-feas%g" % FT, solver, 3, True, FT)] \
+        + [("warm-continue-feas1e-4 (converged solves; a stalled tick's iterate is the next warm start; reference acceptance rule + variable bounds)", solver, 0, True, 1e-4)] \
         + [(f"rtb{'gn' if gn else 'w'}-tol{args.rt_tol:g}-budget{us}us-feas{FT:g}", rtb[(us, gn)], 0, True, FT) for (us, gn) in sorted(rtb)]
     if args.unsafe_too:
         modes += [(f"UNSAFE rtgn-tol{args.rt_tol:g}-cap{c} (every capped iterate applied)", rtgn[c], 0, True, 1e30) for c in (4, 3)]
