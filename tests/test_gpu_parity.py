@@ -127,8 +127,10 @@ def test_long_horizon_tight_tubes(solver):
         assert set(np.unique(st)) <= {0, 2, 3}, np.bincount(st)          # converged | stalled (local infeasibility) | numerical
         assert (st == 3).mean() <= 0.002
         ok = st == 0
-        # measured (round 3, barrier restarts of stalled solves): 99.76 % converged, slowest problem 190 iterations; reference cap: 500 (BoundMPC.py:122)
-        assert ok.mean() >= 0.995 and it.max() <= 260, (ok.mean(), it.max())
+        # Requirement of the round-3 verdict: >= 99.8 % converged, slowest problem <= 120 iterations -- NOT met.  The bounds below are a
+        # regression guard around what the round-4 kernel does (Gauss-Newton fallback at every barrier level: 99.68 % converged, slowest 170, mean 32.8;
+        # round 3: 99.63 %, 203, 35.2); the reference's iteration cap is 500 (BoundMPC.py:122)
+        assert ok.mean() >= 0.996 and it.max() <= 220 and it.mean() <= 34.0, (ok.mean(), it.max(), it.mean())
         assert (kkt[ok] <= 1e-8).all()
         g = o["g"].cpu().numpy()[ok].reshape(-1, 30, 43)
         assert np.abs(g[:, :, :36]).max() < 1e-6 and g[:, :, 36:].max() < 1e-6
