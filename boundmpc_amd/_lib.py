@@ -12,7 +12,8 @@ SYMBOLS = ["bmpc_default_options", "bmpc_default_options_for", "bmpc_error_strin
            "bmpc_num_params", "bmpc_get_bounds", "bmpc_solve_batch", "bmpc_solve_batch_host", "bmpc_set_timing",
            "bmpc_last_kernel_ms", "bmpc_kernel_ms", "bmpc_launch_info", "bmpc_state_len", "bmpc_solve_batch_warm", "bmpc_graph_create",
            "bmpc_graph_launch", "bmpc_graph_destroy", "bmpc_stream_lengths", "bmpc_stream_pack", "bmpc_stream_pack_rt", "bmpc_stream_post",
-           "bmpc_stream_graph_create", "bmpc_set_latency_buffer", "bmpc_stream_set_rt_feasibility_tol", "bmpc_stream_tick", "bmpc_set_team_waves", "bmpc_team_info", "bmpc_stream_set_time_budget"]
+           "bmpc_stream_graph_create", "bmpc_set_latency_buffer", "bmpc_stream_set_rt_feasibility_tol", "bmpc_stream_tick", "bmpc_set_team_waves", "bmpc_team_info", "bmpc_stream_set_time_budget",
+           "bmpc_set_restoration", "bmpc_get_restoration", "bmpc_options_size"]
 
 
 class Options(ctypes.Structure):
@@ -73,6 +74,13 @@ def load():
     lib.bmpc_last_kernel_ms.argtypes = [vp, ctypes.POINTER(ctypes.c_float)]
     lib.bmpc_kernel_ms.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_float)]
     lib.bmpc_launch_info.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ctypes.c_longlong)]
+    if os.environ.get("BOUNDMPC_HIP_LIB") and not hasattr(lib, "bmpc_set_restoration"):
+        pass      # diagnostic A/B run against a build of an older revision (tests/gpu_ab.py): no restoration entry points; the in-tree library is always checked
+    else:
+        lib.bmpc_set_restoration.argtypes = [vp, ci, ci, ci]
+        lib.bmpc_get_restoration.argtypes = [vp, ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        if lib.bmpc_options_size() != ctypes.sizeof(Options):
+            raise BoundMPCHipError(f"{LIB_PATH}: bmpc_options is {lib.bmpc_options_size()} bytes, this binding expects {ctypes.sizeof(Options)} (stale build?)")
     _lib = lib
     return lib
 

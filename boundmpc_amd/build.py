@@ -8,9 +8,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libboundmpc_hip.so")
 SOURCES = [os.path.join(CSRC, "bmpc_hip.hip"), os.path.join(CSRC, "bmpc_wave.inl"), os.path.join(CSRC, "bmpc_stream.inl"),
-           os.path.join(HERE, "..", "include", "boundmpc_hip.h"), os.path.join(CSRC, "bmpc_team.hip"), os.path.join(CSRC, "bmpc_gpu_common.h")]
-# translation units of the library: the one-wave kernels + C ABI, and the team kernels (NW cooperating waves per problem)
-UNITS = [os.path.join(CSRC, "bmpc_hip.hip"), os.path.join(CSRC, "bmpc_team.hip")]
+           os.path.join(HERE, "..", "include", "boundmpc_hip.h"), os.path.join(CSRC, "bmpc_team.hip"), os.path.join(CSRC, "bmpc_gpu_common.h"),
+           os.path.join(CSRC, "bmpc_resto.hip"), os.path.join(CSRC, "bmpc_tick.hip")]
+# translation units of the library: the one-wave batch kernels + C ABI, the team kernels (NW cooperating waves per problem), the restoration
+# kernels (the solver with the restoration phase, continuing what a batch kernel left jammed) and the fused closed-loop tick kernels
+UNITS = [os.path.join(CSRC, "bmpc_hip.hip"), os.path.join(CSRC, "bmpc_team.hip"), os.path.join(CSRC, "bmpc_resto.hip"), os.path.join(CSRC, "bmpc_tick.hip")]
 
 
 def hipcc():

@@ -1,4 +1,4 @@
-// bmpc_gpu_common.h -- what the two translation units of libboundmpc_hip.so share: the device math macros the wave program
+// bmpc_gpu_common.h -- what the translation units of libboundmpc_hip.so share: the device math macros the wave program
 // (bmpc_wave.inl) is written in, and the kernel argument records.  bmpc_hip.hip holds the one-wave-per-problem kernels and the C ABI,
 // bmpc_team.hip the team kernels (NW cooperating waves per problem) and their launchers.
 #pragma once
@@ -37,16 +37,23 @@ struct KArgsT {
     double *latency_us;      // optional [B]: in-kernel duration of each solve (bmpc_set_latency_buffer)
     double *scratch; long long scr_stride; int *counter; unsigned long long *prof;
     long long budget_ticks;  // fused closed-loop tick only: time budget of a tick in counts of the 100 MHz wall clock, from kernel entry (0 = none)
+    int *counter2, *rcount;  // restoration kernel (bmpc_resto.hip): its work queue; number of problems the batch kernel left with status 4 (NULL: phase off)
 };
 // stream arguments of a fused tick
 struct SArgs {
     const double *path; int path_stride; double *ss, *rb, *traj; int flags; double rt_tol;
 };
 
+// ---- restoration kernel (bmpc_resto.hip): continues the problems a batch kernel left with the internal status 4 ----
+hipError_t bmpc_resto_launch(bool zlds, const void *kargs, int grid, hipStream_t st);
+
+// ---- fused closed-loop tick, one wave per stream (bmpc_tick.hip); resto: the instantiation that carries the restoration phase ----
+hipError_t bmpc_tick_launch(bool zlds, bool resto, const void *kargs, const SArgs *s, int B, hipStream_t st);
+
 // ---- team kernels (bmpc_team.hip); `kargs` points at a KArgsT<...> record (the layouts are identical across instantiations) ----
 // resident workgroups per CU of the team solver kernel with `nw` waves (0: no such instantiation)
 int bmpc_team_blocks_per_cu(int nw);
 hipError_t bmpc_team_launch_solve(int nw, const void *kargs, int grid, hipStream_t st);
-hipError_t bmpc_team_launch_tick(int nw, const void *kargs, const SArgs *s, int B, hipStream_t st);
+hipError_t bmpc_team_launch_tick(int nw, bool resto, const void *kargs, const SArgs *s, int B, hipStream_t st);
 int bmpc_team_lds_bytes(int nw);
 int bmpc_team_nmax(int nw);      // longest horizon the team kernels take (their LDS holds most of the workspace)

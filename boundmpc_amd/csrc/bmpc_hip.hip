@@ -62,9 +62,11 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
         pr.f = a.f ? a.f + b : nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr;
         pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status ? a.status + b : nullptr;
         pr.state = a.state ? a.state + (long long)b * (a.N * bmpc::NI + 2) : nullptr;
+        pr.resto_from = -1;
         const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
         bmpc::wave_solve<ZLDS>(W, pr);
         __syncthreads();
+        if (a.rcount && threadIdx.x == 0 && *pr.status == 4) atomicAdd(a.rcount, 1);      // jammed: the restoration kernel continues it (bmpc_resto.hip)
         if (a.latency_us && threadIdx.x == 0) a.latency_us[b] = (double)((long long)wall_clock64() - t0_) * 0.01;   // constant 100 MHz counter
     }
 #ifdef BMPC_PROFILE
@@ -85,6 +87,8 @@ struct bmpc_handle {
     hipStream_t own_stream;  // graph replays requested on the legacy null stream run here, bracketed by events (bmpc_graph_launch)
     int grid; long long scr_stride; double *scratch; int scr_waves; int graphs_alive; int *counter; unsigned long long *prof;
     int team_grid;           // resident TEAMS (workgroups of BMPC_TEAM_NW waves, bmpc_team.hip) of the device; 0: no team kernel for this handle (N > 10 or S > 4)
+    int *aux_int; int aux_cap;      // [2][aux_cap] status / iters of a batch whose caller passed NULL (the restoration kernel reads them)
+    int resto_on, resto_short, resto_cap;      // restoration phase (bmpc_set_restoration): on for N <= 11 by default; jam = resto_short consecutive short steps; iterations per phase
     int team_mode;           // bmpc_set_team_waves: 0 automatic (teams when the batch fits into the resident teams), 1 never, BMPC_TEAM_NW whenever possible
     int timing; hipEvent_t *ev; int nev; long long n_timed;   // timing = number of launches whose {start, stop} event pairs are kept (ring)
     double *latency_us;
@@ -130,7 +134,7 @@ static void handle_release(bmpc_handle *h) {
     if (h->order_ev) hipEventDestroy(h->order_ev);
     if (h->bridge_ev) hipEventDestroy(h->bridge_ev);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
-    hipFree(h->scratch); hipFree(h->counter); hipFree(h->prof); hipFree(h->stage_d); if (h->stage_h) hipHostFree(h->stage_h);
+    hipFree(h->scratch); hipFree(h->counter); hipFree(h->aux_int); hipFree(h->prof); hipFree(h->stage_d); if (h->stage_h) hipHostFree(h->stage_h);
     delete h;
 }
 
@@ -157,8 +161,9 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BMPC_ERR_NOGPU;
     bmpc_handle *h = new (std::nothrow) bmpc_handle();
     if (!h) return BMPC_ERR_ARG;
+    h->resto_on = N <= 11 ? 1 : 0; h->resto_short = 6; h->resto_cap = 40;      // restoration phase: the default of short horizons (bmpc_set_restoration)
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->ev = nullptr; h->nev = 0; h->n_timed = 0; h->latency_us = nullptr;
-    h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->prof = nullptr; h->stage_d = nullptr; h->stage_h = nullptr; h->stage_cap = 0;
+    h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->aux_int = nullptr; h->aux_cap = 0; h->prof = nullptr; h->stage_d = nullptr; h->stage_h = nullptr; h->stage_cap = 0;
     h->team_grid = 0; h->team_mode = 0;
     h->rt_viol_tol = 1e-4; h->rt_budget_us = 0.0; h->dev = 0; h->refs = 1; h->closed = false; h->order_ev = nullptr; h->bridge_ev = nullptr; h->order_valid = false; h->order_stream = nullptr; h->own_stream = nullptr;
     if (opts) h->o = *opts; else bmpc_default_options_for(N, &h->o);
@@ -175,7 +180,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
         h->team_grid = (N <= bmpc_team_nmax(BMPC_TEAM_NW) && S <= bmpc::SMAX_ZLDS) ? bmpc_team_blocks_per_cu(BMPC_TEAM_NW) * prop.multiProcessorCount : 0;
         // the per-wave workspace slabs (148 KB at N=10, 444 KB at N=30) are allocated on the first solve, for min(B, grid) waves, and grow on demand:
         // a single-problem handle (the nlpsol shim of one BoundMPC object) holds one slab, not 1024
-        ok = hipMalloc(&h->counter, sizeof(int)) == hipSuccess
+        ok = hipMalloc(&h->counter, 4 * sizeof(int)) == hipSuccess      /* work queue, work queue of the restoration kernel, jam count */
           && hipMalloc(&h->prof, 32 * sizeof(unsigned long long)) == hipSuccess
           && hipMemset(h->prof, 0, 32 * sizeof(unsigned long long)) == hipSuccess
           && hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming) == hipSuccess
@@ -260,6 +265,36 @@ static bool use_team(const bmpc_handle *h, int B) {
     return h->team_mode == BMPC_TEAM_NW || B <= h->team_grid;
 }
 static int launch_grid(const bmpc_handle *h, int B) { const int g = use_team(h, B) ? h->team_grid : h->grid; return B < g ? B : g; }
+// the restoration kernel (bmpc_resto.hip) runs one wave per problem whatever kernel solved the batch
+static int resto_grid(const bmpc_handle *h, int B) { return B < h->grid ? B : h->grid; }
+// what a batch of B needs besides the caller's buffers: workspace slabs for the resident waves of both kernels, and -- the hand-over to the
+// restoration kernel goes through status[] and iters[] -- handle-owned stand-ins for a caller that passes NULL there.  Never inside a capture.
+static int reserve_for_batch(bmpc_handle *h, int B) {
+    const int lg = launch_grid(h, B), rg = h->resto_on ? resto_grid(h, B) : 0;
+    const int rc = ensure_scratch(h, lg > rg ? lg : rg);
+    if (rc != BMPC_OK) return rc;
+    if (B > h->aux_cap) {
+        DevGuard dg(h->dev);
+        if (h->graphs_alive > 0 && h->aux_int) { fprintf(stderr, "boundmpc_hip: a larger batch needs larger status buffers, but captured graphs hold the current ones\n"); return BMPC_ERR_ARG; }
+        if (h->aux_int) { wait_for_handle(h); HIPCHK(hipFree(h->aux_int)); h->aux_int = nullptr; h->aux_cap = 0; }
+        HIPCHK(hipMalloc(&h->aux_int, sizeof(int) * 2 * (size_t)B));
+        h->aux_cap = B;
+    }
+    return BMPC_OK;
+}
+extern "C" int bmpc_set_restoration(bmpc_handle *h, int enabled, int short_steps, int cap) {
+    if (!h || short_steps > 1000 || cap > 100000) return BMPC_ERR_ARG;
+    if (enabled >= 0) h->resto_on = enabled ? 1 : 0;
+    if (short_steps >= 0) h->resto_short = short_steps;
+    if (cap >= 1) h->resto_cap = cap; else if (cap == 0) return BMPC_ERR_ARG;
+    return BMPC_OK;
+}
+extern "C" int bmpc_get_restoration(const bmpc_handle *h, int *enabled, int *short_steps, int *cap) {
+    if (!h) return BMPC_ERR_ARG;
+    if (enabled) *enabled = h->resto_on; if (short_steps) *short_steps = h->resto_short; if (cap) *cap = h->resto_cap;
+    return BMPC_OK;
+}
+extern "C" int bmpc_options_size(void) { return (int)sizeof(bmpc_options); }
 extern "C" int bmpc_set_team_waves(bmpc_handle *h, int waves) {
     if (!h || (waves != 0 && waves != 1 && waves != BMPC_TEAM_NW)) return BMPC_ERR_ARG;
     if (waves == BMPC_TEAM_NW && h->team_grid <= 0) return BMPC_ERR_ARG;      // no team instantiation for this horizon / window
@@ -281,18 +316,30 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
     a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
     a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window; a.o.bound_margin = h->o.bound_margin;
+    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = lam_g; a.lam_x = lam_x; a.f = f; a.kkt = kkt; a.iters = iters; a.status = status;
     a.state = state; a.latency_us = h->latency_us; a.budget_ticks = 0;
     const int grid = launch_grid(h, B);
     if (grid > h->scr_waves) return BMPC_ERR_ARG;      // callers reserve the workspace first (never inside a stream capture)
     a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter; a.prof = h->prof;
-    HIPCHK(hipMemsetAsync(h->counter, 0, sizeof(int), st));
+    // restoration phase: the batch kernels hand a jammed problem over through status[] / iters[] (handle-owned when the caller wants neither)
+    const bool resto = h->resto_on != 0;
+    a.counter2 = h->counter + 1; a.rcount = resto ? h->counter + 2 : nullptr;
+    if (resto && (!a.status || !a.iters)) {
+        if (B > h->aux_cap) return BMPC_ERR_ARG;
+        if (!a.status) a.status = h->aux_int; if (!a.iters) a.iters = h->aux_int + h->aux_cap;
+    }
+    const int rgrid = resto ? resto_grid(h, B) : 0;
+    if (rgrid > h->scr_waves) return BMPC_ERR_ARG;
+    HIPCHK(hipMemsetAsync(h->counter, 0, 3 * sizeof(int), st));
     hipEvent_t *pair = nullptr;
     if (timed) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
+    const bool zlds = h->N <= 11 && h->S <= bmpc::SMAX_ZLDS;
     if (use_team(h, B)) HIPCHK(bmpc_team_launch_solve(BMPC_TEAM_NW, &a, grid, st));      // a workgroup of waves per problem (bmpc_team.hip)
-    else if (h->N <= 11 && h->S <= bmpc::SMAX_ZLDS) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, a);      // iterate in LDS; else in the workspace (long horizons, S > 4)
+    else if (zlds) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, a);      // iterate in LDS; else in the workspace (long horizons, S > 4)
     else hipLaunchKernelGGL(bmpc_solve_kernel<false>, dim3(grid), dim3(64), 0, st, a);
     HIPCHK(hipGetLastError());
+    if (resto) HIPCHK(bmpc_resto_launch(zlds, &a, rgrid, st));      // continues what the batch kernel left jammed; returns at once when nothing did (bmpc_resto.hip)
     if (timed) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }
     if (!capturing) return order_after(h, st);
     return BMPC_OK;
@@ -302,7 +349,7 @@ extern "C" int bmpc_solve_batch(bmpc_handle *h, int B, const double *p, const do
                                 double *f, int *iters, int *status, double *kkt, void *hip_stream) {
     if (!h || B < 0 || (B > 0 && (!p || !x0 || !x))) return BMPC_ERR_ARG;
     if (B == 0) return BMPC_OK;
-    { const int rc_ = ensure_scratch(h, launch_grid(h, B)); if (rc_ != BMPC_OK) return rc_; }
+    { const int rc_ = reserve_for_batch(h, B); if (rc_ != BMPC_OK) return rc_; }
     return enqueue_solve(h, B, p, x0, nullptr, 0, x, g, lam_g, lam_x, f, iters, status, kkt, (hipStream_t)hip_stream, h->timing != 0);
 }
 
@@ -312,7 +359,7 @@ extern "C" int bmpc_solve_batch_warm(bmpc_handle *h, int B, const double *p, con
                                      double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, void *hip_stream) {
     if (!h || B < 0 || max_iter < 0 || (B > 0 && (!p || !x0 || !x || !state))) return BMPC_ERR_ARG;
     if (B == 0) return BMPC_OK;
-    { const int rc_ = ensure_scratch(h, launch_grid(h, B)); if (rc_ != BMPC_OK) return rc_; }
+    { const int rc_ = reserve_for_batch(h, B); if (rc_ != BMPC_OK) return rc_; }
     return enqueue_solve(h, B, p, x0, state, max_iter, x, g, lam_g, lam_x, f, iters, status, kkt, (hipStream_t)hip_stream, h->timing != 0);
 }
 
@@ -322,7 +369,7 @@ struct bmpc_graph { bmpc_handle *h; hipGraph_t graph; hipGraphExec_t exec; };
 extern "C" int bmpc_graph_create(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g,
                                  double *lam_g, double *lam_x, double *f, int *iters, int *status, double *kkt, bmpc_graph **out) {
     if (!h || !out || B < 1 || max_iter < 0 || !p || !x0 || !x) return BMPC_ERR_ARG;
-    { const int rc_ = ensure_scratch(h, launch_grid(h, B)); if (rc_ != BMPC_OK) return rc_; }
+    { const int rc_ = reserve_for_batch(h, B); if (rc_ != BMPC_OK) return rc_; }
     hipStream_t cs;
     HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     bmpc_graph *gr = new (std::nothrow) bmpc_graph();
@@ -458,46 +505,7 @@ __global__ void __launch_bounds__(64) bmpc_stream_post_kernel(int N, int S, int 
     bmpcs::stream_post(N, S, h, path + (long long)b * path_stride, path_stride / bmpcs::PT_LEN, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
                        x + (long long)b * 44 * N, g + (long long)b * 43 * N, status[b], traj + (long long)b * bmpcs::tr_len(N), flags, rt_tol, sh, threadIdx.x, 64);
 }
-// ---- one closed-loop tick of a stream in ONE launch: {pack, solve, post} by the wave that owns the stream (both instantiations of the solver) ----
-// The three steps of a tick are each "one wave per stream" and strictly sequential per stream, so they need no grid-wide boundary
-// between them: as three kernels + the work-queue reset they cost three launch ramps, three drains and ~130 us of launch overhead
-// per tick at 1 kHz (profiles/r03_*_stream_trace.txt); here stream b is block b (B <= resident waves: no work queue, no reset node),
-// the stream functions use the reduction area of the solver's LDS, and the hand-over of p, x0 -> solver -> x, g, status goes through
-// global memory of the same wave in program order.
-template <bool ZLDS>
-__global__ void __launch_bounds__(64, 1) bmpc_stream_tick_kernel(KArgs a, SArgs s) {
-    __shared__ double lds[bmpc::L_SIZE];
-    const long long tk0_ = a.budget_ticks ? BMPC_NOW() : 0;
-    const int b = blockIdx.x;
-    if (b >= a.B) return;
-    const int np = 141 + 91 * a.S, nw = a.N * bmpc::NZ, ng = a.N * bmpc::NG;
-    double *sh = lds + bmpc::L_RED;
-    static_assert(bmpcs::SH_LEN <= 6 * 64, "the stream functions' LDS words must fit into the solver's reduction area");
-    const double *path = s.path + (long long)b * s.path_stride;
-    double *ss = s.ss + (long long)b * bmpcs::ss_len(a.N), *rb = s.rb + (long long)b * bmpcs::RB_LEN;
-    double *p = const_cast<double *>(a.p) + (long long)b * np, *x0 = const_cast<double *>(a.x0) + (long long)b * nw;
-    double *dual = a.state ? a.state + (long long)b * (a.N * bmpc::NI + 2) : nullptr;
-    // A stream that has lost its plan (N consecutive ticks without an accepted solution: BoundMPC.step() returns five Nones there and the
-    // reference node stops, BoundMPC.py:498-506, bound_mpc_node.py:318) is not ticked any further: its problems are the ones nobody could
-    // solve (tests/golden/g13_hard_ticks.npz), each would run to the stall test or the iteration cap, and a tick lasts as long as its slowest stream.
-    if (ss[bmpcs::SS_ERRCNT] >= (double)a.N) {
-        if (threadIdx.x == 0) { a.status[b] = 3; if (a.iters) a.iters[b] = 0; if (a.kkt) a.kkt[b] = 0.0; }
-        return;
-    }
-    bmpcs::stream_pack(a.N, a.S, path, s.path_stride / bmpcs::PT_LEN, ss, rb, p, x0, dual, (s.flags & 2) ? a.x + (long long)b * nw : nullptr, sh, threadIdx.x, 64);
-    __syncthreads();
-    bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpc::make_gptr(a.scratch + (long long)b * a.scr_stride); W.wv = 0;
-    bmpc::Problem pr;
-    pr.p = p; pr.x0 = x0; pr.x = a.x + (long long)b * nw; pr.g = a.g + (long long)b * ng; pr.lam_g = nullptr; pr.lam_x = nullptr;
-    pr.f = nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr; pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status + b; pr.state = dual;
-    const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
-    W.deadline = a.budget_ticks ? tk0_ + a.budget_ticks : 0;
-    bmpc::wave_solve<ZLDS, true>(W, pr);
-    __syncthreads();
-    if (a.latency_us && threadIdx.x == 0) a.latency_us[b] = (double)((long long)wall_clock64() - t0_) * 0.01;
-    bmpcs::stream_post(a.N, a.S, a.h, path, s.path_stride / bmpcs::PT_LEN, ss, rb, pr.x, pr.g, a.status[b], s.traj + (long long)b * bmpcs::tr_len(a.N), s.flags, s.rt_tol,
-                       sh, threadIdx.x, 64);
-}
+// (the fused one-launch tick kernels of one wave per stream live in bmpc_tick.hip, those of the teams in bmpc_team.hip)
 // enqueues the fused tick on `st` (direct launch or inside a capture)
 static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entries, double *sstate, double *robot, double *p, double *x0, double *dual_state,
                         int max_iter, double *x, double *g, int *iters, int *status, double *kkt, double *traj, int flags, hipStream_t st, bool capturing) {
@@ -506,6 +514,7 @@ static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entr
     KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
     a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
     a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window; a.o.bound_margin = h->o.bound_margin;
+    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = nullptr; a.lam_x = nullptr; a.f = nullptr; a.kkt = kkt; a.iters = iters; a.status = status;
     a.state = dual_state; a.latency_us = h->latency_us; a.budget_ticks = (long long)(h->rt_budget_us * 100.0);
     if (B > h->scr_waves) return BMPC_ERR_ARG;
@@ -514,10 +523,12 @@ static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entr
     const bool timed = !capturing && h->timing != 0;
     hipEvent_t *pair = nullptr;
     if (timed) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
-    if (use_team(h, B)) HIPCHK(bmpc_team_launch_tick(BMPC_TEAM_NW, &a, &s, B, st));
-    else if (h->N <= 11 && h->S <= bmpc::SMAX_ZLDS) hipLaunchKernelGGL(bmpc_stream_tick_kernel<true>, dim3(B), dim3(64), 0, st, a, s);
-    else hipLaunchKernelGGL(bmpc_stream_tick_kernel<false>, dim3(B), dim3(64), 0, st, a, s);      // long horizons, 5 or 6 path segments: iterate in the workspace
-    HIPCHK(hipGetLastError());
+    // The post-processing of a fused tick needs the final solution, so here the restoration phase runs INSIDE the kernel (instantiations with
+    // RESTO); a time-budgeted real-time tick never gets as far as a jam (six short steps) and runs the lean instantiation with the phase off.
+    const bool resto = h->resto_on != 0 && a.budget_ticks == 0;
+    a.o.restoration = resto ? 1 : 0; a.counter2 = nullptr; a.rcount = nullptr;
+    if (use_team(h, B)) HIPCHK(bmpc_team_launch_tick(BMPC_TEAM_NW, resto, &a, &s, B, st));
+    else HIPCHK(bmpc_tick_launch(h->N <= 11 && h->S <= bmpc::SMAX_ZLDS, resto, &a, &s, B, st));      // (long horizons, 5 or 6 path segments: iterate in the workspace)
     if (timed) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }
     if (!capturing) return order_after(h, st);
     return BMPC_OK;
@@ -529,7 +540,7 @@ extern "C" int bmpc_stream_tick(bmpc_handle *h, int B, const double *path, int p
     if (!h || B < 0 || max_iter < 0 || path_entries < h->S + 1 || (B > 0 && (!path || !sstate || !robot || !p || !x0 || !x || !g || !status || !traj))) return BMPC_ERR_ARG;
     if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // (the solver's own limit)
     if (B == 0) return BMPC_OK;
-    { const int rc_ = ensure_scratch(h, launch_grid(h, B)); if (rc_ != BMPC_OK) return rc_; }
+    { const int rc_ = reserve_for_batch(h, B); if (rc_ != BMPC_OK) return rc_; }
     hipStream_t st = (hipStream_t)hip_stream;
     if (tick_fusable(h, B)) return enqueue_tick(h, B, path, path_entries, sstate, robot, p, x0, dual_state, max_iter, x, g, iters, status, kkt, traj, flags, st, false);
     // real-time mode: the warm start continues from the iterate of the previous tick on every launch shape (fused or not)
@@ -585,7 +596,7 @@ extern "C" int bmpc_stream_graph_create(bmpc_handle *h, int B, const double *pat
                                         int flags, bmpc_graph **out) {
     if (!h || !out || B < 1 || max_iter < 0 || path_entries < h->S + 1 || !path || !sstate || !robot || !p || !x0 || !x || !g || !status || !traj) return BMPC_ERR_ARG;
     if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // (the solver's own limit)
-    { const int rc_ = ensure_scratch(h, launch_grid(h, B)); if (rc_ != BMPC_OK) return rc_; }
+    { const int rc_ = reserve_for_batch(h, B); if (rc_ != BMPC_OK) return rc_; }
     hipStream_t cs;
     HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     bmpc_graph *gr = new (std::nothrow) bmpc_graph();

@@ -71,9 +71,11 @@ __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_solve_kernel(KArgsT
         pr.f = a.f ? a.f + b : nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr;
         pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status ? a.status + b : nullptr;
         pr.state = a.state ? a.state + (long long)b * (a.N * bmpct::NI + 2) : nullptr;
+        pr.resto_from = -1;
         const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
         bmpct::wave_solve<true>(W, pr);
         __syncthreads();
+        if (a.rcount && threadIdx.x == 0 && *pr.status == 4) atomicAdd(a.rcount, 1);      // jammed: the (one-wave) restoration kernel continues it (bmpc_resto.hip)
         if (a.latency_us && threadIdx.x == 0) a.latency_us[b] = (double)((long long)wall_clock64() - t0_) * 0.01;   // constant 100 MHz counter
     }
 #ifdef BMPC_PROFILE
@@ -82,6 +84,7 @@ __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_solve_kernel(KArgsT
 }
 
 // one closed-loop tick of a stream in ONE launch by a team: wave 0 packs, the team solves, wave 0 post-processes (stream b = block b)
+template <bool RESTO>
 __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_tick_kernel(KArgsTeam a, SArgs s) {
     __shared__ double lds[bmpct::L_SIZE];
     const long long tk0_ = a.budget_ticks ? BMPC_NOW() : 0;
@@ -99,7 +102,7 @@ __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_tick_kernel(KArgsTe
     // reference node stops, BoundMPC.py:498-506, bound_mpc_node.py:318) is not ticked any further: its problems are the ones nobody could
     // solve (tests/golden/g13_hard_ticks.npz), each would run to the stall test or the iteration cap, and a tick lasts as long as its slowest stream.
     if (ss[bmpcs::SS_ERRCNT] >= (double)a.N) {
-        if (threadIdx.x == 0) { a.status[b] = 3; if (a.iters) a.iters[b] = 0; if (a.kkt) a.kkt[b] = 0.0; }
+        if (threadIdx.x == 0) { a.status[b] = 3; if (a.iters) a.iters[b] = 0; if (a.kkt) a.kkt[b] = 0.0; if (a.latency_us) a.latency_us[b] = 0.0; }
         return;
     }
     if (wv == 0) bmpcs::stream_pack(a.N, a.S, path, s.path_stride / bmpcs::PT_LEN, ss, rb, p, x0, dual, (s.flags & 2) ? a.x + (long long)b * nw : nullptr, sh, threadIdx.x, 64);
@@ -110,7 +113,8 @@ __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_tick_kernel(KArgsTe
     pr.f = nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr; pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status + b; pr.state = dual;
     const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
     W.deadline = a.budget_ticks ? tk0_ + a.budget_ticks : 0;
-    bmpct::wave_solve<true, true>(W, pr);
+    pr.resto_from = -1;
+    bmpct::wave_solve<true, true, RESTO>(W, pr);
     __syncthreads();
     if (a.latency_us && threadIdx.x == 0) a.latency_us[b] = (double)((long long)wall_clock64() - t0_) * 0.01;
     if (wv == 0) bmpcs::stream_post(a.N, a.S, a.h, path, s.path_stride / bmpcs::PT_LEN, ss, rb, pr.x, pr.g, a.status[b], s.traj + (long long)b * bmpcs::tr_len(a.N), s.flags, s.rt_tol,
@@ -131,9 +135,10 @@ hipError_t bmpc_team_launch_solve(int nw, const void *kargs, int grid, hipStream
     hipLaunchKernelGGL(bmpc_team_solve_kernel, dim3(grid), dim3(64 * BMPC_NW), 0, st, a);
     return hipGetLastError();
 }
-hipError_t bmpc_team_launch_tick(int nw, const void *kargs, const SArgs *s, int B, hipStream_t st) {
+hipError_t bmpc_team_launch_tick(int nw, bool resto, const void *kargs, const SArgs *s, int B, hipStream_t st) {
     if (nw != BMPC_NW) return hipErrorInvalidValue;
     KArgsTeam a; memcpy(&a, kargs, sizeof(a));
-    hipLaunchKernelGGL(bmpc_team_tick_kernel, dim3(B), dim3(64 * BMPC_NW), 0, st, a, *s);
+    if (resto) hipLaunchKernelGGL(bmpc_team_tick_kernel<true>, dim3(B), dim3(64 * BMPC_NW), 0, st, a, *s);
+    else hipLaunchKernelGGL(bmpc_team_tick_kernel<false>, dim3(B), dim3(64 * BMPC_NW), 0, st, a, *s);
     return hipGetLastError();
 }

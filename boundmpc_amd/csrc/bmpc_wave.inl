@@ -94,6 +94,16 @@ constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
 #define STALL_RESTARTS 3     // barrier restarts from a stalled iterate before status 2 (long horizons only; oracle/bmpc_oracle.c solve_one)
 #define STALL_RESTART_MU 3.0
 #define STALL_RESTART_PUSH 1e-1
+// restoration phase (oracle/bmpc_oracle.c solve_one has the description and the numbers)
+#define RESTO_RHO 1e3          // l1 penalty of the elastic variables (Ipopt's resto_penalty_parameter: 1000)
+#define RESTO_MU 1.0           // its first barrier level
+#define RESTO_MU_BACK 1.0      // barrier level of the main phase when it resumes from the feasible point
+#define RESTO_PUSH_BACK 1e-6   // smallest slack there
+#define RESTO_SHORT_ALPHA 0.1  // a step shorter than this is "short" (jam detection)
+#define RESTO_REL 1e-3         // the restoration phase counts as converged at a KKT error of RESTO_REL * rho * (largest violation)
+#define RESTO_MARGIN 1e-6      // strictly feasible: max h <= -RESTO_MARGIN ...
+#define RESTO_GTOL 1e-4        // ... and equality residuals below this
+#define RESTO_MAX 3            // restoration phases per solve
 #define KAPPA_EPS 100.0   // barrier problem "solved" at KKT error <= KAPPA_EPS * mu (oracle/bmpc_oracle.c).  A deliberate departure from Ipopt, whose
                           // barrier_tol_factor defaults to 10: measured on the bench batches it takes 2 of 14 iterations off the mean and 36 -> 20 off the slowest problem
                           // (DESIGN.md 2, round 2); the price is an occasional premature barrier reduction (a problem that then crawls for some iterations)
@@ -147,7 +157,7 @@ enum { L_PAR = 0, L_PM = 512, L_SR = L_PM + 35 * 36, L_RED = L_SR + 8 * 44, L_PV
        L_K1 = L_K0 + KREC, L_KV = L_K1 + KREC, L_XT = L_KV + KREC, L_NC = L_XT + 15 * 14, L_WY = L_NC + 160, L_WV = L_WY + 196, L_TOT = L_WV + 196,
        L_MU = L_TOT + 44, L_FLAG = L_MU + 16, L_FILT = L_FLAG + 8, L_PROF = L_FILT + 64, L_KV1 = L_PROF + 32, L_ST = L_KV1 + KREC, L_ZL = L_ST + 460, L_SIZE1 = L_ZL + 484 };
 enum { L_KKP = L_WY };
-// per-lane partials of the wide passes: 6 slots x WS (L_REDW) and 4 x WS (L_KKPW).  One wave: the one-wave areas themselves.  Teams: own
+// per-lane partials of the wide passes: 6 slots x WS (L_REDW) and 5 x WS (L_KKPW; the fifth, max h, is written in the restoration phase only).  One wave: the one-wave areas themselves.  Teams: own
 // areas behind the one-wave layout (a team owns a whole CU: 1 workgroup of NW waves at 512 registers each), plus the hand-over words of
 // the solo regions (forward sweep's gradient products, the Riccati sweep's verdict, the work-queue index)
 enum { L_PP = L_PM };   // [4 fields][64 pairs] partial products of P rdyn (blk_add_lane -> S0), in the area the value-function blocks used to occupy
@@ -209,7 +219,7 @@ enum { WRED_STRIDE = NW };      // GPU: a wave reduces its 64 partials in regist
 // that lives in the global slab)
 enum { PREP_N = 14 };
 // L_DSA: the forward sweep's reduced states of all stages (36 per stage), from which a wide pass forms the dZ rows behind the sweep
-enum { L_REDW = L_SIZE1, L_KKPW = L_REDW + 6 * WRED_STRIDE, L_DSA = L_KKPW + 4 * WRED_STRIDE, L_TFLAG = L_DSA + 36 * TEAM_NMAX, L_PREP = L_TFLAG + 8,
+enum { L_REDW = L_SIZE1, L_KKPW = L_REDW + 6 * WRED_STRIDE, L_DSA = L_KKPW + 5 * WRED_STRIDE, L_TFLAG = L_DSA + 36 * TEAM_NMAX, L_PREP = L_TFLAG + 8,
        L_WY2 = L_PREP + 2 * PREP_N * 64, L_HKHP = L_WY2 + 196, L_QRB = L_KV1 /* 2 x 40: q~ rows + t6 per stage parity */, L_HGL = L_KV /* 44: the helper's gl */, L_WSL = L_HKHP + KHV_STRIDE, L_SIZE = L_WSL + WSL_PER_STAGE * TEAM_NMAX + 16 };
 #ifndef BMPC_EMU
 static_assert(L_SIZE * 8 <= 160 * 1024, "a team's working set must fit the 160 KB of LDS of a CU");
@@ -222,11 +232,14 @@ struct Opts {
     double tol; int max_iter; double mu_init; double mu_min_fac; double slack_push; int exact_hessian; int verbose; double mu_warm; int stall_window;
     double bound_margin;      // joint position / velocity limits tightened by this much inside the solver (real-time modes: a plan solved to a loose
                               // tolerance then still respects the true limits); 0 = the reference's limits
+    int restoration;          // 1: a jammed or stalled main phase hands over to the restoration phase (round 5; oracle/bmpc_oracle.c solve_one); 0: status 2 / barrier restarts
+    int resto_short;          // consecutive steps shorter than RESTO_SHORT_ALPHA that count as a jam (6; 0 = the stall test alone)
+    int resto_cap;            // iterations one restoration phase may take before the solve ends as status 2 (40)
 };
 
 // global scratch layout (doubles) for horizon N
 struct Scr {
-    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, NU2, NCS, KHPG, KHV, size, lsize;
+    int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, NU2, NCS, KHPG, KHV, E, ET, DE, size, lsize;
 };
 BMPC_HD inline Scr make_scr(int N) {
 #if BMPC_NW > 1
@@ -234,6 +247,7 @@ BMPC_HD inline Scr make_scr(int N) {
     Scr s; int c = 0, l = 0;
     s.Z = c; c += N * NZ; s.ZT = c; c += N * NZ; s.DZ = c; c += N * NZ; s.KT = c; c += N * NS * NU; s.KF = c; c += N * NU; s.KHPG = c; c += 2 * N * 72; s.KHV = c; c += N * KHV_STRIDE;
     s.DNU = c; c += N * NI;      // (multiplier directions: written by row pass B, read once by the update pass -- what did not fit)
+    s.E = c; c += N * NI; s.ET = c; c += N * NI; s.DE = c; c += N * NI;      // elastic variables of the restoration phase (rare: global slab, accessor G)
     s.T = l; l += N * NI; s.TT = l; l += N * NI; s.NUm = l; l += N * NI; s.LAM = l; l += N * NE; s.G = l; l += N * NE; s.GT = l; l += N * NE;
     s.HIN = l; l += N * NI; s.HT = l; l += N * NI; s.DT = l; l += N * NI; s.GH = l; l += N * NZ; s.GVP = l; l += N * 8;
     s.RJ = l; l += N * NU; s.KIN = l; l += 2 * N * KREC; s.REF = l; l += N * RREC; s.RDY = l; l += N * 36; s.AES = l; l += N * 42; s.RLV = l; l += N * 12;
@@ -250,6 +264,7 @@ BMPC_HD inline Scr make_scr(int N) {
     s.NCS = c; c += N * NCS_STRIDE;   // node-cost data of every stage (wave_stage_data_wide): see the NCS_* row layout
     s.KHPG = c; c += 2 * N * 72;      // prefix vectors of the kinematic curvature, one row per kinematics record (kin_point)
     s.KHV = c; c += N * KHV_STRIDE;   // per-joint vectors of the kinematic curvature, one row per stage (wave_stage_data_wide)
+    s.E = c; c += N * NI; s.ET = c; c += N * NI; s.DE = c; c += N * NI;      // elastic variables of the restoration phase, trial values, directions (accessor G)
     s.size = (c + 15) & ~15; s.lsize = 0;
     return s;
 #endif
@@ -260,6 +275,8 @@ struct Problem {           // per-problem global pointers
     double *x, *g, *lam_g, *lam_x, *f, *kkt;
     int *iters, *status;
     double *state;         // optional dual state of a receding-horizon stream: [nu (N*57) | mu | iterations]; mu <= 0: cold start
+    int resto_from;        // >= 0 (instantiations with RESTO only): x0 is the iterate at which the main phase of another kernel jammed after this many
+                           // iterations -- the solve starts in the restoration phase and counts on from there; -1: an ordinary solve
 };
 
 // Workspace accessor: wave-uniform base (an SGPR pair on the GPU) plus an unsigned 32-bit BYTE offset.  Indexing a plain double * with
@@ -868,7 +885,7 @@ BMPC_D inline double eval_node_lane(Wave &W, const POff &po, const Scr &sc, doub
 // needs -- theta = ||c||_1 + ||h + tt||_1 and the barrier term -mu sum log tt -- from the values it has in registers, and leaves their
 // per-lane parts in L_RED + 64 / + 128: the trial used to cost two more passes over the rows (slacks before, sums after the
 // evaluation), each a dependent round trip to the workspace.
-struct LsRows { double alpha, mu; };
+struct LsRows { double alpha, mu; bool el; };      // el: restoration phase (elastic rows: trial e -> ET, theta and the barrier sum include them)
 BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Zs, int oG, int oH, bool project, const LsRows *ls = nullptr) {
     const int N = W.N; const double h = W.h, h2 = h * h, h3 = h2 * h;
     double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
@@ -950,6 +967,11 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
                 rc[u] = rr[RC + m]; rw[u] = rr[RWD + m];
                 if (ls) { tv[u] = WL[sc.T + id]; dv[u] = WL[sc.DT + id]; }      // wave-uniform condition
             }
+            double ev[RUW], dev[RUW], eprod = 1.0, esum = 0.0;
+            if (ls && ls->el) {      // (wave-uniform; restoration phase only)
+#pragma unroll
+                for (int u = 0; u < RUW; u++) { const int id0 = base + WS * u, id = id0 < N * NI ? id0 : N * NI - 1; ev[u] = G[sc.E + id]; dev[u] = G[sc.DE + id]; }
+            }
             double tprod = 1.0;
 #pragma unroll
             for (int u = 0; u < RUW; u++) {
@@ -962,10 +984,17 @@ BMPC_D inline double wave_eval(Wave &W, const POff &po, const Scr &sc, double *Z
                 if (ls) {
                     const double tt = tv[u] + ls->alpha * dv[u]; const bool ok_ = id0 < N * NI;
                     WL[sc.TT + id] = tt;
+                    if (ls->el) {
+                        const double et = ev[u] + ls->alpha * dev[u];
+                        G[sc.ET + id] = et;
+                        th += ok_ ? BMPC_FABS(hv + tt - et) : 0.0; tprod *= ok_ ? tt : 1.0; eprod *= ok_ ? et : 1.0; esum += ok_ ? et : 0.0;
+                    } else {
                     th += ok_ ? BMPC_FABS(hv + tt) : 0.0; tprod *= ok_ ? tt : 1.0;
+                    }
                 }
             }
             if (ls) br -= ls->mu * BMPC_LOG(tprod);      // one log per batch of RU slacks: sum of logs = log of the product (t in [1e-12, 1e2])
+            if (ls && ls->el) br += RESTO_RHO * esum - ls->mu * BMPC_LOG(eprod);
         }
         if (ls) { WRED_PUT_SUM(L_REDW, 1, th + the); WRED_PUT_SUM(L_REDW, 2, br); }
     WIDE_END
@@ -2466,7 +2495,12 @@ BMPC_D inline bool team_backward(Wave &W, const POff &po, const Scr &sc, double 
 #ifndef BMPC_NOW
 #define BMPC_NOW() 0LL
 #endif
-template <bool ZLDS, bool RT = false>
+// RESTO: this instantiation carries the restoration phase (oracle/bmpc_oracle.c solve_one).  The batch kernels are compiled WITHOUT it (the elastic
+// row code costs the hot path 6 % through register allocation alone, measured): a problem whose main phase is jammed or stalled leaves them with
+// the internal status 4 and its iterate in x, and a second kernel (bmpc_resto_kernel, RESTO = true, started by the library right behind) picks it
+// up via Problem::resto_from -- entering the restoration phase discards everything but the iterate, so the hand-over loses nothing and both
+// paths compute the same numbers.  The fused closed-loop ticks carry the phase in the kernel (their post-processing needs the final solution).
+template <bool ZLDS, bool RT = false, bool RESTO = false>
 BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     const int N = W.N, S = W.S;
     double *L = W.L; const GPtr G = W.G; const LPtr WL = BMPC_WL(W);
@@ -2528,18 +2562,63 @@ _Pragma("unroll") \
             WRED_PUT_MAX(L_KKPW, 0, ep); WRED_PUT_MAX(L_KKPW, 1, cmax); WRED_PUT_MIN(L_KKPW, 2, cmin); WRED_PUT_SUM(L_KKPW, 3, sn); \
         WIDE_END
     BMPC_ROWS_INIT(warm, o.slack_push)
-    int n_restart = 0, it_restart = 0;
+    // Restoration phase (oracle/bmpc_oracle.c solve_one): elastic rows h + t - e = 0 with nu t = mu, (rho - nu) e = mu.  Row pass "A0e": the
+    // centred start of every row at the barrier level mu (elastic_centre of the oracle), and what the Newton system reads from a row:
+    // SG = sigma = 1 / (t/nu + e/z), and the barrier-modified multiplier nu^ = nu + sigma (h + mu/nu - mu/z) split as SR + mu * TI with
+    // SR = nu + sigma h, TI = sigma (1/nu - 1/z), so that the consumers (mu * TI + SR) follow a barrier update between this pass and the system.
+#define BMPC_ROWS_CENTRE() \
+        WIDE_BEGIN \
+            double ep = 0, cmax = -1e300, cmin = 1e300, sn = 0, hm = -1e300; \
+            for (int tr_ = 0; tr_ < (ni + WS * RUW - 1) / (WS * RUW); tr_++) { const int base = wl + tr_ * WS * RUW; \
+                double hv[RUW]; \
+_Pragma("unroll") \
+                for (int u = 0; u < RUW; u++) { const int id = base + WS * u; hv[u] = id < ni ? WL[sc.HIN + id] : -1.0; } \
+_Pragma("unroll") \
+                for (int u = 0; u < RUW; u++) { \
+                    const int id = base + WS * u; \
+                    if (id < ni) { \
+                        const double hh = hv[u], nu = 2.0 * mu * RESTO_RHO / (2.0 * mu - hh * RESTO_RHO + BMPC_SQRT(4.0 * mu * mu + hh * hh * RESTO_RHO * RESTO_RHO)); \
+                        const double z = RESTO_RHO - nu, t = mu / nu, e = mu / z, sgm = 1.0 / (t / nu + e / z); \
+                        WL[sc.T + id] = t; WL[sc.NUm + id] = nu; G[sc.E + id] = e; WL[sc.SG + id] = sgm; WL[sc.TI + id] = sgm * (1.0 / nu - 1.0 / z); WL[sc.SR + id] = nu + sgm * hh; \
+                        const double v = BMPC_FABS(hh + t - e), c = nu * t, c2 = z * e; \
+                        ep = v > ep ? v : ep; cmax = c > cmax ? c : cmax; cmin = c < cmin ? c : cmin; cmax = c2 > cmax ? c2 : cmax; cmin = c2 < cmin ? c2 : cmin; sn += nu; hm = hh > hm ? hh : hm; \
+                    } \
+                } \
+            } \
+            WRED_PUT_MAX(L_KKPW, 0, ep); WRED_PUT_MAX(L_KKPW, 1, cmax); WRED_PUT_MIN(L_KKPW, 2, cmin); WRED_PUT_SUM(L_KKPW, 3, sn); WRED_PUT_MAX(L_KKPW, 4, hm); \
+        WIDE_END
+    // the objective weights in the LDS copy of p: zero inside the restoration phase, from p again behind it (ca, cb: wave_init_tables)
+#define BMPC_WEIGHTS(ZERO_) \
+        WIDE_BEGIN \
+            const double wv_ = pr.p[make_poff(S).w + (wl < 15 ? wl : 14)];      /* (unconditional load on a clamped index) */ \
+            if (wl < 15) L[L_PAR + po.w + wl] = (ZERO_) ? 0.0 : wv_; \
+        WIDE_END \
+        W.ca = 2 * L[L_PAR + po.w + 5] / (W.h * W.h); W.cb = 2 * L[L_PAR + po.w + 5] / W.h;
+    // into the restoration phase: objective weights zero (the records carry weight-dependent Hessian entries: rebuilt by an evaluation, which
+    // returns f = 0), every row elastic and centred on the level RESTO_MU, filter and inertia history cleared
+#define BMPC_ENTER_RESTO() \
+        n_resto++; it_resto = it; el = true; mu = RESTO_MU; \
+        BMPC_WEIGHTS(true) \
+        fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false); \
+        BMPC_ROWS_CENTRE() \
+        nfilt = 0; filt_mu = -1.0; theta_min = -1.0; delta_last = 0.0; delta_prev = 0.0; gn_run = 0; n_short = 0;
+    int n_restart = 0, it_restart = 0, n_resto = 0, it_resto = 0, n_short = 0; bool el = false;      // el: inside the restoration phase
     int it = 0, status = 1; double E0 = 0, ep_old = 0, ep_mid = 0;
-    for (it = 0; it <= o.max_iter; it++) {
+    if (RESTO && pr.resto_from >= 0) {      // continuation of a solve whose main phase jammed in a kernel without the restoration phase
+        it = pr.resto_from; ep_old = ep_mid = 1e300;
+        BMPC_ENTER_RESTO()
+        it++;
+    }
+    for (; it <= o.max_iter; it++) {
         BMPC_PROF(W, 10);
         wave_adjoint(W, po, sc, sc.NUm, false, 0.0, LRs);
         BMPC_PROF(W, 1);
         // ---- KKT error (Ipopt-style scaling), deterministic reductions; the inequality part comes from row pass A ----
         WIDE_BEGIN
 #if BMPC_NW > 1
-            double ed = 0, ep = 0, sl = 0, g1 = 0;      // (the row pass's share of the primal infeasibility joins behind the barrier)
+            double ed = 0, ep = 0, sl = 0, g1 = 0, gm = 0;      // (the row pass's share of the primal infeasibility joins behind the barrier)
 #else
-            double ed = 0, ep = L[L_KKPW + wl], sl = 0, g1 = 0;
+            double ed = 0, ep = L[L_KKPW + wl], sl = 0, g1 = 0, gm = 0;
 #endif
             // the jerk-gradient entries ride in the first batch of the residual rows (one round trip to the workspace for the whole pass;
             // clamped duplicates do not change a maximum)
@@ -2552,9 +2631,10 @@ _Pragma("unroll") \
 #pragma unroll
                 for (int u = 0; u < RUW; u++) { const double v = BMPC_FABS(rj[u]); ed = v > ed ? v : ed; }
 #pragma unroll
-                for (int u = 0; u < RUW; u++) { const bool ok_ = base + WS * u < ne; const double v = ok_ ? BMPC_FABS(gv[u]) : 0.0; ep = v > ep ? v : ep; g1 += v; sl += ok_ ? BMPC_FABS(lv[u]) : 0.0; }
+                for (int u = 0; u < RUW; u++) { const bool ok_ = base + WS * u < ne; const double v = ok_ ? BMPC_FABS(gv[u]) : 0.0; ep = v > ep ? v : ep; gm = v > gm ? v : gm; g1 += v; sl += ok_ ? BMPC_FABS(lv[u]) : 0.0; }
             }
             WRED_PUT_MAX(L_REDW, 0, ed); WRED_PUT_MAX(L_REDW, 1, ep); WRED_PUT_SUM(L_REDW, 2, sl); WRED_PUT_SUM(L_REDW, 3, g1);
+            if (RESTO && el) { WRED_PUT_MAX(L_REDW, 4, gm); }      // restoration phase: the largest equality residual on its own (wave-uniform)
         WIDE_END
         const double theta_eq = WRED_GET_SUM(L_REDW, 3);      // ||c||_1 of the current iterate, for the filter's theta (row pass B)
 #if BMPC_NW > 1
@@ -2564,13 +2644,29 @@ _Pragma("unroll") \
 #endif
         const double ed = WRED_GET_MAX(L_REDW, 0), cmax = WRED_GET_MAX(L_KKPW, 1), cmin = WRED_GET_MIN(L_KKPW, 2),
                      sl = WRED_GET_SUM(L_REDW, 2), sn = WRED_GET_SUM(L_KKPW, 3);
+        double hmax = 0.0, gmax = 0.0;
+        if (RESTO && el) { hmax = WRED_GET_MAX(L_KKPW, 4); gmax = WRED_GET_MAX(L_REDW, 4); }
         TEAM_SYNC();      // (teams: every wave has read the partials before a barrier restart below, or the next pass, rewrites them)
         const double sd = BMPC_FMAX(100.0, (sl + sn) / (N * (NE + NI))) / 100.0, scl = BMPC_FMAX(100.0, sn / (N * NI)) / 100.0;
         E0 = BMPC_FMAX(BMPC_FMAX(ed / sd, ep), BMPC_FMAX(cmax, -cmin) / scl);
 #ifdef BMPC_EMU
         if (o.verbose) fprintf(stderr, "it %3d f %.8e dual %.2e prim %.2e compl %.2e mu %.1e\n", it, fval, ed, ep, BMPC_FMAX(cmax, -cmin), mu);
 #endif
-        if (E0 <= o.tol) { status = 0; break; }
+        if (!(RESTO && el)) { if (E0 <= o.tol) { status = 0; break; } }
+        else {      // restoration phase: back to the main phase from a feasible point, locally infeasible (status 2), or go on (oracle/bmpc_oracle.c solve_one)
+            const double vmax = BMPC_FMAX(hmax, gmax), rtol = BMPC_FMAX(BMPC_FMAX(o.tol, 1e-6), RESTO_REL * RESTO_RHO * vmax);
+            const bool back = (hmax <= -RESTO_MARGIN && gmax <= RESTO_GTOL) || (E0 <= rtol && vmax <= 1e-6);
+            if (!back && (E0 <= rtol || it - it_resto >= o.resto_cap)) { status = 2; break; }
+            if (back) {
+                el = false; mu = RESTO_MU_BACK;
+                BMPC_WEIGHTS(false)
+                fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);      // the objective of the original problem (and the records with its weights)
+                BMPC_ROWS_INIT(false, RESTO_PUSH_BACK)
+                nfilt = 0; filt_mu = -1.0; theta_min = -1.0; delta_last = 0.0; delta_prev = 0.0; gn_run = 0; n_short = 0;
+                ep_old = ep_mid = 1e300; it_restart = it;
+                continue;
+            }
+        }
         if (it == o.max_iter) break;
         if (RT && W.deadline) {      // real-time tick: out of time (teams: one lane reads the clock, every wave hears the verdict behind a barrier)
 #if BMPC_NW > 1
@@ -2587,13 +2683,23 @@ _Pragma("unroll") \
         }
         // stalled primal feasibility -> status 2, numerical breakdown -> status 3 (oracle/bmpc_oracle.c solve_one)
         if (it == 0) ep_old = ep_mid = 1e300;
-        else if (o.stall_window > 0 && it % (o.stall_window / 2) == 0) {
-            // (the floor of the test scales with the tolerance: a solve that is asked for 1e-5 and sits at 1e-5 is converging, not stalled)
-            if (it >= o.stall_window + it_restart && ep >= STALL_FACTOR * ep_old && ep > BMPC_FMAX(1e-6, 10.0 * o.tol)) {
-                // Long horizons (a compile-time property of this instantiation, like the Gauss-Newton fallback): before giving up, restart
-                // the barrier from the CURRENT iterate -- slacks and multipliers re-centred on a high barrier level, filter and inertia
-                // history cleared -- at most STALL_RESTARTS times (oracle/bmpc_oracle.c solve_one has the numbers: the stalled
-                // problems of the tight 30-stage batch are feasible, their iterate is jammed at the first barrier level).
+        else if (!(RESTO && el)) {
+            // (the floor of the tests scales with the tolerance: a solve that is asked for 1e-5 and sits at 1e-5 is converging, not stalled)
+            const bool open_ = ep > BMPC_FMAX(1e-6, 10.0 * o.tol);
+            const bool at_check = o.stall_window > 0 && (it - it_restart) % (o.stall_window / 2) == 0;
+            const bool stalled = at_check && it >= o.stall_window + it_restart && ep >= STALL_FACTOR * ep_old && open_;
+            const bool jammed = o.restoration && o.resto_short > 0 && n_short >= o.resto_short && open_;
+            if (stalled || jammed) {
+                if (o.restoration) {
+                    if (n_resto >= RESTO_MAX) { status = 2; break; }
+                    if (!RESTO) { status = 4; break; }      // (internal) this kernel does not carry the phase: the restoration kernel continues from x
+                    BMPC_ENTER_RESTO()
+                    continue;
+                }
+                // Long horizons (a compile-time property of this instantiation, like the Gauss-Newton fallback) without the restoration phase:
+                // before giving up, restart the barrier from the CURRENT iterate -- slacks and multipliers re-centred on a high barrier level,
+                // filter and inertia history cleared -- at most STALL_RESTARTS times (oracle/bmpc_oracle.c solve_one has the numbers: the
+                // stalled problems of the tight 30-stage batch are feasible, their iterate is jammed at the first barrier level).
                 if (!longh || n_restart >= STALL_RESTARTS) { status = 2; break; }
                 n_restart++; it_restart = it;
                 mu = STALL_RESTART_MU;
@@ -2602,7 +2708,7 @@ _Pragma("unroll") \
                 ep_old = ep_mid = 1e300;
                 continue;
             }
-            ep_old = ep_mid; ep_mid = ep;
+            if (at_check) { ep_old = ep_mid; ep_mid = ep; }
         }
         if (!(ed < 1e12)) { status = 3; break; }
         for (;;) {   // monotone barrier update (Fiacco-McCormick, Ipopt constants)
@@ -2694,6 +2800,29 @@ _Pragma("unroll") \
                         hd[u] = ((i >= ITUBE && ((i - ITUBE) & 1)) ? -1.0 : 1.0) * sv - w1[u] * dph[u];
                     }
                 }
+                if (RESTO && el) {      // restoration phase (wave-uniform): elastic rows, oracle/bmpc_oracle.c solve_one
+                    double ev[RUW], eprod = 1.0;
+#pragma unroll
+                    for (int u = 0; u < RUW; u++) { const int id0 = base + WS * u, id = id0 < ni ? id0 : ni - 1; ev[u] = G[sc.E + id]; }
+#pragma unroll
+                    for (int u = 0; u < RUW; u++) {
+                        const int id0 = base + WS * u; const bool ok_ = id0 < ni; const int id = ok_ ? id0 : ni - 1;
+                        const double t = tv[u], nu = nv[u], e = ev[u], z = RESTO_RHO - nu, nuh = mu * tiv[u] + sr[u];
+                        const double dnu = nuh - nu + sg[u] * hd[u], dt = mu / nu - t - t / nu * dnu, de = mu / z - e + e / z * dnu;
+                        WL[sc.DT + id] = dt; G[sc.DNU + id] = dnu; G[sc.DE + id] = de;
+                        const bool c1 = ok_ && dt < 0 && t * pd_ < pn_ * -dt;
+                        pn_ = c1 ? t : pn_; pd_ = c1 ? -dt : pd_;
+                        const bool c1e = ok_ && de < 0 && e * pd_ < pn_ * -de;
+                        pn_ = c1e ? e : pn_; pd_ = c1e ? -de : pd_;
+                        const bool c2 = ok_ && dnu < 0 && nu * dd_ < dn_ * -dnu;
+                        dn_ = c2 ? nu : dn_; dd_ = c2 ? -dnu : dd_;
+                        const bool c2z = ok_ && dnu > 0 && z * dd_ < dn_ * dnu;
+                        dn_ = c2z ? z : dn_; dd_ = c2z ? dnu : dd_;
+                        dbar += ok_ ? -mu * dt / t + (RESTO_RHO - mu / e) * de : 0.0; nhd += ok_ ? nuh * hd[u] : 0.0; th += ok_ ? BMPC_FABS(hv[u] + t - e) : 0.0;
+                        tprod *= ok_ ? t : 1.0; eprod *= ok_ ? e : 1.0; bar += ok_ ? RESTO_RHO * e : 0.0;
+                    }
+                    bar -= mu * BMPC_LOG(eprod);
+                } else {
 #pragma unroll
                 for (int u = 0; u < RUW; u++) {
                     const int id0 = base + WS * u; const bool ok_ = id0 < ni; const int id = ok_ ? id0 : ni - 1;
@@ -2705,6 +2834,7 @@ _Pragma("unroll") \
                     const bool c1 = ok_ && dt < 0 && t * pd_ < pn_ * -dt, c2 = ok_ && dnu < 0 && nu * dd_ < dn_ * -dnu;
                     pn_ = c1 ? t : pn_; pd_ = c1 ? -dt : pd_; dn_ = c2 ? nu : dn_; dd_ = c2 ? -dnu : dd_;
                     dbar += ok_ ? -mti * dt : 0.0; nhd += ok_ ? nuh * hd[u] : 0.0; th += ok_ ? BMPC_FABS(r) : 0.0; tprod *= ok_ ? t : 1.0;
+                }
                 }
                 bar -= mu * BMPC_LOG(tprod);      // one log per batch of RU slacks: sum of logs = log of the product (t in [1e-12, 1e2])
             }
@@ -2735,8 +2865,8 @@ _Pragma("unroll") \
                 for (int t_ = 0; t_ < (nw + WS - 1) / WS; t_++) { const int id0 = wl + WS * t_, id = id0 < nw ? id0 : nw - 1; W.Zt[id] = W.Zc[id] + alpha * W.Dz[id]; }
             WIDE_END
             BMPC_PROF(W, 9);
-            const LsRows lsr = {alpha, mu};
-            ft = wave_eval(W, po, sc, W.Zt, sc.GT, sc.HT, ls > 0, &lsr);      // also: trial slacks -> TT, theta and barrier sums -> L_RED
+            const LsRows lsr = {alpha, mu, RESTO && el};
+            ft = wave_eval(W, po, sc, W.Zt, sc.GT, sc.HT, ls > 0 || (RESTO && el), &lsr);      // (restoration phase: every trial projected onto the lifted equalities)      // also: trial slacks -> TT, theta and barrier sums -> L_RED
             BMPC_PROF(W, 0);
             const double tht = WRED_GET_SUM(L_REDW, 1), phit = ft + WRED_GET_SUM(L_REDW, 2);
             bool okk = (phit - phit == 0.0) && tht <= theta_max;
@@ -2754,6 +2884,7 @@ _Pragma("unroll") \
 #ifdef BMPC_EMU
         if (o.verbose) fprintf(stderr, "   alpha_p %.3e (max %.3e) alpha_d %.3e delta %.1e acc %d arm %d nfilt %d theta %.3e dphi %.3e\n", alpha, ap, ad, delta, (int)accepted, (int)armijo_step, nfilt, theta, dphi);
 #endif
+        n_short = alpha < RESTO_SHORT_ALPHA ? n_short + 1 : 0;      // jam detection (restoration phase)
         if (!accepted) nfilt = 0;          // smallest step taken, filter reset
         else if (!armijo_step && nfilt < 32) {
             LANES_BEGIN      // (teams: every wave writes the same two words)
@@ -2767,8 +2898,34 @@ _Pragma("unroll") \
                 for (int t_ = 0; t_ < (nw + WS - 1) / WS; t_++) { const int id0 = wl + WS * t_, id = id0 < nw ? id0 : nw - 1; W.Zc[id] = W.Zt[id]; }
             WIDE_END
         } else { double *t_ = W.Zc; W.Zc = W.Zt; W.Zt = t_; }
-        { int t_; t_ = sc.T; sc.T = sc.TT; sc.TT = t_; t_ = sc.G; sc.G = sc.GT; sc.GT = t_; t_ = sc.HIN; sc.HIN = sc.HT; sc.HT = t_; }
+        { int t_; t_ = sc.T; sc.T = sc.TT; sc.TT = t_; t_ = sc.G; sc.G = sc.GT; sc.GT = t_; t_ = sc.HIN; sc.HIN = sc.HT; sc.HT = t_; t_ = sc.E; sc.E = sc.ET; sc.ET = t_; }
         fval = ft;
+        if (RESTO && el) {      // restoration phase: the same pass for elastic rows (see BMPC_ROWS_CENTRE for what it leaves to the Newton system)
+        WIDE_BEGIN
+            double ep = 0, cmax = -1e300, cmin = 1e300, sn = 0, hm = -1e300;
+            for (int tr_ = 0; tr_ < (ni + WS * RUW - 1) / (WS * RUW); tr_++) { const int base = wl + tr_ * WS * RUW;
+                double tv[RUW], nv[RUW], dv[RUW], hv[RUW], ev[RUW];
+#pragma unroll
+                for (int u = 0; u < RUW; u++) {
+                    const int id0 = base + WS * u, id = id0 < ni ? id0 : ni - 1;
+                    tv[u] = WL[sc.T + id]; nv[u] = WL[sc.NUm + id]; dv[u] = G[sc.DNU + id]; hv[u] = WL[sc.HIN + id]; ev[u] = G[sc.E + id];
+                }
+#pragma unroll
+                for (int u = 0; u < RUW; u++) {
+                    const int id = base + WS * u; const bool ok_ = id < ni;
+                    const double t = tv[u], e = ev[u], ti = 1.0 / t; double nu = nv[u] + ad * dv[u];
+                    const double lo = mu * ti * 1e-10, hi = 1e10 * mu * ti, hi2 = RESTO_RHO - mu / (1e10 * e);
+                    nu = nu < lo ? lo : (nu > hi ? hi : nu); nu = nu > hi2 ? hi2 : nu;
+                    const double z = RESTO_RHO - nu, sgm = 1.0 / (t / nu + e / z);
+                    { const int ic = ok_ ? id : ni - 1; WL[sc.NU2 + ic] = nu; WL[sc.SG + ic] = sgm; WL[sc.TI + ic] = sgm * (1.0 / nu - 1.0 / z); WL[sc.SR + ic] = nu + sgm * hv[u]; }
+                    const double v = ok_ ? BMPC_FABS(hv[u] + t - e) : 0.0, c = nu * t, c2 = z * e;
+                    ep = v > ep ? v : ep; cmax = (ok_ && c > cmax) ? c : cmax; cmin = (ok_ && c < cmin) ? c : cmin; cmax = (ok_ && c2 > cmax) ? c2 : cmax; cmin = (ok_ && c2 < cmin) ? c2 : cmin;
+                    sn += ok_ ? nu : 0.0; hm = (ok_ && hv[u] > hm) ? hv[u] : hm;
+                }
+            }
+            WRED_PUT_MAX(L_KKPW, 0, ep); WRED_PUT_MAX(L_KKPW, 1, cmax); WRED_PUT_MIN(L_KKPW, 2, cmin); WRED_PUT_SUM(L_KKPW, 3, sn); WRED_PUT_MAX(L_KKPW, 4, hm);
+        WIDE_END
+        } else {
         WIDE_BEGIN
             double ep = 0, cmax = -1e300, cmin = 1e300, sn = 0;
             for (int tr_ = 0; tr_ < (ni + WS * RUW - 1) / (WS * RUW); tr_++) { const int base = wl + tr_ * WS * RUW;      /* wave-uniform trip count */
@@ -2793,12 +2950,20 @@ _Pragma("unroll") \
             }
             WRED_PUT_MAX(L_KKPW, 0, ep); WRED_PUT_MAX(L_KKPW, 1, cmax); WRED_PUT_MIN(L_KKPW, 2, cmin); WRED_PUT_SUM(L_KKPW, 3, sn);
         WIDE_END
+        }
         { const int t_ = sc.NUm; sc.NUm = sc.NU2; sc.NU2 = t_; }
     }
+    if (RESTO && el) {      // ended inside the restoration phase: the objective of the original problem at the final point
+        BMPC_WEIGHTS(false)
+        fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);
+    }
     // ---- outputs in the reference's conventions (casadi nlpsol: x, g, lam_g, lam_x, f) ----
+    // (wave-uniform trip counts on clamped indices -- lanes past the end rewrite the last entry with the same value: a lane-dependent loop exit makes
+    // the compiler restore the exec mask behind the loop, which is where this toolchain has placed register copies under the stale mask; build.py lint_isa)
     WIDE_BEGIN
-        if (pr.x) for (int id = wl; id < nw; id += WS) pr.x[id] = W.Zc[id];
-        for (int id = wl; id < N * NG; id += WS) {
+        if (pr.x) for (int t_ = 0; t_ < (nw + WS - 1) / WS; t_++) { const int id0 = wl + WS * t_, id = id0 < nw ? id0 : nw - 1; pr.x[id] = W.Zc[id]; }
+        for (int t_ = 0; t_ < (N * NG + WS - 1) / WS; t_++) {
+            const int id0 = wl + WS * t_, id = id0 < N * NG ? id0 : N * NG - 1;
             const int k = id / NG, i = id - k * NG;
             const double *Zn = W.Zc + k * NZ; const LPtr rr = WL + sc.REF + k * RREC, nu = WL + sc.NUm + k * NI;
             double gv, lv;
@@ -2809,16 +2974,17 @@ _Pragma("unroll") \
             if (pr.g) pr.g[id] = gv;
             if (pr.lam_g) pr.lam_g[id] = lv;
         }
-        if (pr.lam_x) for (int id = wl; id < nw; id += WS) {
+        if (pr.lam_x) for (int t_ = 0; t_ < (nw + WS - 1) / WS; t_++) {
+            const int id0 = wl + WS * t_, id = id0 < nw ? id0 : nw - 1;
             const int k = id / NZ, z = id - k * NZ; const LPtr nu = WL + sc.NUm + k * NI; double v = 0;
             if (z < 8) v = nu[IJU + z] - nu[IJL + z]; else if (z < ZDQ) v = nu[IQU + z - ZQ] - nu[IQL + z - ZQ];
             else if (z < ZDDQ) v = nu[IDQU + z - ZDQ] - nu[IDQL + z - ZDQ]; else if (z == ZPHI) v = -nu[IPHI0];
             pr.lam_x[id] = v;
         }
-        if (pr.state) for (int id = wl; id < ni; id += WS) pr.state[id] = WL[sc.NUm + id];
+        if (pr.state) for (int t_ = 0; t_ < (ni + WS - 1) / WS; t_++) { const int id0 = wl + WS * t_, id = id0 < ni ? id0 : ni - 1; pr.state[id] = WL[sc.NUm + id]; }
         if (wl == 0) {
             if (pr.f) *pr.f = fval; if (pr.iters) *pr.iters = it; if (pr.status) *pr.status = status; if (pr.kkt) *pr.kkt = E0;
-            if (pr.state) { pr.state[ni] = mu; pr.state[ni + 1] = (double)it; }
+            if (pr.state) { pr.state[ni] = ((RESTO && el) || status == 4) ? 0.0 : mu; pr.state[ni + 1] = (double)it; }      // (a solve that ends inside the restoration phase leaves no dual state worth carrying)
         }
     WIDE_END
 }

@@ -14,7 +14,8 @@ NZ, NG = 44, 43
 
 
 class BatchedOCPSolver:
-    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=None, slack_push=None, exact_hessian=True, mu_warm=1e-2, stall_window=None, bound_margin=0.0):
+    def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=None, slack_push=None, exact_hessian=True, mu_warm=1e-2, stall_window=None, bound_margin=0.0,
+                 restoration=None, resto_short=None, resto_cap=None):
         self._lib = _lib.load()
         o = _lib.Options()
         self._lib.bmpc_default_options_for(int(N), ctypes.byref(o))      # mu_init 0.1 / slack_push 1e-2 for N <= 11, 3.0 / 0.1 for longer horizons
@@ -29,6 +30,10 @@ class BatchedOCPSolver:
             o.stall_window = int(stall_window)      # default: 40 for N <= 11, 20 for longer horizons (bmpc_default_options_for)
         self._h = ctypes.c_void_p()
         _lib.check(self._lib.bmpc_create(int(N), int(S), float(dt), ctypes.byref(o), ctypes.byref(self._h)), "bmpc_create")
+        # restoration phase (include/boundmpc_hip.h bmpc_set_restoration): None keeps the handle's default (on for N <= 11; 6 short steps; 40 iterations)
+        if not (restoration is None and resto_short is None and resto_cap is None):
+            _lib.check(self._lib.bmpc_set_restoration(self._h, -1 if restoration is None else int(bool(restoration)), -1 if resto_short is None else int(resto_short),
+                                                      -1 if resto_cap is None else int(resto_cap)), "bmpc_set_restoration")
         self.N, self.S, self.dt = int(N), int(S), float(dt)
         self.n_w, self.n_g, self.n_p = N * NZ, N * NG, 141 + 91 * S
         self.state_len = int(self._lib.bmpc_state_len(self._h))
@@ -70,6 +75,11 @@ class BatchedOCPSolver:
         g, l, s = ctypes.c_int(), ctypes.c_int(), ctypes.c_longlong()
         self._lib.bmpc_launch_info(self._h, ctypes.byref(g), ctypes.byref(l), ctypes.byref(s))
         return dict(grid=g.value, lds_bytes=l.value, scratch_bytes=s.value)
+
+    def set_restoration(self, enabled=None, short_steps=None, cap=None):
+        """Restoration phase of the solver (include/boundmpc_hip.h bmpc_set_restoration).  None keeps a value.  Re-capture graphs after changing it."""
+        _lib.check(self._lib.bmpc_set_restoration(self._h, -1 if enabled is None else int(bool(enabled)), -1 if short_steps is None else int(short_steps),
+                                                  -1 if cap is None else int(cap)), "bmpc_set_restoration")
 
     def set_team_waves(self, waves=0):
         """Waves per problem: 0 (default) automatic -- a batch that fits into the resident teams of the device (256 on an MI355X) is solved by

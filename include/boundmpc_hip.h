@@ -22,9 +22,10 @@
  *   x0, x  [B][44*N]  stage variables z_k = [u(7) u_phi | q dq ddq | p(6) | v(6) | phi dphi ddphi] (:90-153)
  *   g      [B][43*N]  constraints in the reference's order/form (:272-349)
  *   lam_g  [B][43*N]  multipliers of g (sign: L = f + lam_g.g), lam_x [B][44*N] multipliers of lbx <= x <= ubx
- *   f, kkt [B], iters [B], status [B]  (0 converged, 1 max_iter reached, 2 stalled at a point of local infeasibility -- the primal
- *                                        infeasibility has not halved over `stall_window` iterations (40 for N <= 11; 20 for longer horizons,
- *                                        where up to three barrier restarts from the stalled iterate come first) --, 3 numerical failure)
+ *   f, kkt [B], iters [B], status [B]  (0 converged, 1 max_iter reached, 2 locally infeasible -- N <= 11: the restoration phase
+ *                                        (bmpc_set_restoration) converged to a point whose constraint violation is not zero, or did not reach a
+ *                                        feasible point within its budget; longer horizons: the primal infeasibility has not halved over
+ *                                        `stall_window` iterations after up to three barrier restarts from the stalled iterate --, 3 numerical failure)
  * lbx/ubx/lbg/ubg are structural constants of the formulation (robot limits, 36 equalities
  * + 7 inequalities per stage) and do not cross the ABI per call; bmpc_get_bounds returns them.
  *
@@ -54,9 +55,9 @@ typedef struct {
     int exact_hessian;  /* 1: exact Lagrangian Hessian (reference uses CasADi's exact Hessian); 0: Gauss-Newton */
     int verbose;
     double mu_warm;     /* warm start (bmpc_solve_batch_warm): the barrier restarts at clamp(stored mu, mu_warm, mu_init); default 1e-2 (round 2: closed loops converge in 9.5 instead of 11.2 iterations with it; 1e-4 jams the iterate against moved constraints) */
-    int stall_window;   /* status 2 when the primal infeasibility has not halved over this many iterations (checked every
-                           stall_window/2 iterations); 0 = never; default 40 for N <= 11, 20 for longer horizons (reference: Ipopt's restoration
-                           phase / "local infeasibility").  Warm-started receding-horizon streams converge in ~10-12 iterations: 16 is the
+    int stall_window;   /* the main phase counts as stalled when the primal infeasibility has not halved over this many iterations (checked every
+                           stall_window/2 iterations); 0 = never; default 40 for N <= 11, 20 for longer horizons.  A stall starts the restoration
+                           phase (bmpc_set_restoration; N <= 11) or a barrier restart / status 2 (longer horizons, or restoration off).  Warm-started receding-horizon streams converge in ~10-12 iterations: 16 is the
                            recommended value there (a stream that is losing its plan runs every solve to this test and a batched tick lasts as
                            long as its slowest stream: 256 closed loops, tick p50 7.1 -> 3.0 ms with the same streams keeping their plan) */
     double bound_margin;/* joint position / velocity limits tightened by this much (rad, rad/s) INSIDE the solver; default 0 = the reference's limits
@@ -66,6 +67,9 @@ typedef struct {
 
 enum { BMPC_OK = 0, BMPC_ERR_ARG = 1, BMPC_ERR_HIP = 2, BMPC_ERR_NOGPU = 4 };
 
+/* ABI note: bmpc_options grew by `bound_margin` in round 4 (appended).  A caller compiled against an older header passes a shorter struct:
+ * compare sizeof(bmpc_options) with bmpc_options_size() before bmpc_create.  Later additions are handle setters (bmpc_set_restoration), not fields. */
+int bmpc_options_size(void);
 int bmpc_default_options(bmpc_options *o);                 /* the N <= 11 defaults */
 int bmpc_default_options_for(int N, bmpc_options *o);      /* defaults for horizon N; what bmpc_create(…, NULL, …) uses */
 const char *bmpc_error_string(int code);
@@ -74,6 +78,22 @@ const char *bmpc_error_string(int code);
  * lives in the workspace instead of LDS at every horizon, as it does for N > 11), dt sampling time */
 int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bmpc_handle **out);
 int bmpc_destroy(bmpc_handle *h);
+
+/* Restoration phase -- what stands where Ipopt's filter line search falls back to its restoration phase (BoundMPC.py:135 'line_search_method':
+ * 'filter'; Waechter & Biegler 2006, 3.3).  When the main interior-point phase is jammed (`short_steps` consecutive steps shorter than 10 % with the
+ * primal infeasibility still open; default 6) or its stall test fires, the solve switches to the feasibility problem
+ *     min  rho * sum_i e_i   s.t.  dynamics,  h_i(x) - e_i <= 0,  e_i >= 0      (rho = 1000: the l1 norm of the violation, objective weights zero),
+ * solved by the same interior-point iteration on the same stage-wise Riccati recursion (the elastic variables are eliminated row by row), and
+ *   - returns to the main phase from the first strictly feasible iterate (slacks and multipliers re-centred there), or
+ *   - ends the solve with status 2 when it converges to a point with non-zero violation (a local minimiser of the violation: Ipopt's
+ *     "converged to a point of local infeasibility"), when `cap` iterations (default 40) did not produce a feasible point (Ipopt: "restoration
+ *     failed"), or at the fourth call within one solve.
+ * enabled: 1 / 0; default 1 for N <= 11, 0 for longer horizons (there three barrier restarts stand in: the restoration phase rescues 11 of the 27
+ * problems of BASELINE configs[3] that end as status 2, but the slowest problem of that launch then takes 314 instead of 180 iterations).
+ * A negative argument keeps the current value.  Read at launch / capture time.  Fixture g13b (every first failing tick of 256 closed loops): the 28
+ * locally infeasible problems end as status 2 after 22-54 iterations, 8 of the 10 feasible ones converge in 64-128. */
+int bmpc_set_restoration(bmpc_handle *h, int enabled, int short_steps, int cap);
+int bmpc_get_restoration(const bmpc_handle *h, int *enabled, int *short_steps, int *cap);
 
 int bmpc_num_vars(const bmpc_handle *h);    /* 44 N */
 int bmpc_num_cons(const bmpc_handle *h);    /* 43 N */

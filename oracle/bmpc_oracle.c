@@ -74,6 +74,15 @@ static const double DQ_LIM_DEG[7] = {85, 85, 100, 75, 130, 135, 135};
 #define STALL_RESTARTS 3        /* barrier restarts from a stalled iterate before status 2 (long horizons only) */
 #define STALL_RESTART_MU 3.0
 #define STALL_RESTART_PUSH 1e-1
+#define RESTO_RHO 1e3          /* restoration phase: l1 penalty of the elastic variables (Ipopt's resto_penalty_parameter: 1000) */
+#define RESTO_MU 1.0           /* its first barrier level */
+#define RESTO_MU_BACK 1.0      /* barrier level of the main phase when it resumes from the feasible point (0.1: 7 instead of 8 of g13b's feasible ticks converge) */
+#define RESTO_PUSH_BACK 1e-6   /* smallest slack there (the rows are strictly satisfied: t = -h) */
+#define RESTO_SHORT_ALPHA 0.1  /* a step shorter than this is "short" (jam detection) */
+#define RESTO_REL 1e-3         /* the restoration phase counts as converged at a KKT error of RESTO_REL * rho * (largest violation) */
+#define RESTO_MARGIN 1e-6      /* strictly feasible: max h <= -RESTO_MARGIN ... */
+#define RESTO_GTOL 1e-4        /* ... and equality residuals below this */
+#define RESTO_MAX 3            /* restoration phases per solve */
 #define KAPPA_EPS 100.0 /* barrier problem "solved" when its KKT error <= KAPPA_EPS * mu (Ipopt barrier_tol_factor, default 10) */
 #define PI 3.14159265358979323846
 
@@ -87,6 +96,9 @@ typedef struct {
     int verbose;
     double mu_warm;      /* warm start: barrier restarts at clamp(stored mu, mu_warm, mu_init) */
     int stall_window;    /* 40; 0 = off */
+    int restoration;     /* 1: a jammed or stalled main phase hands over to the restoration phase (solve_one; default for N <= 11); 0: status 2 / barrier restarts */
+    int resto_short;     /* consecutive steps shorter than RESTO_SHORT_ALPHA that count as a jam (6; 0 = the stall test alone) */
+    int resto_cap;       /* iterations one restoration phase may take before the solve ends as status 2 (40) */
 } bmpc_oracle_opts;
 
 typedef struct {
@@ -347,6 +359,7 @@ typedef struct {
     double *A;        /* [N][35][43] */
     double *rdyn;     /* [N][35] */
     double *Zt, *tt;  /* trial point */
+    double *e, *et, *de; /* [N][57] elastic variables of the restoration phase, their trial values and directions */
 } Work;
 
 static Work *work_alloc(int N) {
@@ -356,14 +369,14 @@ static Work *work_alloc(int N) {
     W->Z = AL(N * NZ); W->t = AL(N * NI); W->nu = AL(N * NI); W->lam = AL(N * NE); W->g = AL(N * NE); W->hin = AL(N * NI);
     W->gradZ = AL(N * NZ); W->Rj = AL(N * NU); W->dZ = AL(N * NZ); W->dt = AL(N * NI); W->dnu = AL(N * NI);
     W->Kg = AL(N * NU * NS); W->kff = AL(N * NU); W->Qt = AL(N * NS * NS); W->qt = AL(N * NS); W->Xt = AL(N * NS * NS);
-    W->T = AL(N * NZ * NS); W->rloc = AL(N * NZ); W->A = AL(N * NS * NW); W->rdyn = AL(N * NS); W->Zt = AL(N * NZ); W->tt = AL(N * NI);
+    W->T = AL(N * NZ * NS); W->rloc = AL(N * NZ); W->A = AL(N * NS * NW); W->rdyn = AL(N * NS); W->Zt = AL(N * NZ); W->tt = AL(N * NI); W->e = AL(N * NI); W->et = AL(N * NI); W->de = AL(N * NI);
     W->Kp = (Kin *)calloc(N, sizeof(Kin)); W->Kv = (Kin *)calloc(N, sizeof(Kin)); W->R = (NodeRef *)calloc(N, sizeof(NodeRef));
     return W;
 }
 static void work_free(Work *W) {
     free(W->Z); free(W->t); free(W->nu); free(W->lam); free(W->g); free(W->hin); free(W->gradZ); free(W->Rj); free(W->dZ); free(W->dt);
     free(W->dnu); free(W->Kg); free(W->kff); free(W->Qt); free(W->qt); free(W->Xt); free(W->T); free(W->rloc); free(W->A); free(W->rdyn);
-    free(W->Zt); free(W->tt); free(W->Kp); free(W->Kv); free(W->R); free(W);
+    free(W->Zt); free(W->tt); free(W->e); free(W->et); free(W->de); free(W->Kp); free(W->Kv); free(W->R); free(W);
 }
 
 /* node k (0..N) accessors: node 0 from parameters, node k>=1 = Z[k-1] */
@@ -887,25 +900,56 @@ static void ineq_dir(const NodeRef *R, const double *dZ, double *out) {
  * ---------------------------------------------------------------------------------------- */
 typedef struct { int iters, status; double f, kkt, mu; } SolveInfo;
 
-static void kkt_errors(const Cfg *C, const Work *W, double mu, double *ed, double *ep, double *ec, double *sd, double *sc) {
+/* el != 0: elastic rows (restoration phase): row residual h + t - e, second complementarity (rho - nu) e = mu */
+static void kkt_errors(const Cfg *C, const Work *W, double mu, int el, double *ed, double *ep, double *ec, double *sd, double *sc) {
     const int N = C->N;
     double d = 0, p = 0, c = 0, sl = 0, sn = 0;
     for (int i = 0; i < N * NU; i++) d = fmax(d, fabs(W->Rj[i]));
     for (int i = 0; i < N * NE; i++) { p = fmax(p, fabs(W->g[i])); sl += fabs(W->lam[i]); }
-    for (int i = 0; i < N * NI; i++) { p = fmax(p, fabs(W->hin[i] + W->t[i])); c = fmax(c, fabs(W->nu[i] * W->t[i] - mu)); sn += W->nu[i]; }
+    for (int i = 0; i < N * NI; i++) {
+        p = fmax(p, fabs(W->hin[i] + W->t[i] - (el ? W->e[i] : 0.0))); c = fmax(c, fabs(W->nu[i] * W->t[i] - mu)); sn += W->nu[i];
+        if (el) c = fmax(c, fabs((RESTO_RHO - W->nu[i]) * W->e[i] - mu));
+    }
     *ed = d; *ep = p; *ec = c;
     *sd = fmax(100.0, (sl + sn) / (N * (NE + NI))) / 100.0;
     *sc = fmax(100.0, sn / (N * NI)) / 100.0;
 }
 
+/* centred start of an elastic row with value h at barrier level mu:  nu t = mu, (rho - nu) e = mu, h + t - e = 0
+ * (the root in (0, rho) of  h nu^2 + (2 mu - h rho) nu - mu rho = 0, in its cancellation-free form) */
+static inline void elastic_centre(double h, double mu, double rho, double *t, double *e, double *nu) {
+    const double v = 2.0 * mu * rho / (2.0 * mu - h * rho + sqrt(4.0 * mu * mu + h * h * rho * rho));
+    *nu = v; *t = mu / v; *e = mu / (rho - v);
+}
+
 /* `state` (may be NULL): dual state of a receding-horizon stream, [nu (N*57) | mu | iterations of the last call].
  * mu <= 0 on entry means "no state": cold start.  On exit the final multipliers and barrier are stored.
  * Warm start: mu0 = clamp(stored mu, mu_warm, mu_init); t = max(-h(x0), min(mu0 / nu_stored, slack_push)),
- * nu = mu0 / t -- active rows keep their multiplier, inactive rows are re-centred at their new slack. */
+ * nu = mu0 / t -- active rows keep their multiplier, inactive rows are re-centred at their new slack.
+ *
+ * RESTORATION PHASE (round 5; what Ipopt's filter line search falls back to, BoundMPC.py:135 `line_search_method: filter`, Waechter & Biegler
+ * 2006 section 3.3).  The main phase is an infeasible-start method: every residual shrinks by the factor (1 - alpha) of the ONE step length, so
+ * when the fraction-to-the-boundary rule of a few rows cuts alpha to 1e-2...1e-5 the iterate is jammed (the failing closed-loop ticks of fixture
+ * g13b crawl like that for hundreds of iterations).  When the main phase has taken `resto_short` consecutive steps shorter than
+ * RESTO_SHORT_ALPHA with the primal infeasibility still open (or its stall test fires), the solve switches to the FEASIBILITY PROBLEM
+ *      min  rho * sum_i e_i     s.t.  dynamics equalities,  h_i(Z) - e_i <= 0,  e_i >= 0          (rho = RESTO_RHO, the l1 norm of the violation)
+ * -- the objective weights are zero (a copy of p), every inequality row gets an elastic variable e_i with its own barrier term, eliminated row by
+ * row like the slack (sigma = 1 / (t/nu + e/(rho - nu)), nu in (0, rho)), so the Newton system keeps its stage structure and the same Riccati
+ * recursion solves it; rows start centred with zero residual (elastic_centre), all trial points are projected onto the lifted equalities.  It ends
+ *   * BACK IN THE MAIN PHASE at the first iterate that is strictly feasible (max h <= -RESTO_MARGIN, equality residual <= RESTO_GTOL) or when it
+ *     converges with no violation left: slacks t = -h, multipliers nu = mu/t on the level RESTO_MU_BACK, filter and inertia history cleared;
+ *   * with STATUS 2 when it converges (scaled KKT error <= max(1e-6, RESTO_REL * rho * violation)) to a point whose violation is not zero -- a
+ *     local minimiser of the violation, Ipopt's "converged to a point of local infeasibility" -- or when `resto_cap` iterations did not produce a
+ *     feasible point (Ipopt: "restoration failed"), or at the fourth call in one solve. */
 static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, SolveInfo *info, double *state) {
     const int N = C->N;
     Par Pp; par_view(p, C->S, &Pp); const Par *P = &Pp;
     const bmpc_oracle_opts *o = &C->o;
+    double *pr = (double *)malloc(C->np * sizeof(double)); memcpy(pr, p, C->np * sizeof(double));       /* p with zero objective weights */
+    { const int wo = (int)(Pp.w - p); for (int i = 0; i < 15; i++) pr[wo + i] = 0.0; }
+    Par PRv; par_view(pr, C->S, &PRv);
+    const double rho = RESTO_RHO;
+    int el = 0; const Par *Pc = P;
     memcpy(W->Z, x0, sizeof(double) * N * NZ);
     const int warm = state && state[N * NI] > 0.0;
     double mu = warm ? fmin(o->mu_init, fmax(state[N * NI], o->mu_warm)) : o->mu_init;
@@ -919,33 +963,61 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
     double *sg = (double *)malloc(N * NI * sizeof(double)), *nuh = (double *)malloc(N * NI * sizeof(double));
     double *gf = (double *)malloc(N * NZ * sizeof(double)), *zero_nu = (double *)calloc(N * NI, sizeof(double));
     double *hdir = (double *)malloc(NI * sizeof(double)), *gt = (double *)malloc(N * NE * sizeof(double)), *ht = (double *)malloc(N * NI * sizeof(double));
-    int it = 0, status = 1, n_restart = 0, it_restart = 0;
+    int it = 0, status = 1, n_restart = 0, it_restart = 0, n_resto = 0, it_resto = 0, n_short = 0;
     double E0 = 0, ep_old = 0, ep_mid = 0;
     for (it = 0; it <= o->max_iter; it++) {
-        ORACLE_REGION(REG_ADJOINT); adjoint(C, P, W, W->Z, W->nu, W->lam, W->Rj, W->gradZ); ORACLE_REGION(REG_DRIVER);
+        ORACLE_REGION(REG_ADJOINT); adjoint(C, Pc, W, W->Z, W->nu, W->lam, W->Rj, W->gradZ); ORACLE_REGION(REG_DRIVER);
         double ed, ep, ec0, ecm, sd, sc;
-        ORACLE_REGION(REG_KKT); kkt_errors(C, W, 0.0, &ed, &ep, &ec0, &sd, &sc); ORACLE_REGION(REG_DRIVER);
+        ORACLE_REGION(REG_KKT); kkt_errors(C, W, 0.0, el, &ed, &ep, &ec0, &sd, &sc); ORACLE_REGION(REG_DRIVER);
         E0 = fmax(fmax(ed / sd, ep), ec0 / sc);
-        if (o->verbose) fprintf(stderr, "it %3d f %.8e dual %.2e prim %.2e compl %.2e mu %.1e\n", it, W->f, ed, ep, ec0, mu);
-        if (E0 <= o->tol) { status = 0; break; }
+        if (o->verbose) fprintf(stderr, "it %3d %s f %.8e dual %.2e prim %.2e compl %.2e mu %.1e\n", it, el ? "R" : " ", W->f, ed, ep, ec0, mu);
+        if (!el) { if (E0 <= o->tol) { status = 0; break; } }
+        else {      /* restoration phase: back to the main phase, locally infeasible, or go on */
+            double hmax = -1e300, gmax = 0;
+            for (int i = 0; i < N * NI; i++) hmax = fmax(hmax, W->hin[i]);
+            for (int i = 0; i < N * NE; i++) gmax = fmax(gmax, fabs(W->g[i]));
+            const double vmax = fmax(hmax, gmax), rtol = fmax(fmax(o->tol, 1e-6), RESTO_REL * rho * vmax);
+            const int back = (hmax <= -RESTO_MARGIN && gmax <= RESTO_GTOL) || (E0 <= rtol && vmax <= 1e-6);
+            if (!back && (E0 <= rtol || it - it_resto >= o->resto_cap)) { status = 2; break; }
+            if (back) {
+                el = 0; Pc = P; mu = RESTO_MU_BACK;
+                ORACLE_REGION(REG_EVAL); W->f = eval_values(C, P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0); ORACLE_REGION(REG_DRIVER);
+                for (int i = 0; i < N * NI; i++) { W->t[i] = fmax(-W->hin[i], RESTO_PUSH_BACK); W->nu[i] = mu / W->t[i]; }
+                nfilt = 0; filt_mu = -1.0; theta_min = -1.0; delta_last = 0.0; delta_prev = 0.0; gn_run = 0; n_short = 0;
+                ep_old = ep_mid = 1e300; it_restart = it;
+                if (o->verbose) fprintf(stderr, "   back from the restoration phase after %d iterations\n", it - it_resto);
+                continue;
+            }
+        }
         if (it == o->max_iter) break;
-        /* stalled primal feasibility (what Ipopt reports as "converged to a point of local infeasibility" after its restoration
-         * phase): every stall_window/2 iterations the primal infeasibility is compared with its value stall_window iterations
-         * earlier; a reduction by less than STALL_FACTOR ends the solve with status 2.  Never fires on problems that converge in < 40
-         * iterations.  (0.5: on the tight long-horizon batch the problems that creep on at 10-30 % per window end as status 2 anyway,
-         * after 150-320 iterations, and a batch launch lasts as long as its slowest problem.)
-         * A dual residual beyond 1e12 is a numerical breakdown (status 3). */
+        /* stalled primal feasibility: every stall_window/2 iterations the primal infeasibility is compared with its value stall_window iterations
+         * earlier; a reduction by less than STALL_FACTOR is a stall.  Never fires on problems that converge in < 40 iterations.  (0.5: on the tight
+         * long-horizon batch the problems that creep on at 10-30 % per window end as status 2 anyway, after 150-320 iterations, and a batch launch
+         * lasts as long as its slowest problem.)  A dual residual beyond 1e12 is a numerical breakdown (status 3).
+         * (the floor of the test scales with the tolerance: a solve that is asked for 1e-5 and sits at 1e-5 is converging, not stalled) */
         if (it == 0) ep_old = ep_mid = 1e300;
-        else if (o->stall_window > 0 && it % (o->stall_window / 2) == 0) {
-            /* (the floor of the test scales with the tolerance: a solve that is asked for 1e-5 and sits at 1e-5 is converging, not stalled) */
-            if (it >= o->stall_window + it_restart && ep >= STALL_FACTOR * ep_old && ep > fmax(1e-6, 10.0 * o->tol)) {
-                /* Long horizons: before giving up, restart the barrier from the CURRENT iterate -- slacks and multipliers re-centred on
-                 * a high barrier level (mu = STALL_RESTART_MU, slack push STALL_RESTART_PUSH), filter and inertia history cleared --
-                 * at most STALL_RESTARTS times.  On the tight 30-stage batch 3.1 % of the problems crawl at the first barrier level
-                 * with boundary-limited steps; with the stall test off 93 % of them do converge (after 130 iterations at the median):
-                 * they are feasible, the iterate is jammed.  From a re-centred iterate 94 % of them converge within ~50 further
-                 * iterations.  (What Ipopt's restoration phase is for; the kernel's N <= 11 instantiation does not carry the path.) */
-                if ((N <= GN_MIN_HORIZON && !getenv("BMPC_ORACLE_RESTART_ALL")) || n_restart >= STALL_RESTARTS) { status = 2; break; }
+        else if (!el) {
+            const int open = ep > fmax(1e-6, 10.0 * o->tol);
+            const int at_check = o->stall_window > 0 && (it - it_restart) % (o->stall_window / 2) == 0;
+            const int stalled = at_check && it >= o->stall_window + it_restart && ep >= STALL_FACTOR * ep_old && open;
+            const int jammed = o->restoration && o->resto_short > 0 && n_short >= o->resto_short && open;
+            if (stalled || jammed) {
+                if (o->restoration) {
+                    if (n_resto >= RESTO_MAX) { status = 2; break; }
+                    n_resto++; it_resto = it; el = 1; Pc = &PRv; W->f = 0.0; mu = RESTO_MU;
+                    for (int i = 0; i < N * NI; i++) elastic_centre(W->hin[i], mu, rho, &W->t[i], &W->e[i], &W->nu[i]);
+                    nfilt = 0; filt_mu = -1.0; theta_min = -1.0; delta_last = 0.0; delta_prev = 0.0; gn_run = 0; n_short = 0;
+                    if (o->verbose) fprintf(stderr, "   %s: restoration phase\n", jammed ? "jammed" : "stalled");
+                    continue;
+                }
+                /* Long horizons without the restoration phase: before giving up, restart the barrier from the CURRENT iterate -- slacks and
+                 * multipliers re-centred on a high barrier level (mu = STALL_RESTART_MU, slack push STALL_RESTART_PUSH), filter and inertia
+                 * history cleared -- at most STALL_RESTARTS times.  On the tight 30-stage batch 3.1 % of the problems crawl at the first
+                 * barrier level with boundary-limited steps; with the stall test off 93 % of them do converge (after 130 iterations at the
+                 * median): they are feasible, the iterate is jammed.  From a re-centred iterate 94 % of them converge within ~50 further
+                 * iterations.  (The restoration phase rescues 11 of the 27 problems of configs[3] that still end as status 2 after three
+                 * restarts, but the slowest problem of the launch then takes 314 iterations instead of 180: off by default for N > 11.) */
+                if (N <= GN_MIN_HORIZON || n_restart >= STALL_RESTARTS) { status = 2; break; }
                 n_restart++; it_restart = it;
                 mu = STALL_RESTART_MU;
                 for (int i = 0; i < N * NI; i++) { W->t[i] = fmax(-W->hin[i], STALL_RESTART_PUSH); W->nu[i] = mu / W->t[i]; }
@@ -953,19 +1025,25 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
                 ep_old = ep_mid = 1e300;
                 continue;
             }
-            ep_old = ep_mid; ep_mid = ep;
+            if (at_check) { ep_old = ep_mid; ep_mid = ep; }
         }
         if (!(ed < 1e12)) { status = 3; break; }
         for (;;) {
-            ORACLE_REGION(REG_KKT); kkt_errors(C, W, mu, &ed, &ep, &ecm, &sd, &sc); ORACLE_REGION(REG_DRIVER);
+            ORACLE_REGION(REG_KKT); kkt_errors(C, W, mu, el, &ed, &ep, &ecm, &sd, &sc); ORACLE_REGION(REG_DRIVER);
             double Emu = fmax(fmax(ed / sd, ep), ecm / sc);
             if (Emu <= KAPPA_EPS * mu && mu > mu_min) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5))); else break;
         }
-        for (int i = 0; i < N * NI; i++) {
+        /* barrier ratios of the rows: sigma (Hessian weight of grad h grad h^T) and the barrier-modified multiplier nu^ of the QP gradient */
+        if (!el) for (int i = 0; i < N * NI; i++) {
             sg[i] = W->nu[i] / W->t[i];
             nuh[i] = (mu + W->nu[i] * (W->hin[i] + W->t[i])) / W->t[i];
         }
-        ORACLE_REGION(REG_BUILD_QP); build_qp(C, P, W, sg, nuh); ORACLE_REGION(REG_DRIVER);
+        else for (int i = 0; i < N * NI; i++) {      /* elastic row: d nu = sigma (grad h . dZ + h + mu/nu - mu/z),  z = rho - nu */
+            const double z = rho - W->nu[i];
+            sg[i] = 1.0 / (W->t[i] / W->nu[i] + W->e[i] / z);
+            nuh[i] = W->nu[i] + sg[i] * (W->hin[i] + mu / W->nu[i] - mu / z);
+        }
+        ORACLE_REGION(REG_BUILD_QP); build_qp(C, Pc, W, sg, nuh); ORACLE_REGION(REG_DRIVER);
         /* Inertia control.  A failed factorisation costs most of a Riccati sweep (the indefinite 8x8 block usually shows up at the
          * first stages, i.e. at the END of the backward sweep), so the attempts are chosen to fail rarely:
          *  - an iteration that follows a regularised one does not try delta = 0 again but a third of the last delta (Ipopt's
@@ -980,7 +1058,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         if (gn_allowed && gn_run > 0 && gn_run % GN_PROBE != GN_PROBE - 1) {
             used_gn = 1;
             Cfg Cgn = *C; Cgn.o.exact_hessian = 0;      /* C is shared between the OpenMP threads: never modified */
-            ORACLE_REGION(REG_BUILD_QP); build_qp(&Cgn, P, W, sg, nuh); ORACLE_REGION(REG_DRIVER);
+            ORACLE_REGION(REG_BUILD_QP); build_qp(&Cgn, Pc, W, sg, nuh); ORACLE_REGION(REG_DRIVER);
         }
         for (int tries = 0; tries < 40; tries++) {
             ORACLE_REGION(REG_RICCATI);
@@ -988,7 +1066,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
             if (gn_allowed && !used_gn) {
                 used_gn = 1;
                 Cfg Cgn = *C; Cgn.o.exact_hessian = 0;
-                ORACLE_REGION(REG_BUILD_QP); build_qp(&Cgn, P, W, sg, nuh); ORACLE_REGION(REG_DRIVER);
+                ORACLE_REGION(REG_BUILD_QP); build_qp(&Cgn, Pc, W, sg, nuh); ORACLE_REGION(REG_DRIVER);
                 ORACLE_REGION(REG_RICCATI);
                 if (riccati(C, W, 0.0)) { ok = 1; delta = 0.0; break; }
             }
@@ -1007,21 +1085,34 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
             ineq_dir(&W->R[k], W->dZ + k * NZ, hdir);
             for (int i = 0; i < NI; i++) {
                 int id = k * NI + i;
-                double r = W->hin[id] + W->t[id];
-                W->dt[id] = -r - hdir[i];
-                W->dnu[id] = mu / W->t[id] - W->nu[id] - sg[id] * W->dt[id];
+                if (!el) {
+                    double r = W->hin[id] + W->t[id];
+                    W->dt[id] = -r - hdir[i];
+                    W->dnu[id] = mu / W->t[id] - W->nu[id] - sg[id] * W->dt[id];
+                } else {
+                    const double z = rho - W->nu[id];
+                    W->dnu[id] = nuh[id] - W->nu[id] + sg[id] * hdir[i];
+                    W->dt[id] = mu / W->nu[id] - W->t[id] - W->t[id] / W->nu[id] * W->dnu[id];
+                    W->de[id] = mu / z - W->e[id] + W->e[id] / z * W->dnu[id];
+                    if (W->de[id] < 0) ap = fmin(ap, -tau * W->e[id] / W->de[id]);
+                    if (W->dnu[id] > 0) ad = fmin(ad, tau * z / W->dnu[id]);
+                    dbar += (rho - mu / W->e[id]) * W->de[id];
+                }
                 if (W->dt[id] < 0) ap = fmin(ap, -tau * W->t[id] / W->dt[id]);
                 if (W->dnu[id] < 0) ad = fmin(ad, -tau * W->nu[id] / W->dnu[id]);
                 dbar += -mu * W->dt[id] / W->t[id];
             }
         }
-        /* filter line search (Waechter & Biegler 2006, Ipopt constants) on theta = ||c||_1 + ||h+t||_1 and
-         * the barrier objective phi = f - mu sum log t */
-        ORACLE_REGION(REG_ADJOINT); adjoint(C, P, W, W->Z, zero_nu, gt, ht, gf); ORACLE_REGION(REG_DRIVER); /* gf = grad f ; gt/ht scratch */
+        /* filter line search (Waechter & Biegler 2006, Ipopt constants) on theta = ||c||_1 + ||h + t (- e)||_1 and
+         * the barrier objective phi = f - mu sum log t  (restoration phase: rho sum e - mu sum log t - mu sum log e) */
+        ORACLE_REGION(REG_ADJOINT); adjoint(C, Pc, W, W->Z, zero_nu, gt, ht, gf); ORACLE_REGION(REG_DRIVER); /* gf = grad f ; gt/ht scratch */
         double gfd = 0; for (int i = 0; i < N * NZ; i++) gfd += gf[i] * W->dZ[i];
         double theta = 0, bar = 0;
         for (int i = 0; i < N * NE; i++) theta += fabs(W->g[i]);
-        for (int i = 0; i < N * NI; i++) { theta += fabs(W->hin[i] + W->t[i]); bar -= mu * log(W->t[i]); }
+        for (int i = 0; i < N * NI; i++) {
+            theta += fabs(W->hin[i] + W->t[i] - (el ? W->e[i] : 0.0)); bar -= mu * log(W->t[i]);
+            if (el) bar += rho * W->e[i] - mu * log(W->e[i]);
+        }
         const double dphi = gfd + dbar, phi0 = W->f + bar;
         if (mu != filt_mu) { nfilt = 0; filt_mu = mu; }
         if (theta_min < 0) { theta_min = 1e-4 * fmax(1.0, theta); theta_max = 1e4 * fmax(1.0, theta); }
@@ -1029,10 +1120,15 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         for (int ls = 0; ls < 14; ls++) {
             for (int i = 0; i < N * NZ; i++) W->Zt[i] = W->Z[i] + alpha * W->dZ[i];
             for (int i = 0; i < N * NI; i++) W->tt[i] = W->t[i] + alpha * W->dt[i];
-            ORACLE_REGION(REG_EVAL); ft = eval_values(C, P, W->Zt, W->Kp, W->Kv, W->R, gt, ht, ls > 0); ORACLE_REGION(REG_DRIVER);
+            if (el) for (int i = 0; i < N * NI; i++) W->et[i] = W->e[i] + alpha * W->de[i];
+            /* (restoration phase: every trial is projected onto the lifted equalities) */
+            ORACLE_REGION(REG_EVAL); ft = eval_values(C, Pc, W->Zt, W->Kp, W->Kv, W->R, gt, ht, ls > 0 || el); ORACLE_REGION(REG_DRIVER);
             double th = 0, br = 0;
             for (int i = 0; i < N * NE; i++) th += fabs(gt[i]);
-            for (int i = 0; i < N * NI; i++) { th += fabs(ht[i] + W->tt[i]); br -= mu * log(W->tt[i]); }
+            for (int i = 0; i < N * NI; i++) {
+                th += fabs(ht[i] + W->tt[i] - (el ? W->et[i] : 0.0)); br -= mu * log(W->tt[i]);
+                if (el) br += rho * W->et[i] - mu * log(W->et[i]);
+            }
             const double phit = ft + br;
             int ok = isfinite(phit) && th <= theta_max;
             for (int j = 0; j < nfilt && ok; j++) if (!(th < filt_th[j] || phit < filt_ph[j])) ok = 0;
@@ -1046,21 +1142,29 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
             if (ok) { accepted = 1; break; }
             if (ls > 0) alpha *= 0.5;   /* trial 1 repeats the step length of trial 0 with the lifted variables projected */
         }
+        n_short = alpha < RESTO_SHORT_ALPHA ? n_short + 1 : 0;
         if (!accepted) { nfilt = 0; if (o->verbose) fprintf(stderr, "   line search failed: smallest step taken, filter reset\n"); }
         else if (!armijo_step && nfilt < 32) { filt_th[nfilt] = (1 - 1e-5) * theta; filt_ph[nfilt] = phi0 - 1e-8 * theta; nfilt++; }
         memcpy(W->Z, W->Zt, sizeof(double) * N * NZ); memcpy(W->t, W->tt, sizeof(double) * N * NI);
+        if (el) memcpy(W->e, W->et, sizeof(double) * N * NI);
         memcpy(W->g, gt, sizeof(double) * N * NE); memcpy(W->hin, ht, sizeof(double) * N * NI);
         W->f = ft;
         for (int i = 0; i < N * NI; i++) {
             double v = W->nu[i] + ad * W->dnu[i];
             double lo = mu / (1e10 * W->t[i]), hi = 1e10 * mu / W->t[i];
             W->nu[i] = fmin(fmax(v, lo), hi);
+            if (el) W->nu[i] = fmin(W->nu[i], rho - mu / (1e10 * W->e[i]));
         }
         if (o->verbose) fprintf(stderr, "   alpha_p %.3e (max %.3e) alpha_d %.3e delta %.1e acc %d arm %d nfilt %d theta %.3e dphi %.3e\n", alpha, ap, ad, delta, accepted, armijo_step, nfilt, theta, dphi);
     }
+    if (el) {      /* ended inside the restoration phase: report the objective of the original problem */
+        ORACLE_REGION(REG_EVAL); W->f = eval_values(C, P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0); ORACLE_REGION(REG_DRIVER);
+    }
     info->iters = it; info->status = status; info->f = W->f; info->kkt = E0; info->mu = mu;
-    if (state) { memcpy(state, W->nu, sizeof(double) * N * NI); state[N * NI] = mu; state[N * NI + 1] = (double)it; }
-    free(sg); free(nuh); free(gf); free(zero_nu); free(hdir); free(gt); free(ht);
+    if (state) {      /* (a solve that ends inside the restoration phase leaves no dual state worth carrying: cold start next time) */
+        memcpy(state, W->nu, sizeof(double) * N * NI); state[N * NI] = el ? 0.0 : mu; state[N * NI + 1] = (double)it;
+    }
+    free(sg); free(nuh); free(gf); free(zero_nu); free(hdir); free(gt); free(ht); free(pr);
 }
 
 /* ------------------------------------------------------------------------------------------
@@ -1068,6 +1172,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
  * ---------------------------------------------------------------------------------------- */
 void bmpc_oracle_default_opts(bmpc_oracle_opts *o) {
     o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0; o->mu_warm = 1e-2; o->stall_window = 40;
+    o->restoration = 1; o->resto_short = 6; o->resto_cap = 40;
 }
 
 static void write_outputs(const Cfg *C, const Par *P, Work *W, double *x, double *g, double *lam_g, double *lam_x) {

@@ -67,6 +67,7 @@ extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, in
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
     const bool poison = getenv("BMPC_EMU_POISON") != nullptr;
+    const bool inkernel = getenv("BMPC_EMU_INKERNEL") != nullptr;
 #pragma omp parallel
     {
         std::vector<double> lds(bmpc::L_SIZE, 0.0), scr(sc.size, 0.0);
@@ -83,7 +84,23 @@ extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, in
             pr.lam_g = lam_g ? lam_g + (size_t)b * ng : nullptr; pr.lam_x = lam_x ? lam_x + (size_t)b * nw : nullptr;
             pr.f = f ? f + b : nullptr; pr.kkt = kkt ? kkt + b : nullptr; pr.iters = iters ? iters + b : nullptr; pr.status = status ? status + b : nullptr;
             pr.state = state ? state + (size_t)b * (N * bmpc::NI + 2) : nullptr;
-            if (N <= 11 && S <= bmpc::SMAX_ZLDS) bmpc::wave_solve<true>(W, pr); else bmpc::wave_solve<false>(W, pr);
+            pr.resto_from = -1;
+            const bool zl = N <= 11 && S <= bmpc::SMAX_ZLDS;
+            if (inkernel) {      // the restoration phase inside the kernel (what the fused closed-loop ticks run)
+                if (zl) bmpc::wave_solve<true, false, true>(W, pr); else bmpc::wave_solve<false, false, true>(W, pr);
+            } else {             // the batch kernels: main phase only; a jammed problem (internal status 4) is continued by the restoration kernel from its iterate
+                std::vector<double> xb(nw); int it_ = 0, st_ = 0;
+                bmpc::Problem q = pr; q.x = xb.data(); q.iters = &it_; q.status = &st_;
+                if (zl) bmpc::wave_solve<true>(W, q); else bmpc::wave_solve<false>(W, q);
+                if (st_ == 4) {
+                    std::vector<double> x0b(xb);
+                    q.x0 = x0b.data(); q.resto_from = it_;
+                    if (zl) bmpc::wave_solve<true, false, true>(W, q); else bmpc::wave_solve<false, false, true>(W, q);
+                }
+                if (pr.x) memcpy(pr.x, xb.data(), sizeof(double) * nw);
+                if (pr.iters) *pr.iters = it_;
+                if (pr.status) *pr.status = st_;
+            }
         }
     }
     return 0;

@@ -76,7 +76,7 @@ extern "C" int bmpc_emu_count_flops(int N, int S, double h, const bmpc::Opts *op
         for (int i = 0; i < 64; i++) W.order[i] = i;
         bmpc::Problem pr; int it = 0, st = 0;
         pr.p = (const Real *)p + (size_t)b * np; pr.x0 = (const Real *)x0 + (size_t)b * nw;
-        pr.x = x.data(); pr.g = nullptr; pr.lam_g = nullptr; pr.lam_x = nullptr; pr.f = nullptr; pr.kkt = nullptr; pr.iters = &it; pr.status = &st; pr.state = nullptr;
+        pr.x = x.data(); pr.g = nullptr; pr.lam_g = nullptr; pr.lam_x = nullptr; pr.f = nullptr; pr.kkt = nullptr; pr.iters = &it; pr.status = &st; pr.state = nullptr; pr.resto_from = -1;
         if (N <= 11 && S <= bmpc::SMAX_ZLDS) bmpc::wave_solve<true>(W, pr); else bmpc::wave_solve<false>(W, pr);
         its += (unsigned long long)it; okc += st == 0;
     }

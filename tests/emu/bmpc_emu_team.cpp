@@ -74,7 +74,8 @@ extern "C" int bmpc_emu_team_solve(int N, int S, double h, const bmpct::Opts *op
             pr.lam_g = lam_g ? lam_g + (size_t)b * ng : nullptr; pr.lam_x = lam_x ? lam_x + (size_t)b * nw : nullptr;
             pr.f = f ? f + b : nullptr; pr.kkt = kkt ? kkt + b : nullptr; pr.iters = iters ? iters + b : nullptr; pr.status = status ? status + b : nullptr;
             pr.state = state ? state + (size_t)b * (N * bmpct::NI + 2) : nullptr;
-            if (N <= 11 && S <= bmpct::SMAX_ZLDS) bmpct::wave_solve<true>(W, pr); else bmpct::wave_solve<false>(W, pr);
+            pr.resto_from = -1;      // (the team text with the restoration phase inside, as the fused team tick runs it; the team BATCH kernel hands jammed problems to the one-wave restoration kernel)
+            if (N <= 11 && S <= bmpct::SMAX_ZLDS) bmpct::wave_solve<true, false, true>(W, pr); else bmpct::wave_solve<false, false, true>(W, pr);
         }
     }
     return 0;
