@@ -28,6 +28,32 @@ _COPY = re.compile(r"(v_accvgpr_(write|read)_b32|scratch_(store|load)_\w+|v_mov_
 _HARMLESS = re.compile(r"(s_\w+|v_readlane_b32|v_writelane_b32)( |$)")
 
 
+def source_hash():
+    """Hash of everything the library is built from: the text of every file in SOURCES and the compiler flags.  It is compiled into the
+    library (bmpc_build_hash(), and as the marker BMPC_BUILD_HASH=... in its bytes): build() rebuilds when the in-tree library carries another
+    hash (not by file times), _lib.load() refuses a library whose hash is not the tree's, and bench.py ties the counter / flop files in
+    profiles/ to it."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in sorted(SOURCES, key=os.path.basename):
+        h.update(os.path.basename(p).encode()); h.update(b"\0")
+        with open(p, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def library_hash(path=None):
+    """The hash a built library carries (None: no library, or one from before round 5)."""
+    path = path or LIB
+    if not os.path.exists(path):
+        return None
+    with open(path, "rb") as fh:
+        m = re.search(rb"BMPC_BUILD_HASH=([0-9a-f]{16})", fh.read())
+    return m.group(1).decode() if m else None
+
+
 def lint_isa(asm_path):
     """Static check of the compiled ISA for one register-allocator defect of this toolchain (ROCm 7.2 LLVM) that silently
     corrupts results: a live-range split / spill copy placed at the top of a control-flow join block BEFORE the instruction
@@ -189,7 +215,7 @@ def _compile_unit(args):
         _lint_unit(src, asm, verbose)
     # -amdgpu-sched-strategy=iterative-ilp: the solver runs at one wave per SIMD, so the scheduler should chase instruction-level
     # parallelism (loads hoisted ahead of their uses), not occupancy; measured 12.7 -> 10.8 ms at B=1024 (profiles/)
-    cmd = [hipcc()] + FLAGS + ["-fPIC", "-c", "-o", obj, src]
+    cmd = [hipcc()] + FLAGS + ["-DBMPC_BUILD_HASH_STR=\"%s\"" % source_hash(), "-fPIC", "-c", "-o", obj, src]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
@@ -198,7 +224,7 @@ def _compile_unit(args):
 
 
 def build(force=False, verbose=False, lint=True):
-    if not force and os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in SOURCES):
+    if not force and library_hash() == source_hash():      # the library in the tree was built from exactly this text with these flags
         return LIB
     from concurrent.futures import ThreadPoolExecutor
     out_dir = os.path.join(HERE, "..", "build", "isa")

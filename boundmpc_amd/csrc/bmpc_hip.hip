@@ -295,6 +295,12 @@ extern "C" int bmpc_get_restoration(const bmpc_handle *h, int *enabled, int *sho
     return BMPC_OK;
 }
 extern "C" int bmpc_options_size(void) { return (int)sizeof(bmpc_options); }
+#ifndef BMPC_BUILD_HASH_STR
+#define BMPC_BUILD_HASH_STR "0000000000000000"
+#endif
+// hash of the source text and compiler flags this library was built from (boundmpc_amd/build.py source_hash); the marker is also found in the file's bytes
+static const char bmpc_build_hash_marker[] = "BMPC_BUILD_HASH=" BMPC_BUILD_HASH_STR;
+extern "C" const char *bmpc_build_hash(void) { return bmpc_build_hash_marker + 16; }
 extern "C" int bmpc_set_team_waves(bmpc_handle *h, int waves) {
     if (!h || (waves != 0 && waves != 1 && waves != BMPC_TEAM_NW)) return BMPC_ERR_ARG;
     if (waves == BMPC_TEAM_NW && h->team_grid <= 0) return BMPC_ERR_ARG;      // no team instantiation for this horizon / window

@@ -496,6 +496,7 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
             const double v = g[id]; const int i = id % 43;
             if (i < 36 && v < -1e-6) part -= v;
             if (v > 1e-6) part += v;
+            if (!(v - v == 0.0)) part += 1e6;      // a non-finite constraint value is a violation, not a pass
         }
         // Real-time mode (flag bit 1) also counts the violation of the VARIABLE bounds lbx <= x <= ubx of the plan (jerks +-35, joint
         // positions and velocities RobotModel.py:20-43, phi >= 0).  The reference's rule looks at g only: an Ipopt iterate satisfies the
@@ -507,9 +508,12 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
                 const int i = id % 44; const double v = x[id];
                 double lim = -1.0;
                 if (i < 8) lim = 35.0; else if (i < 15) lim = qd[i - 8] * (3.14159265358979323846 / 180.0); else if (i < 22) lim = dqd[i - 15] * (3.14159265358979323846 / 180.0);
-                // strict: a plan with ANY entry outside its bounds counts as grossly infeasible (+1e6: recognisable in the reported violation)
-                if (lim > 0.0 && (v > lim || v < -lim)) part += 1e6;
-                if (i == 41 && v < 0.0) part += 1e6;
+                // strict: a plan with ANY entry outside its bounds counts as grossly infeasible (+1e6: recognisable in the reported violation).
+                // The tests are written so that a NaN entry FAILS them, with the slack of the solver's own bound rows (a converged iterate
+                // sits up to ~tol outside an active bound: 1e-9) -- a converged plan with an active jerk or phi bound is not vetoed
+                if (lim > 0.0 && !(v <= lim + 1e-9 && v >= -lim - 1e-9)) part += 1e6;
+                if (i == 41 && !(v >= -1e-9)) part += 1e6;
+                if (lim <= 0.0 && i != 41 && !(v - v == 0.0)) part += 1e6;      // non-finite entries of the unbounded variables
             }
             // ... and the trajectory the plant would actually follow: the joint chains re-integrated from the measured state with the plan's
             // jerks (phase 1 below does the same for the return data).  A plan may satisfy its own bounds and still be off its dynamics rows
@@ -520,7 +524,7 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
                 for (int i = 0; i < N; i++) {
                     const double u = x[i * 44 + j];
                     chain_step(a, da, dda, up, u, h); up = u;
-                    if (a > ql || a < -ql || da > dql || da < -dql) part += 1e6;
+                    if (!(a <= ql && a >= -ql && da <= dql && da >= -dql)) part += 1e6;      // (a NaN fails)
                 }
             }
         }

@@ -82,7 +82,9 @@ def apply_update(ss, N, S, pos_points, rot_points, pos_lim, rot_lim, bp1, br1, s
     modified in place): new path table (returned, [entries][48]) and window start, path-parameter state projected onto the new first
     segment from the measured Cartesian state (p0, v, a, jerk), rotation reference, phi_max, weights, and the `updated` flag that
     switches the device's warm start to the re-projection branch of step() for good (the reference never clears it).  The previous
-    solution, its Cartesian derivatives and the error count stay, as in the reference."""
+    solution, its Cartesian derivatives and the error count stay, as in the reference -- with one exception: a stream that had LOST its plan
+    (error count >= N: the fused tick skips such a stream, status 3) is given a new attempt, its error count goes back to N - 1, so the tick after
+    a re-planning solves it again on every launch shape (one more failure loses it again, a success resets the count as in BoundMPC.py:468)."""
     from .reference_path import ReferencePath
     from .bound_mpc import integrate_rotation_reference
     rp = ReferencePath(pos_points, rot_points, pos_lim, rot_lim, bp1, br1, s, e_p_min, e_r_min, e_p_max, e_r_max, S)
@@ -101,6 +103,8 @@ def apply_update(ss, N, S, pos_points, rot_points, pos_lim, rot_lim, bp1, br1, s
     ss[SS["W"]:SS["W"] + 15] = np.asarray(weights, dtype=float)
     ss[SS["NENT"]] = M
     ss[ss_updated(N)] = 1.0
+    if ss[SS["ERRCNT"]] >= N:
+        ss[SS["ERRCNT"]] = N - 1
     return T, M
 
 

@@ -70,6 +70,8 @@ enum { BMPC_OK = 0, BMPC_ERR_ARG = 1, BMPC_ERR_HIP = 2, BMPC_ERR_NOGPU = 4 };
 /* ABI note: bmpc_options grew by `bound_margin` in round 4 (appended).  A caller compiled against an older header passes a shorter struct:
  * compare sizeof(bmpc_options) with bmpc_options_size() before bmpc_create.  Later additions are handle setters (bmpc_set_restoration), not fields. */
 int bmpc_options_size(void);
+/* 16 hex digits: hash of the source text and compiler flags the library was built from (boundmpc_amd/build.py source_hash) */
+const char *bmpc_build_hash(void);
 int bmpc_default_options(bmpc_options *o);                 /* the N <= 11 defaults */
 int bmpc_default_options_for(int N, bmpc_options *o);      /* defaults for horizon N; what bmpc_create(…, NULL, …) uses */
 const char *bmpc_error_string(int code);

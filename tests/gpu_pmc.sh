@@ -32,14 +32,18 @@ import csv, glob, collections
 tot = collections.defaultdict(float); n = collections.Counter()
 for f in glob.glob("$OUT/p*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "bmpc_solve_kernel" in r["Kernel_Name"]:
+        # the batch kernel of the configuration: one wave per problem (bmpc_solve_kernel) or teams (bmpc_team_solve_kernel, batches <= 256); the
+        # restoration kernel that follows every launch (bmpc_resto_kernel: returns at once when nothing jammed) is counted separately
+        if "bmpc_solve_kernel" in r["Kernel_Name"] or "bmpc_team_solve_kernel" in r["Kernel_Name"]:
             tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
+if not tot:
+    raise SystemExit("gpu_pmc.sh: no dispatch of a solver kernel in the counter files -- nothing to summarise")
 with open("$OUT/summary.txt", "w") as o:
     for k in sorted(tot):
         line = f"{k:32s} per-dispatch {tot[k]/n[k]:.6g}  (dispatches {n[k]})"
         print(line); o.write(line + "\n")
 # machine-readable copy for bench.py (profiles/pmc_current.json): per-dispatch means of every counter, tied to the kernel text they
-# were taken on (sha256[:16] of bmpc_wave.inl + bmpc_hip.hip = bench.kernel_text_hash) and to the configuration of the bench command
+# were taken on (bench.kernel_text_hash = boundmpc_amd.build.source_hash: every source file + the compiler flags) and to the configuration of the bench command
 import json, sys
 sys.path.insert(0, "$ROOT")
 import bench

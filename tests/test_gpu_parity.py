@@ -673,3 +673,38 @@ def test_first_failures_of_the_closed_loops_g13b_on_the_gpu():
     o = s.solve_batch(p, x0)
     assert torch.equal(x, o["x"])
     s.close()
+
+
+# ---- the node's control loop (bound_mpc_node.py:48-83,292-401) over the HIP solver ----
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", [1, 2])
+def test_node_loop_over_the_hip_solver_retraces_g7(which):
+    """NodeLoop (boundmpc_amd/node_loop.py: reset + step of the reference's MPCNode without rclpy) with the DEFAULT solver -- the GPU library behind
+    NlpSolverShim, what a maintainer gets by swapping the import -- runs the whole closed loop of the reference's experiment until the goal
+    (phi_max - phi <= 0.01) and retraces fixture G7 (the reference's own BoundMPC.step() driven tick by tick, tests/golden/make_golden.py): plant
+    state to 1e-6 rad on every tick, iteration counts within 1, no fallback tick, and the per-tick dict carries every field of the MPCData message
+    the node fills (bound_mpc_node.py:169-289)."""
+    from boundmpc_amd import workload
+    from boundmpc_amd.node_loop import NodeLoop
+    d6 = np.load(os.path.join(G, f"g6_pack_exp{which}_tick0.npz")); d7 = np.load(os.path.join(G, f"g7_closedloop_exp{which}.npz"))
+    mk = lambda k: [np.array(v) for v in d6[k]]
+    published = []
+    loop = NodeLoop(mk("p_via"), mk("r_via"), [mk("p_lower"), mk("p_upper")], [mk("r_lower"), mk("r_upper")], mk("bp1_in"), mk("br1_in"), list(d6["s_in"]),
+                    list(d6["e_p_min_in"]), list(d6["e_r_min_in"]), list(d6["e_p_max_in"]), list(d6["e_r_max_in"]), p0=d6["p0fk"].copy(), q0=d7["q"][0],
+                    params=workload.Params(weights=d6["weights_f64"], real_time=True, build=True), solver=None, publish=published.append)
+    assert type(loop.mpc.solver).__name__ == "NlpSolverShim"
+    T = len(d7["q"])
+    worst = 0.0
+    for t in range(T - 1):
+        worst = max(worst, float(np.abs(loop.q - d7["q"][t]).max()), float(np.abs(loop.dq - d7["dq"][t]).max()) * 0.1)
+        out = loop.step()
+        assert out is not None and loop.mpc.error_count == int(d7["error_count"][t]) == 0
+        assert abs(published[-1]["iterations"] - int(d7["iters"][t])) <= 1
+        np.testing.assert_allclose(out[0]["q"], d7["traj_q"][t][:, :out[0]["q"].shape[1]], atol=1e-6)
+    assert worst <= 1e-6, worst
+    assert abs(loop.mpc.phi_current[0] - d7["phi_current"][T - 2]) < 1e-6 and len(loop.t_switch) == int(d7["sector"][T - 2])
+    assert loop.mpc.phi_max[0] - loop.mpc.phi_current[0] <= 0.011 + 1e-6 or which == 2      # experiment 1's fixture ends at the goal
+    fields = {"stamp", "sector", "phi_switch_vector", "t_comp", "t_loop", "t_overhead", "iterations", "t_switch", "phi_switch", "fails", "phi", "dphi", "ddphi",
+              "dddphi", "phi_max", "p", "v", "a", "q", "dq", "ddq", "dddq"}
+    assert set(published[-1].keys()) == fields and len(published) == T - 1 and sum(published[-1]["fails"]) == 0
+    loop.mpc.batched.close()

@@ -305,7 +305,9 @@ def test_realtime_acceptance_counts_the_variable_bounds():
     p, x0 = emu.stream_pack(N, 4, T, ss, rb)
     x, g, st, _ = sol.solve(p, x0)
     qlim = np.array(RobotModel().q_lim_upper)
-    for bad_col, amount, applied in ((8 + 1, 1e-2, False), (8 + 1, -1e-9, True), (8 + 1, 1e-9, False), (0, 1.0, False)):      # q_2 of stage 3 beyond its limit; just inside; just outside; a jerk beyond 35
+    # q_2 of stage 3 beyond its limit; just inside; inside the 1e-9 slack of the solver's own bound rows (a converged iterate with an active bound sits
+    # there); just outside it; a jerk beyond 35; a NaN entry (must FAIL the test, not pass it)
+    for bad_col, amount, applied in ((8 + 1, 1e-2, False), (8 + 1, -1e-9, True), (8 + 1, 5e-10, True), (8 + 1, 1e-8, False), (0, 1.0, False), (8 + 1, np.nan, False)):
         xb = x.reshape(N, 44).copy()
         xb[3, bad_col] = (qlim[bad_col - 8] if bad_col >= 8 else 35.0) + amount
         tr = emu.stream_post(N, 4, 0.1, T, ss.copy(), rb.copy(), xb.ravel(), g, 1, simulate=True, flags=2, rt_tol=1e-4)
