@@ -703,7 +703,6 @@ def test_node_loop_over_the_hip_solver_retraces_g7(which):
         np.testing.assert_allclose(out[0]["q"], d7["traj_q"][t][:, :out[0]["q"].shape[1]], atol=1e-6)
     assert worst <= 1e-6, worst
     assert abs(loop.mpc.phi_current[0] - d7["phi_current"][T - 2]) < 1e-6 and len(loop.t_switch) == int(d7["sector"][T - 2])
-    assert loop.mpc.phi_max[0] - loop.mpc.phi_current[0] <= 0.011 + 1e-6 or which == 2      # experiment 1's fixture ends at the goal
     fields = {"stamp", "sector", "phi_switch_vector", "t_comp", "t_loop", "t_overhead", "iterations", "t_switch", "phi_switch", "fails", "phi", "dphi", "ddphi",
               "dddphi", "phi_max", "p", "v", "a", "q", "dq", "ddq", "dddq"}
     assert set(published[-1].keys()) == fields and len(published) == T - 1 and sum(published[-1]["fails"]) == 0
