@@ -462,11 +462,19 @@ extern "C" int bmpc_solve_batch_host(bmpc_handle *h, int B, const double *p, con
     double *hp = h->stage_h, *hx0 = hp + b * np, *hx = hx0 + b * nw, *hlx = hx + b * nw, *hg = hlx + b * nw, *hlg = hg + b * ng, *hf = hlg + b * ng, *hk = hf + b;
     const int *hit = (const int *)(hk + b), *hst = hit + b;
 #define TRY(x) do { if (rc == BMPC_OK && (x) != hipSuccess) rc = BMPC_ERR_HIP; } while (0)
+    // on a non-blocking stream of the handle (round 5; it was the legacy null stream, on which the call serialised against every blocking stream
+    // of a torch process): the staged copies and the launch touch only the handle's own buffers
+    hipStream_t hs = nullptr;
+    {
+        DevGuard dg(h->dev);
+        if (!h->own_stream && hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) return BMPC_ERR_HIP;
+        hs = h->own_stream;
+    }
     memcpy(hp, p, b * np * sizeof(double)); memcpy(hx0, x0, b * nw * sizeof(double));
-    TRY(hipMemcpyAsync(dp, hp, n_in * sizeof(double), hipMemcpyHostToDevice, nullptr));
-    if (rc == BMPC_OK) rc = bmpc_solve_batch(h, B, dp, dx0, dx, dg, dlg, dlx, df, dit, dst, dk, nullptr);
-    TRY(hipMemcpyAsync(hx, dx, n_out * sizeof(double) + b * 2 * sizeof(int), hipMemcpyDeviceToHost, nullptr));
-    TRY(hipStreamSynchronize(nullptr));
+    TRY(hipMemcpyAsync(dp, hp, n_in * sizeof(double), hipMemcpyHostToDevice, hs));
+    if (rc == BMPC_OK) rc = bmpc_solve_batch(h, B, dp, dx0, dx, dg, dlg, dlx, df, dit, dst, dk, hs);
+    TRY(hipMemcpyAsync(hx, dx, n_out * sizeof(double) + b * 2 * sizeof(int), hipMemcpyDeviceToHost, hs));
+    TRY(hipStreamSynchronize(hs));
     if (rc == BMPC_OK) {
         memcpy(x, hx, b * nw * sizeof(double));
         if (g) memcpy(g, hg, b * ng * sizeof(double));

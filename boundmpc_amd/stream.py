@@ -108,6 +108,63 @@ def apply_update(ss, N, S, pos_points, rot_points, pos_lim, rot_lim, bp1, br1, s
     return T, M
 
 
+def _poff(S):
+    """Offsets of the parameter vector p (casadi_ocp_formulation.py:361-376; the same map as make_poff in csrc/bmpc_wave.inl)."""
+    o, c = {}, 0
+    for k, n in (("q0", 7), ("dq0", 7), ("ddq0", 7), ("phi0", 3), ("p0", 6), ("v0", 6), ("iwref0", 3), ("dtau", 3), ("ipar", 3 * S), ("io1", 3 * S), ("io2", 3 * S),
+                 ("xphid", 3), ("jerk", 7), ("jerkphi", 1), ("sw", S + 1), ("jacr", 9), ("jacl", 9), ("pref", 6 * S), ("dpref", 6 * S), ("dpn", 3 * S),
+                 ("bp1", 3 * S), ("bp2", 3 * S), ("br1", 3 * S), ("br2", 3 * S), ("a4", 9 * (S + 1)), ("a3", 9 * (S + 1)), ("a2", 9 * (S + 1)),
+                 ("a1", 9 * (S + 1)), ("a0", 9 * (S + 1)), ("w", 15), ("phimax", 1), ("dphimax", 1), ("v1", 3 * S), ("v2", 3 * S), ("v3", 3 * S), ("qd", 7)):
+        o[k] = c; c += n
+    o["size"] = c
+    return o
+
+
+def tube_excess_of_state(p, S=4, rows=False):
+    """BoundMPC's contract is the error bound: how far is the MEASURED state of a tick outside its tubes?  `p` [B][n_p] are the parameter vectors
+    packed for a tick (device or host copies of what bmpc_stream_pack wrote): they hold the measured pose p0, the path parameter phi0 and the
+    window of the path with its tube quartics, i.e. everything the five tube rows of casadi_ocp_formulation.py:316-349 need -- evaluated here at
+    NODE 0, the state the plant is in (the NLP constrains nodes 1..N: node 0 is where the previous plans have taken the plant).  At node 0 the
+    orientation-error components are the packed init_par / init_orth1 / init_orth2 of the current segment (compute_initial_rot_errors,
+    util_functions.py:11-31: the exact zyx split of the measured orientation error), the position error is p0 - p_d(phi0).
+    Returns (excess_pos [B][2], excess_rot [B][3]) in the LINEAR form |l_m| - |w_m| (metres, radians; <= 0: inside): position rows along bp1, bp2
+    (rows 39, 40 of a stage), orientation rows tangential, br1, br2 (rows 38, 41, 42).  rows=True: (l [B][5], w [B][5]) in the row order 38..42
+    instead (the reference's rows are l^2 - w^2)."""
+    p = np.atleast_2d(np.asarray(p, dtype=float))
+    o, B = _poff(S), len(p)
+    want_rows, rows = rows, np.arange(B)
+    sw = p[:, o["sw"]:o["sw"] + S + 1]
+    phi = p[:, o["phi0"]]
+    seg = np.full(B, S - 1)
+    for i in range(S - 2, -1, -1):      # bound_mpc_functions.py:13-20
+        seg = np.where(phi < sw[:, i + 1], i, seg)
+    segb = np.minimum(seg, max(S - 2, 0))      # bp1 / bp2 never select the last window segment (:34-40)
+    x = phi - sw[rows, seg]
+    col = lambda key, n, sg: np.stack([p[rows, o[key] + c * S + sg] for c in range(n)], axis=1)      # [coord][seg] blocks
+    b = np.zeros((B, 9))
+    for ch in range(9):
+        a4, a3, a2, a1, a0 = (p[rows, o[k] + ch * (S + 1) + seg] for k in ("a4", "a3", "a2", "a1", "a0"))
+        b[:, ch] = (((a4 * x + a3) * x + a2) * x + a1) * x + a0
+    pref, dpref = col("pref", 6, seg), col("dpref", 6, seg)
+    e_p = p[:, o["p0"]:o["p0"] + 3] - (pref[:, :3] + dpref[:, :3] * x[:, None])
+    bp = (col("bp1", 3, segb), col("bp2", 3, segb))
+    l, w = np.zeros((B, 5)), np.zeros((B, 5))
+    for m in range(2):
+        off, hw = 0.5 * (b[:, m] + b[:, 2 + m]), 0.5 * (b[:, m] - b[:, 2 + m])
+        l[:, 1 + m], w[:, 1 + m] = np.einsum("bi,bi->b", e_p, bp[m]) - off, hw
+    dn, br1, br2 = col("dpn", 3, seg), col("br1", 3, seg), col("br2", 3, seg)
+    ini = lambda key: np.stack([p[rows, o[key] + 3 * seg + c] for c in range(3)], axis=1)      # [seg][xyz] blocks
+    ipar, io1, io2 = ini("ipar"), ini("io1"), ini("io2")
+    l[:, 0], w[:, 0] = np.einsum("bi,bi->b", dn, ipar), b[:, 8]
+    for m, (br, io) in enumerate(((br1, io1), (br2, io2))):
+        off, hw = 0.5 * (b[:, 4 + m] + b[:, 6 + m]), 0.5 * (b[:, 4 + m] - b[:, 6 + m])
+        l[:, 3 + m], w[:, 3 + m] = np.einsum("bi,bi->b", br, io) - off, hw
+    if want_rows:
+        return l, w
+    ex = np.abs(l) - np.abs(w)
+    return ex[:, 1:3], ex[:, [0, 3, 4]]
+
+
 def robot_record(q, dq, ddq, p_lie, v, x_phi_d, jerk):
     return np.concatenate([q, dq, ddq, p_lie, v, x_phi_d, jerk]).astype(float)
 

@@ -438,7 +438,7 @@ def test_256_streams_time_budgeted_tick_meets_the_1_khz_budget_over_130_ticks():
         sb = bstream.StreamBatch(slv, mpcs)
         sb.set_robot(np.stack(recs))
         assert slv.team_info(B)["waves"] == 4      # 256 streams = the resident teams of an MI355X
-        ms, Q, applied = [], [], []
+        ms, Q, applied, tube_p, tube_r, row_p = [], [], [], [], [], []
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for t in range(T):
             if t == 0:      # cold start from rest: to tolerance, without a budget
@@ -448,6 +448,13 @@ def test_256_streams_time_budgeted_tick_meets_the_1_khz_budget_over_130_ticks():
                 e0.record(); sb.tick_graph(simulate=True, warm_dual=True, accept_capped=True); e1.record(); e1.synchronize()
                 ms.append(e0.elapsed_time(e1))
                 applied.append(float((sb.traj[:, -2] > 0.5).double().mean().item()))
+                # what BoundMPC promises is the error bound: the measured state of every tick against its tubes (stream.tube_excess_of_state: the tube
+                # rows of casadi_ocp_formulation.py:316-349 at node 0 of the packed problem), and the first-stage rows of every applied plan
+                has_plan = (sb.state[:, bstream.SS["ERRCNT"]] < 10).cpu().numpy()
+                ex_p, ex_r = bstream.tube_excess_of_state(sb.p.cpu().numpy())
+                tube_p.append(np.where(has_plan, ex_p.max(axis=1), -np.inf)); tube_r.append(np.where(has_plan, ex_r.max(axis=1), -np.inf))
+                app = (sb.traj[:, -2] > 0.5).cpu().numpy()
+                row_p.append(np.where(app, sb.g.reshape(B, 10, 43)[:, 0, 39:41].cpu().numpy().max(axis=1), -np.inf))
             Q.append(sb.robot[:, :7].clone())
         alive = float((sb.state[:, bstream.SS["VALID"]] > 0.5).double().mean().item())
         Q = torch.stack(Q).cpu().numpy()
@@ -459,3 +466,14 @@ def test_256_streams_time_budgeted_tick_meets_the_1_khz_budget_over_130_ticks():
     assert np.percentile(ms, 50) <= 1.0 and np.percentile(ms, 99) <= 1.3
     assert alive >= 0.75 and np.mean(applied) >= 0.8
     assert (np.abs(Q) <= qlim + 1e-9).all()
+    # tube compliance of the executed trajectories (round 5).  Position tube (exact): measured 0.15 % of the plant samples outside, by at most 1.8e-4 m
+    # (tube half widths 0.01 ... 0.5 m); the position rows of the applied plans' first stage are within the acceptance threshold.  Orientation (the
+    # exact split of the measured orientation error, which the NLP constrains only through its per-tick linearisation): 2.8 % of the samples, <= 0.15 rad
+    # -- the loops that solve every tick to 1e-8 show 6.0 % / 0.18 rad on the same measure: it is a property of the reference's formulation.
+    tube_p, tube_r, row_p = np.array(tube_p), np.array(tube_r), np.array(row_p)
+    n = np.isfinite(tube_p).sum()
+    print(f"tube compliance of {n} plant samples: position outside {(tube_p > 1e-6).sum() / n:.2e} (max {max(tube_p.max(), 0):.1e} m), orientation outside "
+          f"{(tube_r > 1e-6).sum() / n:.2e} (max {max(tube_r.max(), 0):.2e} rad); applied plans: largest first-stage position row {max(row_p.max(), 0):.1e} m^2")
+    assert (tube_p > 1e-6).sum() / n <= 5e-3 and tube_p.max() <= 1e-3
+    assert (tube_r > 1e-6).sum() / n <= 0.08 and tube_r.max() <= 0.3
+    assert row_p.max() <= 1e-2

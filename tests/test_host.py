@@ -383,3 +383,26 @@ def test_node_loop_retraces_the_reference_closed_loop_g7(which):
     assert published[-1]["stamp"] == pytest.approx((T - 1) * 0.1) and published[-1]["q"].shape[0] == 7
     # the switch bookkeeping saw every window shift of the path (sector of the fixture)
     assert len(loop.t_switch) == int(d7["sector"][T - 2])
+
+
+def test_tube_excess_of_the_measured_state_equals_the_nlp_rows():
+    """stream.tube_excess_of_state evaluates the five tube rows of casadi_ocp_formulation.py:316-349 at NODE 0 of a packed problem, i.e. at the state
+    the plant is in.  Pinned on the recorded closed loops of the reference (G7): the plant integrates the plan exactly, so the measured state of
+    tick t+1 is node 1 of tick t's solution and the rows must agree with g[38:43] of stage 0 there (reference form l^2 - w^2, evaluated by the
+    oracle's restatement of the reference's NLP): the position rows to 1e-9 (same geometry), the orientation rows to what separates the exact
+    split of the measured orientation error at t+1 from tick t's linearisation of it (<= 5e-3 rad^2)."""
+    from boundmpc_amd import stream as bstream
+    from oracle import nlp
+    for which in (1, 2):
+        d = np.load(os.path.join(os.path.dirname(__file__), "golden", f"g7_closedloop_exp{which}.npz"))
+        l, w = bstream.tube_excess_of_state(d["p"], rows=True)
+        sq = l ** 2 - w ** 2
+        wp = wr = 0.0
+        for t in range(len(d["p"]) - 1):
+            if int(d["status"][t]) != 0 or int(d["error_count"][t]) != 0:
+                continue
+            _, g = nlp.nlp_eval(d["x"][t], d["p"][t], 10, 4, 0.1)
+            wp = max(wp, np.abs(sq[t + 1, 1:3] - g[39:41]).max()); wr = max(wr, np.abs(sq[t + 1, [0, 3, 4]] - g[[38, 41, 42]]).max())
+        assert wp < 1e-9 and wr < 5e-3, (which, wp, wr)      # (measured: 1e-15 and 3.0e-3 / ... rad^2 against tube widths^2 of 0.07 ... 0.6 rad^2)
+        ex_p, ex_r = bstream.tube_excess_of_state(d["p"])
+        assert ex_p.max() <= 1e-8 and ex_r.max() <= 0.0      # the converged closed loops of the reference's experiments stay inside their tubes
