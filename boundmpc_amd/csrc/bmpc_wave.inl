@@ -2606,6 +2606,7 @@ _Pragma("unroll") \
     int it = 0, status = 1; double E0 = 0, ep_old = 0, ep_mid = 0;
     if (RESTO && pr.resto_from >= 0) {      // continuation of a solve whose main phase jammed in a kernel without the restoration phase
         it = pr.resto_from; ep_old = ep_mid = 1e300;
+        if (longh) n_restart = STALL_RESTARTS;      // (long horizons hand over only behind their last barrier restart)
         BMPC_ENTER_RESTO()
         it++;
     }
@@ -2688,9 +2689,10 @@ _Pragma("unroll") \
             const bool open_ = ep > BMPC_FMAX(1e-6, 10.0 * o.tol);
             const bool at_check = o.stall_window > 0 && (it - it_restart) % (o.stall_window / 2) == 0;
             const bool stalled = at_check && it >= o.stall_window + it_restart && ep >= STALL_FACTOR * ep_old && open_;
-            const bool jammed = o.restoration && o.resto_short > 0 && n_short >= o.resto_short && open_;
+            // long horizons: barrier restarts come first (below), the restoration phase is the last resort behind them and is not entered on a jam
+            const bool jammed = o.restoration && !longh && o.resto_short > 0 && n_short >= o.resto_short && open_;
             if (stalled || jammed) {
-                if (o.restoration) {
+                if (o.restoration && (!longh || n_restart >= STALL_RESTARTS)) {
                     if (n_resto >= RESTO_MAX) { status = 2; break; }
                     if (!RESTO) { status = 4; break; }      // (internal) this kernel does not carry the phase: the restoration kernel continues from x
                     BMPC_ENTER_RESTO()

@@ -90,10 +90,16 @@ int bmpc_destroy(bmpc_handle *h);
  *   - ends the solve with status 2 when it converges to a point with non-zero violation (a local minimiser of the violation: Ipopt's
  *     "converged to a point of local infeasibility"), when `cap` iterations (default 40) did not produce a feasible point (Ipopt: "restoration
  *     failed"), or at the fourth call within one solve.
- * enabled: 1 / 0; default 1 for N <= 11, 0 for longer horizons (there three barrier restarts stand in: the restoration phase rescues 11 of the 27
- * problems of BASELINE configs[3] that end as status 2, but the slowest problem of that launch then takes 314 instead of 180 iterations).
+ * enabled: 1 / 0; default 1 for N <= 11, 0 for longer horizons.  Long horizons (N > 11) keep their three barrier restarts from a stalled iterate
+ * and, when enabled, enter the restoration phase as the LAST RESORT behind them (never on a jam: a tight 30-stage solve takes short steps for its
+ * first 15 iterations anyway): it rescues 11 of the 27 problems of BASELINE configs[3] that end as status 2 (99.67 -> 99.80 % converged), but the
+ * slowest problem of that launch then takes 314 instead of 180 iterations; instead of the restarts it would be worse (oracle/bmpc_oracle.c).
  * A negative argument keeps the current value.  Read at launch / capture time.  Fixture g13b (every first failing tick of 256 closed loops): the 28
- * locally infeasible problems end as status 2 after 22-54 iterations, 8 of the 10 feasible ones converge in 64-128. */
+ * locally infeasible problems end as status 2 after 22-54 iterations, 8 of the 10 feasible ones converge in 64-128 (tests/test_gpu_parity.py).
+ * Batch solves: the batch kernels are compiled without the phase (carrying it costs their hot path 6 %); a jammed problem is continued by a second
+ * kernel started right behind (it returns at once when nothing jammed), with identical numbers.  Fused closed-loop ticks carry it in the kernel;
+ * time-budgeted real-time ticks (bmpc_stream_set_time_budget) run without it.  Warm-started closed loops: cap = 24 keeps the same streams alive as 40
+ * and a stream that is losing its plan then costs a tick about what the stall test did (bench_stream.py --resto-cap). */
 int bmpc_set_restoration(bmpc_handle *h, int enabled, int short_steps, int cap);
 int bmpc_get_restoration(const bmpc_handle *h, int *enabled, int *short_steps, int *cap);
 

@@ -14,7 +14,7 @@ flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-DBMPC_PROFILE"
         ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-duplicate-decl-specifier"]
 objs = []
 procs = []
-for unit in ("bmpc_hip", "bmpc_team"):      # the two translation units of the library, side by side
+for unit in ("bmpc_hip", "bmpc_team", "bmpc_resto", "bmpc_tick"):      # the translation units of the library, side by side (stamps only in the batch kernels)
     objs.append(os.path.join(ROOT, "gpurun_out", unit + "_prof.o"))
     procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + ["-c", "-o", objs[-1], os.path.join(csrc, unit + ".hip")]))
 assert all(pr.wait() == 0 for pr in procs)
