@@ -81,6 +81,11 @@ class BatchedOCPSolver:
         _lib.check(self._lib.bmpc_set_restoration(self._h, -1 if enabled is None else int(bool(enabled)), -1 if short_steps is None else int(short_steps),
                                                   -1 if cap is None else int(cap)), "bmpc_set_restoration")
 
+    def get_restoration(self):
+        e, s_, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        _lib.check(self._lib.bmpc_get_restoration(self._h, ctypes.byref(e), ctypes.byref(s_), ctypes.byref(c)), "bmpc_get_restoration")
+        return dict(enabled=bool(e.value), short_steps=s_.value, cap=c.value)
+
     def set_team_waves(self, waves=0):
         """Waves per problem: 0 (default) automatic -- a batch that fits into the resident teams of the device (256 on an MI355X) is solved by
         workgroups of 4 cooperating waves, a larger one by one wave per problem; 1 never teams; 4 teams whenever the kernel exists

@@ -33,7 +33,7 @@
  * scratch.  Errors are integer return codes (no exceptions cross the ABI); per-problem
  * failure is data (status[]), as in the reference (BoundMPC.py:465-489).
  * Thread-safety: one in-flight bmpc_solve_batch per handle.
- * Memory: the handle's device workspace (one 148 KB slab per resident wave at N=10, 444 KB at N=30, 592 KB at N=40) is allocated by the first solve
+ * Memory: the handle's device workspace (one 173 KB slab per resident wave at N=10, 519 KB at N=30, 693 KB at N=40) is allocated by the first solve
  * or graph capture, for min(B, resident waves) waves, and grows when a later call brings a larger batch (after a host wait for
  * the handle's own last launch; other streams and handles of the process are not stalled); while captured graphs of the handle exist it cannot grow -- capture for the largest batch first.
  */
