@@ -146,3 +146,28 @@ _Z5good2v:
         asm = os.path.join(ROOT, "build", "isa", unit)
         if os.path.exists(asm):
             assert b.lint_isa_masked_loads(asm) == []
+
+
+def test_library_carries_the_hash_of_its_sources(tmp_path, monkeypatch):
+    """Round 5: the library is tied to the text it was built from.  build.source_hash() covers every source file and the compiler flags; the built
+    library carries it (bmpc_build_hash, and as a marker in its bytes, which build() reads instead of file times); _lib.load() refuses an in-tree
+    library whose hash differs; bench.kernel_text_hash -- the key of profiles/pmc_current.json and flops_current.json -- is the same hash."""
+    import bench
+    from boundmpc_amd import _lib, build
+    build.build()
+    want = build.source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", want) and build.library_hash() == want and bench.kernel_text_hash() == want
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.bmpc_build_hash.restype = ctypes.c_char_p
+    assert lib.bmpc_build_hash().decode() == want and lib.bmpc_options_size() == ctypes.sizeof(_lib.Options)
+    # every translation unit and every header the kernels include is part of the hash
+    names = {os.path.basename(p) for p in build.SOURCES}
+    assert {"bmpc_hip.hip", "bmpc_team.hip", "bmpc_resto.hip", "bmpc_tick.hip", "bmpc_wave.inl", "bmpc_stream.inl", "bmpc_gpu_common.h", "boundmpc_hip.h"} <= names
+    # a library from other sources is refused at load time
+    monkeypatch.setattr(build, "source_hash", lambda: "0" * 16)
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.BoundMPCHipError, match="built from other sources"):
+        _lib.load()
+    monkeypatch.undo()
+    _lib._lib = None
+    assert _lib.load() is not None
