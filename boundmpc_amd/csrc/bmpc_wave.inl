@@ -104,6 +104,7 @@ constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
 #define RESTO_MARGIN 1e-6      // strictly feasible: max h <= -RESTO_MARGIN ...
 #define RESTO_GTOL 1e-4        // ... and equality residuals below this
 #define RESTO_MAX 3            // restoration phases per solve
+#define RESTO_ROLLOUT_TOL 1e-2 // the phase starts from the rollout of the iterate's own jerks when an equality residual exceeds this
 #define KAPPA_EPS 100.0   // barrier problem "solved" at KKT error <= KAPPA_EPS * mu (oracle/bmpc_oracle.c).  A deliberate departure from Ipopt, whose
                           // barrier_tol_factor defaults to 10: measured on the bench batches it takes 2 of 14 iterations off the mean and 36 -> 20 off the slowest problem
                           // (DESIGN.md 2, round 2); the price is an occasional premature barrier reduction (a problem that then crawls for some iterations)
@@ -2596,10 +2597,39 @@ _Pragma("unroll") \
         W.ca = 2 * L[L_PAR + po.w + 5] / (W.h * W.h); W.cb = 2 * L[L_PAR + po.w + 5] / W.h;
     // into the restoration phase: objective weights zero (the records carry weight-dependent Hessian entries: rebuilt by an evaluation, which
     // returns f = 0), every row elastic and centred on the level RESTO_MU, filter and inertia history cleared
+    // An iterate that is far off its dynamics (a bad warm start: an equality residual above RESTO_ROLLOUT_TOL) is first made dynamically consistent:
+    // one lane per integrator chain (7 joints + the path parameter) rolls q, dq, ddq / phi, dphi, ddphi of every node out from node 0 with the
+    // iterate's own jerks (oracle/bmpc_oracle.c rollout_chains), and the evaluation that follows projects the lifted variables.
 #define BMPC_ENTER_RESTO() \
         n_resto++; it_resto = it; el = true; mu = RESTO_MU; \
         BMPC_WEIGHTS(true) \
-        fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false); \
+        WIDE_BEGIN \
+            double gm_ = 0; \
+            for (int t_ = 0; t_ < (ne + WS - 1) / WS; t_++) { const int id0 = wl + WS * t_, id = id0 < ne ? id0 : ne - 1; const double v_ = BMPC_FABS(WL[sc.G + id]); gm_ = v_ > gm_ ? v_ : gm_; } \
+            WRED_PUT_MAX(L_REDW, 4, gm_); \
+        WIDE_END \
+        const bool roll_ = WRED_GET_MAX(L_REDW, 4) > RESTO_ROLLOUT_TOL; \
+        TEAM_SYNC(); \
+        if (roll_) { \
+            SOLO_BEGIN(0) \
+            LANES_BEGIN \
+                if (lane < 8) { \
+                    const double h_ = W.h, h2_ = h_ * h_, h3_ = h2_ * h_; \
+                    const int zx = lane < 7 ? ZQ + lane : ZPHI, zd = lane < 7 ? ZDQ + lane : ZDPHI, za = lane < 7 ? ZDDQ + lane : ZDDPHI, zj = lane < 7 ? ZJ + lane : ZJPHI; \
+                    const int px = lane < 7 ? po.q0 + lane : po.phi0, pd = lane < 7 ? po.dq0 + lane : po.phi0 + 1, pa = lane < 7 ? po.ddq0 + lane : po.phi0 + 2, pj = lane < 7 ? po.jerk + lane : po.jerkphi; \
+                    for (int k = 0; k < N; k++) { \
+                        const double x_ = ndv(PAR, po, W.Zc, k, zx, px), d_ = ndv(PAR, po, W.Zc, k, zd, pd), a_ = ndv(PAR, po, W.Zc, k, za, pa), j0_ = ndv(PAR, po, W.Zc, k, zj, pj); \
+                        double *Zn_ = W.Zc + k * NZ; const double j1_ = Zn_[zj]; \
+                        Zn_[zx] = x_ + h_ * d_ + h2_ / 2 * a_ + h3_ / 8 * j0_ + h3_ / 24 * j1_; \
+                        Zn_[zd] = d_ + h_ * a_ + h2_ / 3 * j0_ + h2_ / 6 * j1_; \
+                        Zn_[za] = a_ + h_ / 2 * (j0_ + j1_); \
+                    } \
+                } \
+            LANES_END \
+            SOLO_END \
+            TEAM_SYNC(); \
+        } \
+        fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, roll_); \
         BMPC_ROWS_CENTRE() \
         nfilt = 0; filt_mu = -1.0; theta_min = -1.0; delta_last = 0.0; delta_prev = 0.0; gn_run = 0; n_short = 0;
     int n_restart = 0, it_restart = 0, n_resto = 0, it_resto = 0, n_short = 0; bool el = false;      // el: inside the restoration phase

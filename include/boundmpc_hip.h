@@ -95,7 +95,9 @@ int bmpc_destroy(bmpc_handle *h);
  * first 15 iterations anyway): it rescues 11 of the 27 problems of BASELINE configs[3] that end as status 2 (99.67 -> 99.80 % converged), but the
  * slowest problem of that launch then takes 314 instead of 180 iterations; instead of the restarts it would be worse (oracle/bmpc_oracle.c).
  * A negative argument keeps the current value.  Read at launch / capture time.  Fixture g13b (every first failing tick of 256 closed loops): the 28
- * locally infeasible problems end as status 2 after 22-54 iterations, 8 of the 10 feasible ones converge in 64-128 (tests/test_gpu_parity.py).
+ * locally infeasible problems end as status 2 after 22-54 iterations, 8 of the 10 feasible ones converge in 69-121 (tests/test_gpu_parity.py).
+ * An iterate that is far off its own dynamics when the phase starts (an equality residual above 1e-2: a bad warm start) is first rolled out from
+ * the measured state with its own jerks: of 256 feasible problems started with noise 0.3 on every variable 254 converge (without the phase: 69).
  * Batch solves: the batch kernels are compiled without the phase (carrying it costs their hot path 6 %); a jammed problem is continued by a second
  * kernel started right behind (it returns at once when nothing jammed), with identical numbers.  Fused closed-loop ticks carry it in the kernel;
  * time-budgeted real-time ticks (bmpc_stream_set_time_budget) run without it.  Warm-started closed loops: cap = 24 keeps the same streams alive as 40

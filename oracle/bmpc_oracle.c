@@ -83,6 +83,7 @@ static const double DQ_LIM_DEG[7] = {85, 85, 100, 75, 130, 135, 135};
 #define RESTO_MARGIN 1e-6      /* strictly feasible: max h <= -RESTO_MARGIN ... */
 #define RESTO_GTOL 1e-4        /* ... and equality residuals below this */
 #define RESTO_MAX 3            /* restoration phases per solve */
+#define RESTO_ROLLOUT_TOL 1e-2 /* the phase starts from the rollout of the iterate's own jerks when an equality residual exceeds this */
 #define KAPPA_EPS 100.0 /* barrier problem "solved" when its KKT error <= KAPPA_EPS * mu (Ipopt barrier_tol_factor, default 10) */
 #define PI 3.14159265358979323846
 
@@ -396,6 +397,25 @@ static inline double nd_phi(const Par *P, const double *Z, int k, int d) {
  * function evaluation: f, equality residuals g[N][36], inequality values h[N][57]
  * (casadi_ocp_formulation.py:88-349)
  * ---------------------------------------------------------------------------------------- */
+/* roll the integrator chains out from node 0 with the jerks of Z: q, dq, ddq, phi, dphi, ddphi of every node are overwritten by what the (linear)
+ * dynamics give, so that those 24 residual rows vanish; the lifted variables follow by an evaluation with project != 0 (restoration phase) */
+static void rollout_chains(const Cfg *C, const Par *P, double *Z) {
+    const int N = C->N; const double h = C->h, h2 = h * h, h3 = h2 * h;
+    for (int k = 0; k < N; k++) {
+        const double *q = nd_q(P, Z, k), *dq = nd_dq(P, Z, k), *ddq = nd_ddq(P, Z, k), *j0 = nd_j(P, Z, k);
+        double *Zn = Z + k * NZ;
+        for (int i = 0; i < 7; i++) {
+            Zn[ZQ + i] = q[i] + h * dq[i] + h2 / 2 * ddq[i] + h3 / 8 * j0[i] + h3 / 24 * Zn[ZJ + i];
+            Zn[ZDQ + i] = dq[i] + h * ddq[i] + h2 / 3 * j0[i] + h2 / 6 * Zn[ZJ + i];
+            Zn[ZDDQ + i] = ddq[i] + h / 2 * (j0[i] + Zn[ZJ + i]);
+        }
+        const double ph = nd_phi(P, Z, k, 0), dph = nd_phi(P, Z, k, 1), ddph = nd_phi(P, Z, k, 2), jp0 = nd_jphi(P, Z, k), jp1 = Zn[ZJPHI];
+        Zn[ZPHI] = ph + h * dph + h2 / 2 * ddph + h3 / 8 * jp0 + h3 / 24 * jp1;
+        Zn[ZDPHI] = dph + h * ddph + h2 / 3 * jp0 + h2 / 6 * jp1;
+        Zn[ZDDPHI] = ddph + h / 2 * (jp0 + jp1);
+    }
+}
+
 /* project != 0 (trial points of the line search after a rejected first trial): the lifted variables pos, i-omega and v of every
  * node are overwritten IN Z by the values their defining equalities give for the trial (q, dq) -- pos = fk(q^), v = J(q^) dq^,
  * i-omega by the trapezoidal recursion from node 0 -- so that those 12 residual rows vanish identically and the trial is judged
@@ -935,7 +955,8 @@ static inline void elastic_centre(double h, double mu, double rho, double *t, do
  *      min  rho * sum_i e_i     s.t.  dynamics equalities,  h_i(Z) - e_i <= 0,  e_i >= 0          (rho = RESTO_RHO, the l1 norm of the violation)
  * -- the objective weights are zero (a copy of p), every inequality row gets an elastic variable e_i with its own barrier term, eliminated row by
  * row like the slack (sigma = 1 / (t/nu + e/(rho - nu)), nu in (0, rho)), so the Newton system keeps its stage structure and the same Riccati
- * recursion solves it; rows start centred with zero residual (elastic_centre), all trial points are projected onto the lifted equalities.  It ends
+ * recursion solves it; an iterate far off its dynamics is first rolled out (rollout_chains), rows start centred with zero residual
+ * (elastic_centre), all trial points are projected onto the lifted equalities.  It ends
  *   * BACK IN THE MAIN PHASE at the first iterate that is strictly feasible (max h <= -RESTO_MARGIN, equality residual <= RESTO_GTOL) or when it
  *     converges with no violation left: slacks t = -h, multipliers nu = mu/t on the level RESTO_MU_BACK, filter and inertia history cleared;
  *   * with STATUS 2 when it converges (scaled KKT error <= max(1e-6, RESTO_REL * rho * violation)) to a point whose violation is not zero -- a
@@ -1008,6 +1029,17 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
                 if (o->restoration && (!longh || n_restart >= STALL_RESTARTS)) {
                     if (n_resto >= RESTO_MAX) { status = 2; break; }
                     n_resto++; it_resto = it; el = 1; Pc = &PRv; W->f = 0.0; mu = RESTO_MU;
+                    {   /* an iterate that is far off its dynamics (a bad warm start: equality residuals above RESTO_ROLLOUT_TOL) is first made
+                         * dynamically consistent -- the states rolled out from the measured state with its own jerks, the lifted variables projected
+                         * -- so that the phase only has the inequality rows to repair: 256 tight problems from a warm start with noise 0.3 on every
+                         * variable: 254 converge in 42 iterations on average; without the rollout 8 within the phase's budget (256 without a budget,
+                         * 130 iterations); the closed-loop ticks of g13b (residuals ~1e-3) are not touched by it */
+                        double gm_ = 0; for (int i = 0; i < N * NE; i++) gm_ = fmax(gm_, fabs(W->g[i]));
+                        if (gm_ > RESTO_ROLLOUT_TOL) {
+                            rollout_chains(C, P, W->Z);
+                            ORACLE_REGION(REG_EVAL); W->f = eval_values(C, Pc, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 1); ORACLE_REGION(REG_DRIVER);
+                        }
+                    }
                     for (int i = 0; i < N * NI; i++) elastic_centre(W->hin[i], mu, rho, &W->t[i], &W->e[i], &W->nu[i]);
                     nfilt = 0; filt_mu = -1.0; theta_min = -1.0; delta_last = 0.0; delta_prev = 0.0; gn_run = 0; n_short = 0;
                     if (o->verbose) fprintf(stderr, "   %s: restoration phase\n", jammed ? "jammed" : "stalled");

@@ -653,7 +653,8 @@ def test_first_failures_of_the_closed_loops_g13b_on_the_gpu():
     for waves in (1, 4):
         s = BatchedOCPSolver(10, 4, 0.1); s.set_team_waves(waves)
         o = s.solve_batch(p, x0); st, it, f = o["status"].cpu().numpy(), o["iters"].cpu().numpy(), o["f"].cpu().numpy()
-        assert np.array_equal(st, ref["status"]) and np.abs(it - ref["iters"]).max() <= 8, (waves, st, it)
+        di = np.abs(it - ref["iters"])
+        assert np.array_equal(st, ref["status"]) and di[st == 0].max() <= 8 and (di <= 8).sum() >= 36, (waves, st, it)      # (the two that fail after three phases may leave at different counts)
         assert (st[~feas] == 2).all() and it[~feas].max() <= 60
         conv = feas & (st == 0)
         assert conv.sum() >= 8 and it[conv].max() <= 135
@@ -707,3 +708,28 @@ def test_node_loop_over_the_hip_solver_retraces_g7(which):
               "dddphi", "phi_max", "p", "v", "a", "q", "dq", "ddq", "dddq"}
     assert set(published[-1].keys()) == fields and len(published) == T - 1 and sum(published[-1]["fails"]) == 0
     loop.mpc.batched.close()
+
+
+@pytest.mark.gpu
+def test_bad_warm_starts_are_rescued_by_the_restoration_phase_on_the_gpu():
+    """256 feasible tight N = 10 problems started from a warm start with noise 0.3 on every variable (far off its own dynamics): with the restoration
+    phase (rollout of the iterate's jerks, elastic feasibility problem, feasible point handed back to the main phase) >= 97 % converge at the
+    handle's defaults, on both launch shapes, with the oracle's statuses; with the phase switched off (round 4) a quarter does."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    from oracle import c_oracle
+    P, X, _ = workload.make_batch(256, seed=50, N=10, tight=True)
+    X2 = X + np.random.default_rng(5).normal(size=X.shape) * 0.3
+    ref = c_oracle.solve(P, X2, 10, 4, 0.1, opts=c_oracle.default_opts(max_iter=300), nthreads=8)
+    p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X2, device="cuda")
+    for waves in (1, 4):
+        s = BatchedOCPSolver(10, 4, 0.1, max_iter=300); s.set_team_waves(waves)
+        o = s.solve_batch(p, x0); st, it = o["status"].cpu().numpy(), o["iters"].cpu().numpy()
+        assert (st == 0).mean() >= 0.97 and (st == ref["status"]).mean() >= 0.99 and np.abs(it - ref["iters"])[st == ref["status"]].max() <= 10, (waves, np.bincount(st), np.abs(it - ref["iters"]).max())
+        ok = (st == 0) & (ref["status"] == 0)
+        dq = (o["x"].cpu().numpy()[ok] - ref["x"][ok]).reshape(-1, 10, 44)[:, :, 8:15]
+        assert np.sqrt((dq ** 2).mean(axis=(1, 2))).max() < 1e-5
+        s.set_restoration(False)
+        o = s.solve_batch(p, x0)
+        assert (o["status"].cpu().numpy() == 0).mean() <= 0.4
+        s.close()
