@@ -733,3 +733,28 @@ def test_bad_warm_starts_are_rescued_by_the_restoration_phase_on_the_gpu():
         o = s.solve_batch(p, x0)
         assert (o["status"].cpu().numpy() == 0).mean() <= 0.4
         s.close()
+
+
+@pytest.mark.gpu
+def test_long_horizon_restoration_as_the_last_resort_behind_the_restarts():
+    """configs[3] (N = 30, tight tubes, seed 2): problems 690 and 695 of the batch are two of the 27 that end as status 2 after their three barrier
+    restarts.  With the restoration phase switched on for this long-horizon handle it follows the third restart (never a jam): 690 then converges
+    (after ~314 iterations: the price), 695 stays status 2, like the oracle; the other problems of the window are untouched (the phase
+    is behind the restarts); the hand-over runs through bmpc_solve_kernel<false> -> bmpc_resto_kernel<false>."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    from oracle import c_oracle
+    P, X, _ = workload.make_batch(8192, seed=2, N=30, tight=True, rows=(688, 696))
+    p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
+    s = BatchedOCPSolver(30, 4, 0.1)
+    assert s.get_restoration()["enabled"] is False      # default of long horizons
+    off = s.solve_batch(p, x0); st_off, it_off = off["status"].cpu().numpy(), off["iters"].cpu().numpy()
+    assert st_off[2] == 2 and st_off[7] == 2 and (np.delete(st_off, [2, 7]) == 0).all()
+    s.set_restoration(True)
+    on = s.solve_batch(p, x0); st_on, it_on = on["status"].cpu().numpy(), on["iters"].cpu().numpy()
+    ref = c_oracle.solve(P, X, 30, 4, 0.1, opts=c_oracle.default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=1), nthreads=8)
+    assert np.array_equal(st_on, ref["status"]) and st_on[2] == 0 and st_on[7] == 2 and it_on[2] > it_off[2]
+    keep = np.delete(np.arange(8), [2, 7])
+    assert np.array_equal(it_on[keep], it_off[keep]) and torch.equal(on["x"][torch.tensor(keep, device="cuda")], off["x"][torch.tensor(keep, device="cuda")])
+    assert float(on["kkt"][2]) <= 1e-8
+    s.close()
