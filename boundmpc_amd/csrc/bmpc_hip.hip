@@ -88,7 +88,7 @@ struct bmpc_handle {
     int grid; long long scr_stride; double *scratch; int scr_waves; int graphs_alive; int *counter; unsigned long long *prof;
     int team_grid;           // resident TEAMS (workgroups of BMPC_TEAM_NW waves, bmpc_team.hip) of the device; 0: no team kernel for this handle (N > 10 or S > 4)
     int *aux_int; int aux_cap;      // [2][aux_cap] status / iters of a batch whose caller passed NULL (the restoration kernel reads them)
-    int resto_on, resto_short, resto_cap;      // restoration phase (bmpc_set_restoration): on for N <= 11 by default; jam = resto_short consecutive short steps; iterations per phase
+    int resto_on, resto_short, resto_cap;      // restoration phase (bmpc_set_restoration): mode 0 off / 1 full (default N <= 11) / 2 after a numerical breakdown only (default N > 11); jam = resto_short consecutive short steps; iterations per phase
     int team_mode;           // bmpc_set_team_waves: 0 automatic (teams when the batch fits into the resident teams), 1 never, BMPC_TEAM_NW whenever possible
     int timing; hipEvent_t *ev; int nev; long long n_timed;   // timing = number of launches whose {start, stop} event pairs are kept (ring)
     double *latency_us;
@@ -161,7 +161,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BMPC_ERR_NOGPU;
     bmpc_handle *h = new (std::nothrow) bmpc_handle();
     if (!h) return BMPC_ERR_ARG;
-    h->resto_on = N <= 11 ? 1 : 0; h->resto_short = 6; h->resto_cap = 40;      // restoration phase: the default of short horizons (bmpc_set_restoration)
+    h->resto_on = N <= 11 ? 1 : 2; h->resto_short = 6; h->resto_cap = 40;      // restoration phase: full for short horizons, after a numerical breakdown only for long ones (bmpc_set_restoration)
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->ev = nullptr; h->nev = 0; h->n_timed = 0; h->latency_us = nullptr;
     h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->aux_int = nullptr; h->aux_cap = 0; h->prof = nullptr; h->stage_d = nullptr; h->stage_h = nullptr; h->stage_cap = 0;
     h->team_grid = 0; h->team_mode = 0;
@@ -284,7 +284,8 @@ static int reserve_for_batch(bmpc_handle *h, int B) {
 }
 extern "C" int bmpc_set_restoration(bmpc_handle *h, int enabled, int short_steps, int cap) {
     if (!h || short_steps > 1000 || cap > 100000) return BMPC_ERR_ARG;
-    if (enabled >= 0) h->resto_on = enabled ? 1 : 0;
+    if (enabled > 2) return BMPC_ERR_ARG;
+    if (enabled >= 0) h->resto_on = enabled;
     if (short_steps >= 0) h->resto_short = short_steps;
     if (cap >= 1) h->resto_cap = cap; else if (cap == 0) return BMPC_ERR_ARG;
     return BMPC_OK;

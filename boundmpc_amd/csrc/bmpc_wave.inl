@@ -233,7 +233,8 @@ struct Opts {
     double tol; int max_iter; double mu_init; double mu_min_fac; double slack_push; int exact_hessian; int verbose; double mu_warm; int stall_window;
     double bound_margin;      // joint position / velocity limits tightened by this much inside the solver (real-time modes: a plan solved to a loose
                               // tolerance then still respects the true limits); 0 = the reference's limits
-    int restoration;          // 1: a jammed or stalled main phase hands over to the restoration phase (round 5; oracle/bmpc_oracle.c solve_one); 0: status 2 / barrier restarts
+    int restoration;          // 1: a jammed, stalled or numerically broken main phase hands over to the restoration phase (round 5; oracle/bmpc_oracle.c solve_one;
+                              // long horizons: behind the barrier restarts); 2: only a numerical breakdown does; 0: never (status 2 / 3)
     int resto_short;          // consecutive steps shorter than RESTO_SHORT_ALPHA that count as a jam (6; 0 = the stall test alone)
     int resto_cap;            // iterations one restoration phase may take before the solve ends as status 2 (40)
 };
@@ -276,8 +277,8 @@ struct Problem {           // per-problem global pointers
     double *x, *g, *lam_g, *lam_x, *f, *kkt;
     int *iters, *status;
     double *state;         // optional dual state of a receding-horizon stream: [nu (N*57) | mu | iterations]; mu <= 0: cold start
-    int resto_from;        // >= 0 (instantiations with RESTO only): x0 is the iterate at which the main phase of another kernel jammed after this many
-                           // iterations -- the solve starts in the restoration phase and counts on from there; -1: an ordinary solve
+    int resto_from;        // >= 0 (instantiations with RESTO only): x0 is the iterate at which the main phase of another kernel jammed after (low 20 bits)
+                           // iterations and (bits 20..) barrier restarts -- the solve starts in the restoration phase and counts on from there; -1: an ordinary solve
 };
 
 // Workspace accessor: wave-uniform base (an SGPR pair on the GPU) plus an unsigned 32-bit BYTE offset.  Indexing a plain double * with
@@ -2635,8 +2636,7 @@ _Pragma("unroll") \
     int n_restart = 0, it_restart = 0, n_resto = 0, it_resto = 0, n_short = 0; bool el = false;      // el: inside the restoration phase
     int it = 0, status = 1; double E0 = 0, ep_old = 0, ep_mid = 0;
     if (RESTO && pr.resto_from >= 0) {      // continuation of a solve whose main phase jammed in a kernel without the restoration phase
-        it = pr.resto_from; ep_old = ep_mid = 1e300;
-        if (longh) n_restart = STALL_RESTARTS;      // (long horizons hand over only behind their last barrier restart)
+        it = pr.resto_from & 0xfffff; n_restart = pr.resto_from >> 20; ep_old = ep_mid = 1e300;      // (the hand-over carries the restart count of a long horizon)
         BMPC_ENTER_RESTO()
         it++;
     }
@@ -2714,15 +2714,18 @@ _Pragma("unroll") \
         }
         // stalled primal feasibility -> status 2, numerical breakdown -> status 3 (oracle/bmpc_oracle.c solve_one)
         if (it == 0) ep_old = ep_mid = 1e300;
-        else if (!(RESTO && el)) {
+        if (!(RESTO && el)) {
             // (the floor of the tests scales with the tolerance: a solve that is asked for 1e-5 and sits at 1e-5 is converging, not stalled)
             const bool open_ = ep > BMPC_FMAX(1e-6, 10.0 * o.tol);
-            const bool at_check = o.stall_window > 0 && (it - it_restart) % (o.stall_window / 2) == 0;
+            const bool at_check = it > 0 && o.stall_window > 0 && (it - it_restart) % (o.stall_window / 2) == 0;
             const bool stalled = at_check && it >= o.stall_window + it_restart && ep >= STALL_FACTOR * ep_old && open_;
+            // a dual residual beyond 1e12 is a numerical breakdown of the main phase: with the restoration phase available the solve goes there (the
+            // rollout and the re-centred rows discard what broke) instead of ending as status 3
+            const bool broken = !(ed < 1e12) && o.restoration > 0;
             // long horizons: barrier restarts come first (below), the restoration phase is the last resort behind them and is not entered on a jam
-            const bool jammed = o.restoration && !longh && o.resto_short > 0 && n_short >= o.resto_short && open_;
-            if (stalled || jammed) {
-                if (o.restoration && (!longh || n_restart >= STALL_RESTARTS)) {
+            const bool jammed = o.restoration == 1 && !longh && o.resto_short > 0 && n_short >= o.resto_short && open_;
+            if (stalled || jammed || broken) {
+                if (broken || (o.restoration == 1 && (!longh || n_restart >= STALL_RESTARTS))) {
                     if (n_resto >= RESTO_MAX) { status = 2; break; }
                     if (!RESTO) { status = 4; break; }      // (internal) this kernel does not carry the phase: the restoration kernel continues from x
                     BMPC_ENTER_RESTO()
@@ -3015,7 +3018,7 @@ _Pragma("unroll") \
         }
         if (pr.state) for (int t_ = 0; t_ < (ni + WS - 1) / WS; t_++) { const int id0 = wl + WS * t_, id = id0 < ni ? id0 : ni - 1; pr.state[id] = WL[sc.NUm + id]; }
         if (wl == 0) {
-            if (pr.f) *pr.f = fval; if (pr.iters) *pr.iters = it; if (pr.status) *pr.status = status; if (pr.kkt) *pr.kkt = E0;
+            if (pr.f) *pr.f = fval; if (pr.iters) *pr.iters = status == 4 ? (it | (n_restart << 20)) : it; if (pr.status) *pr.status = status; if (pr.kkt) *pr.kkt = E0;
             if (pr.state) { pr.state[ni] = ((RESTO && el) || status == 4) ? 0.0 : mu; pr.state[ni + 1] = (double)it; }      // (a solve that ends inside the restoration phase leaves no dual state worth carrying)
         }
     WIDE_END

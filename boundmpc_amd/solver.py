@@ -32,7 +32,7 @@ class BatchedOCPSolver:
         _lib.check(self._lib.bmpc_create(int(N), int(S), float(dt), ctypes.byref(o), ctypes.byref(self._h)), "bmpc_create")
         # restoration phase (include/boundmpc_hip.h bmpc_set_restoration): None keeps the handle's default (on for N <= 11; 6 short steps; 40 iterations)
         if not (restoration is None and resto_short is None and resto_cap is None):
-            _lib.check(self._lib.bmpc_set_restoration(self._h, -1 if restoration is None else int(bool(restoration)), -1 if resto_short is None else int(resto_short),
+            _lib.check(self._lib.bmpc_set_restoration(self._h, -1 if restoration is None else int(restoration), -1 if resto_short is None else int(resto_short),
                                                       -1 if resto_cap is None else int(resto_cap)), "bmpc_set_restoration")
         self.N, self.S, self.dt = int(N), int(S), float(dt)
         self.n_w, self.n_g, self.n_p = N * NZ, N * NG, 141 + 91 * S
@@ -77,14 +77,15 @@ class BatchedOCPSolver:
         return dict(grid=g.value, lds_bytes=l.value, scratch_bytes=s.value)
 
     def set_restoration(self, enabled=None, short_steps=None, cap=None):
-        """Restoration phase of the solver (include/boundmpc_hip.h bmpc_set_restoration).  None keeps a value.  Re-capture graphs after changing it."""
-        _lib.check(self._lib.bmpc_set_restoration(self._h, -1 if enabled is None else int(bool(enabled)), -1 if short_steps is None else int(short_steps),
+        """Restoration phase of the solver (include/boundmpc_hip.h bmpc_set_restoration).  enabled: False / 0 never, True / 1 full (jam, stall, numerical
+        breakdown; default for N <= 11), 2 after a numerical breakdown only (default for N > 11).  None keeps a value.  Re-capture graphs after changing it."""
+        _lib.check(self._lib.bmpc_set_restoration(self._h, -1 if enabled is None else int(enabled), -1 if short_steps is None else int(short_steps),
                                                   -1 if cap is None else int(cap)), "bmpc_set_restoration")
 
     def get_restoration(self):
         e, s_, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         _lib.check(self._lib.bmpc_get_restoration(self._h, ctypes.byref(e), ctypes.byref(s_), ctypes.byref(c)), "bmpc_get_restoration")
-        return dict(enabled=bool(e.value), short_steps=s_.value, cap=c.value)
+        return dict(enabled=e.value == 1, mode=e.value, short_steps=s_.value, cap=c.value)
 
     def set_team_waves(self, waves=0):
         """Waves per problem: 0 (default) automatic -- a batch that fits into the resident teams of the device (256 on an MI355X) is solved by

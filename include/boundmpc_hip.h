@@ -90,10 +90,13 @@ int bmpc_destroy(bmpc_handle *h);
  *   - ends the solve with status 2 when it converges to a point with non-zero violation (a local minimiser of the violation: Ipopt's
  *     "converged to a point of local infeasibility"), when `cap` iterations (default 40) did not produce a feasible point (Ipopt: "restoration
  *     failed"), or at the fourth call within one solve.
- * enabled: 1 / 0; default 1 for N <= 11, 0 for longer horizons.  Long horizons (N > 11) keep their three barrier restarts from a stalled iterate
- * and, when enabled, enter the restoration phase as the LAST RESORT behind them (never on a jam: a tight 30-stage solve takes short steps for its
- * first 15 iterations anyway): it rescues 11 of the 27 problems of BASELINE configs[3] that end as status 2 (99.67 -> 99.80 % converged), but the
- * slowest problem of that launch then takes 314 instead of 180 iterations; instead of the restarts it would be worse (oracle/bmpc_oracle.c).
+ * enabled: 0 never (status 2 / 3 as in round 4); 1 full -- on a jam, a stall or a NUMERICAL BREAKDOWN of the main phase (dual residual beyond 1e12,
+ * which without the phase ends the solve as status 3); 2 after a numerical breakdown only.  Default 1 for N <= 11, 2 for longer horizons.  Long
+ * horizons (N > 11) keep their three barrier restarts from a stalled iterate; in mode 1 the phase follows them as the LAST RESORT (never on a jam: a
+ * tight 30-stage solve takes short steps for its first 15 iterations anyway): it rescues 14 of the 26 problems of BASELINE configs[3] that end as
+ * status 2 (99.68 -> 99.84 % converged), but the slowest problem of that launch then takes 314 instead of 170 iterations and the launch 37 % longer;
+ * instead of the restarts it would be worse (oracle/bmpc_oracle.c).  Mode 2 costs such a batch nothing and rescues far-off starts: 64 loose N = 20
+ * problems started with noise 0.3 on every variable: 64 converge (mode 0: 50, 14 numerical breakdowns).
  * A negative argument keeps the current value.  Read at launch / capture time.  Fixture g13b (every first failing tick of 256 closed loops): the 28
  * locally infeasible problems end as status 2 after 22-54 iterations, 8 of the 10 feasible ones converge in 69-121 (tests/test_gpu_parity.py).
  * An iterate that is far off its own dynamics when the phase starts (an equality residual above 1e-2: a bad warm start) is first rolled out from

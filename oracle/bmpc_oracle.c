@@ -97,7 +97,8 @@ typedef struct {
     int verbose;
     double mu_warm;      /* warm start: barrier restarts at clamp(stored mu, mu_warm, mu_init) */
     int stall_window;    /* 40; 0 = off */
-    int restoration;     /* 1: a jammed or stalled main phase hands over to the restoration phase (solve_one; default for N <= 11); 0: status 2 / barrier restarts */
+    int restoration;     /* 1: a jammed, stalled or numerically broken main phase hands over to the restoration phase (solve_one; default for N <= 11; long
+                            horizons: behind the barrier restarts); 2: only a numerical breakdown does (default for N > 11); 0: never (status 2 / 3) */
     int resto_short;     /* consecutive steps shorter than RESTO_SHORT_ALPHA that count as a jam (6; 0 = the stall test alone) */
     int resto_cap;       /* iterations one restoration phase may take before the solve ends as status 2 (40) */
 } bmpc_oracle_opts;
@@ -1017,16 +1018,20 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
          * lasts as long as its slowest problem.)  A dual residual beyond 1e12 is a numerical breakdown (status 3).
          * (the floor of the test scales with the tolerance: a solve that is asked for 1e-5 and sits at 1e-5 is converging, not stalled) */
         if (it == 0) ep_old = ep_mid = 1e300;
-        else if (!el) {
+        if (!el) {
             const int open = ep > fmax(1e-6, 10.0 * o->tol);
-            const int at_check = o->stall_window > 0 && (it - it_restart) % (o->stall_window / 2) == 0;
+            const int at_check = it > 0 && o->stall_window > 0 && (it - it_restart) % (o->stall_window / 2) == 0;
+            /* a dual residual beyond 1e12 is a numerical breakdown of the main phase (a far-off start: multipliers of 1e10 against curvature
+             * of the wrong sign): with the restoration phase available the solve goes there -- the rollout and the re-centred rows discard
+             * what broke -- instead of ending as status 3 */
+            const int broken = !(ed < 1e12) && o->restoration > 0;
             const int stalled = at_check && it >= o->stall_window + it_restart && ep >= STALL_FACTOR * ep_old && open;
             /* long horizons (N > GN_MIN_HORIZON): barrier restarts come first (below), the restoration phase is the last resort behind them and is
              * not entered on a jam (a typical tight 30-stage solve takes short steps for its first 15 iterations) */
             const int longh = N > GN_MIN_HORIZON;
-            const int jammed = o->restoration && !longh && o->resto_short > 0 && n_short >= o->resto_short && open;
-            if (stalled || jammed) {
-                if (o->restoration && (!longh || n_restart >= STALL_RESTARTS)) {
+            const int jammed = o->restoration == 1 && !longh && o->resto_short > 0 && n_short >= o->resto_short && open;
+            if (stalled || jammed || broken) {
+                if (broken || (o->restoration == 1 && (!longh || n_restart >= STALL_RESTARTS))) {
                     if (n_resto >= RESTO_MAX) { status = 2; break; }
                     n_resto++; it_resto = it; el = 1; Pc = &PRv; W->f = 0.0; mu = RESTO_MU;
                     {   /* an iterate that is far off its dynamics (a bad warm start: equality residuals above RESTO_ROLLOUT_TOL) is first made
@@ -1042,7 +1047,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
                     }
                     for (int i = 0; i < N * NI; i++) elastic_centre(W->hin[i], mu, rho, &W->t[i], &W->e[i], &W->nu[i]);
                     nfilt = 0; filt_mu = -1.0; theta_min = -1.0; delta_last = 0.0; delta_prev = 0.0; gn_run = 0; n_short = 0;
-                    if (o->verbose) fprintf(stderr, "   %s: restoration phase\n", jammed ? "jammed" : "stalled");
+                    if (o->verbose) fprintf(stderr, "   %s: restoration phase\n", broken ? "broken" : (jammed ? "jammed" : "stalled"));
                     continue;
                 }
                 /* Long horizons without the restoration phase: before giving up, restart the barrier from the CURRENT iterate -- slacks and

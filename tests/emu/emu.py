@@ -54,7 +54,7 @@ def solve(p, x0, N, S, h, opts=None, lane_order=0, nthreads=0, state=None):
     B = p.shape[0]
     out = dict(x=np.zeros((B, N * 44)), g=np.zeros((B, N * 43)), lam_g=np.zeros((B, N * 43)), lam_x=np.zeros((B, N * 44)),
                f=np.zeros(B), iters=np.zeros(B, dtype=np.int32), status=np.zeros(B, dtype=np.int32), kkt=np.zeros(B))
-    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=0) if N > 11 else default_opts())
+    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2) if N > 11 else default_opts())
     rc = lib().bmpc_emu_solve(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(B), _p(p), _p(x0), _p(state) if state is not None else None,
                               _p(out["x"]), _p(out["g"]), _p(out["lam_g"]), _p(out["lam_x"]), _p(out["f"]), _p(out["iters"]),
                               _p(out["status"]), _p(out["kkt"]), ctypes.c_int(lane_order), ctypes.c_int(nthreads))
@@ -86,7 +86,7 @@ def solve_team(p, x0, N, S, h, nw=4, opts=None, lane_order=0, wave_order=0, nthr
     B = p.shape[0]
     out = dict(x=np.zeros((B, N * 44)), g=np.zeros((B, N * 43)), lam_g=np.zeros((B, N * 43)), lam_x=np.zeros((B, N * 44)),
                f=np.zeros(B), iters=np.zeros(B, dtype=np.int32), status=np.zeros(B, dtype=np.int32), kkt=np.zeros(B))
-    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=0) if N > 11 else default_opts())
+    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2) if N > 11 else default_opts())
     rc = team_lib(nw).bmpc_emu_team_solve(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(B), _p(p), _p(x0),
                                           _p(state) if state is not None else None, _p(out["x"]), _p(out["g"]), _p(out["lam_g"]), _p(out["lam_x"]),
                                           _p(out["f"]), _p(out["iters"]), _p(out["status"]), _p(out["kkt"]), ctypes.c_int(lane_order),
@@ -153,7 +153,7 @@ def count_flops(p, x0, N, S, h, opts=None):
         _fl = ctypes.CDLL(_FLIB)
     p = np.ascontiguousarray(np.atleast_2d(p), dtype=np.float64)
     x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
-    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=0) if N > 11 else default_opts())
+    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2) if N > 11 else default_opts())
     out = np.zeros(36, dtype=np.uint64)
     rc = _fl.bmpc_emu_count_flops(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(p.shape[0]), _p(p), _p(x0), _p(out))
     assert rc == 0

@@ -330,3 +330,25 @@ def test_bad_warm_starts_are_rescued_by_the_restoration_phase():
     assert same.mean() >= 0.9      # mostly the minimiser the reference's cold start reaches (the NLP is non-convex: a few end in a neighbouring one)
     dq = (o["x"][ok] - e["x"][ok]).reshape(-1, 10, 44)[:, :, 8:15]
     assert np.sqrt((dq ** 2).mean(axis=(1, 2))).max() < 1e-5
+
+
+def test_numerical_breakdowns_of_far_off_starts_go_to_the_restoration_phase():
+    """A dual residual beyond 1e12 used to end a solve as status 3.  With the restoration phase available (mode 1, and mode 2 = the default of long
+    horizons: after a numerical breakdown ONLY, so that configs[3] pays nothing) the solve goes there instead: 32 loose N = 20 problems started with
+    noise 0.3 on every variable: all converge (mode 0: a quarter breaks down); the other (N, S) of fixture G12 with the same noise on their recorded
+    warm starts: 12 of 12, 15 of 16, 10 of 10 (mode 0: none -- they stall).  Kernel text (hand-over, incl. the restart count of a long horizon) == oracle."""
+    from boundmpc_amd import workload
+    P, X, _ = workload.make_batch(32, seed=7, N=20, workers=4)
+    X2 = X + np.random.default_rng(3).normal(size=X.shape) * 0.3
+    o, e = c_oracle.solve(P, X2, 20, 4, 0.1, nthreads=4), emu.solve(P, X2, 20, 4, 0.1, nthreads=4)
+    off = c_oracle.solve(P, X2, 20, 4, 0.1, opts=c_oracle.default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=0), nthreads=4)
+    assert (o["status"] == 0).all() and np.array_equal(o["status"], e["status"]) and (off["status"] == 3).sum() >= 4
+    d = np.load(os.path.join(G, "g12_pack_other_sizes.npz"))
+    for key, N, S, want in (("n5s2", 5, 2, 12), ("n8s3", 8, 3, 15), ("n6s5", 6, 5, 10)):
+        Pk = np.where(np.isfinite(d[key + "_p"]), d[key + "_p"], 0.0); Xk = d[key + "_x0"]; dt = float(d[key + "_dt"])
+        Xn = Xk + np.random.default_rng(3).normal(size=Xk.shape) * 0.3
+        o = c_oracle.solve(Pk, Xn, N, S, dt, opts=c_oracle.default_opts(max_iter=300), nthreads=4)
+        e = emu.solve(Pk, Xn, N, S, dt, opts=emu.default_opts(max_iter=300), nthreads=4)
+        off = c_oracle.solve(Pk, Xn, N, S, dt, opts=c_oracle.default_opts(max_iter=300, restoration=0), nthreads=4)
+        assert (o["status"] == 0).sum() >= want and np.array_equal(o["status"], e["status"]) and np.abs(o["iters"] - e["iters"]).max() <= 8, key
+        assert (off["status"] == 0).sum() == 0, key

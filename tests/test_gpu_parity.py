@@ -747,7 +747,7 @@ def test_long_horizon_restoration_as_the_last_resort_behind_the_restarts():
     P, X, _ = workload.make_batch(8192, seed=2, N=30, tight=True, rows=(688, 696))
     p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
     s = BatchedOCPSolver(30, 4, 0.1)
-    assert s.get_restoration()["enabled"] is False      # default of long horizons
+    assert s.get_restoration()["mode"] == 2      # default of long horizons: after a numerical breakdown only
     off = s.solve_batch(p, x0); st_off, it_off = off["status"].cpu().numpy(), off["iters"].cpu().numpy()
     assert st_off[2] == 2 and st_off[7] == 2 and (np.delete(st_off, [2, 7]) == 0).all()
     s.set_restoration(True)
@@ -757,4 +757,26 @@ def test_long_horizon_restoration_as_the_last_resort_behind_the_restarts():
     keep = np.delete(np.arange(8), [2, 7])
     assert np.array_equal(it_on[keep], it_off[keep]) and torch.equal(on["x"][torch.tensor(keep, device="cuda")], off["x"][torch.tensor(keep, device="cuda")])
     assert float(on["kkt"][2]) <= 1e-8
+    s.close()
+
+
+@pytest.mark.gpu
+def test_numerical_breakdowns_of_far_off_starts_go_to_the_restoration_phase_on_the_gpu():
+    """64 loose N = 20 problems started with noise 0.3 on every variable of the warm start.  Mode 0 (round 4): a fifth ends as status 3 (dual residual
+    beyond 1e12).  The default of long horizons (mode 2: restoration after a numerical breakdown only) hands those to the restoration kernel -- rollout,
+    feasibility problem, main phase again -- and all 64 converge, with the oracle's statuses; the restart count of the long horizon travels with the
+    hand-over."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    from oracle import c_oracle
+    P, X, _ = workload.make_batch(64, seed=7, N=20)
+    X2 = X + np.random.default_rng(3).normal(size=X.shape) * 0.3
+    p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X2, device="cuda")
+    ref = c_oracle.solve(P, X2, 20, 4, 0.1, nthreads=8)
+    s = BatchedOCPSolver(20, 4, 0.1)
+    o = s.solve_batch(p, x0); st = o["status"].cpu().numpy()
+    assert (st == 0).all() and np.array_equal(st, ref["status"]) and float(o["kkt"].max()) <= 1e-8
+    s.set_restoration(0)
+    o0 = s.solve_batch(p, x0); st0 = o0["status"].cpu().numpy()
+    assert (st0 == 3).sum() >= 8 and (st0 == 0).sum() <= 56
     s.close()
