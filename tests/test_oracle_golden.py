@@ -463,3 +463,19 @@ def test_first_failures_of_all_256_closed_loops_g13b():
     patient = c_oracle.default_opts(max_iter=500, stall_window=0, restoration=0)      # round 4's patient handle, for the record
     a = c_oracle.solve(d["p"][feas], d["x0"][feas], 10, 4, 0.1, opts=patient, nthreads=4)
     assert (a["status"] == 0).sum() >= 8 and a["iters"][a["status"] == 0].min() >= 60
+
+
+def test_oracle_converges_from_starts_far_from_the_reference_warm_start():
+    """The restoration phase (rollout of the iterate's own jerks, elastic feasibility problem, strictly feasible point handed back) makes the solve
+    independent of the reference's warm start: 128 feasible N = 10 problems from all zeros / uniform(-1, 1) / the cold start + noise 1.0 on every
+    variable.  (Round 4's algorithm -- restoration = 0 -- stalls on three quarters of the first and on all of the others; the GPU counterpart is
+    test_the_solver_does_not_depend_on_the_reference_warm_start, the full battery tests/gpu_robustness.py.)"""
+    from boundmpc_amd import workload
+    P, X, _ = workload.make_batch(128, seed=60, N=10)
+    rng = np.random.default_rng(11)
+    for name, X0, lo, hi_off in (("zeros", np.zeros_like(X), 0.94, 0.25), ("uniform", rng.uniform(-1, 1, X.shape), 0.99, 0.02), ("noise 1.0", X + rng.normal(size=X.shape), 0.99, 0.02)):
+        o = c_oracle.solve(P, X0, 10, 4, 0.1, nthreads=8)
+        assert (o["status"] == 0).mean() >= lo and o["iters"].max() <= 100 and o["kkt"][o["status"] == 0].max() <= 1e-8, (name, np.bincount(o["status"]))
+        o0 = c_oracle.solve(P, X0, 10, 4, 0.1, opts=c_oracle.default_opts(restoration=0), nthreads=8)
+        assert (o0["status"] == 0).mean() <= hi_off, name
+
