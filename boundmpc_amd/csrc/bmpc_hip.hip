@@ -88,6 +88,7 @@ struct bmpc_handle {
     int grid; long long scr_stride; double *scratch; int scr_waves; int graphs_alive; int *counter; unsigned long long *prof;
     int team_grid;           // resident TEAMS (workgroups of BMPC_TEAM_NW waves, bmpc_team.hip) of the device; 0: no team kernel for this handle (N > 10 or S > 4)
     int *aux_int; int aux_cap;      // [2][aux_cap] status / iters of a batch whose caller passed NULL (the restoration kernel reads them)
+    int start_rollout;      // 1 (default): a cold solve whose x0 is far off its own dynamics starts from the rollout of x0's jerks (bmpc_set_start_rollout)
     int resto_on, resto_short, resto_cap;      // restoration phase (bmpc_set_restoration): mode 0 off / 1 full (default N <= 11) / 2 after a numerical breakdown only (default N > 11); jam = resto_short consecutive short steps; iterations per phase
     int team_mode;           // bmpc_set_team_waves: 0 automatic (teams when the batch fits into the resident teams), 1 never, BMPC_TEAM_NW whenever possible
     int timing; hipEvent_t *ev; int nev; long long n_timed;   // timing = number of launches whose {start, stop} event pairs are kept (ring)
@@ -161,6 +162,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BMPC_ERR_NOGPU;
     bmpc_handle *h = new (std::nothrow) bmpc_handle();
     if (!h) return BMPC_ERR_ARG;
+    h->start_rollout = 1;
     h->resto_on = N <= 11 ? 1 : 2; h->resto_short = 6; h->resto_cap = 40;      // restoration phase: full for short horizons, after a numerical breakdown only for long ones (bmpc_set_restoration)
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->ev = nullptr; h->nev = 0; h->n_timed = 0; h->latency_us = nullptr;
     h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->aux_int = nullptr; h->aux_cap = 0; h->prof = nullptr; h->stage_d = nullptr; h->stage_h = nullptr; h->stage_cap = 0;
@@ -295,6 +297,12 @@ extern "C" int bmpc_get_restoration(const bmpc_handle *h, int *enabled, int *sho
     if (enabled) *enabled = h->resto_on; if (short_steps) *short_steps = h->resto_short; if (cap) *cap = h->resto_cap;
     return BMPC_OK;
 }
+extern "C" int bmpc_set_start_rollout(bmpc_handle *h, int enabled) {
+    if (!h || enabled < 0 || enabled > 1) return BMPC_ERR_ARG;
+    h->start_rollout = enabled;
+    return BMPC_OK;
+}
+extern "C" int bmpc_get_start_rollout(const bmpc_handle *h) { return h ? h->start_rollout : -1; }
 extern "C" int bmpc_options_size(void) { return (int)sizeof(bmpc_options); }
 #ifndef BMPC_BUILD_HASH_STR
 #define BMPC_BUILD_HASH_STR "0000000000000000"
@@ -323,7 +331,7 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
     a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
     a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window; a.o.bound_margin = h->o.bound_margin;
-    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap;
+    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap; a.o.start_rollout = h->start_rollout;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = lam_g; a.lam_x = lam_x; a.f = f; a.kkt = kkt; a.iters = iters; a.status = status;
     a.state = state; a.latency_us = h->latency_us; a.budget_ticks = 0;
     const int grid = launch_grid(h, B);
@@ -529,7 +537,7 @@ static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entr
     KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
     a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
     a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window; a.o.bound_margin = h->o.bound_margin;
-    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap;
+    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap; a.o.start_rollout = h->start_rollout;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = nullptr; a.lam_x = nullptr; a.f = nullptr; a.kkt = kkt; a.iters = iters; a.status = status;
     a.state = dual_state; a.latency_us = h->latency_us; a.budget_ticks = (long long)(h->rt_budget_us * 100.0);
     if (B > h->scr_waves) return BMPC_ERR_ARG;

@@ -105,6 +105,7 @@ constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
 #define RESTO_GTOL 1e-4        // ... and equality residuals below this
 #define RESTO_MAX 3            // restoration phases per solve
 #define RESTO_ROLLOUT_TOL 1e-2 // the phase starts from the rollout of the iterate's own jerks when an equality residual exceeds this
+#define START_ROLLOUT_TOL 0.5 // a cold solve starts from the rollout of x0's own jerks when an integrator-chain residual of x0 exceeds this (oracle/bmpc_oracle.c solve_one)
 #define KAPPA_EPS 100.0   // barrier problem "solved" at KKT error <= KAPPA_EPS * mu (oracle/bmpc_oracle.c).  A deliberate departure from Ipopt, whose
                           // barrier_tol_factor defaults to 10: measured on the bench batches it takes 2 of 14 iterations off the mean and 36 -> 20 off the slowest problem
                           // (DESIGN.md 2, round 2); the price is an occasional premature barrier reduction (a problem that then crawls for some iterations)
@@ -237,6 +238,7 @@ struct Opts {
                               // long horizons: behind the barrier restarts); 2: only a numerical breakdown does; 0: never (status 2 / 3)
     int resto_short;          // consecutive steps shorter than RESTO_SHORT_ALPHA that count as a jam (6; 0 = the stall test alone)
     int resto_cap;            // iterations one restoration phase may take before the solve ends as status 2 (40)
+    int start_rollout;        // 1: a cold solve whose x0 is far off its own dynamics (START_ROLLOUT_TOL) starts from the rollout of x0's jerks; 0: from x0 as given
 };
 
 // global scratch layout (doubles) for horizon N
@@ -2525,14 +2527,58 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     WIDE_END
     wave_init_tables(W, po);
     const double *PAR = L + L_PAR;
+    // the integrator chains of the iterate rolled out from node 0 with the iterate's own jerks (oracle/bmpc_oracle.c rollout_chains): one lane per
+    // chain (7 joints + the path parameter); the evaluation that follows projects the lifted variables
+#define BMPC_ROLLOUT() \
+            SOLO_BEGIN(0) \
+            LANES_BEGIN \
+                if (lane < 8) { \
+                    const double h_ = W.h, h2_ = h_ * h_, h3_ = h2_ * h_; \
+                    const int zx = lane < 7 ? ZQ + lane : ZPHI, zd = lane < 7 ? ZDQ + lane : ZDPHI, za = lane < 7 ? ZDDQ + lane : ZDDPHI, zj = lane < 7 ? ZJ + lane : ZJPHI; \
+                    const int px = lane < 7 ? po.q0 + lane : po.phi0, pd = lane < 7 ? po.dq0 + lane : po.phi0 + 1, pa = lane < 7 ? po.ddq0 + lane : po.phi0 + 2, pj = lane < 7 ? po.jerk + lane : po.jerkphi; \
+                    for (int k = 0; k < N; k++) { \
+                        const double x_ = ndv(PAR, po, W.Zc, k, zx, px), d_ = ndv(PAR, po, W.Zc, k, zd, pd), a_ = ndv(PAR, po, W.Zc, k, za, pa), j0_ = ndv(PAR, po, W.Zc, k, zj, pj); \
+                        double *Zn_ = W.Zc + k * NZ; const double j1_ = Zn_[zj]; \
+                        Zn_[zx] = x_ + h_ * d_ + h2_ / 2 * a_ + h3_ / 8 * j0_ + h3_ / 24 * j1_; \
+                        Zn_[zd] = d_ + h_ * a_ + h2_ / 3 * j0_ + h2_ / 6 * j1_; \
+                        Zn_[za] = a_ + h_ / 2 * (j0_ + j1_); \
+                    } \
+                } \
+            LANES_END \
+            SOLO_END \
+            TEAM_SYNC();
     // warm start (oracle/bmpc_oracle.c solve_one): barrier restarts at clamp(stored mu, mu_warm, mu_init); the stored
     // multiplier of a row bounds its initial slack from below by mu/nu, so active rows keep their multiplier
     const double mu_state = pr.state ? pr.state[ni] : 0.0;
     const bool warm = mu_state > 0.0;
     double mu = warm ? BMPC_FMIN(o.mu_init, BMPC_FMAX(mu_state, o.mu_warm)) : o.mu_init; const double mu_min = o.tol * o.mu_min_fac;
     double delta_last = 0.0, delta_prev = 0.0, filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0, gn_run = 0;
+    // A cold start that is not a trajectory (oracle/bmpc_oracle.c solve_one: a residual of the integrator chains of x0 above START_ROLLOUT_TOL -- noise,
+    // zeros, the plan of another problem) is made one first: the chains rolled out with x0's own jerks, the lifted variables projected by the first
+    // evaluation.  Warm solves (the ticks of a closed loop: shifted plans with a dual state) and continued solves are not touched.
+    bool roll0_ = false;
+    if (!warm && o.start_rollout && o.max_iter > 0 && !(RESTO && pr.resto_from >= 0)) {      // (max_iter = 0 is the evaluation of f, g AT x0)
+        WIDE_BEGIN
+            double gm_ = 0;
+            const double h_ = W.h, h2_ = h_ * h_, h3_ = h2_ * h_;
+            for (int t_ = 0; t_ < (N * 8 + WS - 1) / WS; t_++) {      // items (node, chain); wave-uniform trip count, clamped item
+                const int id0 = wl + WS * t_, id = id0 < N * 8 ? id0 : N * 8 - 1, k = id >> 3, c = id & 7;
+                const int zx = c < 7 ? ZQ + c : ZPHI, zd = c < 7 ? ZDQ + c : ZDPHI, za = c < 7 ? ZDDQ + c : ZDDPHI, zj = c < 7 ? ZJ + c : ZJPHI;
+                const int px = c < 7 ? po.q0 + c : po.phi0, pd = c < 7 ? po.dq0 + c : po.phi0 + 1, pa = c < 7 ? po.ddq0 + c : po.phi0 + 2, pj = c < 7 ? po.jerk + c : po.jerkphi;
+                const double x_ = ndv(PAR, po, W.Zc, k, zx, px), d_ = ndv(PAR, po, W.Zc, k, zd, pd), a_ = ndv(PAR, po, W.Zc, k, za, pa), j0_ = ndv(PAR, po, W.Zc, k, zj, pj);
+                const double *Zn_ = W.Zc + k * NZ; const double j1_ = Zn_[zj];
+                const double r0_ = BMPC_FABS(x_ + h_ * d_ + h2_ / 2 * a_ + h3_ / 8 * j0_ + h3_ / 24 * j1_ - Zn_[zx]);
+                const double r1_ = BMPC_FABS(d_ + h_ * a_ + h2_ / 3 * j0_ + h2_ / 6 * j1_ - Zn_[zd]), r2_ = BMPC_FABS(a_ + h_ / 2 * (j0_ + j1_) - Zn_[za]);
+                gm_ = r0_ > gm_ ? r0_ : gm_; gm_ = r1_ > gm_ ? r1_ : gm_; gm_ = r2_ > gm_ ? r2_ : gm_;
+            }
+            WRED_PUT_MAX(L_REDW, 4, gm_);
+        WIDE_END
+        roll0_ = WRED_GET_MAX(L_REDW, 4) > START_ROLLOUT_TOL;
+        TEAM_SYNC();
+        if (roll0_) { BMPC_ROLLOUT() }
+    }
     BMPC_PROF(W, 15);
-    double fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);
+    double fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, roll0_);
     BMPC_PROF(W, 0);
     // Row pass "A" (57 rows per node, lane-strided, three rows in flight per lane): multipliers nu, barrier ratios
     // sigma = nu/t, 1/t, sigma*(h+t), and the inequality part of the KKT error.  first = initialisation of t, nu.
@@ -2611,25 +2657,7 @@ _Pragma("unroll") \
         WIDE_END \
         const bool roll_ = WRED_GET_MAX(L_REDW, 4) > RESTO_ROLLOUT_TOL; \
         TEAM_SYNC(); \
-        if (roll_) { \
-            SOLO_BEGIN(0) \
-            LANES_BEGIN \
-                if (lane < 8) { \
-                    const double h_ = W.h, h2_ = h_ * h_, h3_ = h2_ * h_; \
-                    const int zx = lane < 7 ? ZQ + lane : ZPHI, zd = lane < 7 ? ZDQ + lane : ZDPHI, za = lane < 7 ? ZDDQ + lane : ZDDPHI, zj = lane < 7 ? ZJ + lane : ZJPHI; \
-                    const int px = lane < 7 ? po.q0 + lane : po.phi0, pd = lane < 7 ? po.dq0 + lane : po.phi0 + 1, pa = lane < 7 ? po.ddq0 + lane : po.phi0 + 2, pj = lane < 7 ? po.jerk + lane : po.jerkphi; \
-                    for (int k = 0; k < N; k++) { \
-                        const double x_ = ndv(PAR, po, W.Zc, k, zx, px), d_ = ndv(PAR, po, W.Zc, k, zd, pd), a_ = ndv(PAR, po, W.Zc, k, za, pa), j0_ = ndv(PAR, po, W.Zc, k, zj, pj); \
-                        double *Zn_ = W.Zc + k * NZ; const double j1_ = Zn_[zj]; \
-                        Zn_[zx] = x_ + h_ * d_ + h2_ / 2 * a_ + h3_ / 8 * j0_ + h3_ / 24 * j1_; \
-                        Zn_[zd] = d_ + h_ * a_ + h2_ / 3 * j0_ + h2_ / 6 * j1_; \
-                        Zn_[za] = a_ + h_ / 2 * (j0_ + j1_); \
-                    } \
-                } \
-            LANES_END \
-            SOLO_END \
-            TEAM_SYNC(); \
-        } \
+        if (roll_) { BMPC_ROLLOUT() } \
         fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, roll_); \
         BMPC_ROWS_CENTRE() \
         nfilt = 0; filt_mu = -1.0; theta_min = -1.0; delta_last = 0.0; delta_prev = 0.0; gn_run = 0; n_short = 0;

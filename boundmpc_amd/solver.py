@@ -15,7 +15,7 @@ NZ, NG = 44, 43
 
 class BatchedOCPSolver:
     def __init__(self, N, S, dt, tol=1e-8, max_iter=500, mu_init=None, slack_push=None, exact_hessian=True, mu_warm=1e-2, stall_window=None, bound_margin=0.0,
-                 restoration=None, resto_short=None, resto_cap=None):
+                 restoration=None, resto_short=None, resto_cap=None, start_rollout=None):
         self._lib = _lib.load()
         o = _lib.Options()
         self._lib.bmpc_default_options_for(int(N), ctypes.byref(o))      # mu_init 0.1 / slack_push 1e-2 for N <= 11, 3.0 / 0.1 for longer horizons
@@ -34,6 +34,8 @@ class BatchedOCPSolver:
         if not (restoration is None and resto_short is None and resto_cap is None):
             _lib.check(self._lib.bmpc_set_restoration(self._h, -1 if restoration is None else int(restoration), -1 if resto_short is None else int(resto_short),
                                                       -1 if resto_cap is None else int(resto_cap)), "bmpc_set_restoration")
+        if start_rollout is not None:      # rollout of a cold start that is not a trajectory (bmpc_set_start_rollout; default on)
+            _lib.check(self._lib.bmpc_set_start_rollout(self._h, int(bool(start_rollout))), "bmpc_set_start_rollout")
         self.N, self.S, self.dt = int(N), int(S), float(dt)
         self.n_w, self.n_g, self.n_p = N * NZ, N * NG, 141 + 91 * S
         self.state_len = int(self._lib.bmpc_state_len(self._h))
@@ -81,6 +83,14 @@ class BatchedOCPSolver:
         breakdown; default for N <= 11), 2 after a numerical breakdown only (default for N > 11).  None keeps a value.  Re-capture graphs after changing it."""
         _lib.check(self._lib.bmpc_set_restoration(self._h, -1 if enabled is None else int(enabled), -1 if short_steps is None else int(short_steps),
                                                   -1 if cap is None else int(cap)), "bmpc_set_restoration")
+
+    def set_start_rollout(self, enabled=True):
+        """A cold solve whose x0 violates its own integrator chains by more than 0.5 starts from the rollout of x0's jerks (include/boundmpc_hip.h
+        bmpc_set_start_rollout; default on; warm solves and the reference's own starts are never touched).  Re-capture graphs after changing it."""
+        _lib.check(self._lib.bmpc_set_start_rollout(self._h, int(bool(enabled))), "bmpc_set_start_rollout")
+
+    def get_start_rollout(self):
+        return bool(self._lib.bmpc_get_start_rollout(self._h))
 
     def get_restoration(self):
         e, s_, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()

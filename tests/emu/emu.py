@@ -16,7 +16,7 @@ class Opts(ctypes.Structure):
     _fields_ = [("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("mu_init", ctypes.c_double),
                 ("mu_min_fac", ctypes.c_double), ("slack_push", ctypes.c_double),
                 ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double), ("stall_window", ctypes.c_int),
-                ("bound_margin", ctypes.c_double), ("restoration", ctypes.c_int), ("resto_short", ctypes.c_int), ("resto_cap", ctypes.c_int)]
+                ("bound_margin", ctypes.c_double), ("restoration", ctypes.c_int), ("resto_short", ctypes.c_int), ("resto_cap", ctypes.c_int), ("start_rollout", ctypes.c_int)]
 
 
 def build(force=False):
@@ -38,7 +38,7 @@ def lib():
 
 
 def default_opts(**kw):
-    o = Opts(1e-8, 500, 0.1, 0.1, 1e-2, 1, 0, 1e-2, 40, 0.0, 1, 6, 40)
+    o = Opts(1e-8, 500, 0.1, 0.1, 1e-2, 1, 0, 1e-2, 40, 0.0, 1, 6, 40, 1)
     for k, v in kw.items():
         setattr(o, k, v)
     return o

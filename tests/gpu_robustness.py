@@ -1,6 +1,6 @@
 """Diagnostic (GPU box; `--cpu`: oracle only, no GPU): robustness battery of the solver as a replacement for Ipopt -- feasible problems of the synthetic
 generator started from deliberately bad points (Gaussian noise on every variable of the reference's cold start, zeros, uniform noise), at the handle's
-defaults (restoration phase on) and with the phase off (round 4's behaviour); GPU against the CPU oracle problem by problem.
+defaults (rollout of a cold start that is not a trajectory, restoration phase behind it), with x0 taken as given (restoration phase alone) and with neither (round 4's behaviour); GPU against the CPU oracle problem by problem.
 Usage: python tests/gpu_robustness.py [--cpu]"""
 import os, sys, time
 import numpy as np
@@ -19,10 +19,13 @@ def opts(N, **kw):
 
 
 def case(name, P, X, N=10):
-    o = c_oracle.solve(P, X, N, 4, 0.1, opts=opts(N) if N <= 11 else opts(N, restoration=2), nthreads=16)
-    o0 = c_oracle.solve(P, X, N, 4, 0.1, opts=opts(N, restoration=0), nthreads=16)
+    rm = 1 if N <= 11 else 2
+    o = c_oracle.solve(P, X, N, 4, 0.1, opts=opts(N, restoration=rm), nthreads=16)
+    o1 = c_oracle.solve(P, X, N, 4, 0.1, opts=opts(N, restoration=rm, start_rollout=0), nthreads=16)
+    o0 = c_oracle.solve(P, X, N, 4, 0.1, opts=opts(N, restoration=0, start_rollout=0), nthreads=16)
     line = (f"{name:28s} oracle, defaults: {int((o['status'] == 0).sum()):3d} of {len(P)} converge (status {np.bincount(o['status'], minlength=4).tolist()}, "
-            f"iterations mean {o['iters'].mean():.1f} max {int(o['iters'].max())}); restoration off: {int((o0['status'] == 0).sum()):3d} (status {np.bincount(o0['status'], minlength=4).tolist()})")
+            f"iterations mean {o['iters'].mean():.1f} max {int(o['iters'].max())}); x0 as given, restoration phase alone: {int((o1['status'] == 0).sum()):3d} (mean {o1['iters'].mean():.1f}); "
+            f"neither (round 4): {int((o0['status'] == 0).sum()):3d} (status {np.bincount(o0['status'], minlength=4).tolist()})")
     if not CPU:
         s = BatchedOCPSolver(N, 4, 0.1, max_iter=500)
         g = s.solve_batch(torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")); st, it = g["status"].cpu().numpy(), g["iters"].cpu().numpy()

@@ -649,9 +649,9 @@ def test_first_failures_of_the_closed_loops_g13b_on_the_gpu():
     d = np.load(os.path.join(G, "g13b_first_failures_256_streams.npz"))
     p, x0 = torch.tensor(d["p"], device="cuda"), torch.tensor(d["x0"], device="cuda")
     feas = (d["slsqp_eq"] < 1e-8) & (d["slsqp_ineq"] < 1e-8) & (d["slsqp_bounds"] < 1e-8)
-    ref = c_oracle.solve(d["p"], d["x0"], 10, 4, 0.1, opts=c_oracle.default_opts(max_iter=500), nthreads=8)
+    ref = c_oracle.solve(d["p"], d["x0"], 10, 4, 0.1, opts=c_oracle.default_opts(max_iter=500, start_rollout=0), nthreads=8)
     for waves in (1, 4):
-        s = BatchedOCPSolver(10, 4, 0.1); s.set_team_waves(waves)
+        s = BatchedOCPSolver(10, 4, 0.1, start_rollout=False); s.set_team_waves(waves)      # (x0 as given: in the loop these ticks are warm solves)
         o = s.solve_batch(p, x0); st, it, f = o["status"].cpu().numpy(), o["iters"].cpu().numpy(), o["f"].cpu().numpy()
         di = np.abs(it - ref["iters"])
         assert np.array_equal(st, ref["status"]) and di[st == 0].max() <= 8 and (di <= 8).sum() >= 36, (waves, st, it)      # (the two that fail after three phases may leave at different counts)
@@ -666,7 +666,7 @@ def test_first_failures_of_the_closed_loops_g13b_on_the_gpu():
         assert (st != 0).all() and (st == d["oracle_status"]).mean() >= 0.9      # (a stalled solve may end as status 2 in one and 3 in the other)
         s.close()
     # the hand-over must not depend on the caller's optional outputs: status / iters NULL (handle-owned stand-ins)
-    s = BatchedOCPSolver(10, 4, 0.1)
+    s = BatchedOCPSolver(10, 4, 0.1, start_rollout=False)
     x = torch.empty((38, 440), device="cuda", dtype=torch.float64)
     from boundmpc_amd import _lib
     _lib.check(s._lib.bmpc_solve_batch(s._h, 38, p.data_ptr(), x0.data_ptr(), x.data_ptr(), None, None, None, None, None, None, None, None), "bmpc_solve_batch")
@@ -720,10 +720,11 @@ def test_bad_warm_starts_are_rescued_by_the_restoration_phase_on_the_gpu():
     from oracle import c_oracle
     P, X, _ = workload.make_batch(256, seed=50, N=10, tight=True)
     X2 = X + np.random.default_rng(5).normal(size=X.shape) * 0.3
-    ref = c_oracle.solve(P, X2, 10, 4, 0.1, opts=c_oracle.default_opts(max_iter=300), nthreads=8)
+    # (start_rollout off: x0 as given -- with the default these starts are rolled out before the first iteration and never need the phase; last lines)
+    ref = c_oracle.solve(P, X2, 10, 4, 0.1, opts=c_oracle.default_opts(max_iter=300, start_rollout=0), nthreads=8)
     p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X2, device="cuda")
     for waves in (1, 4):
-        s = BatchedOCPSolver(10, 4, 0.1, max_iter=300); s.set_team_waves(waves)
+        s = BatchedOCPSolver(10, 4, 0.1, max_iter=300, start_rollout=False); s.set_team_waves(waves)
         o = s.solve_batch(p, x0); st, it = o["status"].cpu().numpy(), o["iters"].cpu().numpy()
         assert (st == 0).mean() >= 0.97 and (st == ref["status"]).mean() >= 0.99 and np.abs(it - ref["iters"])[st == ref["status"]].max() <= 10, (waves, np.bincount(st), np.abs(it - ref["iters"]).max())
         ok = (st == 0) & (ref["status"] == 0)
@@ -732,6 +733,13 @@ def test_bad_warm_starts_are_rescued_by_the_restoration_phase_on_the_gpu():
         s.set_restoration(False)
         o = s.solve_batch(p, x0)
         assert (o["status"].cpu().numpy() == 0).mean() <= 0.4
+        # the handle's defaults: the cold start that is not a trajectory is rolled out first -- all converge, with or without the phase, in the oracle's iterations
+        s.set_start_rollout(True)
+        ref1 = c_oracle.solve(P, X2, 10, 4, 0.1, opts=c_oracle.default_opts(max_iter=300, restoration=0), nthreads=8)
+        o = s.solve_batch(p, x0); st, it = o["status"].cpu().numpy(), o["iters"].cpu().numpy()
+        assert (st == 0).all() and (ref1["status"] == 0).all() and it.mean() <= 20 and np.abs(it - ref1["iters"]).max() <= 3, (waves, np.bincount(st), it.mean())
+        dq = (o["x"].cpu().numpy() - ref1["x"]).reshape(-1, 10, 44)[:, :, 8:15]
+        assert np.sqrt((dq ** 2).mean(axis=(1, 2))).max() < 1e-5
         s.close()
 
 
@@ -772,22 +780,28 @@ def test_numerical_breakdowns_of_far_off_starts_go_to_the_restoration_phase_on_t
     P, X, _ = workload.make_batch(64, seed=7, N=20)
     X2 = X + np.random.default_rng(3).normal(size=X.shape) * 0.3
     p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X2, device="cuda")
-    ref = c_oracle.solve(P, X2, 20, 4, 0.1, nthreads=8)
-    s = BatchedOCPSolver(20, 4, 0.1)
+    ref = c_oracle.solve(P, X2, 20, 4, 0.1, opts=c_oracle.default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2, start_rollout=0), nthreads=8)
+    s = BatchedOCPSolver(20, 4, 0.1, start_rollout=False)      # (x0 as given, so that the main phase does break down; the default rolls these starts out first)
     o = s.solve_batch(p, x0); st = o["status"].cpu().numpy()
     assert (st == 0).all() and np.array_equal(st, ref["status"]) and float(o["kkt"].max()) <= 1e-8
     s.set_restoration(0)
     o0 = s.solve_batch(p, x0); st0 = o0["status"].cpu().numpy()
     assert (st0 == 3).sum() >= 8 and (st0 == 0).sum() <= 56
+    s.set_start_rollout(True); s.set_restoration(2)      # the handle's defaults: rolled out first (one problem still breaks down and goes to the phase), a third of the iterations
+    ref1 = c_oracle.solve(P, X2, 20, 4, 0.1, nthreads=8)
+    o1 = s.solve_batch(p, x0); st1, it1 = o1["status"].cpu().numpy(), o1["iters"].cpu().numpy()
+    assert (st1 == 0).all() and np.array_equal(st1, ref1["status"]) and it1.mean() <= 0.5 * o["iters"].float().mean().item() and np.abs(it1 - ref1["iters"]).max() <= 8
     s.close()
 
 
 @pytest.mark.gpu
 def test_the_solver_does_not_depend_on_the_reference_warm_start():
     """128 feasible N = 10 problems (loose tubes, seed 60; tests/gpu_robustness.py is the full battery) started from all zeros, from uniform(-1, 1) noise in
-    place of the reference's cold start and from that cold start + Gaussian noise 1.0 on every variable: at the handle's defaults >= 94 % converge
-    (all zeros) / >= 99 % (the others), to the solutions of the oracle with the oracle's statuses problem by problem; with the restoration phase
-    switched off (round 4's solver) at most a quarter converges from zeros and none from the noisy starts."""
+    place of the reference's cold start and from that cold start + Gaussian noise 1.0 on every variable.  At the handle's defaults (a cold start that
+    is not a trajectory is rolled out before the first iteration; restoration phase behind it) ALL converge, from zeros in the iterations of the
+    reference's cold start, to the solutions of the oracle with the oracle's statuses problem by problem.  With x0 taken as given the restoration
+    phase alone rescues >= 94 % / 99 % of them in about three times the iterations; with neither (round 4's solver) at most a quarter converges from
+    zeros and none from the noisy starts."""
     import torch
     from boundmpc_amd import BatchedOCPSolver, workload
     from oracle import c_oracle
@@ -796,16 +810,22 @@ def test_the_solver_does_not_depend_on_the_reference_warm_start():
     starts = {"zeros": (np.zeros_like(X), 0.94, 0.25), "uniform": (rng.uniform(-1, 1, X.shape), 0.99, 0.02), "noise 1.0": (X + rng.normal(size=X.shape), 0.99, 0.02)}
     s = BatchedOCPSolver(10, 4, 0.1)
     p = torch.tensor(P, device="cuda")
+    cold = s.solve_batch(p, torch.tensor(X, device="cuda"))
     for name, (X0, lo, hi_off) in starts.items():
-        ref = c_oracle.solve(P, X0, 10, 4, 0.1, nthreads=8)
-        s.set_restoration(1)
-        o = s.solve_batch(p, torch.tensor(X0, device="cuda")); st = o["status"].cpu().numpy()
-        assert (st == 0).mean() >= lo and np.array_equal(st, ref["status"]) and np.abs(o["iters"].cpu().numpy() - ref["iters"]).max() <= 6, (name, np.bincount(st))
-        ok = st == 0
-        dq = (o["x"].cpu().numpy()[ok] - ref["x"][ok]).reshape(-1, 10, 44)[:, :, 8:15]
-        assert np.sqrt((dq ** 2).mean(axis=(1, 2))).max() < 1e-5, name
+        x0 = torch.tensor(X0, device="cuda")
+        for roll in (True, False):
+            ref = c_oracle.solve(P, X0, 10, 4, 0.1, opts=c_oracle.default_opts(start_rollout=int(roll)), nthreads=8)
+            s.set_restoration(1); s.set_start_rollout(roll)
+            o = s.solve_batch(p, x0); st, it = o["status"].cpu().numpy(), o["iters"].cpu().numpy()
+            assert (st == 0).mean() >= (1.0 if roll else lo) and np.array_equal(st, ref["status"]) and np.abs(it - ref["iters"]).max() <= 6, (name, roll, np.bincount(st))
+            ok = st == 0
+            dq = (o["x"].cpu().numpy()[ok] - ref["x"][ok]).reshape(-1, 10, 44)[:, :, 8:15]
+            assert np.sqrt((dq ** 2).mean(axis=(1, 2))).max() < 1e-5, (name, roll)
+            if roll:
+                assert it.mean() <= 22, (name, it.mean())
+                if name == "zeros":      # all zeros rolled out IS the reference's cold start (up to round-off: FK(q0) in place of the given p0)
+                    assert np.abs(it - cold["iters"].cpu().numpy()).max() <= 1 and (o["x"] - cold["x"]).abs().reshape(-1, 10, 44)[:, :, 8:15].max().item() < 1e-6
         s.set_restoration(0)
-        o0 = s.solve_batch(p, torch.tensor(X0, device="cuda"))
+        o0 = s.solve_batch(p, x0)
         assert (o0["status"].cpu().numpy() == 0).mean() <= hi_off, name
     s.close()
-
