@@ -829,3 +829,29 @@ def test_the_solver_does_not_depend_on_the_reference_warm_start():
         o0 = s.solve_batch(p, x0)
         assert (o0["status"].cpu().numpy() == 0).mean() <= hi_off, name
     s.close()
+
+
+@pytest.mark.gpu
+def test_far_off_cold_starts_of_other_sizes():
+    """The rollout of a cold start that is not a trajectory on the other instantiations: the recorded starts of fixture G12 -- (N, S) = (5, 2), (8, 3),
+    (6, 5), (12, 6): the iterate in the workspace for S > 4 / N > 11 -- and synthetic batches of N = 1, 2 and 40 stages, each with noise 0.3 and 1.0
+    (0.5) on every variable: every problem converges, with the oracle's status and (within 2) its iterations."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    from oracle import c_oracle
+    d = np.load(os.path.join(G, "g12_pack_other_sizes.npz"))
+    cases = []
+    for key, N, S in (("n5s2", 5, 2), ("n8s3", 8, 3), ("n6s5", 6, 5), ("n12s6", 12, 6)):
+        P = np.where(np.isfinite(d[key + "_p"]), d[key + "_p"], 0.0)
+        for nz in (0.3, 1.0):
+            cases.append((N, S, float(d[key + "_dt"]), P, d[key + "_x0"] + np.random.default_rng(3).normal(size=d[key + "_x0"].shape) * nz))
+    for N in (1, 2, 40):
+        P, X, _ = workload.make_batch(32, seed=9, N=N)
+        cases.append((N, 4, 0.1, P, X + np.random.default_rng(4).normal(size=X.shape) * 0.5))
+    for N, S, dt, P, X0 in cases:
+        ref = c_oracle.solve(P, X0, N, S, dt, nthreads=8)
+        s = BatchedOCPSolver(N, S, dt)
+        o = s.solve_batch(torch.tensor(P, device="cuda"), torch.tensor(X0, device="cuda")); st, it = o["status"].cpu().numpy(), o["iters"].cpu().numpy()
+        assert (st == 0).all() and np.array_equal(st, ref["status"]) and np.abs(it - ref["iters"]).max() <= 2, (N, S, np.bincount(st), np.abs(it - ref["iters"]).max())
+        s.close()
+
