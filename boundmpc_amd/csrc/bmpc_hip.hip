@@ -88,7 +88,7 @@ struct bmpc_handle {
     int grid; long long scr_stride; double *scratch; int scr_waves; int graphs_alive; int *counter; unsigned long long *prof;
     int team_grid;           // resident TEAMS (workgroups of BMPC_TEAM_NW waves, bmpc_team.hip) of the device; 0: no team kernel for this handle (N > 10 or S > 4)
     int *aux_int; int aux_cap;      // [2][aux_cap] status / iters of a batch whose caller passed NULL (the restoration kernel reads them)
-    int start_rollout;      // 1 (default): a cold solve whose x0 is far off its own dynamics starts from the rollout of x0's jerks (bmpc_set_start_rollout)
+    int start_rollout;      // 1 (default): a stateless solve whose x0 is far off its own dynamics starts from the rollout of x0's jerks (bmpc_set_start_rollout)
     int resto_on, resto_short, resto_cap;      // restoration phase (bmpc_set_restoration): mode 0 off / 1 full (default N <= 11) / 2 after a numerical breakdown only (default N > 11); jam = resto_short consecutive short steps; iterations per phase
     int team_mode;           // bmpc_set_team_waves: 0 automatic (teams when the batch fits into the resident teams), 1 never, BMPC_TEAM_NW whenever possible
     int timing; hipEvent_t *ev; int nev; long long n_timed;   // timing = number of launches whose {start, stop} event pairs are kept (ring)

@@ -105,7 +105,7 @@ constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
 #define RESTO_GTOL 1e-4        // ... and equality residuals below this
 #define RESTO_MAX 3            // restoration phases per solve
 #define RESTO_ROLLOUT_TOL 1e-2 // the phase starts from the rollout of the iterate's own jerks when an equality residual exceeds this
-#define START_ROLLOUT_TOL 0.5 // a cold solve starts from the rollout of x0's own jerks when an integrator-chain residual of x0 exceeds this (oracle/bmpc_oracle.c solve_one)
+#define START_ROLLOUT_TOL 0.5 // a stateless solve starts from the rollout of x0's own jerks when an integrator-chain residual of x0 exceeds this (oracle/bmpc_oracle.c solve_one)
 #define KAPPA_EPS 100.0   // barrier problem "solved" at KKT error <= KAPPA_EPS * mu (oracle/bmpc_oracle.c).  A deliberate departure from Ipopt, whose
                           // barrier_tol_factor defaults to 10: measured on the bench batches it takes 2 of 14 iterations off the mean and 36 -> 20 off the slowest problem
                           // (DESIGN.md 2, round 2); the price is an occasional premature barrier reduction (a problem that then crawls for some iterations)
@@ -238,7 +238,7 @@ struct Opts {
                               // long horizons: behind the barrier restarts); 2: only a numerical breakdown does; 0: never (status 2 / 3)
     int resto_short;          // consecutive steps shorter than RESTO_SHORT_ALPHA that count as a jam (6; 0 = the stall test alone)
     int resto_cap;            // iterations one restoration phase may take before the solve ends as status 2 (40)
-    int start_rollout;        // 1: a cold solve whose x0 is far off its own dynamics (START_ROLLOUT_TOL) starts from the rollout of x0's jerks; 0: from x0 as given
+    int start_rollout;        // 1: a stateless solve (no dual state buffer) whose x0 is far off its own dynamics (START_ROLLOUT_TOL) starts from the rollout of x0's jerks; 0: from x0 as given
 };
 
 // global scratch layout (doubles) for horizon N
@@ -2555,9 +2555,10 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     double delta_last = 0.0, delta_prev = 0.0, filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0, gn_run = 0;
     // A cold start that is not a trajectory (oracle/bmpc_oracle.c solve_one: a residual of the integrator chains of x0 above START_ROLLOUT_TOL -- noise,
     // zeros, the plan of another problem) is made one first: the chains rolled out with x0's own jerks, the lifted variables projected by the first
-    // evaluation.  Warm solves (the ticks of a closed loop: shifted plans with a dual state) and continued solves are not touched.
+    // evaluation.  Solves that carry a dual state (the ticks of a closed loop -- also the cold one behind a failed restoration --, the drop-in shim) and
+    // continued solves are not touched.
     bool roll0_ = false;
-    if (!warm && o.start_rollout && o.max_iter > 0 && !(RESTO && pr.resto_from >= 0)) {      // (max_iter = 0 is the evaluation of f, g AT x0)
+    if (!pr.state && o.start_rollout && o.max_iter > 0 && !(RESTO && pr.resto_from >= 0)) {      // stateless solves only; (max_iter = 0 is the evaluation of f, g AT x0)
         WIDE_BEGIN
             double gm_ = 0;
             const double h_ = W.h, h2_ = h_ * h_, h3_ = h2_ * h_;

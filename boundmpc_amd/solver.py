@@ -85,8 +85,8 @@ class BatchedOCPSolver:
                                                   -1 if cap is None else int(cap)), "bmpc_set_restoration")
 
     def set_start_rollout(self, enabled=True):
-        """A cold solve whose x0 violates its own integrator chains by more than 0.5 starts from the rollout of x0's jerks (include/boundmpc_hip.h
-        bmpc_set_start_rollout; default on; warm solves and the reference's own starts are never touched).  Re-capture graphs after changing it."""
+        """A stateless solve (solve_batch / solve_host without a dual state) whose x0 violates its own integrator chains by more than 0.5 starts from the
+        rollout of x0's jerks (include/boundmpc_hip.h bmpc_set_start_rollout; default on; solves with a dual state and the reference's own starts are never touched).  Re-capture graphs after changing it."""
         _lib.check(self._lib.bmpc_set_start_rollout(self._h, int(bool(enabled))), "bmpc_set_start_rollout")
 
     def get_start_rollout(self):
@@ -280,6 +280,8 @@ class NlpSolverShim:
 
     def __init__(self, batched: BatchedOCPSolver):
         self._s = batched
+        # behind the reference's BoundMPC every x0 is the reference's own (its cold start or a shifted plan, BoundMPC.py:316-375): taken as given, like Ipopt does
+        batched.set_start_rollout(False)
         self._stats = {"iter_count": 0, "success": False, "return_status": "not run"}
         self._lbx, self._ubx, self._lbg, self._ubg = batched.bounds()
 

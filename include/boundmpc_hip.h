@@ -109,14 +109,14 @@ int bmpc_set_restoration(bmpc_handle *h, int enabled, int short_steps, int cap);
 int bmpc_get_restoration(const bmpc_handle *h, int *enabled, int *short_steps, int *cap);
 
 /* Rollout of a cold start that is not a trajectory (round 5; oracle/bmpc_oracle.c solve_one).  The reference hands Ipopt its own cold start (the
- * measured state repeated, BoundMPC.py:316-321) or the shifted previous plan (:322-375); a caller of this library may hand over anything.  A COLD solve
- * (no dual state) whose x0 violates the integrator chains (the q, dq, ddq, phi, dphi, ddphi rows of g) by more than 0.5 is started from the rollout
+ * measured state repeated, BoundMPC.py:316-321) or the shifted previous plan (:322-375); a caller of this library may hand over anything.  A STATELESS
+ * solve (bmpc_solve_batch / bmpc_solve_batch_host: no dual state buffer) whose x0 violates the integrator chains (the q, dq, ddq, phi, dphi, ddphi rows of g) by more than 0.5 is started from the rollout
  * of x0's own jerks from the measured state, the lifted variables (pos, i-omega, v) projected -- a dynamically consistent trajectory with the same
  * controls.  128 feasible N = 10 problems from the reference's cold start + noise 0.1 ... 2.0 on every variable, from all zeros, from uniform(-1, 1)
  * noise: all converge, in 13-21 iterations on average (through the restoration phase alone: 94-100 % in 30-54; with neither: none).  The reference's
  * own starts are not touched (a cold start is a trajectory; a shifted plan is off by h dq at its last node -- 99 % of 12 267 closed-loop ticks below
  * 0.51 -- and comes with a dual state), nor is any
- * warm solve: on closed loops the same step costs plans.  A call with max_iter = 0 (the evaluation of f and g AT x0) is never rolled out.
+ * solve that carries a dual state buffer (bmpc_solve_batch_warm, the stream ticks -- warm or not): on closed loops the same step costs plans.  A call with max_iter = 0 (the evaluation of f and g AT x0) is never rolled out.
  * enabled: 1 (default) / 0 (x0 as given).  Read at launch / capture time. */
 int bmpc_set_start_rollout(bmpc_handle *h, int enabled);
 int bmpc_get_start_rollout(const bmpc_handle *h);      /* 0 / 1; -1: no handle */

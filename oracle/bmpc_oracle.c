@@ -84,7 +84,7 @@ static const double DQ_LIM_DEG[7] = {85, 85, 100, 75, 130, 135, 135};
 #define RESTO_GTOL 1e-4        /* ... and equality residuals below this */
 #define RESTO_MAX 3            /* restoration phases per solve */
 #define RESTO_ROLLOUT_TOL 1e-2 /* the phase starts from the rollout of the iterate's own jerks when an equality residual exceeds this */
-#define START_ROLLOUT_TOL 0.5 /* a COLD solve starts from the rollout of x0's own jerks when a residual of the integrator chains (q, dq, ddq, phi, dphi, ddphi rows)
+#define START_ROLLOUT_TOL 0.5 /* a STATELESS solve (no dual state buffer) starts from the rollout of x0's own jerks when a residual of the integrator chains (q, dq, ddq, phi, dphi, ddphi rows)
                                 * exceeds this: x0 is not a trajectory.  (The shifted plans of a closed loop are off by h dq at their last node: 12 267 converged
                                 * ticks of 96 replayed loops: median 0.08, 99 % below 0.51; the reference's own loops, fixture G7: at most 0.49 -- and they carry a dual state anyway: warm solves are
                                 * never touched.  The ticks those loops FAIL on start from residuals of 3.5 at the median, but rolling warm starts out costs
@@ -106,7 +106,7 @@ typedef struct {
                             horizons: behind the barrier restarts); 2: only a numerical breakdown does (default for N > 11); 0: never (status 2 / 3) */
     int resto_short;     /* consecutive steps shorter than RESTO_SHORT_ALPHA that count as a jam (6; 0 = the stall test alone) */
     int resto_cap;       /* iterations one restoration phase may take before the solve ends as status 2 (40) */
-    int start_rollout;   /* 1 (default): a cold solve whose x0 is far off its own dynamics (START_ROLLOUT_TOL) starts from the rollout of x0's jerks; 0: from x0 as given */
+    int start_rollout;   /* 1 (default): a stateless solve (no dual state buffer) whose x0 is far off its own dynamics (START_ROLLOUT_TOL) starts from the rollout of x0's jerks; 0: from x0 as given */
 } bmpc_oracle_opts;
 
 typedef struct {
@@ -984,12 +984,13 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
     double mu_min = o->tol * o->mu_min_fac, delta_last = 0.0, delta_prev = 0.0; int gn_run = 0;
     double filt_th[32], filt_ph[32], filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0;
     ORACLE_REGION(REG_EVAL); W->f = eval_values(C, P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0); ORACLE_REGION(REG_DRIVER);
-    if (!warm && o->start_rollout && o->max_iter > 0) {      /* (max_iter = 0 is the evaluation of f, g AT x0) */
+    if (!state && o->start_rollout && o->max_iter > 0) {      /* stateless solves only; (max_iter = 0 is the evaluation of f, g AT x0) */
         /* A cold start that is not a trajectory (an integrator-chain residual above START_ROLLOUT_TOL: noise, zeros, a plan of another problem) is
          * made one first: the chains rolled out from the measured state with x0's own jerks, the lifted variables projected.  128 feasible N = 10
          * problems from the reference's cold start + noise 0.1 ... 2.0 on every variable, from all zeros, from uniform(-1, 1): ALL converge, in
-         * 13-21 iterations on average (through the restoration phase alone: 94-100 %, 30-54 iterations; without either: none).  Warm solves
-         * are not touched: on the closed loops of configs[4] the same step costs plans (17 -> 23 of 256 streams lost). */
+         * 13-21 iterations on average (through the restoration phase alone: 94-100 %, 30-54 iterations; without either: none).  A solve that
+         * carries a dual state (the ticks of a closed loop, the drop-in shim) is never touched, warm or not -- a stream's tick behind a failed
+         * restoration is a cold solve of a shifted plan: on the closed loops of configs[4] the same step costs plans (17 -> 23 of 256 streams lost). */
         double gm_ = 0;
         for (int k = 0; k < N; k++) { const double *gk = W->g + k * NE; for (int i = 0; i < 21; i++) gm_ = fmax(gm_, fabs(gk[GQ + i])); for (int i = 0; i < 3; i++) gm_ = fmax(gm_, fabs(gk[GPHI + i])); }
         if (gm_ > START_ROLLOUT_TOL) {
