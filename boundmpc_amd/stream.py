@@ -190,6 +190,9 @@ class StreamBatch:
     def __init__(self, solver, mpcs, device="cuda"):
         import torch
         self.solver, self.B, self.N, self.S = solver, len(mpcs), solver.N, solver.S
+        # the warm starts of a stream are the reference's own (stream_pack: its cold start or the shifted plan, BoundMPC.py:316-375): taken as given, also
+        # by the stateless ticks (cold duals); on closed loops the rollout of a start that is off its dynamics costs plans (oracle/bmpc_oracle.c solve_one)
+        solver.set_start_rollout(False)
         lens = [ctypes.c_int() for _ in range(4)]
         _lib.check(solver._lib.bmpc_stream_lengths(solver._h, *[ctypes.byref(v) for v in lens]), "bmpc_stream_lengths")
         self.pt_len, self.ss_len, self.rb_len, self.tr_len = (v.value for v in lens)
