@@ -40,6 +40,8 @@ def main():
                     help="threshold of the reference's acceptance rule (summed violation of g, BoundMPC.py:462-465: 1e-4) that decides whether an "
                          "iteration-capped iterate is applied in the real-time modes; an iterate that fails it is not applied, the previous plan is replayed")
     ap.add_argument("--rt-bound-margin", type=float, default=2e-3, help="joint limits tightened inside the solver of the time-budgeted modes (rad, rad/s)")
+    ap.add_argument("--rtfix-mu", default="0.1,0.05", help="barrier levels of the fixed-barrier time-budgeted modes (rtfix-*)")
+    ap.add_argument("--rtfix-budgets", default="625", help="their time budgets in microseconds")
     ap.add_argument("--only", default="", help="comma-separated substrings: run only the modes whose name contains one of them (the converged loop always runs: it is the reference of the deviations)")
     ap.add_argument("--stall-window", type=int, default=16,
                     help="stall window of the converged / warm loops (0: the handle's default, 40 for N <= 11).  A stream that is losing its plan (locally infeasible "
@@ -91,6 +93,15 @@ def main():
         for gn in (False, True):
             rtb[(us, gn)] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=30, mu_warm=args.rt_mu_warm, exact_hessian=not gn, bound_margin=args.rt_bound_margin)
             rtb[(us, gn)].set_timing(True)
+    # time-budgeted modes on a FIXED barrier level (round 5; the classical real-time iteration of an interior-point method): mu_init = mu_warm = final
+    # level = MU, so a tick spends its few iterations as Newton steps on ONE barrier problem whose solution the previous tick left nearby, instead of
+    # restarting the barrier at mu_warm and re-converging through its levels; tol never fires (the complementarity stays at MU): every tick uses its
+    # budget and the reference's acceptance rule (threshold rt_feas_tol) decides.  Larger MU: plans further from the tube / limit rows, more robust.
+    rtf = {}
+    for us in [int(v) for v in args.rtfix_budgets.split(",") if v]:
+        for MU in [float(v) for v in args.rtfix_mu.split(",") if v]:
+            rtf[(us, MU)] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=30, fixed_barrier=MU, bound_margin=args.rt_bound_margin)
+            rtf[(us, MU)].set_timing(True)
     evaluate = BatchedOCPSolver(10, 4, 0.1, max_iter=0)       # f, g at a given point (no iteration)
     reference = BatchedOCPSolver(10, 4, 0.1, tol=args.tol, max_iter=args.max_iter)    # every tick's problem solved to tolerance, untimed
     res, ref_q = [], None
@@ -103,6 +114,7 @@ def main():
         + [("rti-3-feas%g" % FT, solver, 3, True, FT)] \
         + [("warm-continue-feas1e-4 (converged solves; a stalled tick's iterate is the next warm start; reference acceptance rule + variable bounds)", solver, 0, True, 1e-4)] \
         + [(f"rtb{'gn' if gn else 'w'}-tol{args.rt_tol:g}-budget{us}us-feas{FT:g}", rtb[(us, gn)], 0, True, FT) for (us, gn) in sorted(rtb)]
+    modes += [(f"rtfix-mu{MU:g}-tol{args.rt_tol:g}-budget{us}us-feas{FT:g}", rtf[(us, MU)], 0, True, FT) for (us, MU) in sorted(rtf)]
     if args.unsafe_too:
         modes += [(f"UNSAFE rtgn-tol{args.rt_tol:g}-cap{c} (every capped iterate applied)", rtgn[c], 0, True, 1e30) for c in (4, 3)]
     from boundmpc_amd.robot_model import RobotModel
@@ -113,6 +125,7 @@ def main():
     torch.cuda.set_stream(torch.cuda.Stream())
     only = [k for k in args.only.split(",") if k]
     budget_of = {id(rtb[k]): k[0] for k in rtb}
+    budget_of.update({id(rtf[k]): k[0] for k in rtf})
     for mode, slv, cap, warm, feas in modes:
         if only and mode != "converged" and not any(k in mode for k in only):
             continue
@@ -215,8 +228,12 @@ def main():
     met = [r["mode"] for r in res if r["tick_ms_p50"] <= 1.0 and r["tick_ms_p99"] <= 1.3 and r["streams_with_a_plan_at_the_end"] >= 0.75
            and r["joint_limit_violations_of_the_plant_state"] == 0]
     verdict = ("met by " + ", ".join(met)) if met else "not met by any mode of this run"
-    # ONE JSON line a driver can parse like bench.py's: value = ticks/s of the fastest mode that meets the criteria (0 when none does)
-    best = max((r for r in res if r["mode"] in met), key=lambda r: r["ticks_per_s"], default=None)
+    # the STRICT reading (round-4 verdict, item 2b): tick p99 <= 1.0 ms with >= 85 % of the streams holding a plan after the last tick, no plant sample outside
+    # the joint limits; the fixed-barrier modes (rtfix-*) are the ones built for it
+    strict = [r["mode"] for r in res if r["tick_ms_p99"] <= 1.0 and r["streams_with_a_plan_at_the_end"] >= 0.85 and r["joint_limit_violations_of_the_plant_state"] == 0]
+    verdict_strict = ("met by " + ", ".join(strict)) if strict else "not met by any mode of this run"
+    # ONE JSON line a driver can parse like bench.py's: value = ticks/s of the mode reported: of those that meet the strict criteria (else the round-3 ones) the one that keeps most plans (0 when none does)
+    best = max((r for r in res if r["mode"] in (strict or met)), key=lambda r: (r["streams_with_a_plan_at_the_end"], r["ticks_per_s"]), default=None)      # strict modes first; among them the one that keeps most plans
     print(json.dumps({"metric": "closed-loop ticks/s of 256 parallel receding-horizon streams (BASELINE configs[4]: 1 kHz target)", "value": best["ticks_per_s"] if best else 0.0,
                       "unit": "ticks/s", "n_gpus": 1, "higher_is_better": True, "dtype": "f64", "data": "synthetic", "vs_baseline": None,
                       "mode_reported": best["mode"] if best else None, "tick_ms_p50": best["tick_ms_p50"] if best else None, "tick_ms_p99": best["tick_ms_p99"] if best else None,
@@ -225,6 +242,7 @@ def main():
                                  "batch": B, "ticks": T - 1},
                       "batch": B, "ticks": T - 1,
                       "tol": args.tol, "mu_warm": args.mu_warm, "budget_ms": 1.0,
+                      "verdict_on_the_strict_1_kHz_target": verdict_strict + " (criteria: tick p99 <= 1.0 ms, >= 85 % of the streams with a plan after the last tick, no plant sample outside the joint limits)",
                       "verdict_on_the_1_kHz_target": verdict + " (criteria: tick p50 <= 1.0 ms, p99 <= 1.3 ms, >= 75 % of the streams with a plan after the last tick, no plant sample outside the joint limits)",
                       "workload": "256 closed loops, random q0 (seed 3), own experiment1-pattern path, N=10, h=0.1 s; pack+solve+post+plant on device",
                       "results": res}))

