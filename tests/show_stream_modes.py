@@ -1,3 +1,5 @@
+"""Diagnostic: one line per mode of a bench_stream.py JSON output (tick times, iterations, plans kept, distance to the converged loops, tube compliance).
+Usage: python tests/show_stream_modes.py out.json"""
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 for r in d["results"]:
