@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--rt-bound-margin", type=float, default=2e-3, help="joint limits tightened inside the solver of the time-budgeted modes (rad, rad/s)")
     ap.add_argument("--rtfix-mu", default="0.1,0.05", help="barrier levels of the fixed-barrier time-budgeted modes (rtfix-*)")
     ap.add_argument("--rtfix-budgets", default="625", help="their time budgets in microseconds")
+    ap.add_argument("--cfb", default="24,14,1.0", help="converged-fallback mode: iteration cap of the solve to tolerance, Newton steps and barrier level of the fallback")
     ap.add_argument("--only", default="", help="comma-separated substrings: run only the modes whose name contains one of them (the converged loop always runs: it is the reference of the deviations)")
     ap.add_argument("--stall-window", type=int, default=16,
                     help="stall window of the converged / warm loops (0: the handle's default, 40 for N <= 11).  A stream that is losing its plan (locally infeasible "
@@ -102,6 +103,14 @@ def main():
         for MU in [float(v) for v in args.rtfix_mu.split(",") if v]:
             rtf[(us, MU)] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=30, fixed_barrier=MU, bound_margin=args.rt_bound_margin)
             rtf[(us, MU)].set_timing(True)
+    # converged loops with a barrier-level fallback (round 5; StreamBatch.tick_with_fallback): every tick is solved to tolerance with at most 24 iterations (no
+    # restoration phase); the streams that did not converge are solved again from the same warm start on the fixed barrier level 1 (14 Newton steps) and
+    # the reference's acceptance rule at the reference's threshold 1e-4 decides
+    cfb_main = BatchedOCPSolver(10, 4, 0.1, tol=args.tol, mu_warm=args.mu_warm, max_iter=args.max_iter, stall_window=args.stall_window or None)
+    cfb_main.set_restoration(False); cfb_main.set_timing(True)
+    cfb_cap, cfb_k, cfb_mu = int(args.cfb.split(",")[0]), int(args.cfb.split(",")[1]), float(args.cfb.split(",")[2])
+    cfb_level = BatchedOCPSolver(10, 4, 0.1, tol=1e-3, max_iter=cfb_k, fixed_barrier=cfb_mu)
+    cfb_level.set_restoration(False)
     evaluate = BatchedOCPSolver(10, 4, 0.1, max_iter=0)       # f, g at a given point (no iteration)
     reference = BatchedOCPSolver(10, 4, 0.1, tol=args.tol, max_iter=args.max_iter)    # every tick's problem solved to tolerance, untimed
     res, ref_q = [], None
@@ -115,6 +124,7 @@ def main():
         + [("warm-continue-feas1e-4 (converged solves; a stalled tick's iterate is the next warm start; reference acceptance rule + variable bounds)", solver, 0, True, 1e-4)] \
         + [(f"rtb{'gn' if gn else 'w'}-tol{args.rt_tol:g}-budget{us}us-feas{FT:g}", rtb[(us, gn)], 0, True, FT) for (us, gn) in sorted(rtb)]
     modes += [(f"rtfix-mu{MU:g}-tol{args.rt_tol:g}-budget{us}us-feas{FT:g}", rtf[(us, MU)], 0, True, FT) for (us, MU) in sorted(rtf)]
+    modes += [(f"converged-fallback-cap{cfb_cap}-level{cfb_mu:g}-k{cfb_k}-feas1e-4 (solved to tolerance within {cfb_cap} iterations, else {cfb_k} steps on the barrier level {cfb_mu:g}; the reference's rule at 1e-4)", cfb_main, cfb_cap, True, 1e-4)]
     if args.unsafe_too:
         modes += [(f"UNSAFE rtgn-tol{args.rt_tol:g}-cap{c} (every capped iterate applied)", rtgn[c], 0, True, 1e30) for c in (4, 3)]
     from boundmpc_amd.robot_model import RobotModel
@@ -151,7 +161,10 @@ def main():
                     slv.set_time_budget_us(budget)      # read when the tick graph is captured (next tick)
             else:
                 ev0.record()
-                sb.tick_graph(max_iter=cap, warm_dual=warm, simulate=True, accept_capped=capped)
+                if mode.startswith("converged-fallback"):
+                    sb.tick_with_fallback(cfb_level, max_iter=cap, simulate=True)      # (three launches + a host read of the failed count: not a graph)
+                else:
+                    sb.tick_graph(max_iter=cap, warm_dual=warm, simulate=True, accept_capped=capped)
                 ev1.record(); ev1.synchronize()
                 wall.append(ev0.elapsed_time(ev1))         # whole tick {pack, queue reset, solve, post, plant}: HIP events around the graph launch
             ms.append(slv.last_kernel_ms())

@@ -272,6 +272,31 @@ class StreamBatch:
                                 state=self.dual if warm_dual else None, max_iter=max_iter)
         self.post(simulate, stream, accept_capped)
 
+    def tick_with_fallback(self, fallback, max_iter=24, simulate=True, stream=None):
+        """A tick of the converged loops with a barrier-level fallback (round 5): pack -> solve to tolerance with at most `max_iter` iterations (dual state
+        carried) -> the streams whose solve did not converge are solved AGAIN from the same warm start by `fallback`, a handle on a fixed barrier level
+        (BatchedOCPSolver(fixed_barrier=1.0, max_iter=14, ...)): a dozen Newton steps on a smooth barrier problem, far from the tube walls -> post, where
+        the reference's acceptance rule (BoundMPC.py:460-465: solver success or summed violation below the handle's threshold, set it to the reference's 1e-4)
+        decides for every stream.  What the converged loops lose their plans on are ticks whose minimiser cannot be reached (or does not exist) from the
+        shifted plan; a plan of the level-1 problem is still a feasible trajectory, and the next tick usually converges again (CPU replay, 256 streams:
+        14 lose their plan instead of 33; the restoration phase: 17-19, at three times the tick).  The fallback streams restart their dual state cold.
+        Not captured in a graph: the count of failed streams is read on the host."""
+        import torch
+        N57 = self.N * 57
+        self.pack(True, stream)
+        dual0 = self.dual.clone()
+        out = dict(x=self.x, g=self.g, iters=self.iters, status=self.status, kkt=self.kkt)
+        self.solver.solve_batch(self.p, self.x0, out=out, want=("g", "iters", "status", "kkt"), stream=stream, state=self.dual, max_iter=max_iter)
+        idx = torch.nonzero(self.status != 0).flatten()
+        if idx.numel():
+            st = dual0[idx].contiguous(); st[:, N57].clamp_(min=1e-9)      # warm: the multipliers of the shifted plan bound the initial slacks
+            o = fallback.solve_batch(self.p[idx].contiguous(), self.x0[idx].contiguous(), want=("g", "iters", "status", "kkt"), stream=stream, state=st)
+            self.x[idx] = o["x"]; self.g[idx] = o["g"]; self.iters[idx] += o["iters"]; self.kkt[idx] = o["kkt"]
+            self.status[idx] = torch.where(o["status"] == 0, torch.ones_like(o["status"]), o["status"])      # a level plan is never "converged": the rule decides
+            self.dual[idx] = 0.0
+        self.post(simulate, stream, accept_capped=True)
+        return int(idx.numel())
+
     def tick_graph(self, max_iter=0, warm_dual=False, simulate=True, stream=None, accept_capped=False):
         """The same tick replayed from a hipGraph captured on first use (bmpc_stream_graph_create)."""
         key = (int(max_iter), bool(warm_dual), bool(simulate), bool(accept_capped))

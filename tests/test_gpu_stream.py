@@ -513,3 +513,41 @@ def test_256_streams_on_a_fixed_barrier_level_meet_the_strict_1_khz_target():
     assert alive >= 0.90 and applied >= 0.93
     assert (np.abs(Q) <= qlim + 1e-9).all()
     assert (tube_p > 1e-6).sum() / n <= 1e-3 and (tube_r > 1e-6).sum() / n <= 0.02
+
+
+@pytest.mark.gpu
+def test_tick_with_a_barrier_level_fallback():
+    """StreamBatch.tick_with_fallback: converged ticks (at most 24 iterations) whose failures are solved again from the same warm start on a fixed barrier
+    level and judged by the reference's rule at 1e-4.  32 closed loops x 60 ticks: healthy ticks are the plain converged ticks bit for bit (same x as
+    a loop without the fallback while nothing fails); a tick forced to fail (iteration cap 2) is rescued by the fallback -- its plan is applied --
+    where the plain tick replays the previous plan."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, stream as bstream, workload
+    B = 32
+    q0s = workload.random_q0(256, seed=3)[:B]
+    mpcs, recs = [], []
+    for q0 in q0s:
+        m, p0fk = workload.make_mpc(q0)
+        mpcs.append(m)
+        recs.append(bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([m.phi_max[0], 0.0, 0.0]), np.zeros(7)))
+    def loop(with_fallback, ticks=60, fail_at=30):
+        slv = BatchedOCPSolver(10, 4, 0.1, max_iter=100, stall_window=16); slv.set_restoration(False); slv.set_rt_feasibility_tol(1e-4)
+        level = BatchedOCPSolver(10, 4, 0.1, tol=1e-3, max_iter=14, fixed_barrier=1.0); level.set_restoration(False)
+        sb = bstream.StreamBatch(slv, mpcs); sb.set_robot(np.stack(recs)); X, applied, nfb = [], [], []
+        for t in range(ticks):
+            cap = 2 if t == fail_at else 24      # a tick on which no solve can converge
+            if with_fallback:
+                nfb.append(sb.tick_with_fallback(level, max_iter=cap))
+            else:
+                sb.tick(max_iter=cap, warm_dual=True, simulate=True, fused=False, accept_capped=True); nfb.append(0)
+            X.append(sb.x.clone()); applied.append((sb.traj[:, -2] > 0.5).cpu().numpy())
+        alive = (sb.state[:, bstream.SS["VALID"]] > 0.5).cpu().numpy()
+        sb.close(); slv.close(); level.close()
+        return torch.stack(X), np.array(applied), np.array(nfb), alive
+    Xa, app_a, nfb_a, alive_a = loop(True)
+    Xb, app_b, nfb_b, alive_b = loop(False)
+    first = int(np.argmax(nfb_a > 0))
+    assert first > 5 and torch.equal(Xa[:first], Xb[:first])                      # until the first failure the fallback changes nothing
+    assert nfb_a[30] == B and app_a[30].mean() >= 0.9 and app_b[30].mean() <= 0.1      # the forced failure: rescued by the level plans / previous plans replayed
+    assert alive_a.mean() >= alive_b.mean() - 0.04 and alive_a.mean() >= 0.85
+
