@@ -111,6 +111,10 @@ def main():
     cfb_cap, cfb_k, cfb_mu = int(args.cfb.split(",")[0]), int(args.cfb.split(",")[1]), float(args.cfb.split(",")[2])
     cfb_level = BatchedOCPSolver(10, 4, 0.1, tol=1e-3, max_iter=cfb_k, fixed_barrier=cfb_mu)
     cfb_level.set_restoration(False)
+    rtfc = {}      # the fixed-level modes with an ITERATION cap instead of a time budget: every stream takes exactly that many Newton steps -- no clock in the result
+    for MU in [float(v) for v in args.rtfix_mu.split(",") if v][:1]:
+        rtfc[MU] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=30, fixed_barrier=MU, bound_margin=args.rt_bound_margin)
+        rtfc[MU].set_timing(True)
     evaluate = BatchedOCPSolver(10, 4, 0.1, max_iter=0)       # f, g at a given point (no iteration)
     reference = BatchedOCPSolver(10, 4, 0.1, tol=args.tol, max_iter=args.max_iter)    # every tick's problem solved to tolerance, untimed
     res, ref_q = [], None
@@ -124,6 +128,7 @@ def main():
         + [("warm-continue-feas1e-4 (converged solves; a stalled tick's iterate is the next warm start; reference acceptance rule + variable bounds)", solver, 0, True, 1e-4)] \
         + [(f"rtb{'gn' if gn else 'w'}-tol{args.rt_tol:g}-budget{us}us-feas{FT:g}", rtb[(us, gn)], 0, True, FT) for (us, gn) in sorted(rtb)]
     modes += [(f"rtfix-mu{MU:g}-tol{args.rt_tol:g}-budget{us}us-feas{FT:g}", rtf[(us, MU)], 0, True, FT) for (us, MU) in sorted(rtf)]
+    modes += [(f"rtfixcap-mu{MU:g}-cap{c}-feas{FT:g} (fixed barrier level, exactly {c} Newton steps per tick, no clock: reproducible bit for bit)", rtfc[MU], c, True, FT) for MU in sorted(rtfc) for c in (5, 6, 7)]
     modes += [(f"converged-fallback-cap{cfb_cap}-level{cfb_mu:g}-k{cfb_k}-feas1e-4 (solved to tolerance within {cfb_cap} iterations, else {cfb_k} steps on the barrier level {cfb_mu:g}; the reference's rule at 1e-4)", cfb_main, cfb_cap, True, 1e-4)]
     if args.unsafe_too:
         modes += [(f"UNSAFE rtgn-tol{args.rt_tol:g}-cap{c} (every capped iterate applied)", rtgn[c], 0, True, 1e30) for c in (4, 3)]
