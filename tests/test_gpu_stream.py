@@ -575,3 +575,46 @@ def test_fixed_barrier_level_with_an_iteration_cap_is_reproducible_and_meets_the
     assert np.percentile(ms, 50) <= 1.0 and np.percentile(ms, 99) <= 1.3
     assert (tube_p > 1e-6).sum() / n <= 1e-3
 
+
+@pytest.mark.gpu
+def test_fixed_barrier_level_loops_on_the_gpu_retrace_the_cpu_mirror():
+    """The capped fixed-level ticks have no clock in them, so they can be checked like everything else: 6 closed loops x 40 ticks (five Newton steps per
+    tick on the level 0.1, duals and rejected iterates carried, acceptance at 1e-2 incl. the variable bounds) on the GPU -- fused team ticks from a captured
+    graph -- against the CPU mirror: the g++ build of the stream functions (tests/emu) around the CPU oracle with the same options.  Plant joint positions
+    to 1e-6 rad on every tick, the same ticks applied."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, stream as bstream, workload
+    from oracle import c_oracle
+    from tests.emu import emu
+    B, T, N, S, H = 6, 40, 10, 4, 0.1
+    q0s = workload.random_q0(256, seed=3)[:B]
+    mpcs, recs = [], []
+    for q0 in q0s:
+        m, p0fk = workload.make_mpc(q0)
+        mpcs.append(m)
+        recs.append(bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([m.phi_max[0], 0.0, 0.0]), np.zeros(7)))
+    slv = BatchedOCPSolver(N, S, H, tol=1e-3, max_iter=30, fixed_barrier=0.1); slv.set_rt_feasibility_tol(1e-2)
+    sb = bstream.StreamBatch(slv, mpcs); sb.set_robot(np.stack(recs))
+    Qg, Ag = [], []
+    for t in range(T):
+        if t == 0:
+            sb.tick(max_iter=100, warm_dual=True, simulate=True)
+        else:
+            sb.tick_graph(max_iter=5, warm_dual=True, simulate=True, accept_capped=True)
+        torch.cuda.synchronize()
+        Qg.append(sb.robot[:, :7].cpu().numpy().copy()); Ag.append((sb.traj[:, -2] > 0.5).cpu().numpy().copy())
+    sb.close(); slv.close()
+    kw = dict(tol=1e-3, mu_init=0.1, mu_warm=0.1, mu_min_fac=100.0)
+    for b in range(B):
+        Tb, M = bstream.path_table(mpcs[b].ref_path)
+        ss = bstream.initial_state(mpcs[b], N); ss[bstream.SS["NENT"]] = M
+        rb = recs[b].copy(); state = np.zeros((1, c_oracle.state_len(N))); xlast = None
+        for t in range(T):
+            p, x0 = emu.stream_pack(N, S, Tb, ss, rb, dual=state[0], xlast=xlast)
+            r = c_oracle.solve(p, x0, N, S, H, opts=c_oracle.default_opts(max_iter=100 if t == 0 else 5, **kw), nthreads=1, state=state)
+            tr = emu.stream_post(N, S, H, Tb, ss, rb, r["x"][0], r["g"][0], int(r["status"][0]), simulate=True, flags=0 if t == 0 else 2, rt_tol=1e-2)
+            _, fl = bstream.unpack_traj(tr, N)
+            xlast = r["x"][0]
+            assert bool(fl["success"]) == bool(Ag[t][b]), (b, t)
+            np.testing.assert_allclose(rb[bstream.RB["Q"]:bstream.RB["Q"] + 7], Qg[t][b], atol=1e-6, err_msg=f"stream {b} tick {t}")
+
