@@ -9,10 +9,11 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libboundmpc_hip.so")
 SOURCES = [os.path.join(CSRC, "bmpc_hip.hip"), os.path.join(CSRC, "bmpc_wave.inl"), os.path.join(CSRC, "bmpc_stream.inl"),
            os.path.join(HERE, "..", "include", "boundmpc_hip.h"), os.path.join(CSRC, "bmpc_team.hip"), os.path.join(CSRC, "bmpc_gpu_common.h"),
-           os.path.join(CSRC, "bmpc_resto.hip"), os.path.join(CSRC, "bmpc_tick.hip")]
+           os.path.join(CSRC, "bmpc_resto.hip"), os.path.join(CSRC, "bmpc_tick.hip"), os.path.join(CSRC, "bmpc_pair.hip")]
 # translation units of the library: the one-wave batch kernels + C ABI, the team kernels (NW cooperating waves per problem), the restoration
 # kernels (the solver with the restoration phase, continuing what a batch kernel left jammed) and the fused closed-loop tick kernels
-UNITS = [os.path.join(CSRC, "bmpc_hip.hip"), os.path.join(CSRC, "bmpc_team.hip"), os.path.join(CSRC, "bmpc_resto.hip"), os.path.join(CSRC, "bmpc_tick.hip")]
+UNITS = [os.path.join(CSRC, "bmpc_hip.hip"), os.path.join(CSRC, "bmpc_team.hip"), os.path.join(CSRC, "bmpc_resto.hip"), os.path.join(CSRC, "bmpc_tick.hip"),
+         os.path.join(CSRC, "bmpc_pair.hip")]
 
 
 def hipcc():
@@ -24,6 +25,15 @@ def hipcc():
 
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
          "-Wno-unused-variable", "-Wno-unused-value", "-Wno-duplicate-decl-specifier"]
+# per-unit flags.  The pair kernel runs at TWO waves per SIMD (256 registers): there the ILP-chasing scheduler hoists loads until the allocator
+# spills them (1996 B of scratch per lane against 744 with the default strategy, same text); the second wave hides latency instead.
+UNIT_FLAGS = {"bmpc_pair.hip": [f for f in FLAGS if f not in ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")]}
+
+
+def unit_flags(src):
+    return UNIT_FLAGS.get(os.path.basename(src), FLAGS)
+
+
 _COPY = re.compile(r"(v_accvgpr_(write|read)_b32|scratch_(store|load)_\w+|v_mov_b(32|64)(_e32|_e64)?) ")
 _HARMLESS = re.compile(r"(s_\w+|v_readlane_b32|v_writelane_b32)( |$)")
 
@@ -41,6 +51,8 @@ def source_hash():
             h.update(fh.read())
         h.update(b"\0")
     h.update(" ".join(FLAGS).encode())
+    for k in sorted(UNIT_FLAGS):
+        h.update(("|" + k + ":" + " ".join(UNIT_FLAGS[k])).encode())
     return h.hexdigest()[:16]
 
 
@@ -196,7 +208,7 @@ def lint_isa_masked_loads(asm_path, window=400):
 
 def _lint_unit(src, asm, verbose):
     # same flags, device ISA only; a hit fails the build (the compiled code would compute wrong numbers for some lanes)
-    subprocess.check_call([hipcc()] + FLAGS + ["-S", "--cuda-device-only", "-o", asm, src], cwd=CSRC, stderr=subprocess.DEVNULL)
+    subprocess.check_call([hipcc()] + unit_flags(src) + ["-S", "--cuda-device-only", "-o", asm, src], cwd=CSRC, stderr=subprocess.DEVNULL)
     bad = lint_isa(asm)
     if bad:
         raise RuntimeError("ISA lint: register copies ahead of an exec-mask restore (compiler defect, results would be wrong): %r" % (bad,))
@@ -215,7 +227,7 @@ def _compile_unit(args):
         _lint_unit(src, asm, verbose)
     # -amdgpu-sched-strategy=iterative-ilp: the solver runs at one wave per SIMD, so the scheduler should chase instruction-level
     # parallelism (loads hoisted ahead of their uses), not occupancy; measured 12.7 -> 10.8 ms at B=1024 (profiles/)
-    cmd = [hipcc()] + FLAGS + ["-DBMPC_BUILD_HASH_STR=\"%s\"" % source_hash(), "-fPIC", "-c", "-o", obj, src]
+    cmd = [hipcc()] + unit_flags(src) + ["-DBMPC_BUILD_HASH_STR=\"%s\"" % source_hash(), "-fPIC", "-c", "-o", obj, src]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))

@@ -57,3 +57,10 @@ hipError_t bmpc_team_launch_solve(int nw, const void *kargs, int grid, hipStream
 hipError_t bmpc_team_launch_tick(int nw, bool resto, const void *kargs, const SArgs *s, int B, hipStream_t st);
 int bmpc_team_lds_bytes(int nw);
 int bmpc_team_nmax(int nw);      // longest horizon the team kernels take (their LDS holds most of the workspace)
+
+// ---- pair kernel (bmpc_pair.hip): two cooperating waves per problem at two waves per SIMD, one-wave LDS / workspace budget per problem ----
+int bmpc_pair_blocks_per_cu(void);      // resident pairs per CU (4 on an MI355X; 0: the launch configuration does not fit)
+int bmpc_pair_nmax(void);               // longest horizon the pair kernel takes (the iterate-in-LDS instantiation)
+int bmpc_pair_lds_bytes(void);
+long long bmpc_pair_scr_stride(int N);  // doubles of workspace per pair (the one-wave layout)
+hipError_t bmpc_pair_launch_solve(const void *kargs, int grid, hipStream_t st);

@@ -87,6 +87,7 @@ struct bmpc_handle {
     hipStream_t own_stream;  // graph replays requested on the legacy null stream run here, bracketed by events (bmpc_graph_launch)
     int grid; long long scr_stride; double *scratch; int scr_waves; int graphs_alive; int *counter; unsigned long long *prof;
     int team_grid;           // resident TEAMS (workgroups of BMPC_TEAM_NW waves, bmpc_team.hip) of the device; 0: no team kernel for this handle (N > 10 or S > 4)
+    int pair_grid;           // resident PAIRS (workgroups of 2 waves at two waves per SIMD, bmpc_pair.hip); 0: no pair kernel for this handle (N > 11 or S > 4)
     int *aux_int; int aux_cap;      // [2][aux_cap] status / iters of a batch whose caller passed NULL (the restoration kernel reads them)
     int start_rollout;      // 1 (default): a stateless solve whose x0 is far off its own dynamics starts from the rollout of x0's jerks (bmpc_set_start_rollout)
     int resto_on, resto_short, resto_cap;      // restoration phase (bmpc_set_restoration): mode 0 off / 1 full (default N <= 11) / 2 after a numerical breakdown only (default N > 11); jam = resto_short consecutive short steps; iterations per phase
@@ -166,7 +167,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     h->resto_on = N <= 11 ? 1 : 2; h->resto_short = 6; h->resto_cap = 40;      // restoration phase: full for short horizons, after a numerical breakdown only for long ones (bmpc_set_restoration)
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->ev = nullptr; h->nev = 0; h->n_timed = 0; h->latency_us = nullptr;
     h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->aux_int = nullptr; h->aux_cap = 0; h->prof = nullptr; h->stage_d = nullptr; h->stage_h = nullptr; h->stage_cap = 0;
-    h->team_grid = 0; h->team_mode = 0;
+    h->team_grid = 0; h->pair_grid = 0; h->team_mode = 0;
     h->rt_viol_tol = 1e-4; h->rt_budget_us = 0.0; h->dev = 0; h->refs = 1; h->closed = false; h->order_ev = nullptr; h->bridge_ev = nullptr; h->order_valid = false; h->order_stream = nullptr; h->own_stream = nullptr;
     if (opts) h->o = *opts; else bmpc_default_options_for(N, &h->o);
     int dev = 0, per_cu = 0; hipDeviceProp_t prop;
@@ -180,6 +181,8 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
         h->scr_stride = bmpc::make_scr(N).size;
         // teams: a workgroup of BMPC_TEAM_NW waves per problem (bmpc_team.hip; iterate-in-LDS instantiation only)
         h->team_grid = (N <= bmpc_team_nmax(BMPC_TEAM_NW) && S <= bmpc::SMAX_ZLDS) ? bmpc_team_blocks_per_cu(BMPC_TEAM_NW) * prop.multiProcessorCount : 0;
+        // pairs: two waves per problem at two waves per SIMD (bmpc_pair.hip); same workspace layout and LDS budget as one wave per problem
+        h->pair_grid = (N <= bmpc_pair_nmax() && S <= bmpc::SMAX_ZLDS && bmpc_pair_scr_stride(N) == h->scr_stride) ? bmpc_pair_blocks_per_cu() * prop.multiProcessorCount : 0;
         // the per-wave workspace slabs (148 KB at N=10, 444 KB at N=30) are allocated on the first solve, for min(B, grid) waves, and grow on demand:
         // a single-problem handle (the nlpsol shim of one BoundMPC object) holds one slab, not 1024
         ok = hipMalloc(&h->counter, 4 * sizeof(int)) == hipSuccess      /* work queue, work queue of the restoration kernel, jam count */
@@ -260,13 +263,20 @@ static int timing_slot(bmpc_handle *h, hipEvent_t **pair) {
     *pair = h->ev + 2 * (h->n_timed % h->timing);
     return BMPC_OK;
 }
-// Which kernel solves a batch of B: a team of BMPC_TEAM_NW waves per problem when the batch leaves SIMDs idle -- it fits into the resident
-// teams of the device (256 on an MI355X) -- or when the caller asked for teams; else one wave per problem.
-static bool use_team(const bmpc_handle *h, int B) {
-    if (h->team_grid <= 0 || h->team_mode == 1) return false;
-    return h->team_mode == BMPC_TEAM_NW || B <= h->team_grid;
+// Which kernel solves a batch of B (waves per problem): a team of BMPC_TEAM_NW waves when the batch leaves SIMDs idle -- it fits into the resident
+// teams of the device (256 on an MI355X) -- or when the caller asked for teams; a pair (2 waves at two waves per SIMD) for larger batches of the
+// horizons whose iterate lives in LDS; else one wave per problem.
+#ifndef BMPC_PAIR_AUTO
+#define BMPC_PAIR_AUTO 1      // automatic mode: batches beyond the resident teams go to the pair kernel where it exists
+#endif
+static int solve_waves(const bmpc_handle *h, int B) {
+    if (h->team_mode == 1) return 1;
+    if (h->team_mode == 2) return h->pair_grid > 0 ? 2 : 1;
+    if (h->team_grid > 0 && (h->team_mode == BMPC_TEAM_NW || B <= h->team_grid)) return BMPC_TEAM_NW;
+    return (BMPC_PAIR_AUTO && h->team_mode == 0 && h->pair_grid > 0) ? 2 : 1;
 }
-static int launch_grid(const bmpc_handle *h, int B) { const int g = use_team(h, B) ? h->team_grid : h->grid; return B < g ? B : g; }
+static bool use_team(const bmpc_handle *h, int B) { return solve_waves(h, B) == BMPC_TEAM_NW; }
+static int launch_grid(const bmpc_handle *h, int B) { const int w = solve_waves(h, B), g = w == BMPC_TEAM_NW ? h->team_grid : (w == 2 ? h->pair_grid : h->grid); return B < g ? B : g; }
 // the restoration kernel (bmpc_resto.hip) runs one wave per problem whatever kernel solved the batch
 static int resto_grid(const bmpc_handle *h, int B) { return B < h->grid ? B : h->grid; }
 // what a batch of B needs besides the caller's buffers: workspace slabs for the resident waves of both kernels, and -- the hand-over to the
@@ -311,16 +321,18 @@ extern "C" int bmpc_options_size(void) { return (int)sizeof(bmpc_options); }
 static const char bmpc_build_hash_marker[] = "BMPC_BUILD_HASH=" BMPC_BUILD_HASH_STR;
 extern "C" const char *bmpc_build_hash(void) { return bmpc_build_hash_marker + 16; }
 extern "C" int bmpc_set_team_waves(bmpc_handle *h, int waves) {
-    if (!h || (waves != 0 && waves != 1 && waves != BMPC_TEAM_NW)) return BMPC_ERR_ARG;
+    if (!h || (waves != 0 && waves != 1 && waves != 2 && waves != BMPC_TEAM_NW)) return BMPC_ERR_ARG;
     if (waves == BMPC_TEAM_NW && h->team_grid <= 0) return BMPC_ERR_ARG;      // no team instantiation for this horizon / window
+    if (waves == 2 && h->pair_grid <= 0) return BMPC_ERR_ARG;                // no pair instantiation
     h->team_mode = waves;
     return BMPC_OK;
 }
 extern "C" int bmpc_team_info(const bmpc_handle *h, int B, int *waves, int *resident_teams, int *lds_bytes) {
     if (!h) return BMPC_ERR_ARG;
-    if (waves) *waves = use_team(h, B) ? BMPC_TEAM_NW : 1;
-    if (resident_teams) *resident_teams = h->team_grid;
-    if (lds_bytes) *lds_bytes = bmpc_team_lds_bytes(BMPC_TEAM_NW);
+    const int w = solve_waves(h, B);
+    if (waves) *waves = w;
+    if (resident_teams) *resident_teams = w == 2 ? h->pair_grid : h->team_grid;
+    if (lds_bytes) *lds_bytes = w == 2 ? bmpc_pair_lds_bytes() : bmpc_team_lds_bytes(BMPC_TEAM_NW);
     return BMPC_OK;
 }
 // fills the kernel arguments and enqueues {reset of the work-queue counter, solver kernel} on `st`
@@ -351,6 +363,7 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     if (timed) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
     const bool zlds = h->N <= 11 && h->S <= bmpc::SMAX_ZLDS;
     if (use_team(h, B)) HIPCHK(bmpc_team_launch_solve(BMPC_TEAM_NW, &a, grid, st));      // a workgroup of waves per problem (bmpc_team.hip)
+    else if (solve_waves(h, B) == 2) HIPCHK(bmpc_pair_launch_solve(&a, grid, st));           // two waves per problem at two waves per SIMD (bmpc_pair.hip)
     else if (zlds) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, a);      // iterate in LDS; else in the workspace (long horizons, S > 4)
     else hipLaunchKernelGGL(bmpc_solve_kernel<false>, dim3(grid), dim3(64), 0, st, a);
     HIPCHK(hipGetLastError());

@@ -34,8 +34,16 @@
 //   * SOLO_BEGIN(w) ... SOLO_END: a region only wave w executes (the sequential sweeps: adjoint, Riccati, forward; their phases keep the
 //     wavefront-scope fences of the one-wave program), the other waves go on to the next TEAM_SYNC();
 //   * reductions over a wide pass (red_*_w) read the NW x 64 per-lane partials in a fixed order in every wave.
-// With BMPC_NW == 1 (the product kernel of large batches) every one of these reduces to the one-wave text: wl = lane, WS = 64,
-// TEAM_SYNC() = nothing, SOLO = unconditional.
+// With BMPC_NW == 1 every one of these reduces to the one-wave text: wl = lane, WS = 64, TEAM_SYNC() = nothing, SOLO = unconditional.
+//
+// PAIRS (BMPC_NW == 2 with BMPC_WSG; round 6): a team of TWO waves that keeps the one-wave program's budget per problem -- 40 KB of LDS and
+// the workspace in the global slab (WSG) -- and is compiled for TWO waves per SIMD (256 registers per wave): four pairs per CU, so a batch of
+// 1024 problems puts a second wave on every SIMD of the chip, which is what hides the dependent-latency stalls of the sequential sweeps
+// (DESIGN.md 5).  Wave 0 runs the recursions; wave 1 owns what does not depend on them: the references / objective half of an evaluation
+// beside the kinematics, and -- inside the Riccati sweep -- the staging of the node-cost inputs of the NEXT stage from the slab into LDS
+// (its own register prefetch, a stage ahead), the recursion-independent half of the node-cost add, the q~ rows and t6.  What the helper
+// hands over per stage (14 words per lane) goes through the part of the value-function block area that is idle between two Schur updates
+// (L_PREP: single-buffered, hence a second LDS-only barrier per stage, placed where the helper is already waiting).
 #pragma once
 
 #ifndef BMPC_NW
@@ -63,6 +71,13 @@
 #define LIDXW LIDX      // index of a lane's register set inside a wide phase (the emulator of a team: the item lane)
 #endif
 
+#ifndef LIDXH
+#ifdef BMPC_EMU
+#define LIDXH (64 + lane)   // register set of a lane of the HELPER wave (wave 1 of a pair): the emulator keeps one set per lane of the team
+#else
+#define LIDXH LIDX
+#endif
+#endif
 #ifndef BMPC_PROF
 #define BMPC_PROF(W, id)
 #endif
@@ -208,8 +223,33 @@ enum { NCS_MU = 91, NCS_RDP = 103, NCS_ADDV = 109, NCS_ZERO = 121, NCS_DUMMY = 1
 // exactly those trips, not by issue.  Only the Riccati gains, the curvature prefix vectors (both consumed through the sweeps' register
 // prefetch) and, for long horizons, the iterate stay in the global slab.
 constexpr int WSL_PER_STAGE = 10 * NI + 3 * NE + NZ + 8 + NU + 36 + 42 + 12 + 2 * KREC + RREC + NCS_STRIDE;      // make_scr's LDS-resident arrays, doubles per stage
+#if BMPC_NW > 1 && defined(BMPC_WSG)
+constexpr int TEAM_NMAX = 11;      // pairs: the horizons whose iterate lives in LDS (wave_solve<true>); L_DSA (36 per stage) sits in the first 512 words of the block area
+#else
 constexpr int TEAM_NMAX = 10;      // longest horizon a team's LDS holds (the reference's experiments and BASELINE configs[1], [2], [4] run N = 10)
-#if BMPC_NW > 1
+#endif
+#if BMPC_NW > 1 && defined(BMPC_WSG)
+// Pairs: the one-wave layout plus eight words.  The helper wave's staging of a stage (inputs of blk_prep_lane / node_q_row_p / stage_t6) uses the
+// areas the sweep's wave of a team leaves idle during the Riccati sweep: L_NC[0..91) (small blocks, A1, A2), ST_SG, ST_G, L_KHP (= L_WV), L_WY and
+// the two velocity-record buffers L_KV / L_KV1 (cut up below).  Hand-over to the sweep's wave: L_PREP (block area behind the partial products L_PP,
+// idle between the D gather of one Schur phase and the MFMA of the next) and L_QRB (double-buffered by stage parity: the sweep's wave reads the
+// q~ rows of stage k while the helper writes those of stage k - 1).  L_DSA (forward sweep -> wide dZ pass) sits where the trial iterate will be written.
+#ifdef BMPC_EMU
+enum { WRED_STRIDE = WS, L_REDW = L_SIZE1, L_KKPW = L_REDW + 6 * WRED_STRIDE, L_TFLAG = L_KKPW + 5 * WRED_STRIDE };      // the emulator's per-lane slots do not fit the one-wave areas
+#else
+enum { WRED_STRIDE = 64, L_REDW = L_RED, L_KKPW = L_KKP, L_TFLAG = L_SIZE1 };      // GPU: word `wave` of each 64-word slot of the one-wave areas
+#endif
+enum { PREP_N = 14, L_PREP = L_PB + 256 /* add: 10 planes x 64 | c3inc: 3 x 32 | piinc: 6 */, PREP_C3 = 640, PREP_PII = 736, PREP_LEN = 742,
+       L_DSA = L_PB, L_WY2 = L_WY, L_HKHP = L_KHP,
+       L_HKV = L_KV /* 24: axes (KA part) of the velocity record of the next node */, L_QRB = L_KV + 24 /* 2 x 40 */,
+       L_HGL = L_KV1 /* 44: gl of the helper's stage */, L_HRD = L_KV1 + 44 /* 36: its defect vector */, L_HDP = L_KV1 + 80 /* 6: its dp_d */,
+       L_SIZE = L_TFLAG + 8 };
+static_assert(256 + PREP_LEN <= 1024 && 36 * TEAM_NMAX <= 512, "hand-over areas must fit the block area");
+static_assert(24 + 80 <= KREC && 86 <= KREC, "the helper's small staging must fit the two idle record buffers");
+#ifndef BMPC_EMU
+static_assert(L_SIZE * 8 <= 40 * 1024, "a pair's working set must fit a quarter of the LDS of a CU (four pairs per CU)");
+#endif
+#elif BMPC_NW > 1
 #ifdef BMPC_EMU
 enum { WRED_STRIDE = WS };      // the emulator runs the lanes of a wide pass one after the other: per-lane slots, reduced in the GPU's order afterwards
 #else
@@ -246,7 +286,7 @@ struct Scr {
     int Z, ZT, T, TT, NUm, LAM, G, GT, HIN, HT, DZ, DT, DNU, GH, GVP, RJ, KIN, REF, KT, KF, RDY, AES, RLV, SG, TI, SR, NU2, NCS, KHPG, KHV, E, ET, DE, size, lsize;
 };
 BMPC_HD inline Scr make_scr(int N) {
-#if BMPC_NW > 1
+#if BMPC_NW > 1 && !defined(BMPC_WSG)
     // teams: two index spaces -- `l` counts the LDS-resident arrays (offsets from L_WSL, accessor WL), `c` what stays in the global slab (accessor G)
     Scr s; int c = 0, l = 0;
     s.Z = c; c += N * NZ; s.ZT = c; c += N * NZ; s.DZ = c; c += N * NZ; s.KT = c; c += N * NS * NU; s.KF = c; c += N * NU; s.KHPG = c; c += 2 * N * 72; s.KHV = c; c += N * KHV_STRIDE;
@@ -301,7 +341,7 @@ struct GPtr {
 };
 BMPC_D inline GPtr make_gptr(double *base) { GPtr r; r.b = (char *)base; r.o = 0; return r; }
 // accessor of the workspace arrays a team keeps in LDS (make_scr): the global slab itself in the one-wave program
-#if BMPC_NW > 1
+#if BMPC_NW > 1 && !defined(BMPC_WSG)
 typedef double *LPtr;
 #define BMPC_WL(W) ((W).L + L_WSL)
 #else
@@ -774,12 +814,12 @@ BMPC_D inline double red_min_w(const double *r) { double s = r[0]; for (int i = 
 #define WRED_GET_MAX(area, slot) red_max_w(L + (area) + (slot) * WS)
 #define WRED_GET_MIN(area, slot) red_min_w(L + (area) + (slot) * WS)
 #else
-#define WRED_PUT_SUM(area, slot, v) L[(area) + (slot) * NW + W.wv] = wave_sum(v)      // (every lane stores the wave's value to the wave's word)
-#define WRED_PUT_MAX(area, slot, v) L[(area) + (slot) * NW + W.wv] = wave_max(v)
-#define WRED_PUT_MIN(area, slot, v) L[(area) + (slot) * NW + W.wv] = wave_min(v)
-#define WRED_GET_SUM(area, slot) fold_sum(L + (area) + (slot) * NW)
-#define WRED_GET_MAX(area, slot) fold_max(L + (area) + (slot) * NW)
-#define WRED_GET_MIN(area, slot) fold_min(L + (area) + (slot) * NW)
+#define WRED_PUT_SUM(area, slot, v) L[(area) + (slot) * WRED_STRIDE + W.wv] = wave_sum(v)      // (every lane stores the wave's value to the wave's word)
+#define WRED_PUT_MAX(area, slot, v) L[(area) + (slot) * WRED_STRIDE + W.wv] = wave_max(v)
+#define WRED_PUT_MIN(area, slot, v) L[(area) + (slot) * WRED_STRIDE + W.wv] = wave_min(v)
+#define WRED_GET_SUM(area, slot) fold_sum(L + (area) + (slot) * WRED_STRIDE)
+#define WRED_GET_MAX(area, slot) fold_max(L + (area) + (slot) * WRED_STRIDE)
+#define WRED_GET_MIN(area, slot) fold_min(L + (area) + (slot) * WRED_STRIDE)
 #endif
 
 // ========================================================================================
@@ -1854,8 +1894,12 @@ BMPC_D inline void backward_commit_lane(Wave &W, int k, const double *pf, int la
         const int idx = 64 + lane;
         int dst = L_DUMMY;
         dst = idx < NCS_RDP + 6 ? L_ST + ST_REF + RDP + (idx - NCS_RDP) : dst;
+#if BMPC_NW > 1 && defined(BMPC_WSG)
+        dst = idx < NCS_RDP ? L_DUMMY : dst;      // (pairs: L_NC[0..91) and the curvature multipliers belong to the helper wave's stage, helper_commit_lane)
+#else
         dst = idx < NCS_RDP ? L_MU + 4 + (idx - NCS_MU) : dst;
         dst = idx < NCS_MU ? L_NC + idx : dst;
+#endif
         L[dst] = pf[9];
     }
     L[L_RD + l35] = pf[10];
@@ -1871,7 +1915,94 @@ BMPC_D inline void backward_commit_lane(Wave &W, int k, const double *pf, int la
 // ----------------------------------------------------------------------------------------
 // Riccati backward sweep, block form.  Returns false (wave-uniform) if a stage's 8x8 jerk block is not positive definite.
 // ----------------------------------------------------------------------------------------
-#if BMPC_NW > 1
+#if BMPC_NW > 1 && defined(BMPC_WSG)
+// Helper wave of a PAIR's Riccati sweep.  The workspace is in the global slab, so the helper has the sweep's own discipline: the inputs of
+// stage j are loaded into registers a stage ahead (helper_loads_lane) and dropped into LDS in one burst (helper_commit_lane) -- into the areas
+// the sweep's wave leaves idle (layout note at L_PREP).  Then the recursion-independent half of the node-cost add (blk_prep_lane from LDS,
+// exactly the one-wave program's operands), the curvature table, the q~ rows and t6 of the stage.
+BMPC_D inline void helper_loads_lane(Wave &W, const Scr &sc, int j0, double *pf, int lane) {
+    const int N = W.N; const GPtr G = W.G;
+    const int j = j0 >= 0 ? j0 : 0, jn = j < N - 1 ? j + 1 : j;
+    const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l36 = lane < 36 ? lane : 35;
+    pf[0] = G[sc.KIN + (N + jn) * KREC + (lane < 24 ? lane : 23)];      // axes of the velocity point of the next node (kh_qdq_w reads nothing else of that record)
+    pf[1] = G[sc.NCS + j * NCS_STRIDE + lane]; pf[2] = G[sc.NCS + j * NCS_STRIDE + 64 + lane];
+    pf[3] = G[sc.SG + j * NI + li]; pf[4] = G[sc.G + j * NE + le]; pf[5] = G[sc.GH + j * NZ + lz];
+    {   // gl = g^ + its non-trivial entries (backward_commit_lane forms the same sum for the sweep's wave)
+        const int t = lz >= ZV ? lz - ZV + 3 : lz - ZPOS; const bool sp = lz >= ZV || (lz >= ZPOS && lz < ZIW);
+        pf[6] = G[sc.NCS + j * NCS_STRIDE + (sp ? NCS_ADDV + t : NCS_ZERO)];
+    }
+    pf[7] = G[sc.KHV + j * KHV_STRIDE + lane]; pf[8] = G[sc.KHV + j * KHV_STRIDE + 64 + lane]; pf[9] = G[sc.KHV + j * KHV_STRIDE + 128 + (lane < 24 ? lane : 23)];
+    pf[10] = G[sc.RDY + j * 36 + l36];
+}
+BMPC_D inline void helper_commit_lane(Wave &W, const double *pf, int lane) {
+    double *L = W.L;
+    const int lz = lane < NZ ? lane : NZ - 1, li = lane < NI ? lane : NI - 1, le = lane < NE ? lane : NE - 1, l36 = lane < 36 ? lane : 35;
+    L[L_HKV + (lane < 24 ? lane : 23)] = pf[0];
+    L[L_NC + lane] = pf[1];
+    {   // second slot of the NCS row: the rest of the small blocks / A2 (-> L_NC), dp_d (-> the helper's own six words); the rest is not read here
+        const int idx = 64 + lane;
+        int dst = L_DUMMY;
+        dst = (idx >= NCS_RDP && idx < NCS_RDP + 6) ? L_HDP + (idx - NCS_RDP) : dst;
+        dst = idx < NCS_MU ? L_NC + idx : dst;
+        L[dst] = pf[2];
+    }
+    L[L_ST + ST_SG + li] = pf[3]; L[L_ST + ST_G + le] = pf[4]; L[L_HGL + lz] = pf[5] + pf[6];
+    L[L_HKHP + lane] = pf[7]; L[L_HKHP + 64 + lane] = pf[8]; L[L_HKHP + 128 + (lane < 24 ? lane : 23)] = pf[9];
+    L[L_HRD + l36] = pf[10];
+}
+// prep of stage j (pf holds its inputs).  sync2: the second barrier of a stage -- the sweep's wave has read L_PREP of the previous hand-over and
+// finished with the Schur result that overlays it -- sits between the commit and the first store to L_PREP.
+BMPC_D inline void team_blk_prep(Wave &W, const POff &po, const Scr &sc, int j, double delta, LaneRegs *LR, bool sync2) {
+    const int N = W.N;
+    double *L = W.L;
+    const double *K0 = L + (((N - 1 - j) & 1) ? L_K1 : L_K0);      // record of stage j: the sweep's wave committed it as oK1 of stage j + 1 (oK0 of stage N - 1)
+    LANES_BEGIN
+        helper_commit_lane(W, LR[LIDXH].pf, lane);
+        helper_loads_lane(W, sc, j - 1, LR[LIDXH].pf, lane);
+    LANES_END
+    if (sync2) { TEAM_SYNC_LDS(); }
+    LANES_BEGIN
+        BlkIn in; in.K0 = K0; in.KV1 = L + L_HKV; in.KHV = L + L_HKHP; in.NC = L + L_NC; in.mu4 = nullptr; in.dpd = L + L_HDP; in.sgk = L + L_ST + ST_SG;
+        double add[16], c3inc[3], piinc, wpv[2][2];
+        blk_prep_lane(W, po, j, delta, lane, in, add, c3inc, piinc, wpv);
+        blk_store_wy(W, lane, L_WY, wpv);
+        double *o = L + L_PREP + lane;
+        o[0] = add[0]; o[64] = add[1]; o[128] = add[2]; o[192] = add[4]; o[256] = add[5]; o[320] = add[6]; o[384] = add[8]; o[448] = add[9];
+        o[512] = add[10]; o[576] = add[15];
+        {   // the iota increments depend on lane & 31 only (lanes >= 32 repeat 0..31: identical values to the same words), P_ii's on six lanes
+            double *c = L + L_PREP + PREP_C3 + (lane & 31);
+            c[0] = c3inc[0]; c[32] = c3inc[1]; c[64] = c3inc[2];
+            const bool onII = lane >= 32 && lane < 32 + 6;
+            L[onII ? L_PREP + PREP_PII + (lane - 32) : L_DUMMY] = piinc;
+        }
+    LANES_END
+    LANES_BEGIN      // q~ rows (32 chain rows) and t6 of the stage (they need the curvature table this wave just wrote)
+        {
+            const int r = lane < 32 ? lane : 0;
+            const double qr = node_q_row_p(L, L + L_HGL, L + L_WY, L + L_ST + ST_G, K0, r, W.h, W.o.exact_hessian);
+            L[lane < 32 ? L_QRB + (j & 1) * 40 + r : L_DUMMY] = qr;
+        }
+        {
+            const bool on = lane >= 48 && lane < 54; const int c6 = on ? lane - 48 : 0;
+            const double v = stage_t6(W, K0, L + L_HRD, L + L_HDP, c6);
+            L[on ? L_QRB + (j & 1) * 40 + 32 + c6 : L_DUMMY] = v;
+        }
+    LANES_END
+}
+// the sweep's wave picks the helper's results up: into registers at the TOP of the Schur phase (the MFMA result overlays L_PREP)
+struct PrepRegs { double add[16], c3inc[3], piinc; };
+BMPC_D inline void team_prep_fetch(Wave &W, int lane, PrepRegs &r) {
+    const double *o = W.L + L_PREP + lane;
+#pragma unroll
+    for (int q = 0; q < 16; q++) r.add[q] = 0.0;
+    r.add[0] = o[0]; r.add[1] = o[64]; r.add[2] = o[128]; r.add[4] = o[192]; r.add[5] = o[256]; r.add[6] = o[320]; r.add[8] = o[384]; r.add[9] = o[448];
+    r.add[10] = o[512]; r.add[15] = o[576];
+    const double *c = W.L + L_PREP + PREP_C3 + (lane & 31);
+    r.c3inc[0] = c[0]; r.c3inc[1] = c[32]; r.c3inc[2] = c[64];
+    const bool onII = lane >= 32 && lane < 32 + 6;
+    r.piinc = W.L[L_PREP + PREP_PII + (onII ? lane - 32 : 0)];
+}
+#elif BMPC_NW > 1
 // Helper wave of a team's Riccati sweep: the recursion-independent half of the node-cost block add of stage j (blk_prep_lane), computed
 // from the LDS-resident workspace rows of the stage while the sweep's wave works on stage j+1; results to L_PREP[j & 1] (plane-major) and the
 // curvature table of parity j.
@@ -1933,7 +2064,13 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
     const double *PAR = L + L_PAR, *w = PAR + po.w;
     // Teams: every wave of the team runs this function (same control flow, one barrier per stage); the recursion is wave 0's (SOLO(0)), wave 1
     // prepares the node-cost block of the NEXT stage of the sweep beside it (SOLO(1): team_blk_prep), the other waves only keep the barriers.
-#if BMPC_NW > 1
+#if BMPC_NW > 1 && defined(BMPC_WSG)
+    SOLO_BEGIN(1)
+    LANES_BEGIN
+        helper_loads_lane(W, sc, N - 1, LR[LIDXH].pf, lane);
+    LANES_END
+    SOLO_END
+#elif BMPC_NW > 1
     SOLO_BEGIN(1 % NW)
     team_blk_prep(W, po, sc, N - 1, delta);
     SOLO_END
@@ -1950,22 +2087,40 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
     LANES_END
     SOLO_END
     backward_buffers(N, N - 1, W.oK0, W.oK1, W.oKV, W.oKV1);
+#if BMPC_NW > 1 && defined(BMPC_WSG)
+    // pairs: the helper's prep of the last stage reads that stage's record from the buffer the sweep's wave just committed (first barrier), and
+    // the sweep's wave waits for the result (second); once per sweep -- inside the loop the helper runs a stage ahead, beside the recursion
+    TEAM_SYNC_LDS();
+    SOLO_BEGIN(1)
+    team_blk_prep(W, po, sc, N - 1, delta, LR, false);
+    SOLO_END
+#endif
     TEAM_SYNC_LDS();      // (the helper's block data of the last stage is in LDS)
     SOLO_BEGIN(0)
     LANES_BEGIN   // value function of the last node = its node cost: the block add on a zero block
         const double Z4[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, Z3[3] = {0, 0, 0};
-#if BMPC_NW > 1
+#if BMPC_NW > 1 && defined(BMPC_WSG)
+        PrepRegs pq; team_prep_fetch(W, lane, pq);
+        blk_apply_lane(W, lane, Z4, Z3, 0.0, 0.0, pq.add, pq.c3inc, pq.piinc, LR[LIDX].mc);
+#elif BMPC_NW > 1
         team_blk_apply(W, N - 1, lane, Z4, Z3, 0.0, 0.0, LR[LIDX].mc);
 #else
         blk_add_lane(W, po, N - 1, delta, lane, W.oK0, W.oKV1, Z4, Z3, 0.0, 0.0, LR[LIDX].mc);
 #endif
     LANES_END
+#if BMPC_NW > 1 && defined(BMPC_WSG)
+    if (N >= 2) { TEAM_SYNC_LDS(); }      // the second barrier of "stage N": L_PREP has been read (matches the helper's prep of stage N - 2)
+#endif
     SOLO_END
     for (int k = N - 1; k >= 0; k--) {
 #if BMPC_NW > 1
         if (k >= 1) {
             SOLO_BEGIN(1 % NW)
+#ifdef BMPC_WSG
+            team_blk_prep(W, po, sc, k - 1, delta, LR, true);      // beside the recursion's stage k; handed over at the barrier below
+#else
             team_blk_prep(W, po, sc, k - 1, delta);      // beside the recursion's stage k; handed over at the barrier below
+#endif
             SOLO_END
         }
         const int oWYk = (k & 1) ? L_WY2 : L_WY, oFLAGk = L_FLAG + 2 + (k & 1), oQRk = L_QRB + (k & 1) * 40, oT6k = oQRk + 32;
@@ -2234,6 +2389,9 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 const int i = lane >> 3, l = lane & 7, ci = i < l ? i : l, cl = i < l ? l : i; const bool tr = i > l;
                 const double *mc = LR[LIDX].mc;
                 double C[4][4];
+#if BMPC_NW > 1 && defined(BMPC_WSG)
+                PrepRegs pq; team_prep_fetch(W, lane, pq);      // the helper's half of the node-cost add of stage k - 1: read before the Schur result overlays it
+#endif
 #ifdef BMPC_MFMA
                 // GPU build: the rank-8 update D = GS^T KS of the 32 x 32 chain block is the one dense contraction of the stage and
                 // runs on the matrix cores: v_mfma_f64_16x16x4_f64, 2 x 2 tiles x 2 k-steps.  Operand maps (one f64 per lane):
@@ -2282,6 +2440,11 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 #pragma unroll
                         for (int g = 0; g < f; g++) C[f][g] = C[g][f];
                 }
+#if BMPC_NW > 1 && defined(BMPC_WSG)
+                // pairs, second barrier of the stage: L_PREP has been read and the Schur result that overlays it gathered -- the helper (waiting here since
+                // its commit, a few hundred cycles after the stage's first barrier) may write the hand-over of stage k - 2.  k >= 2: that helper call exists.
+                if (k >= 2) { TEAM_SYNC_LDS(); }
+#endif
                 BMPC_PROF(W, 14);
                 // the small roles (chain x iota, iota x iota, gradient) are predicated and evaluated BEFORE any store of this phase,
                 // so that all LDS reads of the phase can be in flight together
@@ -2307,7 +2470,9 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
                 BMPC_PROF(W, 17);
                 // ---- node cost of stage k-1 added to the block just formed (registers), iota couplings, gradient, partial products: no
                 //      store of the chain blocks any more ----
-#if BMPC_NW > 1
+#if BMPC_NW > 1 && defined(BMPC_WSG)
+                blk_apply_lane(W, lane, C, ci3, pii, pvv, pq.add, pq.c3inc, pq.piinc, LR[LIDX].mc);      // (the recursion-independent half came from the helper wave)
+#elif BMPC_NW > 1
                 team_blk_apply(W, k - 1, lane, C, ci3, pii, pvv, LR[LIDX].mc);      // (the recursion-independent half came from the helper wave)
 #else
                 {
@@ -2360,8 +2525,8 @@ BMPC_D inline bool wave_backward_blk(Wave &W, const POff &po, const Scr &sc, dou
 // sb / K0: the staging buffer and the kinematics record of stage k.
 // rlv: the stage's lifted residuals (12), gh: QP-gradient row of the stage indexed by the component of Z (one-wave: null -- the lane's entry was
 // staged at sb[ST_GHF + lane]); item lane t = 0..43; returns the lane's share of (QP gradient) . dZ.
-template <class PK>
-BMPC_D inline double forward_dz_item(Wave &W, int k, int t0, const double *dn, const double *rlv, const PK K0, const double *ghrow, const double *ghf) {
+template <class PR, class PK, class PG>
+BMPC_D inline double forward_dz_item(Wave &W, int k, int t0, const double *dn, const PR rlv, const PK K0, const PG ghrow, bool has_row, const double *ghf) {
     double *L = W.L; const double h = W.h;
     const bool on = t0 < NZ; const int t = on ? t0 : 0;
     const bool isIw = t >= SIOTA && t < NS, isPos = t >= NS && t < NS + 3, isV = t >= NS + 3;
@@ -2382,11 +2547,11 @@ BMPC_D inline double forward_dz_item(Wave &W, int k, int t0, const double *dn, c
     double fa = 0.0; fa = isV ? 1.0 : fa; fa = isIw ? 0.5 * h : fa; fa = isPos ? 1.0 : fa;
     const double v = addv + fa * (s1 + ((isIw || isV) ? 1.0 : 0.0) * s2);
     W.Dz[k * NZ + z] = v;
-    const double ghe = ghrow ? ghrow[z] : ghf[t0];
+    const double ghe = has_row ? ghrow[z] : ghf[t0];      // (has_row: a compile-time constant at every call site)
     return on ? ghe * v : 0.0;      // (QP gradient) . dZ for the line search, summed where dZ is made
 }
 BMPC_D inline void forward_dz_lane(Wave &W, LaneRegs *LR, int k, int lane, const double *dn, const double *sb, const double *K0) {
-    LR[LIDX].ghd += forward_dz_item(W, k, lane, dn, sb + ST_RLVF, K0, (const double *)nullptr, sb + ST_GHF);
+    LR[LIDX].ghd += forward_dz_item(W, k, lane, dn, sb + ST_RLVF, K0, sb, false, sb + ST_GHF);
 }
 // one stage of the forward sweep (two phases since round 4: the reduced state ping-pongs between L_DS and L_DSN by stage parity instead of
 // being copied back in a phase of its own, and the dZ rows of stage k-1 -- which need that stage's complete next state -- ride in the
@@ -2471,7 +2636,7 @@ BMPC_D inline void wave_dz_wide(Wave &W, const Scr &sc, LaneRegs *LR) {
         double ghd = 0.0;
         for (int t_ = 0; t_ < (N * NZ + WS - 1) / WS; t_++) {      // wave-uniform trip count, clamped item (duplicate store of the same value)
             const int id0 = wl + WS * t_, id = id0 < N * NZ ? id0 : N * NZ - 1, k = id / NZ, t = id - k * NZ;
-            const double g_ = forward_dz_item(W, k, t, L + L_DSA + k * 36, WL + sc.RLV + k * 12, WL + sc.KIN + k * KREC, WL + sc.GH + k * NZ, (const double *)nullptr);
+            const double g_ = forward_dz_item(W, k, t, L + L_DSA + k * 36, WL + sc.RLV + k * 12, WL + sc.KIN + k * KREC, WL + sc.GH + k * NZ, true, (const double *)nullptr);
             ghd += id0 < N * NZ ? g_ : 0.0;
         }
         LR[LIDXW].ghd = ghd;

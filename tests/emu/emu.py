@@ -67,14 +67,16 @@ _TLIBS = {}
 
 
 def team_lib(nw=4):
+    """nw = 4 / 2: teams (workspace rows in LDS); nw = "pair": the two-wave team with the workspace in the global slab (BMPC_WSG, csrc/bmpc_pair.hip)"""
     if nw not in _TLIBS:
-        path = os.path.join(_HERE, f"libbmpc_emu_team{nw}.so")
+        pair = nw == "pair"
+        path = os.path.join(_HERE, "libbmpc_emu_pair.so" if pair else f"libbmpc_emu_team{nw}.so")
         src = [os.path.join(_HERE, "bmpc_emu_team.cpp"), _SRC[1]]
         if not os.path.exists(path) or any(os.path.getmtime(path) < os.path.getmtime(s) for s in src):
-            subprocess.check_call(["g++", "-O2", "-fopenmp", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-Wno-enum-compare",
-                                   f"-DBMPC_NW={nw}", "-o", path, src[0]])
+            subprocess.check_call(["g++", "-O2", "-fopenmp", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-Wno-enum-compare"]
+                                  + (["-DBMPC_NW=2", "-DBMPC_WSG"] if pair else [f"-DBMPC_NW={nw}"]) + ["-o", path, src[0]])
         _TLIBS[nw] = ctypes.CDLL(path)
-        assert _TLIBS[nw].bmpc_emu_team_waves() == nw
+        assert _TLIBS[nw].bmpc_emu_team_waves() == (2 if pair else nw)
     return _TLIBS[nw]
 
 

@@ -1,0 +1,36 @@
+"""Diagnostic (GPU box): the pair kernel (two cooperating waves per problem at two waves per SIMD, csrc/bmpc_pair.hip) against the one-wave
+kernel: bitwise comparison of the results and kernel time per batch size, on the bench batches.  Usage: python tests/gpu_pair.py [B ...]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from boundmpc_amd import BatchedOCPSolver, workload  # noqa: E402
+
+Bs = [int(a) for a in sys.argv[1:]] or [256, 1024, 2048, 8192]
+
+
+def run(s, p, x0, n=6):
+    s.set_timing(1)
+    ms = []
+    for _ in range(n):
+        o = s.solve_batch(p, x0, out={}, want=("iters", "status", "kkt")); torch.cuda.synchronize(); ms.append(s.last_kernel_ms())
+    return o, float(np.min(ms[1:]))
+
+
+one, pair = BatchedOCPSolver(10, 4, 0.1), BatchedOCPSolver(10, 4, 0.1)
+one.set_team_waves(1); pair.set_team_waves(2)
+print("pair info", pair.team_info(1024), "one-wave grid", one.launch_info(), flush=True)
+for B in Bs:
+    P, X, _ = workload.make_batch(B, seed=0)
+    p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
+    o1, t1 = run(one, p, x0); o2, t2 = run(pair, p, x0)
+    same = torch.equal(o1["x"], o2["x"]); it1, it2 = o1["iters"].cpu().numpy(), o2["iters"].cpu().numpy()
+    d = (o1["x"] - o2["x"]).reshape(B, 10, 44)[:, :, 8:15]
+    print(f"B={B:5d}: one wave {t1:.3f} ms ({B / t1 * 1e3:.0f}/s), pair {t2:.3f} ms ({B / t2 * 1e3:.0f}/s) ({t1 / t2:.2f}x); bit-equal {same}, "
+          f"joint RMS diff {float(torch.sqrt((d ** 2).mean())):.2e}, iters max {it1.max()} / {it2.max()}, equal iters {bool((it1 == it2).all())}, "
+          f"status0 {(o2['status'] == 0).float().mean().item():.4f}", flush=True)
+one.close(); pair.close()
