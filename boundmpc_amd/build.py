@@ -25,9 +25,8 @@ def hipcc():
 
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
          "-Wno-unused-variable", "-Wno-unused-value", "-Wno-duplicate-decl-specifier"]
-# per-unit flags.  The pair kernel runs at TWO waves per SIMD (256 registers): there the ILP-chasing scheduler hoists loads until the allocator
-# spills them (1996 B of scratch per lane against 744 with the default strategy, same text); the second wave hides latency instead.
-UNIT_FLAGS = {"bmpc_pair.hip": [f for f in FLAGS if f not in ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")]}
+# per-unit flags (none at present; the 256-register experiment of bmpc_pair.hip wanted the default scheduler: 744 B of scratch against 1996 B)
+UNIT_FLAGS = {}
 
 
 def unit_flags(src):

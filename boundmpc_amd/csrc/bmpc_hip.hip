@@ -263,17 +263,15 @@ static int timing_slot(bmpc_handle *h, hipEvent_t **pair) {
     *pair = h->ev + 2 * (h->n_timed % h->timing);
     return BMPC_OK;
 }
-// Which kernel solves a batch of B (waves per problem): a team of BMPC_TEAM_NW waves when the batch leaves SIMDs idle -- it fits into the resident
-// teams of the device (256 on an MI355X) -- or when the caller asked for teams; a pair (2 waves at two waves per SIMD) for larger batches of the
-// horizons whose iterate lives in LDS; else one wave per problem.
-#ifndef BMPC_PAIR_AUTO
-#define BMPC_PAIR_AUTO 1      // automatic mode: batches beyond the resident teams go to the pair kernel where it exists
-#endif
+// Which kernel solves a batch of B (waves per problem): a team of BMPC_TEAM_NW waves when the batch fits into the resident teams of the device
+// (256 on an MI355X: a team owns a CU) or when the caller asked for teams; a pair (2 waves on the one-wave budget: 512 resident, bmpc_pair.hip)
+// when it fits into the resident pairs; else one wave per problem.  bmpc_set_team_waves: 1 = always one wave, 2 = pairs whatever the batch,
+// BMPC_TEAM_NW = teams whatever the batch.
 static int solve_waves(const bmpc_handle *h, int B) {
     if (h->team_mode == 1) return 1;
     if (h->team_mode == 2) return h->pair_grid > 0 ? 2 : 1;
     if (h->team_grid > 0 && (h->team_mode == BMPC_TEAM_NW || B <= h->team_grid)) return BMPC_TEAM_NW;
-    return (BMPC_PAIR_AUTO && h->team_mode == 0 && h->pair_grid > 0) ? 2 : 1;
+    return (h->pair_grid > 0 && B <= h->pair_grid) ? 2 : 1;
 }
 static bool use_team(const bmpc_handle *h, int B) { return solve_waves(h, B) == BMPC_TEAM_NW; }
 static int launch_grid(const bmpc_handle *h, int B) { const int w = solve_waves(h, B), g = w == BMPC_TEAM_NW ? h->team_grid : (w == 2 ? h->pair_grid : h->grid); return B < g ? B : g; }

@@ -1,14 +1,20 @@
-// bmpc_pair.hip -- gfx950 PAIR kernel of the batched BoundMPC OCP solver: two cooperating waves per problem at TWO waves per SIMD.
+// bmpc_pair.hip -- gfx950 PAIR kernel of the batched BoundMPC OCP solver: two cooperating waves per problem on the one-wave budget.
 //
-// The one-wave kernel (bmpc_hip.hip) runs one problem per 64-lane wave at one wave per SIMD (512 registers): nothing hides the dependent
-// latencies of its sequential sweeps (142 k of the 324 k wave clocks of an iteration are stalls).  Here the same wave program
-// (bmpc_wave.inl compiled with BMPC_NW = 2 and BMPC_WSG, namespace bmpcp) runs on a 128-thread workgroup that keeps the one-wave budget
-// per problem -- 40 KB of LDS, the workspace in the global slab -- and is compiled for 256 registers per wave: four pairs per CU, eight
-// waves per CU, two per SIMD.  A batch of 1024 problems (BASELINE configs[1]) then has a second wave on every SIMD of the chip.  Roles:
-// wave 0 runs the recursions (adjoint, Riccati, forward); wave 1 the references / objective half of every evaluation beside the kinematics
-// and, inside the Riccati sweep, the staging and the recursion-independent half of the next stage's node-cost add; the item-parallel row
-// passes run over all 128 lanes.  Results equal the one-wave kernel's bit for bit (same reduction orders).  Launched from the C ABI in
-// bmpc_hip.hip for batches larger than the resident 4-wave teams.
+// The one-wave kernel (bmpc_hip.hip) runs one problem per 64-lane wave; the 4-wave teams (bmpc_team.hip) own a whole CU per problem (their
+// workspace rows live in its 160 KB of LDS), so only 256 problems are resident.  Here the same wave program (bmpc_wave.inl compiled with
+// BMPC_NW = 2 and BMPC_WSG, namespace bmpcp) runs on a 128-thread workgroup that keeps the ONE-WAVE budget per problem -- 40 KB of LDS, the
+// workspace in the global slab -- so two pairs share a CU: 512 problems resident.  Roles: wave 0 runs the recursions (adjoint, Riccati,
+// forward); wave 1 the references / objective half of every evaluation beside the kinematics and, inside the Riccati sweep, the staging (its
+// own register prefetch) and the recursion-independent half of the next stage's node-cost add, the q~ rows and t6; the item-parallel row
+// passes run over all 128 lanes.  Same reduction orders as the team text: results equal the one-wave kernel's up to the order of a few sums
+// behind discrete decisions (bit-equal on the bench batches; 2 of 8192 problems differ by 1e-12).  Launched from the C ABI in bmpc_hip.hip
+// for batches between the resident teams and the resident pairs (256 < B <= 512): 1.18-1.20x the one-wave kernel there.
+//
+// Built as the answer to "a second wave on every SIMD" (round 6): compiled for TWO waves per SIMD (-DBMPC_PAIR_EU=2: 256 registers per wave,
+// four pairs per CU, 1024 problems resident) the same text needs 744 B of scratch per lane and runs 0.58x the one-wave kernel at B = 1024
+// (4.68 vs 2.70 ms; profiles/r06_a_pair_occupancy_ab.txt has the A/B and the resource table per wave role): the LDS budget holds (40 896 B),
+// the register budget does not -- at 512 registers per wave the pair is 1.2x the one-wave kernel per problem.  The product build is the
+// 512-register one (BMPC_PAIR_EU = 1).
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -30,7 +36,12 @@
 #define TEAM_SYNC_LDS() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define WIDE_BEGIN LANES_BEGIN const int wl = W.wv * 64 + lane; (void)wl;
 #define WIDE_END LANES_END TEAM_SYNC();
+#ifdef BMPC_PAIR_ROLE
+// diagnostic compile only (resource table per wave role, tests/kernel_resources.py --pair-roles): the solo regions of the OTHER role are compiled out
+#define SOLO_BEGIN(w) if (W.wv == (w) && (w) == BMPC_PAIR_ROLE) {
+#else
 #define SOLO_BEGIN(w) if (W.wv == (w)) {
+#endif
 #define SOLO_END }
 
 #ifdef BMPC_MARKS
@@ -48,7 +59,7 @@ typedef KArgsT<bmpcp::Opts> KArgsPair;
 static_assert(bmpcp::NW == 2, "pair size");
 
 #ifndef BMPC_PAIR_EU
-#define BMPC_PAIR_EU 2      // waves per SIMD the kernel is compiled for: 256 registers per wave
+#define BMPC_PAIR_EU 1      // waves per SIMD the kernel is compiled for (2 = the 256-register experiment of the header)
 #endif
 __global__ void __launch_bounds__(128, BMPC_PAIR_EU) bmpc_pair_solve_kernel(KArgsPair a) {
     __shared__ double lds[bmpcp::L_SIZE];

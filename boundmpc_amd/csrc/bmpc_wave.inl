@@ -36,14 +36,13 @@
 //   * reductions over a wide pass (red_*_w) read the NW x 64 per-lane partials in a fixed order in every wave.
 // With BMPC_NW == 1 every one of these reduces to the one-wave text: wl = lane, WS = 64, TEAM_SYNC() = nothing, SOLO = unconditional.
 //
-// PAIRS (BMPC_NW == 2 with BMPC_WSG; round 6): a team of TWO waves that keeps the one-wave program's budget per problem -- 40 KB of LDS and
-// the workspace in the global slab (WSG) -- and is compiled for TWO waves per SIMD (256 registers per wave): four pairs per CU, so a batch of
-// 1024 problems puts a second wave on every SIMD of the chip, which is what hides the dependent-latency stalls of the sequential sweeps
-// (DESIGN.md 5).  Wave 0 runs the recursions; wave 1 owns what does not depend on them: the references / objective half of an evaluation
-// beside the kinematics, and -- inside the Riccati sweep -- the staging of the node-cost inputs of the NEXT stage from the slab into LDS
-// (its own register prefetch, a stage ahead), the recursion-independent half of the node-cost add, the q~ rows and t6.  What the helper
-// hands over per stage (14 words per lane) goes through the part of the value-function block area that is idle between two Schur updates
-// (L_PREP: single-buffered, hence a second LDS-only barrier per stage, placed where the helper is already waiting).
+// PAIRS (BMPC_NW == 2 with BMPC_WSG; round 6, csrc/bmpc_pair.hip): a team of TWO waves that keeps the one-wave program's budget per problem -- 40 KB
+// of LDS and the workspace in the global slab (WSG) -- so that two pairs share a CU (512 problems resident; compiled for 256 registers per wave it
+// would be four, but the text needs ~440: bmpc_pair.hip has the numbers).  Wave 0 runs the recursions; wave 1 owns what does not depend on them: the
+// references / objective half of an evaluation beside the kinematics, and -- inside the Riccati sweep -- the staging of the node-cost inputs of the
+// NEXT stage from the slab into LDS (its own register prefetch, a stage ahead), the recursion-independent half of the node-cost add, the q~ rows
+// and t6.  What the helper hands over per stage (14 words per lane) goes through the part of the value-function block area that is idle between
+// two Schur updates (L_PREP: single-buffered, hence a second LDS-only barrier per stage, placed where the helper is already waiting).
 #pragma once
 
 #ifndef BMPC_NW

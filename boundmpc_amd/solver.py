@@ -110,8 +110,8 @@ class BatchedOCPSolver:
 
     def set_team_waves(self, waves=0):
         """Waves per problem: 0 (default) automatic -- a batch that fits into the resident teams of the device (256 on an MI355X) is solved by
-        workgroups of 4 cooperating waves, a larger one by one wave per problem; 1 never teams; 4 teams whenever the kernel exists
-        (N <= 11, S <= 4).  Re-capture graphs after changing it."""
+        workgroups of 4 cooperating waves, one that fits into the resident pairs (512) by workgroups of 2, a larger one by one wave per problem;
+        1 never teams; 2 pairs whatever the batch (N <= 11, S <= 4); 4 teams whenever the kernel exists (N <= 10, S <= 4).  Re-capture graphs after changing it."""
         _lib.check(self._lib.bmpc_set_team_waves(self._h, int(waves)), "bmpc_set_team_waves")
 
     def team_info(self, B):

@@ -240,13 +240,16 @@ int bmpc_last_kernel_ms(bmpc_handle *h, float *ms);
  * (wall-clock counter read when a wavefront takes the problem from the queue and when it has written the outputs); NULL = off. */
 int bmpc_set_latency_buffer(bmpc_handle *h, double *latency_us);
 
-/* Teams: for horizons N <= 10 and S <= 4 the library also holds kernels that put a WORKGROUP OF 4 COOPERATING WAVES on one problem (the
- * item-parallel passes of an iteration run over 256 lanes, the recursions on one wave): about 1.3x faster per iteration, but only a quarter
- * as many problems are resident (256 on an MI355X: a team keeps most of its workspace in the 160 KB of LDS of the CU it owns).  They serve the batches that leave SIMDs idle anyway: closed-loop streams
- * (BASELINE configs[4]: 256) and the single solver(...) call of the drop-in (BoundMPC.py:446-453).  bmpc_set_team_waves(h, 0) (default): a
- * batch is solved by teams when it fits into the resident teams, else by one wave per problem; (h, 1): never; (h, 4): whenever the
- * instantiation exists.  Results agree with the one-wave kernels up to the order of a few sums (same iterates unless a filter decision
- * sits on a rounding error).  bmpc_team_info: waves per problem a batch of B would get, resident teams, LDS bytes of a team. */
+/* Teams and pairs: for short horizons (S <= 4) the library also holds kernels that put several COOPERATING WAVES on one problem (the item-parallel
+ * passes of an iteration run over all their lanes, the recursions on one wave, recursion-independent work beside them on another).  Teams: 4
+ * waves, N <= 10; a team owns a CU (most of its workspace lives in the CU's LDS): 256 resident on an MI355X.  Pairs: 2 waves on the one-wave
+ * budget (40 KB of LDS, workspace in the global slab), N <= 11: 512 resident.  They serve the batches that leave SIMDs idle anyway: closed-loop
+ * streams (BASELINE configs[4]: 256), the single solver(...) call of the drop-in (BoundMPC.py:446-453), batches up to 512.
+ * bmpc_set_team_waves(h, 0) (default): teams when the batch fits into the resident teams, else pairs when it fits into the resident pairs,
+ * else one wave per problem; (h, 1): always one wave; (h, 2): pairs whatever the batch; (h, 4): teams whatever the batch (an error where the
+ * instantiation does not exist).  Results agree with the one-wave kernels up to the order of a few sums (same iterates unless a filter
+ * decision sits on a rounding error).  bmpc_team_info: waves per problem a batch of B would get, resident teams / pairs of that kind, LDS
+ * bytes of its workgroup.  The fused closed-loop ticks run on teams or on one wave per stream. */
 int bmpc_set_team_waves(bmpc_handle *h, int waves);
 int bmpc_team_info(const bmpc_handle *h, int B, int *waves, int *resident_teams, int *lds_bytes);
 

@@ -4,21 +4,25 @@ import ctypes, os, subprocess, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch
-from boundmpc_amd import workload, _lib
+from boundmpc_amd import workload
 
 csrc = os.path.join(ROOT, "boundmpc_amd", "csrc")
-prof_lib = os.path.join(ROOT, "gpurun_out", "libboundmpc_hip_prof.so")
-os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
-flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-DBMPC_PROFILE"] + os.environ.get("BMPC_PROF_DEFS", "").split() + \
-        ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-Wno-unused-variable", "-Wno-unused-value", "-Wno-duplicate-decl-specifier"]
-objs = []
-procs = []
-for unit in ("bmpc_hip", "bmpc_team", "bmpc_resto", "bmpc_tick"):      # the translation units of the library, side by side (stamps only in the batch kernels)
-    objs.append(os.path.join(ROOT, "gpurun_out", unit + "_prof.o"))
-    procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + ["-c", "-o", objs[-1], os.path.join(csrc, unit + ".hip")]))
-assert all(pr.wait() == 0 for pr in procs)
-subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-fPIC", "-shared", "-o", prof_lib] + objs)
+# BMPC_PROF_LIB: a profile library built ahead of the GPU call (python tests/gpu_profile_phases.py --build-only, on the CPU box: build/ travels)
+prof_lib = os.environ.get("BMPC_PROF_LIB") or os.path.join(ROOT, "build", "prof", "libboundmpc_hip_prof.so")
+if "--build-only" in sys.argv or not os.path.exists(prof_lib):
+    from boundmpc_amd import build as _b
+    os.makedirs(os.path.dirname(prof_lib), exist_ok=True)
+    objs = []
+    procs = []
+    for src in _b.UNITS:      # the translation units of the library, side by side, each with the product's flags (stamps only in the batch kernels)
+        unit = os.path.splitext(os.path.basename(src))[0]
+        objs.append(os.path.join(os.path.dirname(prof_lib), unit + "_prof.o"))
+        procs.append(subprocess.Popen([_b.hipcc()] + _b.unit_flags(src) + ["-fPIC", "-DBMPC_PROFILE"] + os.environ.get("BMPC_PROF_DEFS", "").split() + ["-c", "-o", objs[-1], src]))
+    assert all(pr.wait() == 0 for pr in procs)
+    subprocess.check_call([_b.hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", prof_lib] + objs)
+    if "--build-only" in sys.argv:
+        print(prof_lib); sys.exit(0)
+import torch
 lib = ctypes.CDLL(prof_lib)
 vp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
 lib.bmpc_create.argtypes = [ci, ci, cd, vp, ctypes.POINTER(vp)]
@@ -27,7 +31,7 @@ lib.bmpc_get_profile.argtypes = [vp, vp]
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 TIGHT = "tight" in sys.argv[3:]
-TEAM = 4 if "team" in sys.argv[3:] else (1 if "one" in sys.argv[3:] else 0)      # waves per problem: team kernels / one wave / the library's choice
+TEAM = 4 if "team" in sys.argv[3:] else (2 if "pair" in sys.argv[3:] else (1 if "one" in sys.argv[3:] else 0))      # waves per problem: team kernels / pair kernel / one wave / the library's choice
 P, X, _ = workload.make_batch(B, seed=0, N=N, tight=TIGHT)
 h = vp()
 assert lib.bmpc_create(N, 4, 0.1, None, ctypes.byref(h)) == 0

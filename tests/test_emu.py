@@ -246,15 +246,20 @@ def test_flop_counting_build_of_the_kernel_text_runs_the_same_iterations():
 
 
 # ---- team variant of the wave program (NW cooperating waves per problem; tests/emu/bmpc_emu_team.cpp) ----
-@pytest.mark.parametrize("nw", [4, 2])
+@pytest.mark.parametrize("nw", [4, 2, "pair"])
 def test_team_program_matches_oracle_and_is_order_invariant(nw):
-    """The team text (wide passes over 64 NW lanes, helper wave of the Riccati sweep, workspace rows in LDS) against the CPU oracle, and
-    bit-for-bit the same under forward / reverse / scrambled orders of the waves inside a wide phase and of the lanes inside a wave."""
+    """The team text (wide passes over 64 NW lanes, helper wave of the Riccati sweep, workspace rows in LDS; "pair": two waves with the workspace
+    in the global slab and the helper's own staging, csrc/bmpc_pair.hip) against the CPU oracle, and bit-for-bit the same under forward / reverse /
+    scrambled orders of the waves inside a wide phase and of the lanes inside a wave."""
     from boundmpc_amd import workload
     P, X, _ = workload.make_batch(1024, seed=0, rows=(0, 24), workers=1)
     ref = c_oracle.solve(P, X, 10, 4, 0.1, nthreads=4)
     one = emu.solve(P, X, 10, 4, 0.1, nthreads=4)
-    t = emu.solve_team(P, X, 10, 4, 0.1, nw=nw, nthreads=4)
+    os.environ["BMPC_EMU_POISON"] = "1"      # LDS and workspace of every problem start as NaN: a read of a word nobody wrote shows
+    try:
+        t = emu.solve_team(P, X, 10, 4, 0.1, nw=nw, nthreads=4)
+    finally:
+        del os.environ["BMPC_EMU_POISON"]
     assert (t["status"] == ref["status"]).all() and (t["status"] == 0).all()
     assert np.abs(t["iters"] - ref["iters"]).max() <= 1
     d = (t["x"] - ref["x"]).reshape(-1, 10, 44)[:, :, 8:15]
@@ -266,21 +271,23 @@ def test_team_program_matches_oracle_and_is_order_invariant(nw):
         assert np.array_equal(c["x"], t["x"]) and np.array_equal(c["iters"], t["iters"]) and np.array_equal(c["lam_g"], t["lam_g"])
 
 
-def test_team_program_tight_tubes_short_horizons_and_warm_start():
-    """Teams on what stresses the Riccati sweep's retry path (tight tubes: indefinite stage blocks, regularisation), on other short horizons, and
-    on the warm entry (dual state), each against the one-wave program, whose lockstep with the oracle the tests above hold."""
+@pytest.mark.parametrize("nw", [4, "pair"])
+def test_team_program_tight_tubes_short_horizons_and_warm_start(nw):
+    """Teams / pairs on what stresses the Riccati sweep's retry path (tight tubes: indefinite stage blocks, regularisation: the sweep is abandoned at a
+    stage barrier and started again), on other short horizons (pairs: 1, 2 and 11 too -- the barrier pairing of helper and sweep depends on N), and on
+    the warm entry (dual state), each against the one-wave program, whose lockstep with the oracle the tests above hold."""
     from boundmpc_amd import workload
     P, X, _ = workload.make_batch(64, seed=9, N=10, tight=True, rows=(0, 24), workers=1)
-    a, b = emu.solve(P, X, 10, 4, 0.1, nthreads=4), emu.solve_team(P, X, 10, 4, 0.1, nw=4, nthreads=4)
+    a, b = emu.solve(P, X, 10, 4, 0.1, nthreads=4), emu.solve_team(P, X, 10, 4, 0.1, nw=nw, nthreads=4)
     assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["iters"], b["iters"]) and np.abs(a["x"] - b["x"]).max() < 1e-9
-    for N in (3, 7):
+    for N in (3, 7) + ((1, 2, 11) if nw == "pair" else ()):
         P2, X2, _ = workload.make_batch(32, seed=3, N=N, rows=(0, 12), workers=1)
-        a, b = emu.solve(P2, X2, N, 4, 0.1, nthreads=4), emu.solve_team(P2, X2, N, 4, 0.1, nw=4, nthreads=4)
+        a, b = emu.solve(P2, X2, N, 4, 0.1, nthreads=4), emu.solve_team(P2, X2, N, 4, 0.1, nw=nw, nthreads=4)
         assert (b["status"] == 0).all() and np.array_equal(a["iters"], b["iters"]) and np.abs(a["x"] - b["x"]).max() < 1e-9
     P3, X3, _ = workload.make_batch(32, seed=4, rows=(0, 8), workers=1)
     st_a, st_b = np.zeros((8, 572)), np.zeros((8, 572))
     for rep in range(2):      # second solve: warm start from the stored multipliers
-        a = emu.solve(P3, X3, 10, 4, 0.1, nthreads=4, state=st_a); b = emu.solve_team(P3, X3, 10, 4, 0.1, nw=4, nthreads=4, state=st_b)
+        a = emu.solve(P3, X3, 10, 4, 0.1, nthreads=4, state=st_a); b = emu.solve_team(P3, X3, 10, 4, 0.1, nw=nw, nthreads=4, state=st_b)
         assert np.array_equal(a["iters"], b["iters"]) and np.abs(a["x"] - b["x"]).max() < 1e-9 and np.abs(st_a - st_b).max() < 1e-7
 
 

@@ -48,6 +48,65 @@ def test_team_kernel_matches_oracle_and_one_wave_kernel(B):
         assert np.array_equal(o4[k], o4b[k]), k      # bitwise deterministic from launch to launch
 
 
+@pytest.mark.parametrize("B,N", [(300, 10), (512, 10), (64, 11), (40, 5), (3, 1), (5, 2)])
+def test_pair_kernel_matches_oracle_and_one_wave_kernel(B, N):
+    """The pair kernel (two cooperating waves per problem on the one-wave budget, csrc/bmpc_pair.hip): statuses and iterations of the CPU oracle,
+    the one-wave kernel's iterates, bitwise determinism; horizons 1 and 2 exercise the ends of the helper / sweep barrier pairing, 11 the longest."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    from oracle import c_oracle
+    P, X, _ = workload.make_batch(max(B, 64), seed=5, N=N, rows=(0, B))
+    p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
+    one, pair = BatchedOCPSolver(N, 4, 0.1), BatchedOCPSolver(N, 4, 0.1)
+    one.set_team_waves(1); pair.set_team_waves(2)
+    try:
+        assert pair.team_info(B)["waves"] == 2
+        want = ("g", "lam_g", "lam_x", "f", "iters", "status", "kkt")
+        o1 = {k: v.cpu().numpy() for k, v in one.solve_batch(p, x0, out={}, want=want).items()}
+        o2 = {k: v.cpu().numpy() for k, v in pair.solve_batch(p, x0, out={}, want=want).items()}
+        o2b = {k: v.cpu().numpy() for k, v in pair.solve_batch(p, x0, out={}, want=want).items()}
+    finally:
+        one.close(); pair.close()
+    ref = c_oracle.solve(P, X, N, 4, 0.1, nthreads=16)
+    assert (o2["status"] == ref["status"]).all() and (o2["status"] == 0).all()
+    assert np.abs(o2["iters"] - ref["iters"]).max() <= 2
+    d = (o2["x"] - ref["x"]).reshape(B, N, 44)[:, :, 8:15]
+    assert np.sqrt((d ** 2).mean(axis=(1, 2))).max() < 1e-6 and np.sqrt((d ** 2).mean()) < 1e-7      # rad, per problem and over the batch
+    assert o2["kkt"].max() <= 1e-8
+    assert np.array_equal(o2["iters"], o1["iters"])
+    for k in ("x", "g", "lam_g", "lam_x", "f"):
+        np.testing.assert_allclose(o2[k], o1[k], rtol=1e-9, atol=1e-9, err_msg=k)
+        assert np.array_equal(o2[k], o2b[k]), k      # bitwise deterministic from launch to launch
+
+
+def test_pair_kernel_on_tight_tubes_and_through_the_restoration_hand_over():
+    """Pairs where the Riccati sweep is abandoned at a stage barrier and started again (tight tubes: regularisation), and on jammed problems: the
+    pair kernel leaves them with the internal status 4 and the one-wave restoration kernel continues (fixture g13b): statuses of the oracle."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    from oracle import c_oracle
+    G = os.path.join(ROOT, "tests", "golden")
+    P, X, _ = workload.make_batch(64, seed=9, N=10, tight=True, rows=(0, 48))
+    d = np.load(os.path.join(G, "g13b_first_failures_256_streams.npz"))
+    for (Pb, Xb, kw, okw) in ((P, X, {}, {}), (d["p"], d["x0"], dict(max_iter=500), dict(max_iter=500, start_rollout=0))):
+        one, pair = BatchedOCPSolver(10, 4, 0.1, **kw), BatchedOCPSolver(10, 4, 0.1, **kw)
+        one.set_team_waves(1); pair.set_team_waves(2)
+        if okw:
+            one.set_start_rollout(False); pair.set_start_rollout(False)
+        try:
+            p, x0 = torch.tensor(Pb, device="cuda"), torch.tensor(Xb, device="cuda")
+            o1 = {k: v.cpu().numpy() for k, v in one.solve_batch(p, x0, out={}, want=("iters", "status", "f")).items()}
+            o2 = {k: v.cpu().numpy() for k, v in pair.solve_batch(p, x0, out={}, want=("iters", "status", "f")).items()}
+        finally:
+            one.close(); pair.close()
+        ref = c_oracle.solve(Pb, Xb, 10, 4, 0.1, opts=c_oracle.default_opts(**okw) if okw else None, nthreads=16)
+        assert np.array_equal(o2["status"], ref["status"]) and np.array_equal(o2["status"], o1["status"])
+        assert np.abs(o2["iters"] - o1["iters"]).max() <= 4
+        ok = o2["status"] == 0
+        dq = (o2["x"] - o1["x"]).reshape(len(Pb), 10, 44)[ok][:, :, 8:15]
+        assert np.sqrt((dq ** 2).mean()) < 1e-6
+
+
 def test_team_choice_is_automatic_by_batch_size():
     from boundmpc_amd import BatchedOCPSolver
     s = BatchedOCPSolver(10, 4, 0.1)
@@ -55,11 +114,18 @@ def test_team_choice_is_automatic_by_batch_size():
     try:
         r = s.team_info(1)["resident_teams"]
         assert r >= 64 and s.team_info(1)["lds_bytes"] <= 160 * 1024
-        assert s.team_info(1)["waves"] == 4 and s.team_info(r)["waves"] == 4 and s.team_info(r + 1)["waves"] == 1 and s.team_info(1024)["waves"] == 1
-        # horizons beyond a team's LDS: one wave per problem whatever the batch; asking for teams there is an error
-        assert s11.team_info(1)["waves"] == 1 and s30.team_info(1)["waves"] == 1
+        assert s.team_info(1)["waves"] == 4 and s.team_info(r)["waves"] == 4
+        # beyond the resident teams: pairs (two waves on the one-wave budget: twice as many resident) while the batch fits, then one wave per problem
+        rp = s.team_info(r + 1)["resident_teams"]
+        assert s.team_info(r + 1)["waves"] == 2 and rp >= 2 * r and s.team_info(r + 1)["lds_bytes"] <= 40 * 1024
+        assert s.team_info(rp)["waves"] == 2 and s.team_info(rp + 1)["waves"] == 1 and s.team_info(1024)["waves"] == 1
+        # horizons beyond a team's LDS: N = 11 still has its iterate in LDS (pairs), N = 30 runs one wave per problem whatever the batch;
+        # asking for teams or pairs there is an error
+        assert s11.team_info(1)["waves"] == 2 and s30.team_info(1)["waves"] == 1
         with pytest.raises(Exception):
             s30.set_team_waves(4)
+        with pytest.raises(Exception):
+            s30.set_team_waves(2)
     finally:
         s.close(); s11.close(); s30.close()
 
