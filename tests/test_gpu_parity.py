@@ -639,8 +639,8 @@ def test_five_and_six_path_segments_against_the_oracle(N, S):
 @pytest.mark.gpu
 def test_first_failures_of_the_closed_loops_g13b_on_the_gpu():
     """Fixture g13b: every first failing tick of the 256 closed loops of configs[4] as round 4 ran them (38 problems: 28 infeasible for SLSQP, 10
-    feasible).  Round 5, restoration phase (include/boundmpc_hip.h bmpc_set_restoration), at the handle's DEFAULTS, on both launch shapes -- one wave
-    per problem and teams; the batch kernels hand the jammed problems to the restoration kernel (bmpc_resto.hip): the 28 locally infeasible
+    feasible).  Round 5, restoration phase (include/boundmpc_hip.h bmpc_set_restoration), at the handle's DEFAULTS, on every launch shape -- one wave
+    per problem, teams and pairs; the batch kernels hand the jammed problems to the restoration kernel (bmpc_resto.hip): the 28 locally infeasible
     problems end as status 2 within 60 iterations, 8 of the 10 feasible ones converge within 135, every status equals the oracle's, the objectives
     of the converged ones agree to 1e-9 relative.  With the phase switched off the kernels stall on all 38 like round 4's."""
     import torch
@@ -650,7 +650,7 @@ def test_first_failures_of_the_closed_loops_g13b_on_the_gpu():
     p, x0 = torch.tensor(d["p"], device="cuda"), torch.tensor(d["x0"], device="cuda")
     feas = (d["slsqp_eq"] < 1e-8) & (d["slsqp_ineq"] < 1e-8) & (d["slsqp_bounds"] < 1e-8)
     ref = c_oracle.solve(d["p"], d["x0"], 10, 4, 0.1, opts=c_oracle.default_opts(max_iter=500, start_rollout=0), nthreads=8)
-    for waves in (1, 4):
+    for waves in (1, 4, 2):      # one wave per problem, teams, pairs
         s = BatchedOCPSolver(10, 4, 0.1, start_rollout=False); s.set_team_waves(waves)      # (x0 as given: in the loop these ticks are warm solves)
         o = s.solve_batch(p, x0); st, it, f = o["status"].cpu().numpy(), o["iters"].cpu().numpy(), o["f"].cpu().numpy()
         di = np.abs(it - ref["iters"])
