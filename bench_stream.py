@@ -116,7 +116,7 @@ def main():
         rtfc[MU] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=30, fixed_barrier=MU, bound_margin=args.rt_bound_margin)
         rtfc[MU].set_timing(True)
     evaluate = BatchedOCPSolver(10, 4, 0.1, max_iter=0)       # f, g at a given point (no iteration)
-    reference = BatchedOCPSolver(10, 4, 0.1, tol=args.tol, max_iter=args.max_iter)    # every tick's problem solved to tolerance, untimed
+    reference = BatchedOCPSolver(10, 4, 0.1, tol=args.tol, max_iter=args.max_iter, start_rollout=False)    # every tick's problem solved to tolerance, untimed; x0 taken as given, like every stream solve
     res, ref_q = [], None
     FT = args.rt_feas_tol
     modes = [("converged", solver, 0, False, None), ("warm", solver, 0, True, None)] \

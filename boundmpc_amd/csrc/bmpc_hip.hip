@@ -293,11 +293,10 @@ static int reserve_for_batch(bmpc_handle *h, int B) {
     return BMPC_OK;
 }
 extern "C" int bmpc_set_restoration(bmpc_handle *h, int enabled, int short_steps, int cap) {
-    if (!h || short_steps > 1000 || cap > 100000) return BMPC_ERR_ARG;
-    if (enabled > 2) return BMPC_ERR_ARG;
+    if (!h || short_steps > 1000 || cap > 100000 || cap == 0 || enabled > 2) return BMPC_ERR_ARG;      // (every argument is checked before any is applied)
     if (enabled >= 0) h->resto_on = enabled;
     if (short_steps >= 0) h->resto_short = short_steps;
-    if (cap >= 1) h->resto_cap = cap; else if (cap == 0) return BMPC_ERR_ARG;
+    if (cap >= 1) h->resto_cap = cap;
     return BMPC_OK;
 }
 extern "C" int bmpc_get_restoration(const bmpc_handle *h, int *enabled, int *short_steps, int *cap) {
@@ -560,7 +559,7 @@ static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entr
     // The post-processing of a fused tick needs the final solution, so here the restoration phase runs INSIDE the kernel (instantiations with
     // RESTO); a time-budgeted real-time tick never gets as far as a jam (six short steps) and runs the lean instantiation with the phase off.
     const bool resto = h->resto_on != 0 && a.budget_ticks == 0;
-    a.o.restoration = resto ? 1 : 0; a.counter2 = nullptr; a.rcount = nullptr;
+    a.o.restoration = resto ? h->resto_on : 0; a.counter2 = nullptr; a.rcount = nullptr;      // (the handle's MODE, not a flag: 2 = after a numerical breakdown only, as every other launch shape runs it)
     if (use_team(h, B)) HIPCHK(bmpc_team_launch_tick(BMPC_TEAM_NW, resto, &a, &s, B, st));
     else HIPCHK(bmpc_tick_launch(h->N <= 11 && h->S <= bmpc::SMAX_ZLDS, resto, &a, &s, B, st));      // (long horizons, 5 or 6 path segments: iterate in the workspace)
     if (timed) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }

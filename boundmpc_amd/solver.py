@@ -292,9 +292,18 @@ class NlpSolverShim:
     def __init__(self, batched: BatchedOCPSolver):
         self._s = batched
         # behind the reference's BoundMPC every x0 is the reference's own (its cold start or a shifted plan, BoundMPC.py:316-375): taken as given, like Ipopt does
-        batched.set_start_rollout(False)
+        # (a setting of the caller's handle, kept while the shim lives: close() puts the previous value back)
+        self._rollout_was = batched.get_start_rollout() if hasattr(batched._lib, "bmpc_get_start_rollout") else None
+        if self._rollout_was is not None:
+            batched.set_start_rollout(False)
         self._stats = {"iter_count": 0, "success": False, "return_status": "not run"}
         self._lbx, self._ubx, self._lbg, self._ubg = batched.bounds()
+
+    def close(self):
+        """Gives the batched solver back as it was found (the start-rollout setting); the handle itself stays the caller's."""
+        if getattr(self, "_rollout_was", None) is not None and getattr(self._s, "_h", None):
+            self._s.set_start_rollout(self._rollout_was)
+        self._rollout_was = None
 
     def generate_dependencies(self, *a, **k):   # BoundMPC.py:155-157 -- nothing to generate
         return None

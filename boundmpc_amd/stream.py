@@ -192,7 +192,10 @@ class StreamBatch:
         self.solver, self.B, self.N, self.S = solver, len(mpcs), solver.N, solver.S
         # the warm starts of a stream are the reference's own (stream_pack: its cold start or the shifted plan, BoundMPC.py:316-375): taken as given, also
         # by the stateless ticks (cold duals); on closed loops the rollout of a start that is off its dynamics costs plans (oracle/bmpc_oracle.c solve_one)
-        solver.set_start_rollout(False)
+        # (a setting of the caller's handle: the previous value comes back in close(); an A/B library from before the option has no such entry point)
+        self._rollout_was = solver.get_start_rollout() if hasattr(solver._lib, "bmpc_get_start_rollout") else None
+        if self._rollout_was is not None:
+            solver.set_start_rollout(False)
         lens = [ctypes.c_int() for _ in range(4)]
         _lib.check(solver._lib.bmpc_stream_lengths(solver._h, *[ctypes.byref(v) for v in lens]), "bmpc_stream_lengths")
         self.pt_len, self.ss_len, self.rb_len, self.tr_len = (v.value for v in lens)
@@ -318,6 +321,9 @@ class StreamBatch:
         for g in self._graphs.values():
             self.solver._lib.bmpc_graph_destroy(g)
         self._graphs = {}
+        if getattr(self, "_rollout_was", None) is not None and getattr(self.solver, "_h", None):      # the handle's start-rollout setting as it was found
+            self.solver.set_start_rollout(self._rollout_was)
+            self._rollout_was = None
 
     def __del__(self):
         try:

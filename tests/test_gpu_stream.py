@@ -302,6 +302,41 @@ def test_device_tick_other_horizons_and_windows_g12(N, S):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mode", [2, 1])
+def test_fused_tick_runs_the_restoration_mode_of_the_handle(mode):
+    """One handle, one setting, whatever the launch shape: the fused tick (bmpc_stream_tick: one kernel) and the three-kernel tick (pack, batch solve
+    with the restoration kernel behind it, post) of the SAME stream states give the same statuses and iteration counts, tick by tick, through the
+    stretch of the path where ticks jam (phi ~ 5).  Mode 2 (numerical breakdowns only): until round 6 the fused tick ran mode 1 there -- a jammed
+    tick then enters the restoration phase (status 2 after 20-50 iterations) where the three-kernel tick stalls (status 2 after 60-80)."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, stream as bstream, workload
+    B, T = 48, 130
+    q0s = workload.random_q0(256, seed=3)[:B]
+    mpcs, recs = [], []
+    for q0 in q0s:
+        m, p0fk = workload.make_mpc(q0)
+        mpcs.append(m)
+        recs.append(bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([m.phi_max[0], 0.0, 0.0]), np.zeros(7)))
+    sa, sb_ = BatchedOCPSolver(10, 4, 0.1, max_iter=100), BatchedOCPSolver(10, 4, 0.1, max_iter=100)
+    sa.set_restoration(mode); sb_.set_restoration(mode)
+    a, b = bstream.StreamBatch(sa, mpcs), bstream.StreamBatch(sb_, mpcs)
+    a.set_robot(np.stack(recs)); b.set_robot(np.stack(recs))
+    nd, ns, worst, n2 = 0, 0, 0, 0
+    for t in range(T):
+        for k in ("state", "robot", "dual", "x", "traj"):      # the unfused loop starts every tick from the fused loop's state
+            getattr(b, k).copy_(getattr(a, k))
+        a.tick(max_iter=100, warm_dual=True, simulate=True, fused=True)
+        b.tick(max_iter=100, warm_dual=True, simulate=True, fused=False)
+        torch.cuda.synchronize()
+        live = (a.status != 3) | (a.iters > 0)      # (streams that lost their plan are skipped by the fused tick)
+        sta, stb, ia, ib = a.status[live].cpu().numpy(), b.status[live].cpu().numpy(), a.iters[live].cpu().numpy(), b.iters[live].cpu().numpy()
+        ns += int((sta != stb).sum()); d = np.abs(ia - ib); nd += int((d > 4).sum()); worst = max(worst, int(d.max()) if d.size else 0); n2 += int((sta == 2).sum())
+    a.close(); b.close(); sa.close(); sb_.close()
+    assert n2 > 0, "no tick of the run ended as status 2: the test does not reach the jams"
+    assert ns == 0 and nd == 0, (ns, nd, worst, n2)
+
+
+@pytest.mark.gpu
 def test_long_closed_loops_through_the_hard_part_of_the_path():
     """64 random streams over 130 ticks (the benchmark stops at 60): later segments are harder, some streams stall and run their error
     count past N (the reference's `step()` returns None from there on, BoundMPC.py:498-506).  Everything stays finite, the stalled
