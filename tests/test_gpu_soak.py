@@ -16,6 +16,12 @@ pytestmark = pytest.mark.gpu
 TOL_PER_PROBLEM = 1e-6      # rad RMS of one problem's joint trajectory against the oracle (measured: <= 2.3e-6 over 48 000 problems incl. N=30)
 
 
+# problems of a soak batch whose GPU solution is further than TOL_PER_PROBLEM from the oracle's: (N, tight, seed) -> problem indices.  Each is a KKT point to
+# 1e-8 reached through another sequence of accept / reject decisions (round-off amplified by an ill-conditioned end game on the last
+# barrier level, or a restarted long-horizon solve that ends in a neighbouring minimiser).
+KNOWN_FAR = {}
+
+
 @pytest.mark.parametrize("N,tight,seed", [(5, False, 21), (5, True, 22), (16, False, 23), (16, True, 24), (20, False, 25), (20, True, 26), (40, False, 27)])
 def test_soak_other_horizons_against_the_oracle(N, tight, seed):
     import torch
@@ -41,7 +47,9 @@ def test_soak_other_horizons_against_the_oracle(N, tight, seed):
     # problems that converge to the same minimiser agree to round-off x conditioning; a different local minimiser (sensitivity
     # note) would show as a deviation of 1e-3 rad or more: at most one problem per batch may do that, none may sit in between
     far = per > TOL_PER_PROBLEM
-    assert far.sum() <= (2 if (tight or N >= 16) else 0), (int(far.sum()), float(per.max()))      # long horizons: a restarted solve may end in a neighbouring minimiser
+    # the KNOWN cases, by name: a problem that is not on the list fails the test (until round 5 the test allowed any two per batch)
+    idx = set(int(i) for i in np.nonzero(ok)[0][far])
+    assert idx <= KNOWN_FAR.get((N, tight, seed), set()), (sorted(idx), [float(v) for v in per[far]])
     assert np.sqrt((d[~far] ** 2).mean()) < 1e-7
     # same algorithm in another arithmetic order: the iteration counts agree on almost every problem; a few take another trial point
     # somewhere and arrive at the same minimiser some iterations earlier or later (the accuracy check above is the criterion)
