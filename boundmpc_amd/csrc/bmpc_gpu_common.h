@@ -38,6 +38,7 @@ struct KArgsT {
     double *scratch; long long scr_stride; int *counter; unsigned long long *prof;
     long long budget_ticks;  // fused closed-loop tick only: time budget of a tick in counts of the 100 MHz wall clock, from kernel entry (0 = none)
     int *counter2, *rcount;  // restoration kernel (bmpc_resto.hip): its work queue; number of problems the batch kernel left with status 4 (NULL: phase off)
+    const int *order;        // one-wave batch kernel: the work queue hands out order[0], order[1], ... instead of 0, 1, ... (NULL: natural order; bmpc_set_queue_order)
 };
 // stream arguments of a fused tick
 struct SArgs {

@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
         if (threadIdx.x == 0) b = atomicAdd(a.counter, 1);
         b = __builtin_amdgcn_readfirstlane(b);
         if (b >= a.B) break;             // every wave reaches this exit: the queue is finite
+        if (a.order) b = __builtin_amdgcn_readfirstlane(a.order[b]);      // longest-expected-first order of a batch larger than the resident waves (queue_order_kernel)
         bmpc::Problem pr;
         pr.p = a.p + (long long)b * np; pr.x0 = a.x0 + (long long)b * nw;
         pr.x = a.x ? a.x + (long long)b * nw : nullptr; pr.g = a.g ? a.g + (long long)b * ng : nullptr;
@@ -74,6 +75,18 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
 #endif
 }
 
+// Work-queue order of a batch that takes several rounds of the resident waves (bmpc_set_queue_order): rank of every problem by DECREASING key
+// (ties: by index) -> order[rank] = problem.  B threads, each walks the B keys (B <= a few 10^4: microseconds).  A launch lasts until its last
+// wave is done, so problems that are expected to take long should start first; the key is the objective at the start point (evaluation pass).
+__global__ void __launch_bounds__(256) queue_order_kernel(int B, const double *key, int *order) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const double ki = key[i] == key[i] ? key[i] : INFINITY;      // (a NaN key -- f of a garbage x0 -- counts as the largest: the ranks must stay a permutation)
+    int r = 0;
+    for (int j = 0; j < B; j++) { const double kj = key[j] == key[j] ? key[j] : INFINITY; r += (kj > ki || (kj == ki && j < i)) ? 1 : 0; }
+    order[r] = i;
+}
+
 struct bmpc_handle {
     int N, S; double h; bmpc_options o;
     int dev;                 // device the handle was created on: workspace, work queue, events and streams of the handle live there
@@ -91,6 +104,8 @@ struct bmpc_handle {
     int *aux_int; int aux_cap;      // [2][aux_cap] status / iters of a batch whose caller passed NULL (the restoration kernel reads them)
     int start_rollout;      // 1 (default): a stateless solve whose x0 is far off its own dynamics starts from the rollout of x0's jerks (bmpc_set_start_rollout)
     int resto_on, resto_short, resto_cap;      // restoration phase (bmpc_set_restoration): mode 0 off / 1 full (default N <= 11) / 2 after a numerical breakdown only (default N > 11); jam = resto_short consecutive short steps; iterations per phase
+    int queue_order;         // bmpc_set_queue_order: 1 = a batch beyond the resident waves is solved in the order of decreasing f(x0) (default for N > 11), 0 = natural order
+    double *qkey; int *qorder; int q_cap;      // [q_cap] keys and order of the last such batch
     int team_mode;           // bmpc_set_team_waves: 0 automatic (teams when the batch fits into the resident teams), 1 never, BMPC_TEAM_NW whenever possible
     int timing; hipEvent_t *ev; int nev; long long n_timed;   // timing = number of launches whose {start, stop} event pairs are kept (ring)
     double *latency_us;
@@ -136,7 +151,7 @@ static void handle_release(bmpc_handle *h) {
     if (h->order_ev) hipEventDestroy(h->order_ev);
     if (h->bridge_ev) hipEventDestroy(h->bridge_ev);
     if (h->own_stream) hipStreamDestroy(h->own_stream);
-    hipFree(h->scratch); hipFree(h->counter); hipFree(h->aux_int); hipFree(h->prof); hipFree(h->stage_d); if (h->stage_h) hipHostFree(h->stage_h);
+    hipFree(h->scratch); hipFree(h->counter); hipFree(h->aux_int); hipFree(h->qkey); hipFree(h->qorder); hipFree(h->prof); hipFree(h->stage_d); if (h->stage_h) hipHostFree(h->stage_h);
     delete h;
 }
 
@@ -168,6 +183,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->ev = nullptr; h->nev = 0; h->n_timed = 0; h->latency_us = nullptr;
     h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->aux_int = nullptr; h->aux_cap = 0; h->prof = nullptr; h->stage_d = nullptr; h->stage_h = nullptr; h->stage_cap = 0;
     h->team_grid = 0; h->pair_grid = 0; h->team_mode = 0;
+    h->queue_order = N > 11 ? 1 : 0; h->qkey = nullptr; h->qorder = nullptr; h->q_cap = 0;
     h->rt_viol_tol = 1e-4; h->rt_budget_us = 0.0; h->dev = 0; h->refs = 1; h->closed = false; h->order_ev = nullptr; h->bridge_ev = nullptr; h->order_valid = false; h->order_stream = nullptr; h->own_stream = nullptr;
     if (opts) h->o = *opts; else bmpc_default_options_for(N, &h->o);
     int dev = 0, per_cu = 0; hipDeviceProp_t prop;
@@ -290,8 +306,21 @@ static int reserve_for_batch(bmpc_handle *h, int B) {
         HIPCHK(hipMalloc(&h->aux_int, sizeof(int) * 2 * (size_t)B));
         h->aux_cap = B;
     }
+    if (h->queue_order && B > h->q_cap && solve_waves(h, B) == 1 && B > h->grid) {
+        DevGuard dg(h->dev);
+        if (h->graphs_alive > 0 && h->qkey) { fprintf(stderr, "boundmpc_hip: a larger batch needs larger queue-order buffers, but captured graphs hold the current ones\n"); return BMPC_ERR_ARG; }
+        if (h->qkey) { wait_for_handle(h); hipFree(h->qkey); hipFree(h->qorder); h->qkey = nullptr; h->qorder = nullptr; h->q_cap = 0; }
+        HIPCHK(hipMalloc(&h->qkey, sizeof(double) * (size_t)B)); HIPCHK(hipMalloc(&h->qorder, sizeof(int) * (size_t)B));
+        h->q_cap = B;
+    }
     return BMPC_OK;
 }
+extern "C" int bmpc_set_queue_order(bmpc_handle *h, int mode) {
+    if (!h || mode < 0 || mode > 1) return BMPC_ERR_ARG;
+    h->queue_order = mode;
+    return BMPC_OK;
+}
+extern "C" int bmpc_get_queue_order(const bmpc_handle *h) { return h ? h->queue_order : -1; }
 extern "C" int bmpc_set_restoration(bmpc_handle *h, int enabled, int short_steps, int cap) {
     if (!h || short_steps > 1000 || cap > 100000 || cap == 0 || enabled > 2) return BMPC_ERR_ARG;      // (every argument is checked before any is applied)
     if (enabled >= 0) h->resto_on = enabled;
@@ -355,10 +384,25 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     }
     const int rgrid = resto ? resto_grid(h, B) : 0;
     if (rgrid > h->scr_waves) return BMPC_ERR_ARG;
-    HIPCHK(hipMemsetAsync(h->counter, 0, 3 * sizeof(int), st));
+    const bool zlds = h->N <= 11 && h->S <= bmpc::SMAX_ZLDS;
     hipEvent_t *pair = nullptr;
     if (timed) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
-    const bool zlds = h->N <= 11 && h->S <= bmpc::SMAX_ZLDS;
+    a.order = nullptr;
+    if (h->queue_order && !state && solve_waves(h, B) == 1 && B > h->grid && B <= h->q_cap) {
+        // Longest-expected-first: an evaluation pass (the same kernel with max_iter = 0: f at x0, nothing else written), the ranking, then the solve
+        // hands the problems out in that order.  Inside the timed region: it is part of what the batch costs.  A result does not depend on which
+        // wave solves it or when (bitwise invariance under permutation of the batch is a test), so the outputs are those of the natural order.
+        KArgs e = a; e.o.max_iter = 0; e.o.start_rollout = 0; e.x = nullptr; e.g = nullptr; e.lam_g = nullptr; e.lam_x = nullptr; e.kkt = nullptr; e.iters = nullptr; e.status = nullptr;
+        e.f = h->qkey; e.state = nullptr; e.latency_us = nullptr; e.rcount = nullptr; e.order = nullptr;
+        HIPCHK(hipMemsetAsync(h->counter, 0, 3 * sizeof(int), st));
+        if (zlds) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, e);
+        else hipLaunchKernelGGL(bmpc_solve_kernel<false>, dim3(grid), dim3(64), 0, st, e);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(queue_order_kernel, dim3((B + 255) / 256), dim3(256), 0, st, B, (const double *)h->qkey, h->qorder);
+        HIPCHK(hipGetLastError());
+        a.order = h->qorder;
+    }
+    HIPCHK(hipMemsetAsync(h->counter, 0, 3 * sizeof(int), st));
     if (use_team(h, B)) HIPCHK(bmpc_team_launch_solve(BMPC_TEAM_NW, &a, grid, st));      // a workgroup of waves per problem (bmpc_team.hip)
     else if (solve_waves(h, B) == 2) HIPCHK(bmpc_pair_launch_solve(&a, grid, st));           // two waves per problem at two waves per SIMD (bmpc_pair.hip)
     else if (zlds) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, a);      // iterate in LDS; else in the workspace (long horizons, S > 4)
@@ -559,7 +603,7 @@ static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entr
     // The post-processing of a fused tick needs the final solution, so here the restoration phase runs INSIDE the kernel (instantiations with
     // RESTO); a time-budgeted real-time tick never gets as far as a jam (six short steps) and runs the lean instantiation with the phase off.
     const bool resto = h->resto_on != 0 && a.budget_ticks == 0;
-    a.o.restoration = resto ? h->resto_on : 0; a.counter2 = nullptr; a.rcount = nullptr;      // (the handle's MODE, not a flag: 2 = after a numerical breakdown only, as every other launch shape runs it)
+    a.o.restoration = resto ? h->resto_on : 0; a.counter2 = nullptr; a.rcount = nullptr; a.order = nullptr;      // (the handle's MODE, not a flag: 2 = after a numerical breakdown only, as every other launch shape runs it)
     if (use_team(h, B)) HIPCHK(bmpc_team_launch_tick(BMPC_TEAM_NW, resto, &a, &s, B, st));
     else HIPCHK(bmpc_tick_launch(h->N <= 11 && h->S <= bmpc::SMAX_ZLDS, resto, &a, &s, B, st));      // (long horizons, 5 or 6 path segments: iterate in the workspace)
     if (timed) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }

@@ -108,6 +108,14 @@ class BatchedOCPSolver:
         _lib.check(self._lib.bmpc_get_restoration(self._h, ctypes.byref(e), ctypes.byref(s_), ctypes.byref(c)), "bmpc_get_restoration")
         return dict(enabled=e.value == 1, mode=e.value, short_steps=s_.value, cap=c.value)
 
+    def set_queue_order(self, mode):
+        """Work-queue order of a stateless batch larger than the resident waves: 1 = longest-expected-first by the objective at x0 (default for N > 11),
+        0 = natural order (include/boundmpc_hip.h bmpc_set_queue_order).  Results do not depend on it."""
+        _lib.check(self._lib.bmpc_set_queue_order(self._h, int(mode)), "bmpc_set_queue_order")
+
+    def get_queue_order(self):
+        return int(self._lib.bmpc_get_queue_order(self._h))
+
     def set_team_waves(self, waves=0):
         """Waves per problem: 0 (default) automatic -- a batch that fits into the resident teams of the device (256 on an MI355X) is solved by
         workgroups of 4 cooperating waves, one that fits into the resident pairs (512) by workgroups of 2, a larger one by one wave per problem;

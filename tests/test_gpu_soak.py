@@ -82,3 +82,31 @@ def test_cold_start_is_bitwise_deterministic_on_every_entry_path(N):
     for r in runs[1:]:
         assert torch.equal(r, runs[0])
     assert bool(torch.isfinite(runs[0]).all())
+
+
+def test_queue_order_does_not_change_results():
+    """A stateless batch larger than the resident waves is handed out longest-expected-first (bmpc_set_queue_order; default for N > 11: an evaluation
+    pass ranks the problems by the objective at x0): every output equals the natural order's bit for bit, garbage starts (NaN keys) included."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    s10, s = BatchedOCPSolver(10, 4, 0.1), BatchedOCPSolver(16, 4, 0.1)
+    try:
+        assert s10.get_queue_order() == 0 and s.get_queue_order() == 1
+        B = s.launch_info()["grid"] + 300
+        P, X, _ = workload.make_batch(B, seed=41, N=16, tight=True)
+        X[5] = np.nan; X[B - 1] = np.nan      # two starts nobody can evaluate: their keys are NaN, they are solved (to a NaN status 3) like the others
+        p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
+        outs = []
+        for mode in (1, 0, 1):
+            s.set_queue_order(mode)
+            o = s.solve_batch(p, x0, out={}); torch.cuda.synchronize()
+            outs.append({k: v.clone() for k, v in o.items()})
+        ok = torch.ones(B, dtype=torch.bool, device="cuda"); ok[5] = False; ok[B - 1] = False
+        for k in ("x", "g", "lam_g", "f", "iters", "status", "kkt"):
+            assert torch.equal(outs[0][k][ok], outs[1][k][ok]) and torch.equal(outs[0][k][ok], outs[2][k][ok]), k
+        st = outs[0]["status"].cpu().numpy()
+        assert (st[ok.cpu().numpy()] == 0).mean() > 0.95 and st[5] != 0 and st[B - 1] != 0
+        assert (outs[1]["status"].cpu().numpy() == st).all()
+    finally:
+        s10.close(); s.close()
+
