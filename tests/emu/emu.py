@@ -162,3 +162,29 @@ def count_flops(p, x0, N, S, h, opts=None):
     its = int(out[0])
     return dict(iterations=its, converged=int(out[1]), flops=int(out[2]), special=int(out[3]), flops_per_iteration=float(out[2]) / max(its, 1),
                 per_phase={i: int(out[4 + i]) for i in range(32) if out[4 + i]})
+
+
+# ---- mask-aware flop count of the same kernel text (tests/emu/bmpc_emu_useful.cpp): executed vs useful operations by data flow ----
+_ULIB = os.path.join(_HERE, "libbmpc_emu_useful.so")
+_ul = None
+
+
+def count_useful(p, x0, N, S, h, opts=None):
+    """ONE problem: fp64 operations the kernel text executes and, of those, the ones whose result reaches a store (not the dummy word, not a
+    clamped duplicate within the phase) or a decision.  dict: iterations, executed, useful, stores, duplicate_stores, dummy_stores,
+    per_phase {slot: (executed, useful)}."""
+    global _ul
+    src = os.path.join(_HERE, "bmpc_emu_useful.cpp")
+    if not os.path.exists(_ULIB) or any(os.path.getmtime(_ULIB) < os.path.getmtime(s) for s in (src, _SRC[1])):
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wno-unknown-pragmas", "-Wno-enum-compare", "-Wno-format", "-o", _ULIB, src])
+        _ul = None
+    if _ul is None:
+        _ul = ctypes.CDLL(_ULIB)
+    p = np.ascontiguousarray(np.asarray(p, dtype=np.float64).ravel()); x0 = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).ravel())
+    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2) if N > 11 else default_opts())
+    out = np.zeros(72, dtype=np.uint64)
+    rc = _ul.bmpc_emu_count_useful(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), _p(p), _p(x0), _p(out))
+    assert rc == 0
+    return dict(iterations=int(out[0]), converged=int(out[1]), executed=int(out[2]), useful=int(out[3]), stores=int(out[4]), duplicate_stores=int(out[5]),
+                dummy_stores=int(out[6]), per_phase={s_: (int(out[8 + 2 * s_]), int(out[9 + 2 * s_])) for s_ in range(32) if out[8 + 2 * s_]})
+
