@@ -486,3 +486,33 @@ def test_oracle_converges_from_starts_far_from_the_reference_warm_start():
         assert (o1["status"] == 0).mean() >= lo and o1["iters"].max() <= 100 and o1["iters"].mean() >= 1.5 * o["iters"].mean(), (name, np.bincount(o1["status"]))
         o0 = c_oracle.solve(P, X0, 10, 4, 0.1, opts=c_oracle.default_opts(restoration=0, start_rollout=0), nthreads=8)
         assert (o0["status"] == 0).mean() <= hi_off, name
+
+
+def test_orientation_tube_exits_are_reproduced_by_slsqp_driven_closed_loops_g14():
+    """Fixture g14 (tests/golden/make_g14.py): stretches of four closed loops of BASELINE configs[4] driven tick by tick by an INDEPENDENT solver
+    (scipy's SLSQP on the reference's constraint form) and, from the same snapshot, by the oracle.  The plant of the two streams that leave the
+    ORIENTATION tube in the oracle's loop leaves it under SLSQP as well -- same ticks, same excess -- while every applied plan satisfied its tube rows:
+    the NLP constrains the orientation through the per-tick linearisation of the error split (mpc_utils_casadi.py:6-67, casadi_ocp_formulation.py:
+    316-349), the measured state is judged by the exact split (stream.tube_excess_of_state).  A property of the formulation, not of the solver."""
+    from boundmpc_amd import stream as bstream
+    d = np.load(os.path.join(G, "g14_slsqp_closed_loops.npz"))
+    assert d["oracle_streams"] == 32 and d["oracle_streams_leaving"] >= 16 and 0.03 < d["oracle_fraction_outside"] < 0.08      # the 130-tick oracle loops the stretches were cut from
+    for b, leaves, first in zip(d["streams"], d["leaves"], d["first_exit"] - d["start_tick"]):
+        for solver in ("oracle", "slsqp"):      # the stored excess rows are what tube_excess_of_state gives for the stored packed problems
+            ex_p, ex_r = bstream.tube_excess_of_state(d[f"{solver}_p_{b}"])
+            np.testing.assert_allclose(ex_r, d[f"{solver}_ex_r_{b}"], atol=1e-12); np.testing.assert_allclose(ex_p, d[f"{solver}_ex_p_{b}"], atol=1e-12)
+        eo, es = d[f"oracle_ex_r_{b}"].max(axis=1), d[f"slsqp_ex_r_{b}"].max(axis=1)
+        dq = np.abs(d[f"oracle_q_{b}"] - d[f"slsqp_q_{b}"]).max(axis=1)
+        ex_pos = d[f"slsqp_ex_p_{b}"].max()
+        assert ex_pos <= 1e-9      # the POSITION tube is never left (its rows are exact in the NLP)
+        if leaves:
+            # up to and including the first sample outside the tube the two plants are the same plant (SLSQP stops at its iteration limit on
+            # most ticks: ~1e-7 rad), and the excess of that sample is the same
+            assert dq[:first + 1].max() < 5e-6
+            np.testing.assert_allclose(es[:first + 2], eo[:first + 2], atol=2e-4)
+            assert es[first] > 0 and es.max() > 0.01 and (es > 0).sum() >= 3
+            assert d[f"slsqp_applied_{b}"][:first].all()      # every plan ahead of the exit was a solution SLSQP itself calls feasible (violations < 1e-6) and was applied
+            assert d[f"slsqp_eq_{b}"][:first].max() < 1e-6 and d[f"slsqp_iq_{b}"][:first].max() < 1e-6
+        else:
+            assert es.max() < 0 and eo.max() < 0 and dq.max() < 1e-3
+            np.testing.assert_allclose(es, eo, atol=2e-4)
