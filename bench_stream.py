@@ -40,6 +40,7 @@ def main():
                     help="threshold of the reference's acceptance rule (summed violation of g, BoundMPC.py:462-465: 1e-4) that decides whether an "
                          "iteration-capped iterate is applied in the real-time modes; an iterate that fails it is not applied, the previous plan is replayed")
     ap.add_argument("--rt-bound-margin", type=float, default=2e-3, help="joint limits tightened inside the solver of the time-budgeted modes (rad, rad/s)")
+    ap.add_argument("--rt-row-cap", type=float, default=1e-5, help="fixed-level modes: a position tube row (l^2 - w^2, any stage, m^2) above this vetoes the iterate (bmpc_stream_set_rt_position_row_cap; 0 = the summed rule alone)")
     ap.add_argument("--rtfix-mu", default="0.1,0.05", help="barrier levels of the fixed-barrier time-budgeted modes (rtfix-*)")
     ap.add_argument("--rtfix-budgets", default="625", help="their time budgets in microseconds")
     ap.add_argument("--cfb", default="24,14,1.0", help="converged-fallback mode: iteration cap of the solve to tolerance, Newton steps and barrier level of the fallback")
@@ -102,7 +103,7 @@ def main():
     for us in [int(v) for v in args.rtfix_budgets.split(",") if v]:
         for MU in [float(v) for v in args.rtfix_mu.split(",") if v]:
             rtf[(us, MU)] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=30, fixed_barrier=MU, bound_margin=args.rt_bound_margin)
-            rtf[(us, MU)].set_timing(True)
+            rtf[(us, MU)].set_timing(True); rtf[(us, MU)].set_rt_position_row_cap(args.rt_row_cap)
     # converged loops with a barrier-level fallback (round 5; StreamBatch.tick_with_fallback): every tick is solved to tolerance with at most 24 iterations (no
     # restoration phase); the streams that did not converge are solved again from the same warm start on the fixed barrier level 1 (14 Newton steps) and
     # the reference's acceptance rule at the reference's threshold 1e-4 decides
@@ -114,7 +115,7 @@ def main():
     rtfc = {}      # the fixed-level modes with an ITERATION cap instead of a time budget: every stream takes exactly that many Newton steps -- no clock in the result
     for MU in [float(v) for v in args.rtfix_mu.split(",") if v][:1]:
         rtfc[MU] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=30, fixed_barrier=MU, bound_margin=args.rt_bound_margin)
-        rtfc[MU].set_timing(True)
+        rtfc[MU].set_timing(True); rtfc[MU].set_rt_position_row_cap(args.rt_row_cap)
     evaluate = BatchedOCPSolver(10, 4, 0.1, max_iter=0)       # f, g at a given point (no iteration)
     reference = BatchedOCPSolver(10, 4, 0.1, tol=args.tol, max_iter=args.max_iter, start_rollout=False)    # every tick's problem solved to tolerance, untimed; x0 taken as given, like every stream solve
     res, ref_q = [], None

@@ -95,6 +95,7 @@ struct bmpc_handle {
     // launches of one handle share its workspace and work queue, so they are ordered against each other whatever streams the
     // caller uses: every launch records order_ev, a launch on another stream waits for it first
     hipEvent_t order_ev, bridge_ev; bool order_valid; hipStream_t order_stream;
+    double rt_row_cap;       // real-time mode: a position tube row (l^2 - w^2, any stage) above this vetoes the iterate (bmpc_stream_set_rt_position_row_cap); 0 = off
     double rt_viol_tol;      // acceptance threshold of stream_post in real-time mode (flag bit 1); default = the reference's 1e-4
     double rt_budget_us;     // time budget of a fused tick (bmpc_stream_set_time_budget); 0 = none
     hipStream_t own_stream;  // graph replays requested on the legacy null stream run here, bracketed by events (bmpc_graph_launch)
@@ -184,7 +185,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->aux_int = nullptr; h->aux_cap = 0; h->prof = nullptr; h->stage_d = nullptr; h->stage_h = nullptr; h->stage_cap = 0;
     h->team_grid = 0; h->pair_grid = 0; h->team_mode = 0;
     h->queue_order = N > 11 ? 1 : 0; h->qkey = nullptr; h->qorder = nullptr; h->q_cap = 0;
-    h->rt_viol_tol = 1e-4; h->rt_budget_us = 0.0; h->dev = 0; h->refs = 1; h->closed = false; h->order_ev = nullptr; h->bridge_ev = nullptr; h->order_valid = false; h->order_stream = nullptr; h->own_stream = nullptr;
+    h->rt_viol_tol = 1e-4; h->rt_row_cap = 0.0; h->rt_budget_us = 0.0; h->dev = 0; h->refs = 1; h->closed = false; h->order_ev = nullptr; h->bridge_ev = nullptr; h->order_valid = false; h->order_stream = nullptr; h->own_stream = nullptr;
     if (opts) h->o = *opts; else bmpc_default_options_for(N, &h->o);
     int dev = 0, per_cu = 0; hipDeviceProp_t prop;
     bool ok = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess;
@@ -576,11 +577,11 @@ __global__ void __launch_bounds__(64) bmpc_stream_pack_kernel(int N, int S, int 
                        xlast ? xlast + (long long)b * 44 * N : nullptr, sh, threadIdx.x, 64);
 }
 __global__ void __launch_bounds__(64) bmpc_stream_post_kernel(int N, int S, int B, double h, const double *path, int path_stride, double *ss, double *rb,
-                                                             const double *x, const double *g, const int *status, double *traj, int flags, double rt_tol) {
+                                                             const double *x, const double *g, const int *status, double *traj, int flags, double rt_tol, double rt_row_cap) {
     __shared__ double sh[bmpcs::SH_LEN];
     const int b = blockIdx.x;
     bmpcs::stream_post(N, S, h, path + (long long)b * path_stride, path_stride / bmpcs::PT_LEN, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
-                       x + (long long)b * 44 * N, g + (long long)b * 43 * N, status[b], traj + (long long)b * bmpcs::tr_len(N), flags, rt_tol, sh, threadIdx.x, 64);
+                       x + (long long)b * 44 * N, g + (long long)b * 43 * N, status[b], traj + (long long)b * bmpcs::tr_len(N), flags, rt_tol, sh, threadIdx.x, 64, rt_row_cap);
 }
 // (the fused one-launch tick kernels of one wave per stream live in bmpc_tick.hip, those of the teams in bmpc_team.hip)
 // enqueues the fused tick on `st` (direct launch or inside a capture)
@@ -596,7 +597,7 @@ static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entr
     a.state = dual_state; a.latency_us = h->latency_us; a.budget_ticks = (long long)(h->rt_budget_us * 100.0);
     if (B > h->scr_waves) return BMPC_ERR_ARG;
     a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter; a.prof = h->prof;
-    SArgs s; s.path = path; s.path_stride = path_entries * bmpcs::PT_LEN; s.ss = sstate; s.rb = robot; s.traj = traj; s.flags = flags; s.rt_tol = h->rt_viol_tol;
+    SArgs s; s.path = path; s.path_stride = path_entries * bmpcs::PT_LEN; s.ss = sstate; s.rb = robot; s.traj = traj; s.flags = flags; s.rt_tol = h->rt_viol_tol; s.rt_row_cap = h->rt_row_cap;
     const bool timed = !capturing && h->timing != 0;
     hipEvent_t *pair = nullptr;
     if (timed) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
@@ -632,6 +633,11 @@ extern "C" int bmpc_stream_set_rt_feasibility_tol(bmpc_handle *h, double tol) {
     h->rt_viol_tol = tol;      // read at launch / capture time: re-capture a tick graph after changing it
     return BMPC_OK;
 }
+extern "C" int bmpc_stream_set_rt_position_row_cap(bmpc_handle *h, double cap_m2) {
+    if (!h || !(cap_m2 >= 0.0)) return BMPC_ERR_ARG;
+    h->rt_row_cap = cap_m2;      // read at launch / capture time: re-capture a tick graph after changing it
+    return BMPC_OK;
+}
 extern "C" int bmpc_stream_set_time_budget(bmpc_handle *h, double microseconds) {
     if (!h || !(microseconds >= 0.0) || microseconds > 1e7) return BMPC_ERR_ARG;
     h->rt_budget_us = microseconds;      // read at launch / capture time: re-capture a tick graph after changing it
@@ -663,7 +669,7 @@ extern "C" int bmpc_stream_post(bmpc_handle *h, int B, const double *path, int p
     if (h->N > bmpcs::STREAM_NMAX) return BMPC_ERR_ARG;      // (the solver's own limit)
     if (B == 0) return BMPC_OK;
     hipLaunchKernelGGL(bmpc_stream_post_kernel, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, h->h, path,
-                       path_entries * bmpcs::PT_LEN, sstate, robot, x, g, status, traj, flags, h->rt_viol_tol);
+                       path_entries * bmpcs::PT_LEN, sstate, robot, x, g, status, traj, flags, h->rt_viol_tol, h->rt_row_cap);
     HIPCHK(hipGetLastError());
     return BMPC_OK;
 }

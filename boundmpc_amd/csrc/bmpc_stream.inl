@@ -488,7 +488,7 @@ BMPC_HD inline void stream_pack(int N, int S, const double *path, int cap, doubl
 // does after a failed solve (:468-489).  (Round 2 accepted every capped iterate unconditionally; closed loops then ran away.)  Since
 // round 4 a plan with any variable outside its bounds (below) is not accepted either (for thresholds below 1): no accepted plan leaves the joint limits.
 BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int cap, double *ss, double *rb, const double *x, const double *g, int status,
-                                double *traj, int flags, double rt_tol, double *sh, int lane, int nl) {
+                                double *traj, int flags, double rt_tol, double *sh, int lane, int nl, double rt_row_cap = 0.0) {
     // ---- phase 0: feasibility rule :460-465 (strided partial sums, fixed-order total) ----
     {
         double part = 0.0;
@@ -497,6 +497,10 @@ BMPC_HD inline void stream_post(int N, int S, double h, const double *path, int 
             if (i < 36 && v < -1e-6) part -= v;
             if (v > 1e-6) part += v;
             if (!(v - v == 0.0)) part += 1e6;      // a non-finite constraint value is a violation, not a pass
+            // Real-time mode, position tube rows (39, 40: l^2 - w^2 of every stage) held PER ROW (bmpc_stream_set_rt_position_row_cap; 0 = off): the summed rule
+            // lets a single row through by up to the threshold, and a stream that later REPLAYS the tail of such a plan (:468-489) carries the plant out of a
+            // narrow tube by millimetres (round 6: 5.1 mm at a half width of 18 mm, one sample of 32 636, threshold 1e-2).  A row above the cap vetoes the iterate.
+            if ((flags & 2) && rt_row_cap > 0.0 && (i == 39 || i == 40) && v > rt_row_cap) part += 1e6;
         }
         // Real-time mode (flag bit 1) also counts the violation of the VARIABLE bounds lbx <= x <= ubx of the plan (jerks +-35, joint
         // positions and velocities RobotModel.py:20-43, phi >= 0).  The reference's rule looks at g only: an Ipopt iterate satisfies the

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_tick_kernel(KArgsTe
     __syncthreads();
     if (a.latency_us && threadIdx.x == 0) a.latency_us[b] = (double)((long long)wall_clock64() - t0_) * 0.01;
     if (wv == 0) bmpcs::stream_post(a.N, a.S, a.h, path, s.path_stride / bmpcs::PT_LEN, ss, rb, pr.x, pr.g, a.status[b], s.traj + (long long)b * bmpcs::tr_len(a.N), s.flags, s.rt_tol,
-                                    sh, threadIdx.x, 64);
+                                    sh, threadIdx.x, 64, s.rt_row_cap);
 }
 
 int bmpc_team_blocks_per_cu(int nw) {

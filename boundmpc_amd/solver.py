@@ -127,6 +127,11 @@ class BatchedOCPSolver:
         _lib.check(self._lib.bmpc_team_info(self._h, int(B), ctypes.byref(w), ctypes.byref(r), ctypes.byref(l)), "bmpc_team_info")
         return dict(waves=w.value, resident_teams=r.value, lds_bytes=l.value)
 
+    def set_rt_position_row_cap(self, cap_m2):
+        """Real-time stream ticks: a position tube row (l^2 - w^2 of any stage, m^2) above the cap vetoes the iterate (include/boundmpc_hip.h
+        bmpc_stream_set_rt_position_row_cap; 0 = off, the default).  Set it before the tick graph is captured."""
+        _lib.check(self._lib.bmpc_stream_set_rt_position_row_cap(self._h, float(cap_m2)), "bmpc_stream_set_rt_position_row_cap")
+
     def set_rt_feasibility_tol(self, tol):
         """Threshold of the reference's acceptance rule (summed violation of g, BoundMPC.py:462-465) that stream ticks in real-time mode
         apply to an iteration-capped iterate (default 1e-4, the reference's).  Set it before the tick graph is captured."""

@@ -141,6 +141,10 @@ int bmpc_stream_post(bmpc_handle *h, int B, const double *path, int path_entries
 /* Threshold on the summed violation (beyond 1e-6 per row) below which bmpc_stream_post applies an iteration-capped iterate in real-time mode.
  * Default 1e-4 = the reference's rule (BoundMPC.py:462-465).  Read when a post is launched or captured. */
 int bmpc_stream_set_rt_feasibility_tol(bmpc_handle *h, double tol);
+/* Real-time mode (flags bit 1): a position tube row (rows 39, 40 of any stage of g: l^2 - w^2, m^2) above `cap_m2` vetoes the iterate whatever the
+ * summed violation (an excess of d metres at half width w is a row of 2 w d + d^2: 1e-5 keeps every stage of an accepted plan -- also the tail a
+ * stream replays after failed ticks, BoundMPC.py:468-489 -- within 0.5 mm of a 10 mm tube).  0 (default) = off: the reference's summed rule alone. */
+int bmpc_stream_set_rt_position_row_cap(bmpc_handle *h, double cap_m2);
 /* Time budget of a FUSED tick in microseconds from kernel entry; 0 (default) = none.  No further iteration starts once it is used up (status 1):
  * the tick is bounded by budget + one iteration + the post-processing; results of such ticks depend on the clock.  Read at launch / capture time. */
 int bmpc_stream_set_time_budget(bmpc_handle *h, double microseconds);

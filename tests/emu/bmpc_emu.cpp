@@ -45,9 +45,9 @@ extern "C" void bmpc_emu_stream_pack(int N, int S, const double *path, double *s
     bmpcs::stream_pack(N, S, path, (int)ss[bmpcs::SS_NENT], ss, rb, p, x0, dual, xlast, sh, 0, 1);
 }
 extern "C" void bmpc_emu_stream_post(int N, int S, double h, const double *path, double *ss, double *rb, const double *x, const double *g, int status,
-                                     double *traj, int simulate, double rt_tol) {
+                                     double *traj, int simulate, double rt_tol, double rt_row_cap) {
     double sh[bmpcs::SH_LEN];
-    bmpcs::stream_post(N, S, h, path, (int)ss[bmpcs::SS_NENT], ss, rb, x, g, status, traj, simulate, rt_tol, sh, 0, 1);
+    bmpcs::stream_post(N, S, h, path, (int)ss[bmpcs::SS_NENT], ss, rb, x, g, status, traj, simulate, rt_tol, sh, 0, 1, rt_row_cap);
 }
 
 extern "C" void bmpc_emu_jacobian_lin_ddot(const double *q, const double *dq, const double *ddq, double *out) { bmpcs::jacobian_lin_ddot(q, dq, ddq, out); }

@@ -113,12 +113,12 @@ def stream_pack(N, S, path, ss, rb, dual=None, xlast=None):
     return p, x0
 
 
-def stream_post(N, S, h, path, ss, rb, x, g, status, simulate=True, rt_tol=1e-4, flags=0):
+def stream_post(N, S, h, path, ss, rb, x, g, status, simulate=True, rt_tol=1e-4, flags=0, rt_row_cap=0.0):
     """flags: extra bits of the post flags (bit 1 = real-time acceptance rule)"""
     traj = np.zeros(stream_lengths(N)["traj"])
     x = np.ascontiguousarray(x, dtype=np.float64); g = np.ascontiguousarray(g, dtype=np.float64)
     lib().bmpc_emu_stream_post(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), _p(path), _p(ss), _p(rb), _p(x), _p(g), ctypes.c_int(int(status)),
-                               _p(traj), ctypes.c_int(int(simulate) | int(flags)), ctypes.c_double(rt_tol))
+                               _p(traj), ctypes.c_int(int(simulate) | int(flags)), ctypes.c_double(rt_tol), ctypes.c_double(rt_row_cap))
     return traj
 
 

@@ -452,7 +452,7 @@ def test_streams_at_36_stages_fused_tick_matches_the_three_kernel_tick():
     assert fl["success"] and fl["n_valid"] == N and td["q"].shape == (7, N)
 
 
-def _budgeted_closed_loops(slv, budget_us, cap=0):
+def _budgeted_closed_loops(slv, budget_us, cap=0, row_cap=0.0):
     """256 closed loops x 130 ticks under a time budget per fused tick (budget_us; 0 = none) and / or an iteration cap (cap; 0 = the handle's): tick times, plans kept / applied, plant joint positions, tube excess of the measured
     states (stream.tube_excess_of_state: the tube rows of casadi_ocp_formulation.py:316-349 at node 0 of the packed problem) and the first-stage
     position rows of the applied plans."""
@@ -466,6 +466,7 @@ def _budgeted_closed_loops(slv, budget_us, cap=0):
         mpcs.append(m)
         recs.append(bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([m.phi_max[0], 0.0, 0.0]), np.zeros(7)))
     slv.set_rt_feasibility_tol(1e-2)
+    slv.set_rt_position_row_cap(row_cap)
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
         sb = bstream.StreamBatch(slv, mpcs)
@@ -538,7 +539,7 @@ def test_256_streams_on_a_fixed_barrier_level_meet_the_strict_1_khz_target():
     from boundmpc_amd import BatchedOCPSolver
     from boundmpc_amd.robot_model import RobotModel
     slv = BatchedOCPSolver(10, 4, 0.1, tol=1e-3, max_iter=30, fixed_barrier=0.1, bound_margin=2e-3)
-    ms, alive, applied, Q, tube_p, tube_r, row_p = _budgeted_closed_loops(slv, 625)
+    ms, alive, applied, Q, tube_p, tube_r, row_p = _budgeted_closed_loops(slv, 625, row_cap=1e-5)
     qlim = np.array(RobotModel().q_lim_upper)
     n = np.isfinite(tube_p).sum()
     print(f"\n256 streams x {len(ms)} ticks on the barrier level 0.1, 625 us budget: tick p50 {np.percentile(ms, 50):.3f} / p99 {np.percentile(ms, 99):.3f} ms, applied {applied:.3f}, "
@@ -548,6 +549,7 @@ def test_256_streams_on_a_fixed_barrier_level_meet_the_strict_1_khz_target():
     assert alive >= 0.90 and applied >= 0.93
     assert (np.abs(Q) <= qlim + 1e-9).all()
     assert (tube_p > 1e-6).sum() / n <= 1e-3 and (tube_r > 1e-6).sum() / n <= 0.02
+    assert tube_p.max() <= 1e-3      # metres: the EXCESS, not only the fraction (position rows held per row: no accepted plan, replayed tail included, leaves the tube)
 
 
 @pytest.mark.gpu
@@ -598,7 +600,7 @@ def test_fixed_barrier_level_with_an_iteration_cap_is_reproducible_and_meets_the
     runs = []
     for rep in range(2):
         slv = BatchedOCPSolver(10, 4, 0.1, tol=1e-3, max_iter=30, fixed_barrier=0.1, bound_margin=2e-3)
-        runs.append(_budgeted_closed_loops(slv, 0, cap=5))
+        runs.append(_budgeted_closed_loops(slv, 0, cap=5, row_cap=1e-5))
     (ms, alive, applied, Q, tube_p, tube_r, row_p), (ms2, alive2, applied2, Q2, *_rest) = runs
     qlim = np.array(RobotModel().q_lim_upper)
     n = np.isfinite(tube_p).sum()
@@ -609,6 +611,9 @@ def test_fixed_barrier_level_with_an_iteration_cap_is_reproducible_and_meets_the
     assert alive >= 0.90 and applied >= 0.93 and (np.abs(Q) <= qlim + 1e-9).all()
     assert np.percentile(ms, 50) <= 1.0 and np.percentile(ms, 99) <= 1.3
     assert (tube_p > 1e-6).sum() / n <= 1e-3
+    # the EXCESS: until round 6 one plant sample of 32 636 was 5.1 mm outside an 18 mm tube -- a stream that had lost its plan replaying the tail of a plan
+    # the summed rule (1e-2) had let through; with the position rows held per row (1e-5 m^2) the largest excess is negative: nothing leaves the tube
+    assert tube_p.max() <= 1e-3, float(tube_p.max())
 
 
 @pytest.mark.gpu
