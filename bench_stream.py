@@ -116,6 +116,8 @@ def main():
     for MU in [float(v) for v in args.rtfix_mu.split(",") if v][:1]:
         rtfc[MU] = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=30, fixed_barrier=MU, bound_margin=args.rt_bound_margin)
         rtfc[MU].set_timing(True); rtfc[MU].set_rt_position_row_cap(args.rt_row_cap)
+    rtfa = BatchedOCPSolver(10, 4, 0.1, tol=args.rt_tol, max_iter=30, fixed_barrier="auto", bound_margin=args.rt_bound_margin)      # the level that sets itself per stream (round 6)
+    rtfa.set_timing(True); rtfa.set_rt_position_row_cap(args.rt_row_cap)
     evaluate = BatchedOCPSolver(10, 4, 0.1, max_iter=0)       # f, g at a given point (no iteration)
     reference = BatchedOCPSolver(10, 4, 0.1, tol=args.tol, max_iter=args.max_iter, start_rollout=False)    # every tick's problem solved to tolerance, untimed; x0 taken as given, like every stream solve
     res, ref_q = [], None
@@ -130,6 +132,7 @@ def main():
         + [(f"rtb{'gn' if gn else 'w'}-tol{args.rt_tol:g}-budget{us}us-feas{FT:g}", rtb[(us, gn)], 0, True, FT) for (us, gn) in sorted(rtb)]
     modes += [(f"rtfix-mu{MU:g}-tol{args.rt_tol:g}-budget{us}us-feas{FT:g}", rtf[(us, MU)], 0, True, FT) for (us, MU) in sorted(rtf)]
     modes += [(f"rtfixcap-mu{MU:g}-cap{c}-feas{FT:g} (fixed barrier level, exactly {c} Newton steps per tick, no clock: reproducible bit for bit)", rtfc[MU], c, True, FT) for MU in sorted(rtfc) for c in (5, 6, 7)]
+    modes += [(f"rtfixcap-muauto-cap{c}-feas{FT:g} (barrier level held inside the tick, set per stream: clamp(0.02 (phi_max - phi), 0.01, 0.1); exactly {c} Newton steps per tick; the mode bench.py reports for configs[4])", rtfa, c, True, FT) for c in (5, 6)]
     modes += [(f"converged-fallback-cap{cfb_cap}-level{cfb_mu:g}-k{cfb_k}-feas1e-4 (solved to tolerance within {cfb_cap} iterations, else {cfb_k} steps on the barrier level {cfb_mu:g}; the reference's rule at 1e-4)", cfb_main, cfb_cap, True, 1e-4)]
     if args.unsafe_too:
         modes += [(f"UNSAFE rtgn-tol{args.rt_tol:g}-cap{c} (every capped iterate applied)", rtgn[c], 0, True, 1e30) for c in (4, 3)]

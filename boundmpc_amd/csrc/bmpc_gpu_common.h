@@ -42,7 +42,7 @@ struct KArgsT {
 };
 // stream arguments of a fused tick
 struct SArgs {
-    const double *path; int path_stride; double *ss, *rb, *traj; int flags; double rt_tol; double rt_row_cap;
+    const double *path; int path_stride; double *ss, *rb, *traj; int flags; double rt_tol; double rt_row_cap; double lvl_c, lvl_lo, lvl_hi;
 };
 
 // ---- restoration kernel (bmpc_resto.hip): continues the problems a batch kernel left with the internal status 4 ----

@@ -103,6 +103,8 @@ struct bmpc_handle {
     int team_grid;           // resident TEAMS (workgroups of BMPC_TEAM_NW waves, bmpc_team.hip) of the device; 0: no team kernel for this handle (N > 10 or S > 4)
     int pair_grid;           // resident PAIRS (workgroups of 2 waves at two waves per SIMD, bmpc_pair.hip); 0: no pair kernel for this handle (N > 11 or S > 4)
     int *aux_int; int aux_cap;      // [2][aux_cap] status / iters of a batch whose caller passed NULL (the restoration kernel reads them)
+    int hold_mu;            // bmpc_set_barrier_hold: 1 = a solve holds the barrier level it starts on
+    double level_c, level_lo, level_hi;      // bmpc_stream_set_level_rule: stream_pack sets the level of a stream's next tick (level_hi <= 0: off)
     int start_rollout;      // 1 (default): a stateless solve whose x0 is far off its own dynamics starts from the rollout of x0's jerks (bmpc_set_start_rollout)
     int resto_on, resto_short, resto_cap;      // restoration phase (bmpc_set_restoration): mode 0 off / 1 full (default N <= 11) / 2 after a numerical breakdown only (default N > 11); jam = resto_short consecutive short steps; iterations per phase
     int queue_order;         // bmpc_set_queue_order: 1 = a batch beyond the resident waves is solved in the order of decreasing f(x0) (default for N > 11), 0 = natural order
@@ -179,7 +181,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BMPC_ERR_NOGPU;
     bmpc_handle *h = new (std::nothrow) bmpc_handle();
     if (!h) return BMPC_ERR_ARG;
-    h->start_rollout = 1;
+    h->start_rollout = 1; h->hold_mu = 0; h->level_c = 0.0; h->level_lo = 0.0; h->level_hi = 0.0;
     h->resto_on = N <= 11 ? 1 : 2; h->resto_short = 6; h->resto_cap = 40;      // restoration phase: full for short horizons, after a numerical breakdown only for long ones (bmpc_set_restoration)
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->ev = nullptr; h->nev = 0; h->n_timed = 0; h->latency_us = nullptr;
     h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->aux_int = nullptr; h->aux_cap = 0; h->prof = nullptr; h->stage_d = nullptr; h->stage_h = nullptr; h->stage_cap = 0;
@@ -339,6 +341,16 @@ extern "C" int bmpc_set_start_rollout(bmpc_handle *h, int enabled) {
     h->start_rollout = enabled;
     return BMPC_OK;
 }
+extern "C" int bmpc_set_barrier_hold(bmpc_handle *h, int enabled) {
+    if (!h || enabled < 0 || enabled > 1) return BMPC_ERR_ARG;
+    h->hold_mu = enabled;
+    return BMPC_OK;
+}
+extern "C" int bmpc_stream_set_level_rule(bmpc_handle *h, double c, double lo, double hi) {
+    if (!h || !(c >= 0.0) || !(lo >= 0.0) || !(hi >= 0.0) || (hi > 0.0 && !(lo > 0.0 && lo <= hi))) return BMPC_ERR_ARG;
+    h->level_c = c; h->level_lo = lo; h->level_hi = hi;
+    return BMPC_OK;
+}
 extern "C" int bmpc_get_start_rollout(const bmpc_handle *h) { return h ? h->start_rollout : -1; }
 extern "C" int bmpc_options_size(void) { return (int)sizeof(bmpc_options); }
 #ifndef BMPC_BUILD_HASH_STR
@@ -370,7 +382,7 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
     a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
     a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window; a.o.bound_margin = h->o.bound_margin;
-    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap; a.o.start_rollout = h->start_rollout;
+    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap; a.o.start_rollout = h->start_rollout; a.o.hold_mu = h->hold_mu;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = lam_g; a.lam_x = lam_x; a.f = f; a.kkt = kkt; a.iters = iters; a.status = status;
     a.state = state; a.latency_us = h->latency_us; a.budget_ticks = 0;
     const int grid = launch_grid(h, B);
@@ -569,12 +581,12 @@ extern "C" int bmpc_kernel_ms(bmpc_handle *h, int back, float *ms) {
 extern "C" int bmpc_last_kernel_ms(bmpc_handle *h, float *ms) { return bmpc_kernel_ms(h, 0, ms); }
 // ---- receding-horizon streams: device-side packing / post-processing, one 64-lane wave per stream ----
 __global__ void __launch_bounds__(64) bmpc_stream_pack_kernel(int N, int S, int B, const double *path, int path_stride, double *ss, const double *rb,
-                                                             double *p, double *x0, double *dual, const double *xlast) {
+                                                             double *p, double *x0, double *dual, const double *xlast, double lvl_c, double lvl_lo, double lvl_hi) {
     __shared__ double sh[bmpcs::SH_LEN];
     const int b = blockIdx.x;
     bmpcs::stream_pack(N, S, path + (long long)b * path_stride, path_stride / bmpcs::PT_LEN, ss + (long long)b * bmpcs::ss_len(N), rb + (long long)b * bmpcs::RB_LEN,
                        p + (long long)b * (141 + 91 * S), x0 + (long long)b * 44 * N, dual ? dual + (long long)b * (57 * N + 2) : nullptr,
-                       xlast ? xlast + (long long)b * 44 * N : nullptr, sh, threadIdx.x, 64);
+                       xlast ? xlast + (long long)b * 44 * N : nullptr, sh, threadIdx.x, 64, lvl_c, lvl_lo, lvl_hi);
 }
 __global__ void __launch_bounds__(64) bmpc_stream_post_kernel(int N, int S, int B, double h, const double *path, int path_stride, double *ss, double *rb,
                                                              const double *x, const double *g, const int *status, double *traj, int flags, double rt_tol, double rt_row_cap) {
@@ -592,12 +604,12 @@ static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entr
     KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
     a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
     a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window; a.o.bound_margin = h->o.bound_margin;
-    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap; a.o.start_rollout = h->start_rollout;
+    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap; a.o.start_rollout = h->start_rollout; a.o.hold_mu = h->hold_mu;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = nullptr; a.lam_x = nullptr; a.f = nullptr; a.kkt = kkt; a.iters = iters; a.status = status;
     a.state = dual_state; a.latency_us = h->latency_us; a.budget_ticks = (long long)(h->rt_budget_us * 100.0);
     if (B > h->scr_waves) return BMPC_ERR_ARG;
     a.scratch = h->scratch; a.scr_stride = h->scr_stride; a.counter = h->counter; a.prof = h->prof;
-    SArgs s; s.path = path; s.path_stride = path_entries * bmpcs::PT_LEN; s.ss = sstate; s.rb = robot; s.traj = traj; s.flags = flags; s.rt_tol = h->rt_viol_tol; s.rt_row_cap = h->rt_row_cap;
+    SArgs s; s.path = path; s.path_stride = path_entries * bmpcs::PT_LEN; s.ss = sstate; s.rb = robot; s.traj = traj; s.flags = flags; s.rt_tol = h->rt_viol_tol; s.rt_row_cap = h->rt_row_cap; s.lvl_c = h->level_c; s.lvl_lo = h->level_lo; s.lvl_hi = h->level_hi;
     const bool timed = !capturing && h->timing != 0;
     hipEvent_t *pair = nullptr;
     if (timed) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
@@ -659,7 +671,7 @@ extern "C" int bmpc_stream_pack_rt(bmpc_handle *h, int B, const double *path, in
     if (B == 0) return BMPC_OK;
     if (h->closed) return BMPC_ERR_ARG;
     hipLaunchKernelGGL(bmpc_stream_pack_kernel, dim3(B), dim3(64), 0, (hipStream_t)hip_stream, h->N, h->S, B, path, path_entries * bmpcs::PT_LEN,
-                       sstate, robot, p, x0, dual_state, xlast);
+                       sstate, robot, p, x0, dual_state, xlast, h->level_c, h->level_lo, h->level_hi);
     HIPCHK(hipGetLastError());
     return BMPC_OK;
 }

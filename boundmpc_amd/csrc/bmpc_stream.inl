@@ -334,7 +334,7 @@ enum { SH_DTAU = 0, SH_RTAU = 3, SH_JR = 12, SH_JL = 21, SH_PHISW = 30, SH_FLAG 
 // tick continues from it while the plant replays the accepted plan (the reference restarts from the last accepted plan, shifted once,
 // however many ticks ago that was: BoundMPC.py:322-375,468-489).
 BMPC_HD inline void stream_pack(int N, int S, const double *path, int cap, double *ss, const double *rb, double *p, double *x0, double *dual,
-                                const double *xlast, double *sh, int lane, int nl) {
+                                const double *xlast, double *sh, int lane, int nl, double lvl_c = 0.0, double lvl_lo = 0.0, double lvl_hi = 0.0) {
     int nent = (int)ss[SS_NENT];
     nent = nent > cap ? cap : nent; nent = nent < S + 1 ? S + 1 : nent;
     const double phi_cur = ss[SS_PHI];
@@ -477,6 +477,13 @@ BMPC_HD inline void stream_pack(int N, int S, const double *path, int cap, doubl
     }
     BMPCS_SYNC();
     if (lane == 0) ss[SS_SECTOR] = (double)sector;
+    // Barrier level of the stream's NEXT solve (bmpc_stream_set_level_rule; handles that hold the level, bmpc_set_barrier_hold): a stream far from the end
+    // of its path runs on the robust level lvl_hi, near the end -- where the barrier of phi <= phi_max would stall it short of the goal -- on
+    // clamp(lvl_c (phi_max - phi), lvl_lo, lvl_hi).  Written into the mu slot of a WARM dual state (a cold one, mu <= 0, starts on mu_init).
+    if (lane == 0 && dual && lvl_hi > 0.0 && dual[57 * N] > 0.0) {
+        const double lv = lvl_c * (phi_max - phi_cur);
+        dual[57 * N] = lv < lvl_lo ? lvl_lo : (lv > lvl_hi ? lvl_hi : lv);
+    }
 }
 
 // f2 + f3: post-process one stream.  x [N][44] solver result, g [N][43], status; traj: trajectory record (tr_len(N));

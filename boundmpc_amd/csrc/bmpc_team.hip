@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_tick_kernel(KArgsTe
         if (threadIdx.x == 0) { a.status[b] = 3; if (a.iters) a.iters[b] = 0; if (a.kkt) a.kkt[b] = 0.0; if (a.latency_us) a.latency_us[b] = 0.0; }
         return;
     }
-    if (wv == 0) bmpcs::stream_pack(a.N, a.S, path, s.path_stride / bmpcs::PT_LEN, ss, rb, p, x0, dual, (s.flags & 2) ? a.x + (long long)b * nw : nullptr, sh, threadIdx.x, 64);
+    if (wv == 0) bmpcs::stream_pack(a.N, a.S, path, s.path_stride / bmpcs::PT_LEN, ss, rb, p, x0, dual, (s.flags & 2) ? a.x + (long long)b * nw : nullptr, sh, threadIdx.x, 64, s.lvl_c, s.lvl_lo, s.lvl_hi);
     __syncthreads();
     bmpct::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpct::make_gptr(a.scratch + (long long)b * a.scr_stride); W.wv = wv;
     bmpct::Problem pr;

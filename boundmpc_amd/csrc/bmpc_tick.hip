@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(64, 1) bmpc_stream_tick_kernel(KArgs a, SArgs 
         if (threadIdx.x == 0) { a.status[b] = 3; if (a.iters) a.iters[b] = 0; if (a.kkt) a.kkt[b] = 0.0; if (a.latency_us) a.latency_us[b] = 0.0; }
         return;
     }
-    bmpcs::stream_pack(a.N, a.S, path, s.path_stride / bmpcs::PT_LEN, ss, rb, p, x0, dual, (s.flags & 2) ? a.x + (long long)b * nw : nullptr, sh, threadIdx.x, 64);
+    bmpcs::stream_pack(a.N, a.S, path, s.path_stride / bmpcs::PT_LEN, ss, rb, p, x0, dual, (s.flags & 2) ? a.x + (long long)b * nw : nullptr, sh, threadIdx.x, 64, s.lvl_c, s.lvl_lo, s.lvl_hi);
     __syncthreads();
     bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpc::make_gptr(a.scratch + (long long)b * a.scr_stride); W.wv = 0;
     bmpc::Problem pr;

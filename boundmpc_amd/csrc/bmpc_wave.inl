@@ -278,6 +278,8 @@ struct Opts {
     int resto_short;          // consecutive steps shorter than RESTO_SHORT_ALPHA that count as a jam (6; 0 = the stall test alone)
     int resto_cap;            // iterations one restoration phase may take before the solve ends as status 2 (40)
     int start_rollout;        // 1: a stateless solve (no dual state buffer) whose x0 is far off its own dynamics (START_ROLLOUT_TOL) starts from the rollout of x0's jerks; 0: from x0 as given
+    int hold_mu;              // 1: the barrier level a solve starts on (clamp(stored level, mu_warm, mu_init)) is HELD: no barrier update (real-time iteration on a
+                              // per-stream level that the caller / stream_pack sets in the dual state, bmpc_set_barrier_hold; round 6); 0: the monotone update
 };
 
 // global scratch layout (doubles) for horizon N
@@ -2942,7 +2944,7 @@ _Pragma("unroll") \
         for (;;) {   // monotone barrier update (Fiacco-McCormick, Ipopt constants)
             const double ec = BMPC_FMAX(cmax - mu, mu - cmin);
             const double Emu = BMPC_FMAX(BMPC_FMAX(ed / sd, ep), ec / scl);
-            if (Emu <= KAPPA_EPS * mu && mu > mu_min) mu = BMPC_FMAX(mu_min, BMPC_FMIN(0.2 * mu, BMPC_POW15(mu))); else break;
+            if (!o.hold_mu && Emu <= KAPPA_EPS * mu && mu > mu_min) mu = BMPC_FMAX(mu_min, BMPC_FMIN(0.2 * mu, BMPC_POW15(mu))); else break;
         }
         // ---- Newton system: QP gradient, lifted residuals, Riccati ----
         BMPC_PROF(W, 2);

@@ -145,6 +145,14 @@ int bmpc_stream_set_rt_feasibility_tol(bmpc_handle *h, double tol);
  * summed violation (an excess of d metres at half width w is a row of 2 w d + d^2: 1e-5 keeps every stage of an accepted plan -- also the tail a
  * stream replays after failed ticks, BoundMPC.py:468-489 -- within 0.5 mm of a 10 mm tube).  0 (default) = off: the reference's summed rule alone. */
 int bmpc_stream_set_rt_position_row_cap(bmpc_handle *h, double cap_m2);
+/* Real-time iteration on a HELD barrier level (what bench.py reports for BASELINE configs[4]).  bmpc_set_barrier_hold(h, 1): a solve keeps the level it
+ * starts on -- clamp(level stored in the dual state, options.mu_warm, options.mu_init); a cold state starts on mu_init -- instead of walking the barrier
+ * down; `tol` then never fires, the iteration cap or time budget ends every solve.  bmpc_stream_set_level_rule(h, c, lo, hi): bmpc_stream_pack (and the
+ * fused ticks) write the level of a stream's next solve into its warm dual state: clamp(c (phi_max - phi), lo, hi) -- robust level `hi` far from the
+ * end of the path, lower near it, where the barrier of phi <= phi_max would otherwise stall the stream short of its goal (the reference runs Ipopt's
+ * adaptive barrier strategy, BoundMPC.py:130-136).  hi = 0 (default): off.  Use lo = options.mu_warm, hi = options.mu_init.  Read at launch / capture time. */
+int bmpc_set_barrier_hold(bmpc_handle *h, int enabled);
+int bmpc_stream_set_level_rule(bmpc_handle *h, double c, double lo, double hi);
 /* Time budget of a FUSED tick in microseconds from kernel entry; 0 (default) = none.  No further iteration starts once it is used up (status 1):
  * the tick is bounded by budget + one iteration + the post-processing; results of such ticks depend on the clock.  Read at launch / capture time. */
 int bmpc_stream_set_time_budget(bmpc_handle *h, double microseconds);

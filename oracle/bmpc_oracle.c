@@ -107,6 +107,7 @@ typedef struct {
     int resto_short;     /* consecutive steps shorter than RESTO_SHORT_ALPHA that count as a jam (6; 0 = the stall test alone) */
     int resto_cap;       /* iterations one restoration phase may take before the solve ends as status 2 (40) */
     int start_rollout;   /* 1 (default): a stateless solve (no dual state buffer) whose x0 is far off its own dynamics (START_ROLLOUT_TOL) starts from the rollout of x0's jerks; 0: from x0 as given */
+    int hold_mu;         /* 1: the barrier level the solve starts on is held (no barrier update): real-time iteration on a per-stream level; 0 (default): monotone update */
 } bmpc_oracle_opts;
 
 typedef struct {
@@ -1093,7 +1094,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         for (;;) {
             ORACLE_REGION(REG_KKT); kkt_errors(C, W, mu, el, &ed, &ep, &ecm, &sd, &sc); ORACLE_REGION(REG_DRIVER);
             double Emu = fmax(fmax(ed / sd, ep), ecm / sc);
-            if (Emu <= KAPPA_EPS * mu && mu > mu_min) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5))); else break;
+            if (!o->hold_mu && Emu <= KAPPA_EPS * mu && mu > mu_min) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5))); else break;
         }
         /* barrier ratios of the rows: sigma (Hessian weight of grad h grad h^T) and the barrier-modified multiplier nu^ of the QP gradient */
         if (!el) for (int i = 0; i < N * NI; i++) {
@@ -1234,7 +1235,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
  * ---------------------------------------------------------------------------------------- */
 void bmpc_oracle_default_opts(bmpc_oracle_opts *o) {
     o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0; o->mu_warm = 1e-2; o->stall_window = 40;
-    o->restoration = 1; o->resto_short = 6; o->resto_cap = 40; o->start_rollout = 1;
+    o->restoration = 1; o->resto_short = 6; o->resto_cap = 40; o->start_rollout = 1; o->hold_mu = 0;
 }
 
 static void write_outputs(const Cfg *C, const Par *P, Work *W, double *x, double *g, double *lam_g, double *lam_x) {

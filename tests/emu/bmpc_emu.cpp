@@ -40,9 +40,9 @@
 
 // CPU build of the stream functions (same text as the device kernels), one call per stream
 extern "C" void bmpc_emu_stream_lengths(int N, int *out) { out[0] = bmpcs::PT_LEN; out[1] = bmpcs::ss_len(N); out[2] = bmpcs::RB_LEN; out[3] = bmpcs::tr_len(N); }
-extern "C" void bmpc_emu_stream_pack(int N, int S, const double *path, double *ss, const double *rb, double *p, double *x0, double *dual, const double *xlast) {
+extern "C" void bmpc_emu_stream_pack(int N, int S, const double *path, double *ss, const double *rb, double *p, double *x0, double *dual, const double *xlast, double lvl_c, double lvl_lo, double lvl_hi) {
     double sh[bmpcs::SH_LEN];
-    bmpcs::stream_pack(N, S, path, (int)ss[bmpcs::SS_NENT], ss, rb, p, x0, dual, xlast, sh, 0, 1);
+    bmpcs::stream_pack(N, S, path, (int)ss[bmpcs::SS_NENT], ss, rb, p, x0, dual, xlast, sh, 0, 1, lvl_c, lvl_lo, lvl_hi);
 }
 extern "C" void bmpc_emu_stream_post(int N, int S, double h, const double *path, double *ss, double *rb, const double *x, const double *g, int status,
                                      double *traj, int simulate, double rt_tol, double rt_row_cap) {

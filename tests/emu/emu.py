@@ -16,7 +16,7 @@ class Opts(ctypes.Structure):
     _fields_ = [("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("mu_init", ctypes.c_double),
                 ("mu_min_fac", ctypes.c_double), ("slack_push", ctypes.c_double),
                 ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double), ("stall_window", ctypes.c_int),
-                ("bound_margin", ctypes.c_double), ("restoration", ctypes.c_int), ("resto_short", ctypes.c_int), ("resto_cap", ctypes.c_int), ("start_rollout", ctypes.c_int)]
+                ("bound_margin", ctypes.c_double), ("restoration", ctypes.c_int), ("resto_short", ctypes.c_int), ("resto_cap", ctypes.c_int), ("start_rollout", ctypes.c_int), ("hold_mu", ctypes.c_int)]
 
 
 def build(force=False):
@@ -38,7 +38,7 @@ def lib():
 
 
 def default_opts(**kw):
-    o = Opts(1e-8, 500, 0.1, 0.1, 1e-2, 1, 0, 1e-2, 40, 0.0, 1, 6, 40, 1)
+    o = Opts(1e-8, 500, 0.1, 0.1, 1e-2, 1, 0, 1e-2, 40, 0.0, 1, 6, 40, 1, 0)
     for k, v in kw.items():
         setattr(o, k, v)
     return o
@@ -104,12 +104,12 @@ def stream_lengths(N):
     return dict(path_entry=out[0], state=out[1], robot=out[2], traj=out[3])
 
 
-def stream_pack(N, S, path, ss, rb, dual=None, xlast=None):
+def stream_pack(N, S, path, ss, rb, dual=None, xlast=None, level_rule=(0.0, 0.0, 0.0)):
     """path [M][48], ss (updated in place), rb -> (p, x0); xlast: the solver's previous iterate (real-time continuation, bmpc_stream_pack_rt)"""
     p = np.zeros(141 + 91 * S); x0 = np.zeros(44 * N)
     assert path.flags.c_contiguous and ss.flags.c_contiguous and rb.flags.c_contiguous
     lib().bmpc_emu_stream_pack(ctypes.c_int(N), ctypes.c_int(S), _p(path), _p(ss), _p(rb), _p(p), _p(x0), _p(dual) if dual is not None else None,
-                               _p(np.ascontiguousarray(xlast, dtype=np.float64)) if xlast is not None else None)
+                               _p(np.ascontiguousarray(xlast, dtype=np.float64)) if xlast is not None else None, ctypes.c_double(level_rule[0]), ctypes.c_double(level_rule[1]), ctypes.c_double(level_rule[2]))
     return p, x0
 
 

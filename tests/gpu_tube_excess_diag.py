@@ -12,7 +12,8 @@ import torch  # noqa: E402
 from boundmpc_amd import BatchedOCPSolver, stream as bstream, workload  # noqa: E402
 
 FT = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-2
-MU = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1
+MU = (sys.argv[2] if sys.argv[2] == "auto" else float(sys.argv[2])) if len(sys.argv) > 2 else 0.1
+LC = float(os.environ.get("LEVEL_C", "0.1"))
 CAP = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 ROWCAP = float(sys.argv[4]) if len(sys.argv) > 4 else 0.0
 B, T = 256, 131
@@ -22,7 +23,7 @@ for q0 in q0s:
     m, p0fk = workload.make_mpc(q0)
     mpcs.append(m)
     recs.append(bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([m.phi_max[0], 0.0, 0.0]), np.zeros(7)))
-slv = BatchedOCPSolver(10, 4, 0.1, tol=1e-3, max_iter=30, fixed_barrier=MU, bound_margin=2e-3)
+slv = BatchedOCPSolver(10, 4, 0.1, tol=1e-3, max_iter=30, fixed_barrier=MU, bound_margin=2e-3, level_c=LC)
 slv.set_rt_feasibility_tol(FT)
 slv.set_rt_position_row_cap(ROWCAP)
 torch.cuda.set_stream(torch.cuda.Stream())
@@ -46,8 +47,8 @@ for t in range(T):
     errc.append(sb.state[:, bstream.SS["ERRCNT"]].cpu().numpy().copy()); phis.append(sb.state[:, bstream.SS["PHI"]].cpu().numpy().copy())
 exp = np.array(exp); app = np.array(app); gv = np.array(gv); rows = np.array(rows); wid = np.array(wid); errc = np.array(errc); phis = np.array(phis)
 n = np.isfinite(exp).sum()
-print(f"feas tol {FT:g}, level {MU:g}, {CAP} steps, position row cap {ROWCAP:g}: {100 * (exp > 1e-6).sum() / n:.3f} % of {n} plant samples outside the position tube, largest excess {exp.max():.2e} m; "
-      f"applied ticks {100 * app[1:].mean():.1f} %, streams with a plan at the end {100 * float((sb.state[:, bstream.SS['VALID']] > 0.5).double().mean()):.1f} %")
+print(f"feas tol {FT:g}, level {MU} (c = {LC:g}), {CAP} steps, position row cap {ROWCAP:g}: {100 * (exp > 1e-6).sum() / n:.3f} % of {n} plant samples outside the position tube, largest excess {exp.max():.2e} m; "
+      f"applied ticks {100 * app[1:].mean():.1f} %, streams with a plan at the end {100 * float((sb.state[:, bstream.SS['VALID']] > 0.5).double().mean()):.1f} %; mean phi at the end {float(sb.state[:, bstream.SS['PHI']].mean()):.3f}")
 order = np.dstack(np.unravel_index(np.argsort(-exp, axis=None), exp.shape))[0][:6]
 for ti, b in order:
     t = ti + 1      # exp[ti] is the plant state packed at tick ti + 1 = the state the plan applied at tick ti led to

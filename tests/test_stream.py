@@ -356,3 +356,36 @@ def test_stream_functions_at_the_longest_horizons_match_the_host_mirror():
         q, dq, ddq, p_lie, v = integrate_joint(rm, jm, q, dq, ddq, mpc.dt)[:5]
         jerk = traj["dddq"][:, 0].copy()
         np.testing.assert_allclose(rb[:7], q, atol=1e-6)
+
+
+def test_level_rule_of_the_pack_and_held_barrier_level_in_oracle_and_kernel_text():
+    """Round 6, the barrier level that sets itself: (a) the CPU build of stream_pack writes clamp(c (phi_max - phi), lo, hi) into the mu slot of a WARM
+    dual state and leaves a cold one alone; (b) with hold_mu the solve stays on the level it starts on -- the oracle and the kernel text (lane emulator)
+    take the same iterations to the same point and hand the level back unchanged."""
+    from boundmpc_amd import stream as bstream, workload
+    N, S, H = 10, 4, 0.1
+    q0 = workload.random_q0(4, seed=3)[1]
+    mpc, p0fk = workload.make_mpc(q0)
+    T, M = bstream.path_table(mpc.ref_path)
+    ss = bstream.initial_state(mpc, N); ss[bstream.SS["NENT"]] = M
+    rb = bstream.robot_record(q0, np.zeros(7), np.zeros(7), p0fk, np.zeros(6), np.array([mpc.phi_max[0], 0.0, 0.0]), np.zeros(7))
+    dist = float(mpc.phi_max[0] - ss[bstream.SS["PHI"]])
+    for mu0, rule, want in ((0.0, (0.02, 0.01, 0.1), 0.0), (0.05, (0.02, 0.01, 0.1), min(max(0.02 * dist, 0.01), 0.1)), (0.05, (1e-4, 0.01, 0.1), 0.01),
+                            (0.05, (0.0, 0.0, 0.0), 0.05)):
+        dual = np.zeros(c_oracle.state_len(N)); dual[57 * N] = mu0
+        p, x0 = emu.stream_pack(N, S, T, ss.copy(), rb, dual=dual, level_rule=rule)
+        assert abs(dual[57 * N] - want) < 1e-15, (mu0, rule, dual[57 * N], want)
+    # (b) one solve on a held level from a warm state: oracle == kernel text
+    P, X, _ = workload.make_batch(4, seed=0)
+    for level in (0.05, 0.02):
+        kw = dict(tol=1e-3, max_iter=6, mu_init=0.1, mu_warm=0.01, mu_min_fac=10.0, hold_mu=1)
+        sa, sb_ = np.zeros((4, c_oracle.state_len(N))), np.zeros((4, c_oracle.state_len(N)))
+        sa[:, 57 * N] = level; sb_[:, 57 * N] = level; sa[:, :57 * N] = 1.0; sb_[:, :57 * N] = 1.0
+        a = c_oracle.solve(P, X, N, S, H, opts=c_oracle.default_opts(**kw), nthreads=2, state=sa)
+        b = emu.solve(P, X, N, S, H, opts=emu.default_opts(**kw), nthreads=2, state=sb_)
+        assert (a["status"] == 1).all() and (b["status"] == 1).all() and (a["iters"] == 6).all() and (b["iters"] == 6).all()      # `tol` never fires on a held level
+        assert np.allclose(sa[:, 57 * N], level) and np.allclose(sb_[:, 57 * N], level)
+        assert np.abs(a["x"] - b["x"]).max() < 1e-8
+        kw["hold_mu"] = 0
+        c = c_oracle.solve(P, X, N, S, H, opts=c_oracle.default_opts(**kw), nthreads=2, state=sa.copy())
+        assert np.abs(c["x"] - a["x"]).max() > 1e-6      # without the hold the barrier walks down: another iterate
