@@ -32,3 +32,10 @@ timeout -k 10 300 python tests/gpu_team.py 1 16 64 256 > gpurun_out/team_${TAG}.
 tail -12 gpurun_out/team_${TAG}.log
 timeout -k 10 300 python tests/gpu_single_latency.py > gpurun_out/single_call_latency_${TAG}.txt 2>&1 || true
 tail -4 gpurun_out/single_call_latency_${TAG}.txt
+# round 6: pairs (two waves per problem on the one-wave budget, batches 256 < B <= 512) and the longest-expected-first work queue (configs[3])
+timeout -k 10 300 python tests/gpu_profile_phases.py 512 10 pair > gpurun_out/phases_${TAG}_B512_pair.log 2>&1 || true
+timeout -k 10 300 python tests/gpu_profile_phases.py 512 10 one > gpurun_out/phases_${TAG}_B512_one_wave.log 2>&1 || true
+timeout -k 10 300 python tests/gpu_pair.py 257 384 512 > gpurun_out/pair_${TAG}.log 2>&1 || true
+tail -4 gpurun_out/pair_${TAG}.log
+timeout -k 10 400 python tests/gpu_queue_order.py > gpurun_out/queue_order_${TAG}.log 2>&1 || true
+tail -4 gpurun_out/queue_order_${TAG}.log
