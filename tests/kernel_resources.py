@@ -25,7 +25,8 @@ names = {"_Z17bmpc_solve_kernelILb1EE": "bmpc_solve_kernel<ZLDS=true> (batch, N<
          "_Z22bmpc_team_solve_kernel": "bmpc_team_solve_kernel (batch, 4 waves per problem)", "_Z21bmpc_team_tick_kernelILb1EE": "bmpc_team_tick_kernel<RESTO=true> (fused tick, teams)",
          "_Z21bmpc_team_tick_kernelILb0EE": "bmpc_team_tick_kernel<false> (time-budgeted ticks)", "_Z23bmpc_stream_tick_kernelILb1ELb1EE": "bmpc_stream_tick_kernel<ZLDS=true, RESTO=true>",
          "_Z23bmpc_stream_tick_kernelILb1ELb0EE": "bmpc_stream_tick_kernel<true, false>", "_Z23bmpc_stream_tick_kernelILb0ELb1EE": "bmpc_stream_tick_kernel<false, true>",
-         "_Z23bmpc_stream_tick_kernelILb0ELb0EE": "bmpc_stream_tick_kernel<false, false>", "_Z23bmpc_stream_pack_kernel": "bmpc_stream_pack_kernel", "_Z23bmpc_stream_post_kernel": "bmpc_stream_post_kernel"}
+         "_Z23bmpc_stream_tick_kernelILb0ELb0EE": "bmpc_stream_tick_kernel<false, false>", "_Z22bmpc_pair_solve_kernel": "bmpc_pair_solve_kernel (batch, 2 waves per problem, 256 < B <= 512)", "_Z18queue_order_kernel": "queue_order_kernel (ranking of a long-horizon batch)",
+         "_Z23bmpc_stream_pack_kernel": "bmpc_stream_pack_kernel", "_Z23bmpc_stream_post_kernel": "bmpc_stream_post_kernel"}
 print(f"kernel resources of libboundmpc_hip.so, source hash {build.source_hash()} (hipcc -Rpass-analysis=kernel-resource-usage; flags: {' '.join(build.FLAGS)})")
 print("%-78s %5s %5s %8s %6s %6s %8s %4s" % ("kernel", "VGPR", "AGPR", "scratch", "sgprS", "vgprS", "LDS B", "occ"))
 seen = set()
