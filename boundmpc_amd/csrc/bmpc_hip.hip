@@ -78,13 +78,21 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
 // Work-queue order of a batch that takes several rounds of the resident waves (bmpc_set_queue_order): rank of every problem by DECREASING key
 // (ties: by index) -> order[rank] = problem.  B threads, each walks the B keys (B <= a few 10^4: microseconds).  A launch lasts until its last
 // wave is done, so problems that are expected to take long should start first; the key is the objective at the start point (evaluation pass).
+#define BMPC_QUEUE_ORDER_MAX 65536      // the ranking is O(B^2 / lanes): beyond this many problems a batch keeps its natural order
 __global__ void __launch_bounds__(256) queue_order_kernel(int B, const double *key, int *order) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B) return;
-    const double ki = key[i] == key[i] ? key[i] : INFINITY;      // (a NaN key -- f of a garbage x0 -- counts as the largest: the ranks must stay a permutation)
+    __shared__ double tile[256];
+    const int i = blockIdx.x * 256 + threadIdx.x, ic = i < B ? i : B - 1;
+    const double ki = key[ic] == key[ic] ? key[ic] : INFINITY;      // (a NaN key -- f of a garbage x0 -- counts as the largest: the ranks must stay a permutation)
     int r = 0;
-    for (int j = 0; j < B; j++) { const double kj = key[j] == key[j] ? key[j] : INFINITY; r += (kj > ki || (kj == ki && j < i)) ? 1 : 0; }
-    order[r] = i;
+    for (int j0 = 0; j0 < B; j0 += 256) {      // keys staged through LDS a tile at a time: every thread of the block compares against the same 256 keys
+        const int jj = j0 + threadIdx.x;
+        __syncthreads();
+        tile[threadIdx.x] = jj < B ? (key[jj] == key[jj] ? key[jj] : INFINITY) : -INFINITY;
+        __syncthreads();
+        const int n = B - j0 < 256 ? B - j0 : 256;
+        for (int t = 0; t < n; t++) { const double kj = tile[t]; r += (kj > ki || (kj == ki && j0 + t < i)) ? 1 : 0; }
+    }
+    if (i < B) order[r] = i;
 }
 
 struct bmpc_handle {
@@ -309,7 +317,7 @@ static int reserve_for_batch(bmpc_handle *h, int B) {
         HIPCHK(hipMalloc(&h->aux_int, sizeof(int) * 2 * (size_t)B));
         h->aux_cap = B;
     }
-    if (h->queue_order && B > h->q_cap && solve_waves(h, B) == 1 && B > h->grid) {
+    if (h->queue_order && B > h->q_cap && B <= BMPC_QUEUE_ORDER_MAX && solve_waves(h, B) == 1 && B > h->grid) {
         DevGuard dg(h->dev);
         if (h->graphs_alive > 0 && h->qkey) { fprintf(stderr, "boundmpc_hip: a larger batch needs larger queue-order buffers, but captured graphs hold the current ones\n"); return BMPC_ERR_ARG; }
         if (h->qkey) { wait_for_handle(h); hipFree(h->qkey); hipFree(h->qorder); h->qkey = nullptr; h->qorder = nullptr; h->q_cap = 0; }
@@ -401,7 +409,7 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     hipEvent_t *pair = nullptr;
     if (timed) { int rc = timing_slot(h, &pair); if (rc != BMPC_OK) return rc; HIPCHK(hipEventRecord(pair[0], st)); }
     a.order = nullptr;
-    if (h->queue_order && !state && solve_waves(h, B) == 1 && B > h->grid && B <= h->q_cap) {
+    if (h->queue_order && !state && solve_waves(h, B) == 1 && B > h->grid && B <= h->q_cap && B <= BMPC_QUEUE_ORDER_MAX) {
         // Longest-expected-first: an evaluation pass (the same kernel with max_iter = 0: f at x0, nothing else written), the ranking, then the solve
         // hands the problems out in that order.  Inside the timed region: it is part of what the batch costs.  A result does not depend on which
         // wave solves it or when (bitwise invariance under permutation of the batch is a test), so the outputs are those of the natural order.

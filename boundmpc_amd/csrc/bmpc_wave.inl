@@ -2718,6 +2718,7 @@ BMPC_D inline void wave_solve(Wave &W, const Problem &pr) {
     const double mu_state = pr.state ? pr.state[ni] : 0.0;
     const bool warm = mu_state > 0.0;
     double mu = warm ? BMPC_FMIN(o.mu_init, BMPC_FMAX(mu_state, o.mu_warm)) : o.mu_init; const double mu_min = o.tol * o.mu_min_fac;
+    const double mu_entry = mu;      // (hold_mu: the level of the main phase; the restoration phase walks its own barrier down and hands this level back)
     double delta_last = 0.0, delta_prev = 0.0, filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0, gn_run = 0;
     // A cold start that is not a trajectory (oracle/bmpc_oracle.c solve_one: a residual of the integrator chains of x0 above START_ROLLOUT_TOL -- noise,
     // zeros, the plan of another problem) is made one first: the chains rolled out with x0's own jerks, the lifted variables projected by the first
@@ -2884,7 +2885,7 @@ _Pragma("unroll") \
             const bool back = (hmax <= -RESTO_MARGIN && gmax <= RESTO_GTOL) || (E0 <= rtol && vmax <= 1e-6);
             if (!back && (E0 <= rtol || it - it_resto >= o.resto_cap)) { status = 2; break; }
             if (back) {
-                el = false; mu = RESTO_MU_BACK;
+                el = false; mu = o.hold_mu ? mu_entry : RESTO_MU_BACK;
                 BMPC_WEIGHTS(false)
                 fval = wave_eval(W, po, sc, W.Zc, sc.G, sc.HIN, false);      // the objective of the original problem (and the records with its weights)
                 BMPC_ROWS_INIT(false, RESTO_PUSH_BACK)
@@ -2944,7 +2945,7 @@ _Pragma("unroll") \
         for (;;) {   // monotone barrier update (Fiacco-McCormick, Ipopt constants)
             const double ec = BMPC_FMAX(cmax - mu, mu - cmin);
             const double Emu = BMPC_FMAX(BMPC_FMAX(ed / sd, ep), ec / scl);
-            if (!o.hold_mu && Emu <= KAPPA_EPS * mu && mu > mu_min) mu = BMPC_FMAX(mu_min, BMPC_FMIN(0.2 * mu, BMPC_POW15(mu))); else break;
+            if (!(o.hold_mu && !(RESTO && el)) && Emu <= KAPPA_EPS * mu && mu > mu_min) mu = BMPC_FMAX(mu_min, BMPC_FMIN(0.2 * mu, BMPC_POW15(mu))); else break;
         }
         // ---- Newton system: QP gradient, lifted residuals, Riccati ----
         BMPC_PROF(W, 2);

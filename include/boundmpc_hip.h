@@ -195,8 +195,8 @@ int bmpc_team_info(const bmpc_handle *h, int B, int *waves, int *resident_teams,
 
 /* Work-queue order of a batch that takes several rounds of the resident waves (stateless solves, one wave per problem, B > bmpc_launch_info's grid):
  * mode 1 = longest-expected-first -- an evaluation pass ranks the problems by decreasing objective at x0 and the queue hands them out in that
- * order (a launch lasts until its last wave is done); mode 0 = natural order.  Default 1 for N > 11, 0 for shorter horizons.  Results do not
- * depend on the order. */
+ * order (a launch lasts until its last wave is done); mode 0 = natural order.  Default 1 for N > 11, 0 for shorter horizons.  Batches beyond 65 536
+ * problems keep their natural order.  Results do not depend on the order. */
 int bmpc_set_queue_order(bmpc_handle *h, int mode);
 int bmpc_get_queue_order(const bmpc_handle *h);      /* 0 / 1; -1: no handle */
 

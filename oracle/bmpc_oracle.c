@@ -982,6 +982,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
     memcpy(W->Z, x0, sizeof(double) * N * NZ);
     const int warm = state && state[N * NI] > 0.0;
     double mu = warm ? fmin(o->mu_init, fmax(state[N * NI], o->mu_warm)) : o->mu_init;
+    const double mu_entry = mu;      /* hold_mu: the level of the main phase; the restoration phase walks its own barrier down and hands this level back */
     double mu_min = o->tol * o->mu_min_fac, delta_last = 0.0, delta_prev = 0.0; int gn_run = 0;
     double filt_th[32], filt_ph[32], filt_mu = -1.0, theta_min = -1.0, theta_max = 0.0; int nfilt = 0;
     ORACLE_REGION(REG_EVAL); W->f = eval_values(C, P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0); ORACLE_REGION(REG_DRIVER);
@@ -1024,7 +1025,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
             const int back = (hmax <= -RESTO_MARGIN && gmax <= RESTO_GTOL) || (E0 <= rtol && vmax <= 1e-6);
             if (!back && (E0 <= rtol || it - it_resto >= o->resto_cap)) { status = 2; break; }
             if (back) {
-                el = 0; Pc = P; mu = RESTO_MU_BACK;
+                el = 0; Pc = P; mu = o->hold_mu ? mu_entry : RESTO_MU_BACK;
                 ORACLE_REGION(REG_EVAL); W->f = eval_values(C, P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0); ORACLE_REGION(REG_DRIVER);
                 for (int i = 0; i < N * NI; i++) { W->t[i] = fmax(-W->hin[i], RESTO_PUSH_BACK); W->nu[i] = mu / W->t[i]; }
                 nfilt = 0; filt_mu = -1.0; theta_min = -1.0; delta_last = 0.0; delta_prev = 0.0; gn_run = 0; n_short = 0;
@@ -1094,7 +1095,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
         for (;;) {
             ORACLE_REGION(REG_KKT); kkt_errors(C, W, mu, el, &ed, &ep, &ecm, &sd, &sc); ORACLE_REGION(REG_DRIVER);
             double Emu = fmax(fmax(ed / sd, ep), ecm / sc);
-            if (!o->hold_mu && Emu <= KAPPA_EPS * mu && mu > mu_min) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5))); else break;
+            if (!(o->hold_mu && !el) && Emu <= KAPPA_EPS * mu && mu > mu_min) mu = fmax(mu_min, fmin(0.2 * mu, pow(mu, 1.5))); else break;
         }
         /* barrier ratios of the rows: sigma (Hessian weight of grad h grad h^T) and the barrier-modified multiplier nu^ of the QP gradient */
         if (!el) for (int i = 0; i < N * NI; i++) {
