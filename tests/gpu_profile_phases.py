@@ -45,7 +45,7 @@ for rep in range(2):
     assert lib.bmpc_solve_batch(h, B, vp(p.data_ptr()), vp(x0.data_ptr()), vp(x.data_ptr()), None, None, None, None, vp(it.data_ptr()), None, None, None) == 0
     torch.cuda.synchronize(); dt = time.time() - t
     lib.bmpc_get_profile(h, vp(prof.ctypes.data))
-names = ["eval", "adjoint", "kkt+mu", "qp-gradient", "prepare-rlv", "bwd:node(after p5..)", "bwd:stage-in", "forward", "step-dirs", "ls-trial", "nu-update", "(merged into nc:p1)", "st:S1 M-blocks", "st:S3d p1 of next stage", "st:S3a mfma + C", "load", "wide: rlv+iota loop", "st:S3b small roles", "nc:p2+p3 A1/A2/mu/gl", "st:S2a commit + prefetch", "st:S2b cholesky", "st:S0 q~/PR/U/PE", "st:S0b Mci/m", "st:S2 chol+gains", "bwd:staging burst", "eval:kinematics (2N lanes)", "eval:node refs+objective (N lanes)", "adjoint:node gradients (N lanes)", "step-dirs: row loop", "step-dirs: grad.dz + theta loops", "st:S3c stores", "wide: rdy rows + AE loops"]
+names = ["eval", "adjoint", "kkt+mu", "qp-gradient", "prepare-rlv", "bwd:node(after p5..)", "bwd:stage-in", "forward", "step-dirs", "ls-trial", "nu-update", "(merged into nc:p1)", "st:S1 M-blocks", "st:S3d p1 of next stage", "st:S3a mfma + C", "load", "wide: rlv+iota loop", "st:S3b small roles", "nc:p2+p3 A1/A2/mu/gl", "st:S2a commit + prefetch", "st:S2b cholesky", "st:S0 q~/PR/U/PE", "st:S0b Mci/m", "st:S2 chol+gains", "bwd:staging burst", "eval:kinematics (2N lanes)", "eval:node refs+objective (N lanes)", "adjoint:node gradients (wide pass, x2)", "step-dirs: row loop", "step-dirs: grad.dz + theta loops", "st:S3c stores", "wide: rdy rows + AE loops"]
 tot = float(prof.sum()); its = float(it.sum().item())
 print(f"B={B} N={N}{' tight' if TIGHT else ''} waves/problem {TEAM or 'auto'} (team kernels: stamps of lane 0 of wave 0) wall {dt*1e3:.1f} ms, total iterations {its:.0f}, cycles/iteration (lane-0 stamps, profile build) {tot/its:.0f}")
 for n, c in zip(names, prof):

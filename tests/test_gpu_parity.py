@@ -460,15 +460,26 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 # ---------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("key,N,S,h", [("n10", 10, 4, 0.1), ("n30", 30, 4, 0.1), ("n3s2", 3, 2, 0.05), ("n5s3", 5, 3, 0.05), ("n4s5", 4, 5, 0.05)])
 def test_g9_kernel_f_and_g_equal_the_reference_nlp(key, N, S, h):
+    """(every kernel shape that exists for the handle: one wave per problem, pairs, teams -- the evaluation is the same wave program's in each)"""
     from boundmpc_amd import BatchedOCPSolver
     d = np.load(os.path.join(G, "g9_nlp.npz"))
     X, P, F, Gg = d[key + "_x"], d[key + "_p"], d[key + "_f"], d[key + "_g"]
-    s = BatchedOCPSolver(N, S, h, max_iter=0)
-    try:
-        out = s.solve_host(P, X)
-        lbx, ubx, lbg, ubg = s.bounds()
-    finally:
-        s.close()
+    outs = []
+    for waves in (1, 2, 4):
+        if S > 4 or (waves == 2 and N > 11) or (waves == 4 and N > 10):
+            if waves != 1:
+                continue      # no pair / team instantiation for this handle
+        s = BatchedOCPSolver(N, S, h, max_iter=0)
+        try:
+            s.set_team_waves(waves)
+            assert s.team_info(len(P))["waves"] == waves
+            outs.append(s.solve_host(P, X))
+            lbx, ubx, lbg, ubg = s.bounds()
+        finally:
+            s.close()
+    out = outs[0]
+    for o2 in outs[1:]:      # the same numbers from every shape (the node phase of teams / pairs splits lifted residuals and references over two waves: same expressions)
+        np.testing.assert_array_equal(o2["g"], out["g"]); np.testing.assert_array_equal(o2["f"], out["f"])
     assert (out["status"] == 1).all() and (out["iters"] == 0).all()
     np.testing.assert_array_equal(out["x"], X)
     rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
