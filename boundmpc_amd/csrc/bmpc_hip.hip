@@ -54,7 +54,7 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
         int b = 0;
         if (threadIdx.x == 0) b = atomicAdd(a.counter, 1);
         b = __builtin_amdgcn_readfirstlane(b);
-        if (b >= a.B) break;             // every wave reaches this exit: the queue is finite
+        if ((unsigned)b >= (unsigned)a.B) break;      // every wave reaches this exit: the queue is finite (unsigned: a queue word nobody reset ends the wave, it never becomes an address)
         if (a.order) b = __builtin_amdgcn_readfirstlane(a.order[b]);      // longest-expected-first order of a batch larger than the resident waves (queue_order_kernel)
         bmpc::Problem pr;
         pr.p = a.p + (long long)b * np; pr.x0 = a.x0 + (long long)b * nw;
@@ -213,6 +213,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
         // the per-wave workspace slabs (148 KB at N=10, 444 KB at N=30) are allocated on the first solve, for min(B, grid) waves, and grow on demand:
         // a single-problem handle (the nlpsol shim of one BoundMPC object) holds one slab, not 1024
         ok = hipMalloc(&h->counter, 4 * sizeof(int)) == hipSuccess      /* work queue, work queue of the restoration kernel, jam count */
+          && hipMemset(h->counter, 0, 4 * sizeof(int)) == hipSuccess
           && hipMalloc(&h->prof, 32 * sizeof(unsigned long long)) == hipSuccess
           && hipMemset(h->prof, 0, 32 * sizeof(unsigned long long)) == hipSuccess
           && hipEventCreateWithFlags(&h->order_ev, hipEventDisableTiming) == hipSuccess
@@ -382,6 +383,15 @@ extern "C" int bmpc_team_info(const bmpc_handle *h, int B, int *waves, int *resi
     if (lds_bytes) *lds_bytes = w == 2 ? bmpc_pair_lds_bytes() : bmpc_team_lds_bytes(BMPC_TEAM_NW);
     return BMPC_OK;
 }
+// Reset of the work-queue words (queue, restoration queue, jam count) ahead of a batch kernel.  A KERNEL, not hipMemsetAsync: inside a captured graph
+// the runtime (ROCm 7.2) does not reliably order a memset node before the kernel node that follows it when the replay comes behind a cross-stream
+// event wait -- a replayed pair kernel drew its first problem index from a queue word that had not been reset yet (round 6: wrong results, then a
+// memory fault on a negative index; profiles/r06_e_graph_memset_node.txt).  Kernel after kernel is ordered by the queue itself.
+__global__ void __launch_bounds__(64) queue_reset_kernel(int *c) { if (threadIdx.x < 3) c[threadIdx.x] = 0; }
+static hipError_t reset_queue(bmpc_handle *h, hipStream_t st) {
+    hipLaunchKernelGGL(queue_reset_kernel, dim3(1), dim3(64), 0, st, h->counter);
+    return hipGetLastError();
+}
 // fills the kernel arguments and enqueues {reset of the work-queue counter, solver kernel} on `st`
 static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g, double *lam_g,
                          double *lam_x, double *f, int *iters, int *status, double *kkt, hipStream_t st, bool timed, bool capturing = false) {
@@ -415,7 +425,7 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
         // wave solves it or when (bitwise invariance under permutation of the batch is a test), so the outputs are those of the natural order.
         KArgs e = a; e.o.max_iter = 0; e.o.start_rollout = 0; e.x = nullptr; e.g = nullptr; e.lam_g = nullptr; e.lam_x = nullptr; e.kkt = nullptr; e.iters = nullptr; e.status = nullptr;
         e.f = h->qkey; e.state = nullptr; e.latency_us = nullptr; e.rcount = nullptr; e.order = nullptr;
-        HIPCHK(hipMemsetAsync(h->counter, 0, 3 * sizeof(int), st));
+        HIPCHK(reset_queue(h, st));
         if (zlds) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, e);
         else hipLaunchKernelGGL(bmpc_solve_kernel<false>, dim3(grid), dim3(64), 0, st, e);
         HIPCHK(hipGetLastError());
@@ -423,7 +433,7 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
         HIPCHK(hipGetLastError());
         a.order = h->qorder;
     }
-    HIPCHK(hipMemsetAsync(h->counter, 0, 3 * sizeof(int), st));
+    HIPCHK(reset_queue(h, st));
     if (use_team(h, B)) HIPCHK(bmpc_team_launch_solve(BMPC_TEAM_NW, &a, grid, st));      // a workgroup of waves per problem (bmpc_team.hip)
     else if (solve_waves(h, B) == 2) HIPCHK(bmpc_pair_launch_solve(&a, grid, st));           // two waves per problem at two waves per SIMD (bmpc_pair.hip)
     else if (zlds) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, a);      // iterate in LDS; else in the workspace (long horizons, S > 4)
@@ -453,7 +463,7 @@ extern "C" int bmpc_solve_batch_warm(bmpc_handle *h, int B, const double *p, con
     return enqueue_solve(h, B, p, x0, state, max_iter, x, g, lam_g, lam_x, f, iters, status, kkt, (hipStream_t)hip_stream, h->timing != 0);
 }
 
-// ---- hipGraph-captured step: the memset + kernel pair of one (warm-started) solve, instantiated once, replayed per tick ----
+// ---- hipGraph-captured step: {queue reset, solver kernel, restoration kernel} of one (warm-started) solve, instantiated once, replayed per tick ----
 struct bmpc_graph { bmpc_handle *h; hipGraph_t graph; hipGraphExec_t exec; };
 
 extern "C" int bmpc_graph_create(bmpc_handle *h, int B, const double *p, const double *x0, double *state, int max_iter, double *x, double *g,

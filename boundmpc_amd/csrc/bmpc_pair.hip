@@ -78,7 +78,7 @@ __global__ void __launch_bounds__(128, BMPC_PAIR_EU) bmpc_pair_solve_kernel(KArg
         __syncthreads();
         const int b = __builtin_amdgcn_readfirstlane((int)lds[bmpcp::L_TFLAG + 1]);
         __syncthreads();                 // both waves have read the word before the next round rewrites it
-        if (b >= a.B) break;             // both waves of every pair reach this exit: the queue is finite
+        if ((unsigned)b >= (unsigned)a.B) break;             // both waves of every pair reach this exit: the queue is finite
         bmpcp::Problem pr;
         pr.p = a.p + (long long)b * np; pr.x0 = a.x0 + (long long)b * nw;
         pr.x = a.x ? a.x + (long long)b * nw : nullptr; pr.g = a.g ? a.g + (long long)b * ng : nullptr;

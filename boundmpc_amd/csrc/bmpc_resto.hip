@@ -30,9 +30,9 @@ __global__ void __launch_bounds__(64, 1) bmpc_resto_kernel(KArgs a) {
     const int np = 141 + 91 * a.S, nw = a.N * bmpc::NZ, ng = a.N * bmpc::NG;
     for (;;) {
         int b = 0, st = 0;
-        if (threadIdx.x == 0) { b = atomicAdd(a.counter2, 1); st = b < a.B ? a.status[b] : 0; }
+        if (threadIdx.x == 0) { b = atomicAdd(a.counter2, 1); st = (unsigned)b < (unsigned)a.B ? a.status[b] : 0; }
         b = __builtin_amdgcn_readfirstlane(b); st = __builtin_amdgcn_readfirstlane(st);
-        if (b >= a.B) break;             // every wave reaches this exit: the queue is finite
+        if ((unsigned)b >= (unsigned)a.B) break;             // every wave reaches this exit: the queue is finite
         if (st != 4) continue;
         bmpc::Problem pr;
         pr.p = a.p + (long long)b * np; pr.x0 = a.x + (long long)b * nw;      // the iterate the batch kernel left (read before x is rewritten)

@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_solve_kernel(KArgsT
         __syncthreads();
         const int b = __builtin_amdgcn_readfirstlane((int)lds[bmpct::L_TFLAG + 1]);
         __syncthreads();                 // everyone has read the word before the next round rewrites it
-        if (b >= a.B) break;             // every wave of every team reaches this exit: the queue is finite
+        if ((unsigned)b >= (unsigned)a.B) break;             // every wave of every team reaches this exit: the queue is finite
         bmpct::Problem pr;
         pr.p = a.p + (long long)b * np; pr.x0 = a.x0 + (long long)b * nw;
         pr.x = a.x ? a.x + (long long)b * nw : nullptr; pr.g = a.g ? a.g + (long long)b * ng : nullptr;

@@ -213,3 +213,65 @@ def test_team_work_queue_with_more_problems_than_resident_teams():
         assert torch.equal(b["x"], c["x"])
     finally:
         one.close(); team.close()
+
+
+def test_pair_kernel_in_a_captured_graph_and_with_a_dual_state():
+    """The pair kernel behind the other entry points of a handle: a captured step (bmpc_graph_create: queue reset + pair kernel + restoration kernel)
+    replayed over refreshed buffers equals the direct launches bit for bit; warm entry (dual state carried, iteration cap) equals the one-wave
+    kernel's to round-off; the automatic choice picks pairs for 256 < B <= 512."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    B = 300
+    s, one = BatchedOCPSolver(10, 4, 0.1), BatchedOCPSolver(10, 4, 0.1)
+    one.set_team_waves(1)
+    try:
+        assert s.team_info(B)["waves"] == 2      # automatic
+        p = torch.empty((B, 505), dtype=torch.float64, device="cuda"); x0 = torch.empty((B, 440), dtype=torch.float64, device="cuda")
+        st_g, st_d, st_1 = s.new_state(B), s.new_state(B), one.new_state(B)
+        graph = s.capture_step(p, x0, state=st_g, max_iter=4)
+        for t, seed in enumerate((71, 72, 73)):
+            P, X, _ = workload.make_batch(B, seed=seed)
+            p.copy_(torch.tensor(P)); x0.copy_(torch.tensor(X))
+            og = graph.launch(); torch.cuda.synchronize()
+            xg, itg = og["x"].clone(), og["iters"].clone()
+            pc, xc = p.clone(), x0.clone()
+            od = s.solve_batch(pc, xc, state=st_d, max_iter=4)
+            o1 = one.solve_batch(pc, xc, state=st_1, max_iter=4)
+            torch.cuda.synchronize()
+            assert torch.equal(xg, od["x"]) and torch.equal(itg, od["iters"]) and torch.equal(st_g, st_d)
+            assert (od["status"] == 1).all() and torch.equal(od["iters"], o1["iters"])      # capped: four Newton steps each
+            assert float((od["x"] - o1["x"]).abs().max()) < 1e-7 and float((st_d - st_1).abs().max() / st_1.abs().max()) < 1e-7
+        graph.close()
+    finally:
+        s.close(); one.close()
+
+
+@pytest.mark.parametrize("graph_waves,direct_waves", [(2, 1), (1, 2), (2, 4)])
+def test_graph_replays_between_direct_launches_of_another_kernel_on_the_same_handle(graph_waves, direct_waves):
+    """A captured step replayed on the handle's stream (requested on the null stream) between direct null-stream launches of ANOTHER kernel of the same
+    handle -- they share the work-queue words and the workspace.  Until round 6 the queue was reset by a memset node, which the runtime did not order
+    before the kernel node behind a cross-stream wait: the replayed pair kernel drew its indices from a queue nobody had reset (stale results, then a
+    memory fault; profiles/r06_e_graph_memset_node.txt).  The reset is a kernel now."""
+    import torch
+    from boundmpc_amd import BatchedOCPSolver, workload
+    B = 200
+    s, ref = BatchedOCPSolver(10, 4, 0.1), BatchedOCPSolver(10, 4, 0.1)
+    ref.set_team_waves(1)
+    try:
+        p = torch.empty((B, 505), dtype=torch.float64, device="cuda"); x0 = torch.empty((B, 440), dtype=torch.float64, device="cuda")
+        st_g, st_d, st_r = s.new_state(B), s.new_state(B), ref.new_state(B)
+        s.set_team_waves(graph_waves)
+        graph = s.capture_step(p, x0, state=st_g, max_iter=4)
+        s.set_team_waves(direct_waves)
+        for seed in (81, 82, 81):
+            P, X, _ = workload.make_batch(B, seed=seed)
+            p.copy_(torch.tensor(P)); x0.copy_(torch.tensor(X))
+            xg = graph.launch()["x"].clone()
+            od = s.solve_batch(p.clone(), x0.clone(), state=st_d, max_iter=4)
+            o = ref.solve_batch(p.clone(), x0.clone(), out={}, state=st_r, max_iter=4)
+            torch.cuda.synchronize()
+            assert float((xg - o["x"]).abs().max()) < 1e-7 and float((od["x"] - o["x"]).abs().max()) < 1e-7
+            assert float((st_g - st_r).abs().max() / st_r.abs().max()) < 1e-7
+        graph.close()
+    finally:
+        s.close(); ref.close()
