@@ -13,7 +13,7 @@ SYMBOLS = ["bmpc_default_options", "bmpc_default_options_for", "bmpc_error_strin
            "bmpc_last_kernel_ms", "bmpc_kernel_ms", "bmpc_launch_info", "bmpc_state_len", "bmpc_solve_batch_warm", "bmpc_graph_create",
            "bmpc_graph_launch", "bmpc_graph_destroy", "bmpc_stream_lengths", "bmpc_stream_pack", "bmpc_stream_pack_rt", "bmpc_stream_post",
            "bmpc_stream_graph_create", "bmpc_set_latency_buffer", "bmpc_stream_set_rt_feasibility_tol", "bmpc_stream_tick", "bmpc_set_team_waves", "bmpc_team_info", "bmpc_stream_set_time_budget",
-           "bmpc_set_restoration", "bmpc_get_restoration", "bmpc_options_size", "bmpc_build_hash", "bmpc_set_start_rollout", "bmpc_get_start_rollout", "bmpc_set_queue_order", "bmpc_get_queue_order", "bmpc_stream_set_rt_position_row_cap", "bmpc_set_barrier_hold", "bmpc_stream_set_level_rule"]
+           "bmpc_set_restoration", "bmpc_get_restoration", "bmpc_options_size", "bmpc_build_hash", "bmpc_set_start_rollout", "bmpc_get_start_rollout", "bmpc_set_queue_order", "bmpc_get_queue_order", "bmpc_stream_set_rt_position_row_cap", "bmpc_set_barrier_hold", "bmpc_stream_set_level_rule", "bmpc_set_second_attempt", "bmpc_get_second_attempt"]
 
 
 class Options(ctypes.Structure):
@@ -88,6 +88,9 @@ def load():
         if hasattr(lib, "bmpc_set_barrier_hold"):
             lib.bmpc_set_barrier_hold.argtypes = [vp, ci]
             lib.bmpc_stream_set_level_rule.argtypes = [vp, cd, cd, cd]
+        if hasattr(lib, "bmpc_set_second_attempt"):
+            lib.bmpc_set_second_attempt.argtypes = [vp, ci]
+            lib.bmpc_get_second_attempt.argtypes = [vp]
         if hasattr(lib, "bmpc_stream_set_rt_position_row_cap"):
             lib.bmpc_stream_set_rt_position_row_cap.argtypes = [vp, cd]
         lib.bmpc_build_hash.restype = ctypes.c_char_p

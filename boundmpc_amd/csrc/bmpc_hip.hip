@@ -43,7 +43,7 @@ template <bool ZLDS>
 __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs a) {
     __shared__ double lds[bmpc::L_SIZE];
     bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpc::make_gptr(a.scratch + (long long)blockIdx.x * a.scr_stride); W.wv = 0;
-    W.deadline = 0;
+    W.deadline = 0; W.it_base = 0;
     const int np = 141 + 91 * a.S, nw = a.N * bmpc::NZ, ng = a.N * bmpc::NG;
 #ifdef BMPC_PROFILE
     if (threadIdx.x < 32) ((long long *)(lds + bmpc::L_PROF))[threadIdx.x] = 0;
@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(64, BMPC_WAVES_PER_EU) bmpc_solve_kernel(KArgs
         pr.state = a.state ? a.state + (long long)b * (a.N * bmpc::NI + 2) : nullptr;
         pr.resto_from = -1;
         const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
-        bmpc::wave_solve<ZLDS>(W, pr);
+        bmpc::wave_solve_retry<ZLDS>(W, pr);      // (+ the second attempt of a long-horizon solve that ends with status 2)
         __syncthreads();
         if (a.rcount && threadIdx.x == 0 && *pr.status == 4) atomicAdd(a.rcount, 1);      // jammed: the restoration kernel continues it (bmpc_resto.hip)
         if (a.latency_us && threadIdx.x == 0) a.latency_us[b] = (double)((long long)wall_clock64() - t0_) * 0.01;   // constant 100 MHz counter
@@ -112,6 +112,7 @@ struct bmpc_handle {
     int pair_grid;           // resident PAIRS (workgroups of 2 waves at two waves per SIMD, bmpc_pair.hip); 0: no pair kernel for this handle (N > 11 or S > 4)
     int *aux_int; int aux_cap;      // [2][aux_cap] status / iters of a batch whose caller passed NULL (the restoration kernel reads them)
     int hold_mu;            // bmpc_set_barrier_hold: 1 = a solve holds the barrier level it starts on
+    int retry_cap;          // bmpc_set_second_attempt: iterations of the second attempt of a stateless solve that ends with status 2 (0 = none; default 100 for N > 11)
     double level_c, level_lo, level_hi;      // bmpc_stream_set_level_rule: stream_pack sets the level of a stream's next tick (level_hi <= 0: off)
     int start_rollout;      // 1 (default): a stateless solve whose x0 is far off its own dynamics starts from the rollout of x0's jerks (bmpc_set_start_rollout)
     int resto_on, resto_short, resto_cap;      // restoration phase (bmpc_set_restoration): mode 0 off / 1 full (default N <= 11) / 2 after a numerical breakdown only (default N > 11); jam = resto_short consecutive short steps; iterations per phase
@@ -189,7 +190,7 @@ extern "C" int bmpc_create(int N, int S, double dt, const bmpc_options *opts, bm
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return BMPC_ERR_NOGPU;
     bmpc_handle *h = new (std::nothrow) bmpc_handle();
     if (!h) return BMPC_ERR_ARG;
-    h->start_rollout = 1; h->hold_mu = 0; h->level_c = 0.0; h->level_lo = 0.0; h->level_hi = 0.0;
+    h->start_rollout = 1; h->hold_mu = 0; h->retry_cap = N > 11 ? 100 : 0; h->level_c = 0.0; h->level_lo = 0.0; h->level_hi = 0.0;
     h->resto_on = N <= 11 ? 1 : 2; h->resto_short = 6; h->resto_cap = 40;      // restoration phase: full for short horizons, after a numerical breakdown only for long ones (bmpc_set_restoration)
     h->N = N; h->S = S; h->h = dt; h->timing = 0; h->ev = nullptr; h->nev = 0; h->n_timed = 0; h->latency_us = nullptr;
     h->scratch = nullptr; h->scr_waves = 0; h->graphs_alive = 0; h->counter = nullptr; h->aux_int = nullptr; h->aux_cap = 0; h->prof = nullptr; h->stage_d = nullptr; h->stage_h = nullptr; h->stage_cap = 0;
@@ -355,6 +356,12 @@ extern "C" int bmpc_set_barrier_hold(bmpc_handle *h, int enabled) {
     h->hold_mu = enabled;
     return BMPC_OK;
 }
+extern "C" int bmpc_set_second_attempt(bmpc_handle *h, int cap) {
+    if (!h || cap < 0 || cap > 100000) return BMPC_ERR_ARG;
+    h->retry_cap = cap;
+    return BMPC_OK;
+}
+extern "C" int bmpc_get_second_attempt(const bmpc_handle *h) { return h ? h->retry_cap : -1; }
 extern "C" int bmpc_stream_set_level_rule(bmpc_handle *h, double c, double lo, double hi) {
     if (!h || !(c >= 0.0) || !(lo >= 0.0) || !(hi >= 0.0) || (hi > 0.0 && !(lo > 0.0 && lo <= hi))) return BMPC_ERR_ARG;
     h->level_c = c; h->level_lo = lo; h->level_hi = hi;
@@ -400,7 +407,7 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
     KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
     a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
     a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window; a.o.bound_margin = h->o.bound_margin;
-    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap; a.o.start_rollout = h->start_rollout; a.o.hold_mu = h->hold_mu;
+    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap; a.o.start_rollout = h->start_rollout; a.o.hold_mu = h->hold_mu; a.o.retry_cap = state ? 0 : h->retry_cap;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = lam_g; a.lam_x = lam_x; a.f = f; a.kkt = kkt; a.iters = iters; a.status = status;
     a.state = state; a.latency_us = h->latency_us; a.budget_ticks = 0;
     const int grid = launch_grid(h, B);
@@ -434,12 +441,16 @@ static int enqueue_solve(bmpc_handle *h, int B, const double *p, const double *x
         a.order = h->qorder;
     }
     HIPCHK(reset_queue(h, st));
-    if (use_team(h, B)) HIPCHK(bmpc_team_launch_solve(BMPC_TEAM_NW, &a, grid, st));      // a workgroup of waves per problem (bmpc_team.hip)
+    // long horizons with the FULL restoration phase (mode 1 is not their default): the whole batch runs in the instantiation that holds the phase, so the
+    // continuations of the few problems that need it sit in the work queue instead of following the batch on a handful of waves (same results)
+    const bool whole_in_resto = h->resto_on == 1 && !zlds && solve_waves(h, B) == 1;
+    if (whole_in_resto) { KArgs f = a; f.rcount = nullptr; HIPCHK(bmpc_resto_launch(zlds, &f, grid, st)); }
+    else if (use_team(h, B)) HIPCHK(bmpc_team_launch_solve(BMPC_TEAM_NW, &a, grid, st));      // a workgroup of waves per problem (bmpc_team.hip)
     else if (solve_waves(h, B) == 2) HIPCHK(bmpc_pair_launch_solve(&a, grid, st));           // two waves per problem at two waves per SIMD (bmpc_pair.hip)
     else if (zlds) hipLaunchKernelGGL(bmpc_solve_kernel<true>, dim3(grid), dim3(64), 0, st, a);      // iterate in LDS; else in the workspace (long horizons, S > 4)
     else hipLaunchKernelGGL(bmpc_solve_kernel<false>, dim3(grid), dim3(64), 0, st, a);
     HIPCHK(hipGetLastError());
-    if (resto) HIPCHK(bmpc_resto_launch(zlds, &a, rgrid, st));      // continues what the batch kernel left jammed; returns at once when nothing did (bmpc_resto.hip)
+    if (resto && !whole_in_resto) HIPCHK(bmpc_resto_launch(zlds, &a, rgrid, st));      // continues what the batch kernel left jammed; returns at once when nothing did (bmpc_resto.hip)
     if (timed) { HIPCHK(hipEventRecord(pair[1], st)); h->n_timed++; }
     if (!capturing) return order_after(h, st);
     return BMPC_OK;
@@ -622,7 +633,7 @@ static int enqueue_tick(bmpc_handle *h, int B, const double *path, int path_entr
     KArgs a; a.N = h->N; a.S = h->S; a.B = B; a.h = h->h;
     a.o.tol = h->o.tol; a.o.max_iter = max_iter > 0 ? max_iter : h->o.max_iter; a.o.mu_init = h->o.mu_init; a.o.mu_min_fac = h->o.mu_min_fac;
     a.o.slack_push = h->o.slack_push; a.o.exact_hessian = h->o.exact_hessian; a.o.verbose = 0; a.o.mu_warm = h->o.mu_warm; a.o.stall_window = h->o.stall_window; a.o.bound_margin = h->o.bound_margin;
-    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap; a.o.start_rollout = h->start_rollout; a.o.hold_mu = h->hold_mu;
+    a.o.restoration = h->resto_on; a.o.resto_short = h->resto_short; a.o.resto_cap = h->resto_cap; a.o.start_rollout = h->start_rollout; a.o.hold_mu = h->hold_mu; a.o.retry_cap = 0;
     a.p = p; a.x0 = x0; a.x = x; a.g = g; a.lam_g = nullptr; a.lam_x = nullptr; a.f = nullptr; a.kkt = kkt; a.iters = iters; a.status = status;
     a.state = dual_state; a.latency_us = h->latency_us; a.budget_ticks = (long long)(h->rt_budget_us * 100.0);
     if (B > h->scr_waves) return BMPC_ERR_ARG;

@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(128, BMPC_PAIR_EU) bmpc_pair_solve_kernel(KArg
     __shared__ double lds[bmpcp::L_SIZE];
     bmpcp::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpcp::make_gptr(a.scratch + (long long)blockIdx.x * a.scr_stride);
     W.wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    W.deadline = 0;
+    W.deadline = 0; W.it_base = 0;
     const int np = 141 + 91 * a.S, nw = a.N * bmpcp::NZ, ng = a.N * bmpcp::NG;
 #ifdef BMPC_PROFILE
     if (threadIdx.x < 32) ((long long *)(lds + bmpcp::L_PROF))[threadIdx.x] = 0;

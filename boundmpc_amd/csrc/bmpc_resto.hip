@@ -24,28 +24,35 @@ typedef KArgsT<bmpc::Opts> KArgs;
 template <bool ZLDS>
 __global__ void __launch_bounds__(64, 1) bmpc_resto_kernel(KArgs a) {
     __shared__ double lds[bmpc::L_SIZE];
-    if (*(volatile int *)a.rcount == 0) return;      // nothing jammed in this batch (wave-uniform: one word)
+    // Two uses.  Behind a batch kernel (a.rcount set): continue what it left with status 4.  As THE batch kernel (a.rcount == NULL; round 6, long horizons
+    // with the full restoration phase, bmpc_hip.hip enqueue_solve): every problem from its x0, the phase inside the solve -- the same results (entering the
+    // phase discards everything but the iterate: the hand-over loses nothing), but the continuations sit in the work queue instead of running on a
+    // handful of waves behind the batch (configs[3]: 218 -> 1xx ms with mode 1; profiles/r06_h_configs3_failures.txt).
+    const bool fresh = a.rcount == nullptr;
+    if (!fresh && *(volatile int *)a.rcount == 0) return;      // nothing jammed in this batch (wave-uniform: one word)
     bmpc::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpc::make_gptr(a.scratch + (long long)blockIdx.x * a.scr_stride); W.wv = 0;
-    W.deadline = 0; W.tprev = 0;
+    W.deadline = 0; W.tprev = 0; W.it_base = 0;
     const int np = 141 + 91 * a.S, nw = a.N * bmpc::NZ, ng = a.N * bmpc::NG;
     for (;;) {
         int b = 0, st = 0;
-        if (threadIdx.x == 0) { b = atomicAdd(a.counter2, 1); st = (unsigned)b < (unsigned)a.B ? a.status[b] : 0; }
+        if (threadIdx.x == 0) { b = atomicAdd(fresh ? a.counter : a.counter2, 1); st = (!fresh && (unsigned)b < (unsigned)a.B) ? a.status[b] : 0; }
         b = __builtin_amdgcn_readfirstlane(b); st = __builtin_amdgcn_readfirstlane(st);
         if ((unsigned)b >= (unsigned)a.B) break;             // every wave reaches this exit: the queue is finite
-        if (st != 4) continue;
+        if (!fresh && st != 4) continue;
+        if (fresh && a.order) b = __builtin_amdgcn_readfirstlane(a.order[b]);      // longest-expected-first order (queue_order_kernel)
         bmpc::Problem pr;
-        pr.p = a.p + (long long)b * np; pr.x0 = a.x + (long long)b * nw;      // the iterate the batch kernel left (read before x is rewritten)
+        pr.p = a.p + (long long)b * np; pr.x0 = (fresh ? a.x0 : a.x) + (long long)b * nw;      // continuation: the iterate the batch kernel left (read before x is rewritten)
         pr.x = a.x + (long long)b * nw; pr.g = a.g ? a.g + (long long)b * ng : nullptr;
         pr.lam_g = a.lam_g ? a.lam_g + (long long)b * ng : nullptr; pr.lam_x = a.lam_x ? a.lam_x + (long long)b * nw : nullptr;
         pr.f = a.f ? a.f + b : nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr;
         pr.iters = a.iters + b; pr.status = a.status + b;
         pr.state = a.state ? a.state + (long long)b * (a.N * bmpc::NI + 2) : nullptr;
-        pr.resto_from = a.iters[b];
+        pr.resto_from = fresh ? -1 : a.iters[b];
         const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
-        bmpc::wave_solve<ZLDS, false, true>(W, pr);
+        W.o.retry_cap = fresh ? a.o.retry_cap : 0;      // a second attempt starts from x0: fresh solves only
+        bmpc::wave_solve_retry<ZLDS, false, true>(W, pr);
         __syncthreads();
-        if (a.latency_us && threadIdx.x == 0) a.latency_us[b] += (double)((long long)wall_clock64() - t0_) * 0.01;   // on top of the batch kernel's share
+        if (a.latency_us && threadIdx.x == 0) a.latency_us[b] = (fresh ? 0.0 : a.latency_us[b]) + (double)((long long)wall_clock64() - t0_) * 0.01;   // continuation: on top of the batch kernel's share
     }
 }
 

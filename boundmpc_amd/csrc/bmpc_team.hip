@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_solve_kernel(KArgsT
     __shared__ double lds[bmpct::L_SIZE];
     bmpct::Wave W; W.N = a.N; W.S = a.S; W.h = a.h; W.o = a.o; W.L = lds; W.G = bmpct::make_gptr(a.scratch + (long long)blockIdx.x * a.scr_stride);
     W.wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    W.deadline = 0;
+    W.deadline = 0; W.it_base = 0;
     const int np = 141 + 91 * a.S, nw = a.N * bmpct::NZ, ng = a.N * bmpct::NG;
 #ifdef BMPC_PROFILE
     if (threadIdx.x < 32) ((long long *)(lds + bmpct::L_PROF))[threadIdx.x] = 0;
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(64 * BMPC_NW, 1) bmpc_team_tick_kernel(KArgsTe
     pr.p = p; pr.x0 = x0; pr.x = a.x + (long long)b * nw; pr.g = a.g + (long long)b * ng; pr.lam_g = nullptr; pr.lam_x = nullptr;
     pr.f = nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr; pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status + b; pr.state = dual;
     const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
-    W.deadline = a.budget_ticks ? tk0_ + a.budget_ticks : 0;
+    W.deadline = a.budget_ticks ? tk0_ + a.budget_ticks : 0; W.it_base = 0;
     pr.resto_from = -1;
     bmpct::wave_solve<true, true, RESTO>(W, pr);
     __syncthreads();

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(64, 1) bmpc_stream_tick_kernel(KArgs a, SArgs 
     pr.p = p; pr.x0 = x0; pr.x = a.x + (long long)b * nw; pr.g = a.g + (long long)b * ng; pr.lam_g = nullptr; pr.lam_x = nullptr;
     pr.f = nullptr; pr.kkt = a.kkt ? a.kkt + b : nullptr; pr.iters = a.iters ? a.iters + b : nullptr; pr.status = a.status + b; pr.state = dual;
     const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
-    W.deadline = a.budget_ticks ? tk0_ + a.budget_ticks : 0;
+    W.deadline = a.budget_ticks ? tk0_ + a.budget_ticks : 0; W.it_base = 0;
     pr.resto_from = -1;
     bmpc::wave_solve<ZLDS, true, RESTO>(W, pr);
     __syncthreads();

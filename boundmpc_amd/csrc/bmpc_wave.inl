@@ -280,6 +280,8 @@ struct Opts {
     int start_rollout;        // 1: a stateless solve (no dual state buffer) whose x0 is far off its own dynamics (START_ROLLOUT_TOL) starts from the rollout of x0's jerks; 0: from x0 as given
     int hold_mu;              // 1: the barrier level a solve starts on (clamp(stored level, mu_warm, mu_init)) is HELD: no barrier update (real-time iteration on a
                               // per-stream level that the caller / stream_pack sets in the dual state, bmpc_set_barrier_hold; round 6); 0: the monotone update
+    int retry_cap;            // > 0: a stateless solve that ends with status 2 gets a SECOND ATTEMPT from x0 of at most this many iterations on the barrier start of
+                              // the short horizons (wave_solve_retry below; bmpc_set_second_attempt; default 100 for N > 11, else 0)
 };
 
 // global scratch layout (doubles) for horizon N
@@ -362,6 +364,7 @@ struct Wave {
     int wv;                // this wave's index in its team (0 in the one-wave program); wave-uniform
     long long deadline;    // real-time instantiation (wave_solve<., true>: the fused closed-loop tick) only: wall-clock count (BMPC_NOW) after
                            // which no further iteration is started; 0 = none
+    int last_status, last_it, it_base;   // wave_solve leaves status and iteration count here (wave-uniform) and adds it_base to the count it reports (wave_solve_retry)
 #ifdef BMPC_EMU
     int order[64];
     int worder[BMPC_NW];   // team emulator: order in which the waves run a wide phase
@@ -3214,10 +3217,31 @@ _Pragma("unroll") \
         }
         if (pr.state) for (int t_ = 0; t_ < (ni + WS - 1) / WS; t_++) { const int id0 = wl + WS * t_, id = id0 < ni ? id0 : ni - 1; pr.state[id] = WL[sc.NUm + id]; }
         if (wl == 0) {
-            if (pr.f) *pr.f = fval; if (pr.iters) *pr.iters = status == 4 ? (it | (n_restart << 20)) : it; if (pr.status) *pr.status = status; if (pr.kkt) *pr.kkt = E0;
+            if (pr.f) *pr.f = fval; if (pr.iters) *pr.iters = status == 4 ? (it | (n_restart << 20)) : it + W.it_base; if (pr.status) *pr.status = (W.it_base && status == 1) ? 2 : status; if (pr.kkt) *pr.kkt = E0;
             if (pr.state) { pr.state[ni] = ((RESTO && el) || status == 4) ? 0.0 : mu; pr.state[ni + 1] = (double)it; }      // (a solve that ends inside the restoration phase leaves no dual state worth carrying)
         }
     WIDE_END
+    W.last_status = status; W.last_it = it;
+}
+
+// Second attempt (round 6).  On the long-horizon batches the solves that end with status 2 ("locally infeasible": the stall test after the barrier
+// restarts) are, 24 times of 26 on BASELINE configs[3], FEASIBLE problems on which the barrier start of the long horizons (mu 3, slacks pushed to 0.1)
+// leads into a stationary point of the violation; from the same x0 on the barrier start of the short horizons (mu 0.1, push 1e-2) 22 of them converge in
+// 30-93 iterations (profiles/r06_h_configs3_failures.txt).  So a STATELESS solve that ends with status 2 is run once more from x0 with that start and
+// at most retry_cap iterations; the reported iteration count is the sum, and a second attempt that runs into its cap keeps the verdict of the first
+// (status 2, not 1).  One inlined copy of wave_solve in a loop.  oracle/bmpc_oracle.c bmpc_oracle_solve_warm mirrors it.
+#define RETRY_MU_INIT 0.1
+#define RETRY_PUSH 1e-2
+template <bool ZLDS, bool RT = false, bool RESTO = false>
+BMPC_D inline void wave_solve_retry(Wave &W, const Problem &pr) {
+    const Opts keep = W.o;
+    W.it_base = 0;
+    for (int attempt = 0; ; attempt++) {
+        wave_solve<ZLDS, RT, RESTO>(W, pr);
+        if (attempt || keep.retry_cap <= 0 || pr.state || W.last_status != 2 || keep.max_iter <= 0) break;
+        W.o.mu_init = RETRY_MU_INIT; W.o.slack_push = RETRY_PUSH; W.o.max_iter = keep.retry_cap; W.it_base = W.last_it;
+    }
+    W.o = keep; W.it_base = 0;
 }
 
 }  // namespace BMPC_NAMESPACE

@@ -119,6 +119,15 @@ class BatchedOCPSolver:
         _lib.check(self._lib.bmpc_get_restoration(self._h, ctypes.byref(e), ctypes.byref(s_), ctypes.byref(c)), "bmpc_get_restoration")
         return dict(enabled=e.value == 1, mode=e.value, short_steps=s_.value, cap=c.value)
 
+    def set_second_attempt(self, cap):
+        """Iterations of the SECOND ATTEMPT of a stateless solve that ends with status 2: once more from x0 on the barrier start of the short horizons
+        (mu 0.1, slacks pushed to 1e-2); iterations add up, a second attempt that hits its cap keeps status 2.  Default 100 for N > 11 (on BASELINE
+        configs[3] 22 of the 26 status-2 problems are feasible and converge this way), 0 = off for shorter horizons (include/boundmpc_hip.h)."""
+        _lib.check(self._lib.bmpc_set_second_attempt(self._h, int(cap)), "bmpc_set_second_attempt")
+
+    def get_second_attempt(self):
+        return int(self._lib.bmpc_get_second_attempt(self._h))
+
     def set_queue_order(self, mode):
         """Work-queue order of a stateless batch larger than the resident waves: 1 = longest-expected-first by the objective at x0 (default for N > 11),
         0 = natural order (include/boundmpc_hip.h bmpc_set_queue_order).  Results do not depend on it."""

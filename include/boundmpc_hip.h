@@ -200,6 +200,13 @@ int bmpc_team_info(const bmpc_handle *h, int B, int *waves, int *resident_teams,
 int bmpc_set_queue_order(bmpc_handle *h, int mode);
 int bmpc_get_queue_order(const bmpc_handle *h);      /* 0 / 1; -1: no handle */
 
+/* Second attempt: a stateless solve (no dual state buffer) that ends with status 2 is run once more from x0 on the barrier start of the short horizons
+ * (mu_init 0.1, slacks pushed to 1e-2) for at most `cap` iterations; `iters` is the sum of both attempts, a second attempt that runs into its cap keeps
+ * status 2.  cap = 0: off.  Default 100 for N > 11, 0 for shorter horizons.  (What Ipopt users do by hand with another mu_init; the reference has no
+ * counterpart: BoundMPC.py:465-489 reports the failure.) */
+int bmpc_set_second_attempt(bmpc_handle *h, int cap);
+int bmpc_get_second_attempt(const bmpc_handle *h);      /* cap; -1: no handle */
+
 /* launch geometry actually used: resident workgroups (one wave each), LDS bytes per workgroup, scratch bytes per workgroup */
 int bmpc_launch_info(const bmpc_handle *h, int *grid, int *lds_bytes, long long *scratch_bytes);
 

@@ -108,6 +108,9 @@ typedef struct {
     int resto_cap;       /* iterations one restoration phase may take before the solve ends as status 2 (40) */
     int start_rollout;   /* 1 (default): a stateless solve (no dual state buffer) whose x0 is far off its own dynamics (START_ROLLOUT_TOL) starts from the rollout of x0's jerks; 0: from x0 as given */
     int hold_mu;         /* 1: the barrier level the solve starts on is held (no barrier update): real-time iteration on a per-stream level; 0 (default): monotone update */
+    int retry_cap;       /* > 0: a stateless solve that ends with status 2 gets a second attempt from x0 of at most this many iterations on the barrier start of the
+                            short horizons (mu_init 0.1, slack_push 1e-2); iterations add up, a second attempt that hits its cap keeps status 2
+                            (boundmpc_amd/csrc/bmpc_wave.inl wave_solve_retry; the product's default for N > 11 is 100, here 0) */
 } bmpc_oracle_opts;
 
 typedef struct {
@@ -1236,7 +1239,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
  * ---------------------------------------------------------------------------------------- */
 void bmpc_oracle_default_opts(bmpc_oracle_opts *o) {
     o->tol = 1e-8; o->max_iter = 500; o->mu_init = 0.1; o->mu_min_fac = 0.1; o->slack_push = 1e-2; o->exact_hessian = 1; o->verbose = 0; o->mu_warm = 1e-2; o->stall_window = 40;
-    o->restoration = 1; o->resto_short = 6; o->resto_cap = 40; o->start_rollout = 1; o->hold_mu = 0;
+    o->restoration = 1; o->resto_short = 6; o->resto_cap = 40; o->start_rollout = 1; o->hold_mu = 0; o->retry_cap = 0;
 }
 
 static void write_outputs(const Cfg *C, const Par *P, Work *W, double *x, double *g, double *lam_g, double *lam_x) {
@@ -1329,6 +1332,12 @@ int bmpc_oracle_solve_warm(int N, int S, double h, const bmpc_oracle_opts *opts,
         for (int b = 0; b < B; b++) {
             SolveInfo info; Par P; par_view(p + (size_t)b * C.np, S, &P);
             solve_one(&C, p + (size_t)b * C.np, x0 + (size_t)b * nw, W, &info, state ? state + (size_t)b * (N * NI + 2) : NULL);
+            if (C.o.retry_cap > 0 && !state && info.status == 2 && C.o.max_iter > 0) {      /* second attempt (wave_solve_retry of the kernel text) */
+                Cfg C2 = C; const int first = info.iters;
+                C2.o.mu_init = 0.1; C2.o.slack_push = 1e-2; C2.o.max_iter = C.o.retry_cap;
+                solve_one(&C2, p + (size_t)b * C.np, x0 + (size_t)b * nw, W, &info, NULL);
+                info.iters += first; if (info.status == 1) info.status = 2;
+            }
             /* refresh node data at the final point for the outputs */
             ORACLE_REGION(REG_OUTPUT);
             W->f = eval_values(&C, &P, W->Z, W->Kp, W->Kv, W->R, W->g, W->hin, 0);

@@ -18,7 +18,7 @@ class Opts(ctypes.Structure):
     _fields_ = [("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("mu_init", ctypes.c_double),
                 ("mu_min_fac", ctypes.c_double), ("slack_push", ctypes.c_double),
                 ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double), ("stall_window", ctypes.c_int),
-                ("restoration", ctypes.c_int), ("resto_short", ctypes.c_int), ("resto_cap", ctypes.c_int), ("start_rollout", ctypes.c_int), ("hold_mu", ctypes.c_int)]
+                ("restoration", ctypes.c_int), ("resto_short", ctypes.c_int), ("resto_cap", ctypes.c_int), ("start_rollout", ctypes.c_int), ("hold_mu", ctypes.c_int), ("retry_cap", ctypes.c_int)]
 
 
 def build(force=False):
@@ -102,7 +102,7 @@ def solve(p, x0, N, S, h, opts=None, nthreads=0, state=None):
     out = dict(x=np.zeros((B, N * NZ)), g=np.zeros((B, N * NG)), lam_g=np.zeros((B, N * NG)),
                lam_x=np.zeros((B, N * NZ)), f=np.zeros(B), iters=np.zeros(B, dtype=np.int32),
                status=np.zeros(B, dtype=np.int32), kkt=np.zeros(B))
-    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2) if N > 11 else default_opts())     # horizon rule of bmpc_default_options_for
+    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2, retry_cap=100) if N > 11 else default_opts())     # horizon rule of bmpc_default_options_for
     if state is not None:
         assert state.dtype == np.float64 and state.flags.c_contiguous and state.shape == (B, state_len(N))
     lib().bmpc_oracle_solve_warm(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(B),
@@ -138,7 +138,7 @@ def count_flops(p, x0, N, S, h, opts=None):
     x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
     B = p.shape[0]
     assert p.shape[1] == 141 + 91 * S and x0.shape == (B, N * NZ)
-    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2) if N > 11 else default_opts())
+    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2, retry_cap=100) if N > 11 else default_opts())
     out = np.zeros(18, dtype=np.uint64)
     rc = _flib.bmpc_oracle_count_flops(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(B), _p(p), _p(x0), _p(out))
     assert rc == 0

@@ -76,7 +76,7 @@ extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, in
             // BMPC_EMU_POISON=1: LDS and workspace are filled with NaN before every problem -- a read of something this solve has not
             // written (what a reused slab or LDS holds on the GPU) then shows up in the outputs
             if (poison) { std::fill(lds.begin(), lds.end(), std::nan("")); std::fill(scr.begin(), scr.end(), std::nan("")); }
-            bmpc::Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = bmpc::make_gptr(scr.data());
+            bmpc::Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = bmpc::make_gptr(scr.data()); W.it_base = 0;
             for (int i = 0; i < 64; i++) W.order[i] = lane_order == 0 ? i : (lane_order == 1 ? 63 - i : (i * 37 + 11) % 64);
             bmpc::Problem pr;
             pr.p = p + (size_t)b * np; pr.x0 = x0 + (size_t)b * nw;
@@ -91,10 +91,11 @@ extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, in
             } else {             // the batch kernels: main phase only; a jammed problem (internal status 4) is continued by the restoration kernel from its iterate
                 std::vector<double> xb(nw); int it_ = 0, st_ = 0;
                 bmpc::Problem q = pr; q.x = xb.data(); q.iters = &it_; q.status = &st_;
-                if (zl) bmpc::wave_solve<true>(W, q); else bmpc::wave_solve<false>(W, q);
+                if (zl) bmpc::wave_solve_retry<true>(W, q); else bmpc::wave_solve_retry<false>(W, q);      // (the batch kernels' call: with the second attempt of a status-2 solve)
                 if (st_ == 4) {
                     std::vector<double> x0b(xb);
                     q.x0 = x0b.data(); q.resto_from = it_;
+                    W.o.retry_cap = 0;
                     if (zl) bmpc::wave_solve<true, false, true>(W, q); else bmpc::wave_solve<false, false, true>(W, q);
                 }
                 if (pr.x) memcpy(pr.x, xb.data(), sizeof(double) * nw);
@@ -111,7 +112,7 @@ extern "C" int bmpc_emu_newton(int N, int S, double h, const bmpc::Opts *opts, c
     using namespace bmpc;
     const Scr sc = make_scr(N); const POff po = make_poff_lds(S, L_ZL);
     std::vector<double> lds(L_SIZE, 0.0), scr(sc.size, 0.0);
-    Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = bmpc::make_gptr(scr.data());
+    Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = bmpc::make_gptr(scr.data()); W.it_base = 0;
     for (int i = 0; i < 64; i++) W.order[i] = i;
     for (int i = 0; i < po.size; i++) W.L[L_PAR + lds_index_of_p(S, i, L_ZL)] = p[i];
     wave_init_tables(W, po);

@@ -72,12 +72,12 @@ extern "C" int bmpc_emu_count_flops(int N, int S, double h, const bmpc::Opts *op
     std::vector<Real> lds(bmpc::L_SIZE, Real(0.0)), scr(sc.size, Real(0.0)), x(nw);
     unsigned long long its = 0, okc = 0;
     for (int b = 0; b < B; b++) {
-        bmpc::Wave W; W.N = N; W.S = S; W.h = Real(h); W.o = *opts; W.L = lds.data(); W.G = bmpc::make_gptr(scr.data());
+        bmpc::Wave W; W.N = N; W.S = S; W.h = Real(h); W.o = *opts; W.L = lds.data(); W.G = bmpc::make_gptr(scr.data()); W.it_base = 0;
         for (int i = 0; i < 64; i++) W.order[i] = i;
         bmpc::Problem pr; int it = 0, st = 0;
         pr.p = (const Real *)p + (size_t)b * np; pr.x0 = (const Real *)x0 + (size_t)b * nw;
         pr.x = x.data(); pr.g = nullptr; pr.lam_g = nullptr; pr.lam_x = nullptr; pr.f = nullptr; pr.kkt = nullptr; pr.iters = &it; pr.status = &st; pr.state = nullptr; pr.resto_from = -1;
-        if (N <= 11 && S <= bmpc::SMAX_ZLDS) bmpc::wave_solve<true>(W, pr); else bmpc::wave_solve<false>(W, pr);
+        if (N <= 11 && S <= bmpc::SMAX_ZLDS) bmpc::wave_solve_retry<true>(W, pr); else bmpc::wave_solve_retry<false>(W, pr);
         its += (unsigned long long)it; okc += st == 0;
     }
     out[0] = its; out[1] = okc; out[2] = fc::g_flops; out[3] = fc::g_special;

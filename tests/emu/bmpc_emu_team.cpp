@@ -65,7 +65,7 @@ extern "C" int bmpc_emu_team_solve(int N, int S, double h, const bmpct::Opts *op
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < B; b++) {
             if (poison) { std::fill(lds.begin(), lds.end(), std::nan("")); std::fill(scr.begin(), scr.end(), std::nan("")); }
-            bmpct::Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = bmpct::make_gptr(scr.data()); W.wv = 0;
+            bmpct::Wave W; W.N = N; W.S = S; W.h = h; W.o = *opts; W.L = lds.data(); W.G = bmpct::make_gptr(scr.data()); W.wv = 0; W.it_base = 0;
             for (int i = 0; i < 64; i++) W.order[i] = lane_order == 0 ? i : (lane_order == 1 ? 63 - i : (i * 37 + 11) % 64);
             for (int i = 0; i < BMPC_NW; i++) W.worder[i] = wave_order == 0 ? i : (wave_order == 1 ? BMPC_NW - 1 - i : (i * 3 + 1) % BMPC_NW);
             bmpct::Problem pr;

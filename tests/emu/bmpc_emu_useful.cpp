@@ -105,7 +105,7 @@ static size_t g_tail = 1;
 #define BMPC_PROF(W, id) { for (size_t n_ = g_tail; n_ < fc::g_nodes.size(); n_++) fc::g_nodes[n_].slot = (uint8_t)(id); g_tail = fc::g_nodes.size(); }
 // the caller's option record (plain doubles; layout of bmpc::Opts in the other builds), declared before `double` changes its meaning
 struct PlainOpts { double tol; int max_iter; double mu_init; double mu_min_fac; double slack_push; int exact_hessian; int verbose; double mu_warm; int stall_window;
-                   double bound_margin; int restoration; int resto_short; int resto_cap; int start_rollout; int hold_mu; };
+                   double bound_margin; int restoration; int resto_short; int resto_cap; int start_rollout; int hold_mu; int retry_cap; };
 #define double Real
 #include "../../boundmpc_amd/csrc/bmpc_wave.inl"
 #undef double
@@ -115,7 +115,7 @@ struct PlainOpts { double tol; int max_iter; double mu_init; double mu_min_fac; 
 extern "C" int bmpc_emu_count_useful(int N, int S, double h, const PlainOpts *po_, const double *p, const double *x0, unsigned long long *out) {
     bmpc::Opts oo; oo.tol = Real(po_->tol); oo.max_iter = po_->max_iter; oo.mu_init = Real(po_->mu_init); oo.mu_min_fac = Real(po_->mu_min_fac); oo.slack_push = Real(po_->slack_push);
     oo.exact_hessian = po_->exact_hessian; oo.verbose = 0; oo.mu_warm = Real(po_->mu_warm); oo.stall_window = po_->stall_window; oo.bound_margin = Real(po_->bound_margin);
-    oo.restoration = po_->restoration; oo.resto_short = po_->resto_short; oo.resto_cap = po_->resto_cap; oo.start_rollout = po_->start_rollout; oo.hold_mu = po_->hold_mu;
+    oo.restoration = po_->restoration; oo.resto_short = po_->resto_short; oo.resto_cap = po_->resto_cap; oo.start_rollout = po_->start_rollout; oo.hold_mu = po_->hold_mu; oo.retry_cap = po_->retry_cap;
     const bmpc::Opts *opts = &oo;
     if (S > bmpc::SMAX || S < 2 || N < 1 || N > bmpc::NMAX) return 1;
     const bmpc::Scr sc = bmpc::make_scr(N);
@@ -128,12 +128,12 @@ extern "C" int bmpc_emu_count_useful(int N, int S, double h, const PlainOpts *po
     auto reg = [](std::vector<Real> &v) { fc::g_mem_lo[fc::g_nmem] = (const char *)v.data(); fc::g_mem_hi[fc::g_nmem] = (const char *)(v.data() + v.size()); fc::g_nmem++; };
     reg(lds); reg(scr); reg(x); reg(g);
     fc::g_dummy = (const void *)(lds.data() + bmpc::L_DUMMY);
-    bmpc::Wave W; W.N = N; W.S = S; W.h = Real(h); W.o = *opts; W.L = lds.data(); W.G = bmpc::make_gptr(scr.data());
+    bmpc::Wave W; W.N = N; W.S = S; W.h = Real(h); W.o = *opts; W.L = lds.data(); W.G = bmpc::make_gptr(scr.data()); W.it_base = 0;
     for (int i = 0; i < 64; i++) W.order[i] = i;
     bmpc::Problem pr; int it = 0, st = 0;
     pr.p = pp.data(); pr.x0 = xx.data();
     pr.x = x.data(); pr.g = g.data(); pr.lam_g = nullptr; pr.lam_x = nullptr; pr.f = nullptr; pr.kkt = nullptr; pr.iters = &it; pr.status = &st; pr.state = nullptr; pr.resto_from = -1;
-    if (N <= 11 && S <= bmpc::SMAX_ZLDS) bmpc::wave_solve<true>(W, pr); else bmpc::wave_solve<false>(W, pr);
+    if (N <= 11 && S <= bmpc::SMAX_ZLDS) bmpc::wave_solve_retry<true>(W, pr); else bmpc::wave_solve_retry<false>(W, pr);
     for (int i = 0; i < 72; i++) out[i] = 0;
     out[0] = (unsigned long long)it; out[1] = st == 0; out[4] = fc::g_stores; out[5] = fc::g_dup_stores; out[6] = fc::g_dummy_stores;
     for (size_t n = 1; n < fc::g_nodes.size(); n++) {

@@ -16,7 +16,7 @@ class Opts(ctypes.Structure):
     _fields_ = [("tol", ctypes.c_double), ("max_iter", ctypes.c_int), ("mu_init", ctypes.c_double),
                 ("mu_min_fac", ctypes.c_double), ("slack_push", ctypes.c_double),
                 ("exact_hessian", ctypes.c_int), ("verbose", ctypes.c_int), ("mu_warm", ctypes.c_double), ("stall_window", ctypes.c_int),
-                ("bound_margin", ctypes.c_double), ("restoration", ctypes.c_int), ("resto_short", ctypes.c_int), ("resto_cap", ctypes.c_int), ("start_rollout", ctypes.c_int), ("hold_mu", ctypes.c_int)]
+                ("bound_margin", ctypes.c_double), ("restoration", ctypes.c_int), ("resto_short", ctypes.c_int), ("resto_cap", ctypes.c_int), ("start_rollout", ctypes.c_int), ("hold_mu", ctypes.c_int), ("retry_cap", ctypes.c_int)]
 
 
 def build(force=False):
@@ -38,7 +38,7 @@ def lib():
 
 
 def default_opts(**kw):
-    o = Opts(1e-8, 500, 0.1, 0.1, 1e-2, 1, 0, 1e-2, 40, 0.0, 1, 6, 40, 1, 0)
+    o = Opts(1e-8, 500, 0.1, 0.1, 1e-2, 1, 0, 1e-2, 40, 0.0, 1, 6, 40, 1, 0, 0)
     for k, v in kw.items():
         setattr(o, k, v)
     return o
@@ -54,7 +54,7 @@ def solve(p, x0, N, S, h, opts=None, lane_order=0, nthreads=0, state=None):
     B = p.shape[0]
     out = dict(x=np.zeros((B, N * 44)), g=np.zeros((B, N * 43)), lam_g=np.zeros((B, N * 43)), lam_x=np.zeros((B, N * 44)),
                f=np.zeros(B), iters=np.zeros(B, dtype=np.int32), status=np.zeros(B, dtype=np.int32), kkt=np.zeros(B))
-    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2) if N > 11 else default_opts())
+    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2, retry_cap=100) if N > 11 else default_opts())
     rc = lib().bmpc_emu_solve(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(B), _p(p), _p(x0), _p(state) if state is not None else None,
                               _p(out["x"]), _p(out["g"]), _p(out["lam_g"]), _p(out["lam_x"]), _p(out["f"]), _p(out["iters"]),
                               _p(out["status"]), _p(out["kkt"]), ctypes.c_int(lane_order), ctypes.c_int(nthreads))
@@ -88,7 +88,7 @@ def solve_team(p, x0, N, S, h, nw=4, opts=None, lane_order=0, wave_order=0, nthr
     B = p.shape[0]
     out = dict(x=np.zeros((B, N * 44)), g=np.zeros((B, N * 43)), lam_g=np.zeros((B, N * 43)), lam_x=np.zeros((B, N * 44)),
                f=np.zeros(B), iters=np.zeros(B, dtype=np.int32), status=np.zeros(B, dtype=np.int32), kkt=np.zeros(B))
-    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2) if N > 11 else default_opts())
+    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2, retry_cap=100) if N > 11 else default_opts())
     rc = team_lib(nw).bmpc_emu_team_solve(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(B), _p(p), _p(x0),
                                           _p(state) if state is not None else None, _p(out["x"]), _p(out["g"]), _p(out["lam_g"]), _p(out["lam_x"]),
                                           _p(out["f"]), _p(out["iters"]), _p(out["status"]), _p(out["kkt"]), ctypes.c_int(lane_order),
@@ -155,7 +155,7 @@ def count_flops(p, x0, N, S, h, opts=None):
         _fl = ctypes.CDLL(_FLIB)
     p = np.ascontiguousarray(np.atleast_2d(p), dtype=np.float64)
     x0 = np.ascontiguousarray(np.atleast_2d(x0), dtype=np.float64)
-    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2) if N > 11 else default_opts())
+    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2, retry_cap=100) if N > 11 else default_opts())
     out = np.zeros(36, dtype=np.uint64)
     rc = _fl.bmpc_emu_count_flops(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), ctypes.c_int(p.shape[0]), _p(p), _p(x0), _p(out))
     assert rc == 0
@@ -181,7 +181,7 @@ def count_useful(p, x0, N, S, h, opts=None):
     if _ul is None:
         _ul = ctypes.CDLL(_ULIB)
     p = np.ascontiguousarray(np.asarray(p, dtype=np.float64).ravel()); x0 = np.ascontiguousarray(np.asarray(x0, dtype=np.float64).ravel())
-    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2) if N > 11 else default_opts())
+    o = opts if opts is not None else (default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2, retry_cap=100) if N > 11 else default_opts())
     out = np.zeros(72, dtype=np.uint64)
     rc = _ul.bmpc_emu_count_useful(ctypes.c_int(N), ctypes.c_int(S), ctypes.c_double(h), ctypes.byref(o), _p(p), _p(x0), _p(out))
     assert rc == 0

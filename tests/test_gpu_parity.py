@@ -127,10 +127,18 @@ def test_long_horizon_tight_tubes(solver):
         assert set(np.unique(st)) <= {0, 2, 3}, np.bincount(st)          # converged | stalled (local infeasibility) | numerical
         assert (st == 3).mean() <= 0.002
         ok = st == 0
-        # Requirement of the round-3 verdict: >= 99.8 % converged, slowest problem <= 120 iterations -- NOT met.  The bounds below are a
-        # regression guard around what the round-4 kernel does (Gauss-Newton fallback at every barrier level: 99.68 % converged, slowest 170, mean 32.8;
-        # round 3: 99.63 %, 203, 35.2); the reference's iteration cap is 500 (BoundMPC.py:122)
-        assert ok.mean() >= 0.996 and it.max() <= 220 and it.mean() <= 34.0, (ok.mean(), it.max(), it.mean())
+        # Requirement of the round-3 / round-5 verdicts: >= 99.8 % converged, slowest problem <= 120 iterations.  Round 6: the converged fraction is met
+        # -- 99.95 % -- by the SECOND ATTEMPT of the status-2 solves (22 of the 26 are feasible problems that converge from x0 on the barrier start of the
+        # short horizons, profiles/r06_h_configs3_failures.txt); the iteration bound is not (a solve that takes both attempts: 150-263 iterations in sum).
+        # Regression guard around those numbers (first attempt alone: 99.68 %, slowest 170, mean 32.8); the reference's iteration cap is 500 (BoundMPC.py:122)
+        assert s30.get_second_attempt() == 100
+        assert ok.mean() >= 0.999 and it.max() <= 280 and it.mean() <= 34.0, (ok.mean(), it.max(), it.mean())
+        s30.set_second_attempt(0)
+        o1 = s30.solve_batch(p, x0, out={}, want=("iters", "status")); torch.cuda.synchronize()
+        st1, it1 = o1["status"].cpu().numpy(), o1["iters"].cpu().numpy()
+        assert (st1 == 0).mean() >= 0.996 and it1.max() <= 220 and ((st1 == 0) <= ok).all()      # the first attempt alone; what it solves, the default solves
+        assert np.array_equal(it1[st1 == 0], it[st1 == 0]) and torch.equal(o1["x"][torch.tensor(st1 == 0, device="cuda")], o["x"][torch.tensor(st1 == 0, device="cuda")])
+        s30.set_second_attempt(100)
         assert (kkt[ok] <= 1e-8).all()
         g = o["g"].cpu().numpy()[ok].reshape(-1, 30, 43)
         assert np.abs(g[:, :, :36]).max() < 1e-6 and g[:, :, 36:].max() < 1e-6
@@ -142,6 +150,12 @@ def test_long_horizon_tight_tubes(solver):
         o2 = s30.solve_batch(p, x0, out={})
         torch.cuda.synchronize()
         assert torch.equal(o2["x"], o["x"]) and torch.equal(o2["status"], o["status"])
+        # the second attempt problem by problem against the oracle's mirror of the rule: three feasible problems the first attempt gives up on, one that stays
+        hard = np.array([695, 814, 4960, 1658])
+        refh = c_oracle.solve(P[hard], X[hard], 30, 4, 0.1)
+        assert list(st1[hard]) == [2, 2, 2, 2] and list(st[hard]) == [0, 0, 0, 2] and np.array_equal(refh["status"], st[hard]), (st1[hard], st[hard], refh["status"])
+        assert np.abs(refh["iters"] - it[hard]).max() <= 25, (refh["iters"], it[hard])
+        assert np.sqrt(np.mean(((x[hard[:3]] - refh["x"][:3]).reshape(-1, 30, 44)[:, :, 8:15]) ** 2, axis=(1, 2))).max() < 1e-6      # joint trajectories
         # oracle, per problem, on a sample spread over the batch
         idx = np.arange(0, 8192, 32)
         ref = c_oracle.solve(P[idx], X[idx], 30, 4, 0.1)
@@ -767,6 +781,9 @@ def test_long_horizon_restoration_as_the_last_resort_behind_the_restarts():
     p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X, device="cuda")
     s = BatchedOCPSolver(30, 4, 0.1)
     assert s.get_restoration()["mode"] == 2      # default of long horizons: after a numerical breakdown only
+    dflt = s.solve_batch(p, x0, out={}); st_d = dflt["status"].cpu().numpy()
+    assert s.get_second_attempt() == 100 and (st_d == 0).all()      # round 6: with the second attempt of the defaults both converge (test_long_horizon_tight_tubes)
+    s.set_second_attempt(0)                                          # below: the first attempt alone, and what the restoration phase makes of it
     off = s.solve_batch(p, x0); st_off, it_off = off["status"].cpu().numpy(), off["iters"].cpu().numpy()
     assert st_off[2] == 2 and st_off[7] == 2 and (np.delete(st_off, [2, 7]) == 0).all()
     s.set_restoration(True)
@@ -791,7 +808,7 @@ def test_numerical_breakdowns_of_far_off_starts_go_to_the_restoration_phase_on_t
     P, X, _ = workload.make_batch(64, seed=7, N=20)
     X2 = X + np.random.default_rng(3).normal(size=X.shape) * 0.3
     p, x0 = torch.tensor(P, device="cuda"), torch.tensor(X2, device="cuda")
-    ref = c_oracle.solve(P, X2, 20, 4, 0.1, opts=c_oracle.default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2, start_rollout=0), nthreads=8)
+    ref = c_oracle.solve(P, X2, 20, 4, 0.1, opts=c_oracle.default_opts(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2, start_rollout=0, retry_cap=100), nthreads=8)
     s = BatchedOCPSolver(20, 4, 0.1, start_rollout=False)      # (x0 as given, so that the main phase does break down; the default rolls these starts out first)
     o = s.solve_batch(p, x0); st = o["status"].cpu().numpy()
     assert (st == 0).all() and np.array_equal(st, ref["status"]) and float(o["kkt"].max()) <= 1e-8
