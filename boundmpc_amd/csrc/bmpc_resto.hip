@@ -49,8 +49,7 @@ __global__ void __launch_bounds__(64, 1) bmpc_resto_kernel(KArgs a) {
         pr.state = a.state ? a.state + (long long)b * (a.N * bmpc::NI + 2) : nullptr;
         pr.resto_from = fresh ? -1 : a.iters[b];
         const long long t0_ = a.latency_us ? (long long)wall_clock64() : 0;
-        W.o.retry_cap = fresh ? a.o.retry_cap : 0;      // a second attempt starts from x0: fresh solves only
-        bmpc::wave_solve_retry<ZLDS, false, true>(W, pr);
+        bmpc::wave_solve_retry<ZLDS, false, true>(W, pr, fresh ? nullptr : a.x0 + (long long)b * nw);      // (a continuation's second attempt is a fresh solve from the caller's x0)
         __syncthreads();
         if (a.latency_us && threadIdx.x == 0) a.latency_us[b] = (fresh ? 0.0 : a.latency_us[b]) + (double)((long long)wall_clock64() - t0_) * 0.01;   // continuation: on top of the batch kernel's share
     }

@@ -106,6 +106,8 @@ constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
 #define DELTA_KEEP_MIN 1e-5
 #define STALL_FACTOR 0.5     // stall test: primal infeasibility must halve per stall_window iterations
 #define STALL_RESTARTS 3     // barrier restarts from a stalled iterate before status 2 (long horizons only; oracle/bmpc_oracle.c solve_one)
+#define STALL_RESTARTS_RETRY 2   // ... when a second attempt stands behind the solve (Opts::retry_cap) and it has not been through a restoration phase: the third restart
+                             // rescues less than the second attempt does and costs a stall window more (configs[3]: 163 -> 155 ms at 99.95 -> 99.93 %)
 #define STALL_RESTART_MU 3.0
 #define STALL_RESTART_PUSH 1e-1
 // restoration phase (oracle/bmpc_oracle.c solve_one has the description and the numbers)
@@ -2934,7 +2936,7 @@ _Pragma("unroll") \
                 // before giving up, restart the barrier from the CURRENT iterate -- slacks and multipliers re-centred on a high barrier level,
                 // filter and inertia history cleared -- at most STALL_RESTARTS times (oracle/bmpc_oracle.c solve_one has the numbers: the
                 // stalled problems of the tight 30-stage batch are feasible, their iterate is jammed at the first barrier level).
-                if (!longh || n_restart >= STALL_RESTARTS) { status = 2; break; }
+                if (!longh || n_restart >= ((o.retry_cap > 0 && n_resto == 0 && !(RESTO && pr.resto_from >= 0)) ? STALL_RESTARTS_RETRY : STALL_RESTARTS)) { status = 2; break; }
                 n_restart++; it_restart = it;
                 mu = STALL_RESTART_MU;
                 BMPC_ROWS_INIT(false, STALL_RESTART_PUSH)
@@ -3232,14 +3234,19 @@ _Pragma("unroll") \
 // (status 2, not 1).  One inlined copy of wave_solve in a loop.  oracle/bmpc_oracle.c bmpc_oracle_solve_warm mirrors it.
 #define RETRY_MU_INIT 0.1
 #define RETRY_PUSH 1e-2
+// x0_retry: the x0 of the solve when pr is the CONTINUATION of a solve another kernel began (restoration kernel: pr.x0 is the iterate it left): the second
+// attempt is a fresh solve from there.
 template <bool ZLDS, bool RT = false, bool RESTO = false>
-BMPC_D inline void wave_solve_retry(Wave &W, const Problem &pr) {
+BMPC_D inline void wave_solve_retry(Wave &W, const Problem &pr, const double *x0_retry = nullptr) {
     const Opts keep = W.o;
+    Problem q = pr;
     W.it_base = 0;
     for (int attempt = 0; ; attempt++) {
-        wave_solve<ZLDS, RT, RESTO>(W, pr);
+        wave_solve<ZLDS, RT, RESTO>(W, q);
         if (attempt || keep.retry_cap <= 0 || pr.state || W.last_status != 2 || keep.max_iter <= 0) break;
         W.o.mu_init = RETRY_MU_INIT; W.o.slack_push = RETRY_PUSH; W.o.max_iter = keep.retry_cap; W.it_base = W.last_it;
+        W.o.start_rollout = 1;      // (an x0 far off its own dynamics is rolled out for the second attempt even where the caller wanted it taken as given)
+        if (x0_retry) { q.x0 = x0_retry; q.resto_from = -1; }
     }
     W.o = keep; W.it_base = 0;
 }

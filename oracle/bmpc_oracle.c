@@ -72,6 +72,7 @@ static const double DQ_LIM_DEG[7] = {85, 85, 100, 75, 130, 135, 135};
 #define GN_PROBE 3         /* after a Gauss-Newton fallback the following iterations start from the Gauss-Newton Hessian; every GN_PROBE-th tries the exact one again */
 #define STALL_FACTOR 0.5
 #define STALL_RESTARTS 3        /* barrier restarts from a stalled iterate before status 2 (long horizons only) */
+#define STALL_RESTARTS_RETRY 2  /* ... when a second attempt stands behind the solve (retry_cap > 0, stateless) and it has not been through a restoration phase */
 #define STALL_RESTART_MU 3.0
 #define STALL_RESTART_PUSH 1e-1
 #define RESTO_RHO 1e3          /* restoration phase: l1 penalty of the elastic variables (Ipopt's resto_penalty_parameter: 1000) */
@@ -1084,7 +1085,7 @@ static void solve_one(const Cfg *C, const double *p, const double *x0, Work *W, 
                  * iterations.  (With the restoration phase switched on it follows the third restart: it rescues 11 of the 27 problems of configs[3]
                  * that still end as status 2, but the slowest problem of the launch then takes 314 iterations instead of 180: off by default for N > 11.
                  * INSTEAD of the restarts it is worse: 84.9 % of the 139 slowest problems converge, against 88.5 % behind the restarts.) */
-                if (!longh || n_restart >= STALL_RESTARTS) { status = 2; break; }
+                if (!longh || n_restart >= ((o->retry_cap > 0 && n_resto == 0) ? STALL_RESTARTS_RETRY : STALL_RESTARTS)) { status = 2; break; }
                 n_restart++; it_restart = it;
                 mu = STALL_RESTART_MU;
                 for (int i = 0; i < N * NI; i++) { W->t[i] = fmax(-W->hin[i], STALL_RESTART_PUSH); W->nu[i] = mu / W->t[i]; }
@@ -1331,10 +1332,11 @@ int bmpc_oracle_solve_warm(int N, int S, double h, const bmpc_oracle_opts *opts,
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < B; b++) {
             SolveInfo info; Par P; par_view(p + (size_t)b * C.np, S, &P);
-            solve_one(&C, p + (size_t)b * C.np, x0 + (size_t)b * nw, W, &info, state ? state + (size_t)b * (N * NI + 2) : NULL);
+            Cfg C1 = C; if (state) C1.o.retry_cap = 0;      /* (a warm-started solve has no second attempt behind it) */
+            solve_one(&C1, p + (size_t)b * C.np, x0 + (size_t)b * nw, W, &info, state ? state + (size_t)b * (N * NI + 2) : NULL);
             if (C.o.retry_cap > 0 && !state && info.status == 2 && C.o.max_iter > 0) {      /* second attempt (wave_solve_retry of the kernel text) */
                 Cfg C2 = C; const int first = info.iters;
-                C2.o.mu_init = 0.1; C2.o.slack_push = 1e-2; C2.o.max_iter = C.o.retry_cap;
+                C2.o.mu_init = 0.1; C2.o.slack_push = 1e-2; C2.o.max_iter = C.o.retry_cap; C2.o.start_rollout = 1;
                 solve_one(&C2, p + (size_t)b * C.np, x0 + (size_t)b * nw, W, &info, NULL);
                 info.iters += first; if (info.status == 1) info.status = 2;
             }

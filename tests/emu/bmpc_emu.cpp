@@ -95,8 +95,7 @@ extern "C" int bmpc_emu_solve(int N, int S, double h, const bmpc::Opts *opts, in
                 if (st_ == 4) {
                     std::vector<double> x0b(xb);
                     q.x0 = x0b.data(); q.resto_from = it_;
-                    W.o.retry_cap = 0;
-                    if (zl) bmpc::wave_solve<true, false, true>(W, q); else bmpc::wave_solve<false, false, true>(W, q);
+                    if (zl) bmpc::wave_solve_retry<true, false, true>(W, q, pr.x0); else bmpc::wave_solve_retry<false, false, true>(W, q, pr.x0);      // (the restoration kernel's call)
                 }
                 if (pr.x) memcpy(pr.x, xb.data(), sizeof(double) * nw);
                 if (pr.iters) *pr.iters = it_;

@@ -397,18 +397,18 @@ def test_fixed_barrier_level_iterates_follow_the_oracle():
 def test_second_attempt_of_a_long_horizon_solve():
     """Round 6: a stateless long-horizon solve that ends with status 2 is run once more from x0 on the barrier start of the short horizons (kernel text:
     wave_solve_retry; oracle: bmpc_oracle_solve_warm).  Problem 695 of BASELINE configs[3] is one of the 22 feasible problems the first attempt gives up on
-    (profiles/r06_h_configs3_failures.txt): status 2 after 120 iterations without the rule, converged with it, the iterations of both attempts added;
+    (profiles/r06_h_configs3_failures.txt): status 2 after 120 iterations without the rule (with it: two restarts, 90 iterations, then the second attempt), converged with it, the iterations of both attempts added;
     problem 1658 stays at status 2 (the second attempt runs into its cap of 100: the verdict of the first is kept, not status 1)."""
     from boundmpc_amd import workload
     P = np.concatenate([workload.make_batch(8192, seed=2, N=30, tight=True, rows=(b, b + 1))[0] for b in (695, 1658)])
     X = np.concatenate([workload.make_batch(8192, seed=2, N=30, tight=True, rows=(b, b + 1))[1] for b in (695, 1658)])
     long_h = dict(mu_init=3.0, slack_push=0.1, stall_window=20, restoration=2)
     r0 = c_oracle.solve(P, X, 30, 4, 0.1, opts=c_oracle.default_opts(**long_h), nthreads=2)
-    assert list(r0["status"]) == [2, 2] and list(r0["iters"]) == [120, 160]
+    assert list(r0["status"]) == [2, 2] and list(r0["iters"]) == [120, 160]             # (three barrier restarts, then the verdict)
     r1 = c_oracle.solve(P, X, 30, 4, 0.1, nthreads=2)                                     # the defaults of a long horizon: second attempt of 100 iterations
     e1 = emu.solve(P, X, 30, 4, 0.1, nthreads=2)
     assert list(r1["status"]) == [0, 2] and list(e1["status"]) == [0, 2]
-    assert 120 < r1["iters"][0] <= 220 and r1["iters"][1] == 260 and e1["iters"][1] == 260 and abs(int(e1["iters"][0]) - int(r1["iters"][0])) <= 10
+    assert 90 < r1["iters"][0] <= 190 and r1["iters"][1] == 220 and e1["iters"][1] == 220 and abs(int(e1["iters"][0]) - int(r1["iters"][0])) <= 10
     assert np.abs(e1["x"][0] - r1["x"][0]).max() < 1e-4
     f, g = c_oracle.eval_fg(P[0], r1["x"][0], 30, 4, 0.1)                                   # the recovered point is feasible (reference-form rows)
     g = np.asarray(g).reshape(30, 43)
